@@ -1,0 +1,44 @@
+"""pytest configuration: registers the `gpu` marker and puts the repo root on sys.path.
+
+`-m "not gpu"` runs here (no GPU): oracle vs golden fixtures, host logic, C-ABI symbol checks,
+gloo world_size-2 data-parallel tests.  `-m gpu` runs on the MI355X box: parity of the HIP path
+(through the C-ABI) against the oracle.  /root/reference is never read by any test.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def unflatten_adjs(z, prefix=""):
+    """Inverse of make_golden._flatten_adjs: -> adjs[g][ch] = (idx, val, shape)."""
+    G, C = int(z[prefix + "num_graphs"]), int(z[prefix + "num_channels"])
+    idx, val, shp, off = z[prefix + "idx"], z[prefix + "val"], z[prefix + "shape"], z[prefix + "offsets"]
+    adjs = []
+    for g in range(G):
+        row = []
+        for ch in range(C):
+            k = g * C + ch
+            row.append((idx[off[k]:off[k + 1]], val[off[k]:off[k + 1]], shp[k]))
+        adjs.append(row)
+    return adjs
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
