@@ -1,0 +1,155 @@
+/*
+ * kgcn_hip.h -- C ABI of libkgcn_hip.so: the MI355X (gfx950) implementation of kGCN's batched
+ * graph-convolution hot path.
+ *
+ * What this replaces.  The reference loads three TensorFlow custom-op libraries from the
+ * working directory -- tf.load_op_library('./bspmm.so') (kgcn/bspmm_call.py:9,19),
+ * './bconv.so' (kgcn/bconv_call.py:9,26), './batched.so' (kgcn/batched_call.py:9,19,30) --
+ * and calls their ops Bspmm / Bconv / Bspmdt from GraphConv.call and GINAggregate.call
+ * (kgcn/layers.py:77,88,102,435,445,458).  Neither sources nor binaries of those libraries are
+ * in the reference tree, so there is no ABI to copy: the entry points below are what a binding
+ * for this path needs, one per op contract plus the dense contraction, the
+ * fused layer and the tiny reductions that close a forward+backward.
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; every pointer marked "device" is a HIP device pointer owned
+ *    by the CALLER.  The library never allocates or frees device memory and keeps no global
+ *    mutable state besides a thread-local error string; scratch space is passed in and sized
+ *    by the *_workspace_bytes queries.
+ *  - every launch is asynchronous on the given stream (hipStream_t passed as void*); no
+ *    implicit synchronisation.  Entry points are re-entrant.
+ *  - return value: 0 = ok, non-zero = error; text via kgcn_last_error().  No exception crosses
+ *    the ABI.
+ *  - all floating point is IEEE fp32 (fp32 MFMA v_mfma_f32_32x32x2_f32 for contractions: exact
+ *    fp32 fma chains, no reduced-precision inputs), indices int32.
+ *
+ * Adjacency layout in HBM ("batched CSR", one per adjacency channel).  T graphs, each an
+ * [rows x cols] sparse matrix (uniform, = the reference's max_node_num padding,
+ * kgcn/data_util.py:30-37, 410).  Row r of graph t owns entries rowptr[t*rows+r] ..
+ * rowptr[t*rows+r+1]-1 of `cv`; entry e is the pair cv[2e] = column index LOCAL to the graph
+ * (int32 bit pattern), cv[2e+1] = value (fp32 bit pattern).  Entries of a row keep the order
+ * they had in the reference's COO (tf.SparseTensor) input; duplicates are simply repeated
+ * entries (they accumulate, as in TF); rows without entries produce zeros; graphs without
+ * entries (the dummy graphs padding a short batch, kgcn/feed.py:123-126) are legal.
+ */
+#ifndef KGCN_HIP_H_
+#define KGCN_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KGCN_HIP_ABI_VERSION 1
+
+typedef struct kgcn_csr_batch {
+  int32_t num_graphs;        /* T */
+  int32_t rows;              /* M: rows per graph (padded, uniform) */
+  int32_t cols;              /* K: columns per graph = rows of each rhs block */
+  int32_t max_nnz_per_graph; /* max over graphs of stored entries (sizes the LDS staging) */
+  int64_t nnz;               /* total stored entries */
+  const int32_t* rowptr;     /* device, [T*M + 1], absolute offsets into cv (in entries) */
+  const int32_t* cv;         /* device, [2*nnz], interleaved (local col, fp32 value bits) */
+} kgcn_csr_batch;
+
+/* -- library info ------------------------------------------------------------------------ */
+int kgcn_abi_version(void);
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* kgcn_last_error(void);
+/* Name of the code-object architecture the kernels were built for ("gfx950"). */
+const char* kgcn_build_arch(void);
+
+/* -- Bspmm: batched sparse x dense ------------------------------------------------------- */
+/* Replaces op `Bspmm` (kgcn/bspmm_call.py:16; backward use :45, kgcn/bconv_call.py:58,
+ * kgcn/batched_call.py:60) and, because rhs/out are addressed as one strided tensor, also
+ * `Bspmdt` (kgcn/batched_call.py:27: rhs is ONE [T*K, D] tensor -> rhs_graph_stride = K*rhs_ld).
+ *   out[t] = beta * out[t] + A[t] @ rhs[t],   t = 0..T-1
+ * rhs[t] = rhs + t*rhs_graph_stride is [K x d] with leading dimension rhs_ld (floats);
+ * out[t] likewise [M x d].  beta is 0 (overwrite) or 1 (accumulate, used for the channel
+ * add-n).  adjoint_a of the op is served by passing the batched CSR of A^T (the host packer
+ * builds it once per batch); adjoint_b is a host-side transpose of rhs. */
+int kgcn_bspmm_f32(const kgcn_csr_batch* a, const float* rhs, int64_t rhs_ld,
+                   int64_t rhs_graph_stride, int32_t d, float* out, int64_t out_ld,
+                   int64_t out_graph_stride, float beta, void* stream);
+
+/* -- Bconv: fused multi-channel SpMM + channel add-n -------------------------------------- */
+/* Replaces op `Bconv` (kgcn/bconv_call.py:18-23):  out[t] = sum_c A_c[t] @ rhs_c[t].
+ * a_ch is a HOST array of num_channels descriptors; channel c's dense operand is
+ * rhs + c*rhs_channel_stride (so the channels may be column slices of one [T*K, C*d] GEMM
+ * output: rhs_channel_stride = d, rhs_ld = C*d). */
+int kgcn_bconv_f32(const kgcn_csr_batch* a_ch, int32_t num_channels, const float* rhs,
+                   int64_t rhs_ld, int64_t rhs_graph_stride, int64_t rhs_channel_stride,
+                   int32_t d, float* out, int64_t out_ld, int64_t out_graph_stride,
+                   void* stream);
+
+/* -- gradient w.r.t. the sparse values ---------------------------------------------------- */
+/* kgcn/bspmm_call.py:50-55:  dval[e] = sum_k grad[t][row_e,k] * rhs[t][col_e,k]  for every
+ * stored entry e (same order as `cv`).  dval: device [nnz]. */
+int kgcn_spmm_values_grad_f32(const kgcn_csr_batch* a, const float* grad, int64_t grad_ld,
+                              int64_t grad_graph_stride, const float* rhs, int64_t rhs_ld,
+                              int64_t rhs_graph_stride, int32_t d, float* dval, void* stream);
+
+/* -- dense contraction (GraphDense, and the X.W part of the unfused GraphConv) ------------- */
+/* kgcn/layers.py:255-262 (Keras Dense on reshape(X,[-1,Din])) and :99-100 / :112:
+ *   y[m, dout] = x[m, din] @ w + bias        (trans_w = 0: w is [din x dout], ld w_ld)
+ *   y[m, dout] = x[m, din] @ w^T + bias      (trans_w = 1: w is [dout x din], ld w_ld)
+ * bias may be NULL.  fp32 MFMA. */
+int kgcn_dense_fwd_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w,
+                       int64_t w_ld, int32_t trans_w, const float* bias, float* y,
+                       int32_t dout, int64_t y_ld, void* stream);
+
+/* Weight/bias gradients of the contraction:  dw[din,dout] = x^T @ dy,  dbias[dout] = colsum(dy)
+ * (the reduction over all m = B*N rows: TF MatMul/BiasAdd gradients summed by AddN over the
+ * graphs).  Deterministic two-stage reduction through `workspace`.
+ * dw (ld = dout) and dbias may each be NULL. */
+int64_t kgcn_dense_wgrad_workspace_bytes(int64_t m, int32_t din, int32_t dout);
+int kgcn_dense_wgrad_f32(const float* x, int64_t x_ld, const float* dy, int64_t dy_ld, int64_t m,
+                         int32_t din, int32_t dout, float* dw, float* dbias, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+
+/* -- fused GraphConv layer (single adjacency channel) -------------------------------------- */
+/* kgcn/layers.py:64-116, all four branches compute
+ *   out[t] = A[t] @ (x[t] @ w + bias)            x[t]: [N x din], out[t]: [N x dout]
+ * Forward in ONE kernel (x tile -> LDS, fp32 MFMA, aggregation out of LDS; X.W never touches
+ * HBM).  Supported fused shapes are reported by kgcn_graphconv_fused_supported(); other
+ * shapes and multi-channel layers use kgcn_dense_* + kgcn_bconv_f32. */
+int kgcn_graphconv_fused_supported(int32_t n_nodes, int32_t din, int32_t dout,
+                                   int32_t max_nnz_per_graph);
+int kgcn_graphconv_fwd_f32(const kgcn_csr_batch* a, const float* x, const float* w,
+                           const float* bias, int32_t din, int32_t dout, float* out,
+                           void* stream);
+/* Backward in ONE kernel + a small deterministic reduction:
+ *   dfw[t] = A[t]^T @ dout[t];  dx[t] = dfw[t] @ w^T;  dw = sum_t x[t]^T dfw[t];
+ *   dbias = sum_t colsum(dfw[t])          (SURVEY 3.3 / kgcn/bspmm_call.py:45)
+ * at = batched CSR of A^T.  dx may be NULL (first layer). */
+int64_t kgcn_graphconv_bwd_workspace_bytes(int32_t num_graphs, int32_t din, int32_t dout);
+int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, const float* w,
+                           const float* dout_grad, int32_t din, int32_t dout, float* dx,
+                           float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
+                           void* stream);
+
+/* -- GINAggregate -------------------------------------------------------------------------- */
+/* kgcn/layers.py:461-472:  out[t] = sum_c (eps[c] * x[t] + A_c[t] @ x[t]).
+ * eps: device [num_channels] or NULL (the accelerated branches :429-460 drop the eps term). */
+int kgcn_gin_aggregate_f32(const kgcn_csr_batch* a_ch, int32_t num_channels, const float* x,
+                           int32_t d, const float* eps, float* out, void* stream);
+
+/* -- GraphGather ---------------------------------------------------------------------------- */
+/* kgcn/layers.py:163-164: out[b, :] = sum_n x[b, n, :] (padding rows included). */
+int kgcn_graph_gather_fwd_f32(const float* x, int64_t batch, int32_t n_nodes, int32_t d,
+                              float* out, void* stream);
+/* dx[b, n, :] = dout[b, :] */
+int kgcn_graph_gather_bwd_f32(const float* dout_grad, int64_t batch, int32_t n_nodes, int32_t d,
+                              float* dx, void* stream);
+
+/* -- small reductions used by the layer gradients ------------------------------------------- */
+/* out[0] = sum_i a[i]*b[i]  (d eps of GINAggregate).  workspace >= kgcn_dot_workspace_bytes(). */
+int64_t kgcn_dot_workspace_bytes(int64_t n);
+int kgcn_dot_f32(const float* a, const float* b, int64_t n, float* out, void* workspace,
+                 int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KGCN_HIP_H_ */

@@ -1,0 +1,117 @@
+"""ctypes binding of libkgcn_hip.so (the C ABI declared in include/kgcn_hip.h).
+
+There is no CPU fallback: if the shared library is missing or lacks a symbol, importing this
+module raises.  PyTorch is used only for device memory and streams; every call passes raw device
+pointers and the current HIP stream.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libkgcn_hip.so")
+
+c_f32p = ctypes.c_void_p
+c_i64 = ctypes.c_int64
+c_i32 = ctypes.c_int32
+
+
+class CsrBatch(ctypes.Structure):
+    """struct kgcn_csr_batch (include/kgcn_hip.h)."""
+    _fields_ = [
+        ("num_graphs", c_i32),
+        ("rows", c_i32),
+        ("cols", c_i32),
+        ("max_nnz_per_graph", c_i32),
+        ("nnz", c_i64),
+        ("rowptr", ctypes.c_void_p),
+        ("cv", ctypes.c_void_p),
+    ]
+
+
+_CSRP = ctypes.POINTER(CsrBatch)
+
+# name -> (restype, argtypes); must list EVERY function include/kgcn_hip.h declares
+# (tests/test_abi.py parses the header and compares).
+SIGNATURES = {
+    "kgcn_abi_version": (ctypes.c_int, []),
+    "kgcn_last_error": (ctypes.c_char_p, []),
+    "kgcn_build_arch": (ctypes.c_char_p, []),
+    "kgcn_bspmm_f32": (ctypes.c_int, [_CSRP, c_f32p, c_i64, c_i64, c_i32, c_f32p, c_i64, c_i64,
+                                      ctypes.c_float, ctypes.c_void_p]),
+    "kgcn_bconv_f32": (ctypes.c_int, [_CSRP, c_i32, c_f32p, c_i64, c_i64, c_i64, c_i32, c_f32p,
+                                      c_i64, c_i64, ctypes.c_void_p]),
+    "kgcn_spmm_values_grad_f32": (ctypes.c_int, [_CSRP, c_f32p, c_i64, c_i64, c_f32p, c_i64,
+                                                 c_i64, c_i32, c_f32p, ctypes.c_void_p]),
+    "kgcn_dense_fwd_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i64, c_f32p, c_i64, c_i32,
+                                          c_f32p, c_f32p, c_i32, c_i64, ctypes.c_void_p]),
+    "kgcn_dense_wgrad_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32]),
+    "kgcn_dense_wgrad_f32": (ctypes.c_int, [c_f32p, c_i64, c_f32p, c_i64, c_i64, c_i32, c_i32,
+                                            c_f32p, c_f32p, ctypes.c_void_p, c_i64,
+                                            ctypes.c_void_p]),
+    "kgcn_graphconv_fused_supported": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32]),
+    "kgcn_graphconv_fwd_f32": (ctypes.c_int, [_CSRP, c_f32p, c_f32p, c_f32p, c_i32, c_i32,
+                                              c_f32p, ctypes.c_void_p]),
+    "kgcn_graphconv_bwd_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
+    "kgcn_graphconv_bwd_f32": (ctypes.c_int, [_CSRP, c_f32p, c_f32p, c_f32p, c_i32, c_i32,
+                                              c_f32p, c_f32p, c_f32p, ctypes.c_void_p, c_i64,
+                                              ctypes.c_void_p]),
+    "kgcn_gin_aggregate_f32": (ctypes.c_int, [_CSRP, c_i32, c_f32p, c_i32, c_f32p, c_f32p,
+                                              ctypes.c_void_p]),
+    "kgcn_graph_gather_fwd_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i32, c_f32p,
+                                                 ctypes.c_void_p]),
+    "kgcn_graph_gather_bwd_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i32, c_f32p,
+                                                 ctypes.c_void_p]),
+    "kgcn_dot_workspace_bytes": (c_i64, [c_i64]),
+    "kgcn_dot_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i64, c_f32p, ctypes.c_void_p, c_i64,
+                                    ctypes.c_void_p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "kgcn_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C kgcn_amd/csrc` (hipcc --offload-arch=gfx950). There is no "
+            "CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError("kgcn_amd: %s does not export %s (stale build?)" % (LIB_PATH, name)) from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.kgcn_abi_version() != 1:
+        raise ImportError("kgcn_amd: ABI version mismatch: %d" % lib.kgcn_abi_version())
+    return lib
+
+
+lib = _load()
+
+
+class KgcnHipError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    """Raise on a non-zero status, with the library's message (error convention of the ABI)."""
+    if rc != 0:
+        msg = lib.kgcn_last_error()
+        raise KgcnHipError("%s failed: %s" % (what or "kgcn_hip call",
+                                              msg.decode() if msg else "unknown error"))
+
+
+def current_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def require_gpu(t, name):
+    if not t.is_cuda:
+        raise KgcnHipError(
+            "%s must live on the GPU (cuda/HIP device); kgcn_amd has no CPU path" % name)

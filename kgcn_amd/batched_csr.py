@@ -1,0 +1,254 @@
+"""Batched-CSR adjacency container: the HBM layout the HIP kernels read (include/kgcn_hip.h).
+
+The reference feeds adjacency as B x C separate tf.SparseTensorValue (indices [nnz,2], values
+[nnz], dense_shape [2]) per step (kgcn/feed.py:112-126, placeholders from
+kgcn/default_model.py:10).  Here one adjacency channel of the whole batch is ONE pair of device
+arrays, built once per batch (or once per dataset and cached):
+
+    rowptr int32 [T*M + 1]    absolute entry offsets, row r of graph t at index t*M + r
+    cv     int32 [nnz, 2]     (column local to the graph, fp32 value bits), CSR order
+
+Entries of a row keep their COO order (stable sort), duplicates stay separate entries (they
+accumulate like in TF), dummy graphs (nnz = 0) are legal.  The transposed container (A^T of every
+graph) serves adjoint_a=True, i.e. every backward pass (kgcn/bspmm_call.py:45).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def _as_triple(m):
+    """Accept the reference's layouts: (idx, val, shape) tuples/lists or objects exposing
+    .indices/.values/.dense_shape (kgcn/bspmm_call.py:12-14)."""
+    if hasattr(m, "indices") and hasattr(m, "dense_shape"):
+        return m.indices, m.values, m.dense_shape
+    return m[0], m[1], m[2]
+
+
+def _to_numpy(a):
+    if hasattr(a, "detach"):
+        a = a.detach().cpu().numpy()
+    return np.asarray(a)
+
+
+class BatchedCSR:
+    """One adjacency channel of a batch of T graphs, device resident."""
+
+    def __init__(self, rowptr, cv, num_graphs, rows, cols, max_nnz, perm=None, host=None):
+        self.rowptr = rowptr            # torch int32 [T*M+1] (device)
+        self.cv = cv                    # torch int32 [nnz,2] (device)
+        self.num_graphs = int(num_graphs)
+        self.rows = int(rows)
+        self.cols = int(cols)
+        self.max_nnz = int(max_nnz)
+        self.nnz = int(cv.shape[0])
+        self.perm = perm                # torch int64 [nnz]: CSR position -> input (COO) position
+        self._host = host               # (g, r, c, v) numpy arrays in CSR order, for transpose()
+        self._t = None
+        self._desc = None
+        self._struct_src = None         # set by with_values(): container owning the pattern
+        self._vals = None
+
+    # ---- construction -------------------------------------------------------------------------
+    @classmethod
+    def from_arrays(cls, graph, row, col, val, num_graphs, rows, cols, device="cuda"):
+        """Build from flat COO arrays (graph id, local row, local col, value) of all graphs."""
+        import torch
+        graph = np.asarray(graph, np.int64).ravel()
+        row = np.asarray(row, np.int64).ravel()
+        col = np.asarray(col, np.int64).ravel()
+        val = np.asarray(val, np.float32).ravel()
+        nnz = graph.shape[0]
+        if not (row.shape[0] == col.shape[0] == val.shape[0] == nnz):
+            raise ValueError("graph/row/col/val length mismatch")
+        T, M, K = int(num_graphs), int(rows), int(cols)
+        if nnz:
+            if graph.min() < 0 or graph.max() >= T:
+                raise ValueError("graph id out of range")
+            if row.min() < 0 or row.max() >= M:
+                raise ValueError("row index out of range for %d rows" % M)
+            if col.min() < 0 or col.max() >= K:
+                raise ValueError("column index out of range for %d columns" % K)
+        if T * M + 1 >= 2 ** 31 or nnz >= 2 ** 31:
+            raise ValueError("batch too large for int32 offsets")
+        key = graph * M + row
+        if nnz and np.any(key[1:] < key[:-1]):
+            order = np.argsort(key, kind="stable")
+            graph, row, col, val, key = graph[order], row[order], col[order], val[order], key[order]
+        else:
+            order = None
+        counts = np.bincount(key, minlength=T * M) if nnz else np.zeros(T * M, np.int64)
+        rowptr = np.zeros(T * M + 1, np.int64)
+        np.cumsum(counts, out=rowptr[1:])
+        if T and M:
+            per_graph = rowptr[M::M] - rowptr[:-1:M] if M else np.zeros(T, np.int64)
+            max_nnz = int(per_graph.max()) if per_graph.size else 0
+        else:
+            max_nnz = 0
+        cv = np.empty((nnz, 2), np.int32)
+        cv[:, 0] = col
+        cv[:, 1] = val.view(np.int32)
+        dev = torch.device(device)
+        t_rowptr = torch.from_numpy(rowptr.astype(np.int32)).to(dev)
+        t_cv = torch.from_numpy(cv).to(dev)
+        perm = None if order is None else torch.from_numpy(order).to(dev)
+        return cls(t_rowptr, t_cv, T, M, K, max_nnz, perm=perm, host=(graph, row, col, val))
+
+    @classmethod
+    def from_coo_list(cls, mats, rows=None, cols=None, device="cuda"):
+        """mats: T sparse matrices in the reference's COO layout (see _as_triple).  Graphs are
+        padded to the common (max) shape like kgcn/data_util.py:30-37 does with max_node_num."""
+        gs, rs, cs, vs = [], [], [], []
+        M = K = 0
+        for t, m in enumerate(mats):
+            idx, val, shape = _as_triple(m)
+            idx = _to_numpy(idx).reshape(-1, 2)
+            val = _to_numpy(val).reshape(-1)
+            if shape is not None:
+                M = max(M, int(shape[0]))
+                K = max(K, int(shape[1]))
+            if idx.shape[0] != val.shape[0]:
+                raise ValueError("matrix %d: %d indices but %d values" % (t, idx.shape[0], val.shape[0]))
+            if idx.shape[0]:
+                gs.append(np.full(idx.shape[0], t, np.int64))
+                rs.append(idx[:, 0])
+                cs.append(idx[:, 1])
+                vs.append(val)
+        cat = (lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt))
+        return cls.from_arrays(cat(gs, np.int64), cat(rs, np.int64), cat(cs, np.int64),
+                               cat(vs, np.float32), len(mats), rows if rows is not None else M,
+                               cols if cols is not None else K, device=device)
+
+    # ---- derived -------------------------------------------------------------------------------
+    def transpose(self):
+        """Batched CSR of A[t]^T (cached).  Entry order inside a transposed row follows the
+        original row-major order, i.e. ascending original row."""
+        if self._t is None:
+            if self._struct_src is not None:
+                bt = self._struct_src.transpose()          # pattern of A^T (cached there)
+                vt = self._vals if bt.perm is None else self._vals[bt.perm]
+                t = bt.with_values(vt)
+            else:
+                g, r, c, v = self._host
+                t = BatchedCSR.from_arrays(g, c, r, v, self.num_graphs, self.cols, self.rows,
+                                           device=self.rowptr.device)
+            t._t = self
+            self._t = t
+        return self._t
+
+    def with_values(self, values):
+        """Same pattern, new values (device fp32 tensor [nnz] in CSR order).  Used when the
+        adjacency values are themselves differentiable inputs (kgcn/bspmm_call.py:50-55)."""
+        import torch
+        cv = torch.stack((self.cv[:, 0], values.detach().contiguous().view(torch.int32)), dim=1)
+        out = BatchedCSR(self.rowptr, cv.contiguous(), self.num_graphs, self.rows, self.cols,
+                         self.max_nnz, perm=self.perm, host=None)
+        out._struct_src = self if self._struct_src is None else self._struct_src
+        out._vals = values.detach()
+        return out
+
+    @property
+    def values(self):
+        import torch
+        return self.cv[:, 1].contiguous().view(torch.float32)
+
+    @property
+    def device(self):
+        return self.rowptr.device
+
+    def desc(self):
+        """ctypes struct kgcn_csr_batch pointing at the device arrays."""
+        if self._desc is None:
+            self._desc = _lib.CsrBatch(self.num_graphs, self.rows, self.cols, self.max_nnz,
+                                       self.nnz, self.rowptr.data_ptr(),
+                                       self.cv.data_ptr() if self.nnz else 0)
+        return self._desc
+
+    def algorithmic_bytes(self):
+        """CSR bytes of SURVEY 8d: 4(N+1) + 8 nnz per graph-channel."""
+        return 4 * (self.num_graphs * (self.rows + 1)) + 8 * self.nnz
+
+
+class BatchedAdjacency:
+    """All adjacency channels of a batch: what GraphConv / GINAggregate receive as `adj`.
+
+    Built from the reference's list-of-lists adjs[b][ch] (kgcn/default_model.py:10,
+    kgcn/feed.py:112-126) or from per-channel BatchedCSR objects."""
+
+    def __init__(self, channels):
+        if not channels:
+            raise ValueError("at least one adjacency channel is required")
+        t, m, k = channels[0].num_graphs, channels[0].rows, channels[0].cols
+        for c in channels:
+            if (c.num_graphs, c.rows, c.cols) != (t, m, k):
+                raise ValueError("adjacency channels disagree on the batch shape")
+        self.channels = list(channels)
+        self._desc_arr = None
+        self._desc_arr_t = None
+
+    @classmethod
+    def from_adjs(cls, adjs, n_nodes=None, device="cuda"):
+        B = len(adjs)
+        if B == 0:
+            raise ValueError("empty batch")
+        C = len(adjs[0])
+        chans = []
+        for ch in range(C):
+            chans.append(BatchedCSR.from_coo_list([adjs[b][ch] for b in range(B)],
+                                                  rows=n_nodes, cols=n_nodes, device=device))
+        # channels of one batch share the padded size
+        M = max(c.rows for c in chans)
+        K = max(c.cols for c in chans)
+        if any(c.rows != M or c.cols != K for c in chans):
+            chans = [BatchedCSR.from_coo_list([adjs[b][ch] for b in range(B)], rows=M, cols=K,
+                                              device=device) for ch in range(C)]
+        return cls(chans)
+
+    @property
+    def num_graphs(self):
+        return self.channels[0].num_graphs
+
+    @property
+    def n_nodes(self):
+        return self.channels[0].rows
+
+    @property
+    def num_channels(self):
+        return len(self.channels)
+
+    def desc_array(self, transposed=False):
+        """Host array of kgcn_csr_batch descriptors (one per channel) for kgcn_bconv_f32 etc."""
+        attr = "_desc_arr_t" if transposed else "_desc_arr"
+        arr = getattr(self, attr)
+        if arr is None:
+            arr = (_lib.CsrBatch * len(self.channels))()
+            for i, c in enumerate(self.channels):
+                src = c.transpose() if transposed else c
+                d = src.desc()
+                ctypes.memmove(ctypes.byref(arr[i]), ctypes.byref(d), ctypes.sizeof(_lib.CsrBatch))
+            setattr(self, attr, arr)
+        return arr
+
+
+_PACK_CACHE = {}
+
+
+def as_batched_adjacency(adj, n_nodes=None, device="cuda"):
+    """Accept a BatchedAdjacency, a BatchedCSR (single channel) or the reference's adjs[b][ch]
+    list-of-lists; the packed form of a list is cached on the list's identity (the reference
+    re-feeds the same Python objects every epoch)."""
+    if isinstance(adj, BatchedAdjacency):
+        return adj
+    if isinstance(adj, BatchedCSR):
+        return BatchedAdjacency([adj])
+    key = (id(adj), len(adj), n_nodes, str(device))
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] is adj:
+        return hit[1]
+    packed = BatchedAdjacency.from_adjs(adj, n_nodes=n_nodes, device=device)
+    if len(_PACK_CACHE) > 64:
+        _PACK_CACHE.clear()
+    _PACK_CACHE[key] = (adj, packed)
+    return packed

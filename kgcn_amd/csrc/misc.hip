@@ -1,0 +1,165 @@
+// Library bookkeeping (error text, ABI version) and the small reductions of the path:
+// GraphGather (kgcn/layers.py:163-164) forward/backward and the dot product behind d eps of
+// GINAggregate (kgcn/layers.py:469).
+#include "kgcn_common.h"
+
+namespace kgcn {
+
+char* error_buffer() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+int fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(error_buffer(), 512, fmt, ap);
+  va_end(ap);
+  return 1;
+}
+
+// out[b, c] = sum_n x[b, n, c].  One thread per (b, 4 columns) when d % 4 == 0: consecutive
+// threads read consecutive 16-byte words of a row, the n loop strides by d.
+template <int VEC>
+__global__ __launch_bounds__(256) void gather_fwd_kernel(const float* __restrict__ x, long batch,
+                                                         int n_nodes, int d,
+                                                         float* __restrict__ out) {
+  const int dv = d / VEC;
+  const long total = batch * dv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / dv;
+    const int c = (int)(i - b * dv) * VEC;
+    const float* src = x + (b * n_nodes) * (long)d + c;
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    for (int n = 0; n < n_nodes; ++n) {
+      if constexpr (VEC == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)n * d);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += v[j];
+      } else {
+        acc[0] += src[(long)n * d];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) out[b * d + c + j] = acc[j];
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict__ g, long batch,
+                                                         int n_nodes, int d,
+                                                         float* __restrict__ dx) {
+  const int dv = d / VEC;
+  const long total = batch * n_nodes * dv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long bn = i / dv;
+    const int c = (int)(i - bn * dv) * VEC;
+    const long b = bn / n_nodes;
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<f32x4*>(dx + bn * d + c) = *reinterpret_cast<const f32x4*>(g + b * d + c);
+    } else {
+      dx[bn * d + c] = g[b * d + c];
+    }
+  }
+}
+
+constexpr int kDotBlocks = 1024;
+
+__global__ __launch_bounds__(256) void dot_partial_kernel(const float* __restrict__ a,
+                                                          const float* __restrict__ b, long n,
+                                                          float* __restrict__ part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    s += a[i] * b[i];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void dot_final_kernel(const float* __restrict__ part, int nparts,
+                                                        float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+static unsigned grid_for(long total_threads) {
+  long blocks = (total_threads + 255) / 256;
+  const long cap = (long)kNumCU * 16;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+}  // namespace kgcn
+
+using namespace kgcn;
+
+extern "C" int kgcn_abi_version(void) { return KGCN_HIP_ABI_VERSION; }
+extern "C" const char* kgcn_last_error(void) { return error_buffer(); }
+extern "C" const char* kgcn_build_arch(void) { return "gfx950"; }
+
+extern "C" int kgcn_graph_gather_fwd_f32(const float* x, int64_t batch, int32_t n_nodes, int32_t d,
+                                         float* out, void* stream) {
+  if (batch < 0 || n_nodes < 0 || d < 0) return fail("kgcn_graph_gather_fwd_f32: negative shape");
+  if (batch == 0 || d == 0) return 0;
+  if (!out || (!x && n_nodes > 0)) return fail("kgcn_graph_gather_fwd_f32: NULL operand");
+  const bool v4 = (d % 4 == 0) && aligned16(x) && aligned16(out);
+  if (v4)
+    hipLaunchKernelGGL((gather_fwd_kernel<4>), dim3(grid_for(batch * (d / 4))), dim3(256), 0,
+                       as_stream(stream), x, (long)batch, n_nodes, d, out);
+  else
+    hipLaunchKernelGGL((gather_fwd_kernel<1>), dim3(grid_for(batch * d)), dim3(256), 0,
+                       as_stream(stream), x, (long)batch, n_nodes, d, out);
+  return check_launch("gather_fwd_kernel");
+}
+
+extern "C" int kgcn_graph_gather_bwd_f32(const float* dout_grad, int64_t batch, int32_t n_nodes,
+                                         int32_t d, float* dx, void* stream) {
+  if (batch < 0 || n_nodes < 0 || d < 0) return fail("kgcn_graph_gather_bwd_f32: negative shape");
+  if (batch == 0 || d == 0 || n_nodes == 0) return 0;
+  if (!dout_grad || !dx) return fail("kgcn_graph_gather_bwd_f32: NULL operand");
+  const bool v4 = (d % 4 == 0) && aligned16(dout_grad) && aligned16(dx);
+  if (v4)
+    hipLaunchKernelGGL((gather_bwd_kernel<4>), dim3(grid_for(batch * n_nodes * (d / 4))),
+                       dim3(256), 0, as_stream(stream), dout_grad, (long)batch, n_nodes, d, dx);
+  else
+    hipLaunchKernelGGL((gather_bwd_kernel<1>), dim3(grid_for(batch * n_nodes * d)), dim3(256), 0,
+                       as_stream(stream), dout_grad, (long)batch, n_nodes, d, dx);
+  return check_launch("gather_bwd_kernel");
+}
+
+extern "C" int64_t kgcn_dot_workspace_bytes(int64_t n) {
+  (void)n;
+  return (int64_t)kDotBlocks * 4;
+}
+
+extern "C" int kgcn_dot_f32(const float* a, const float* b, int64_t n, float* out, void* workspace,
+                            int64_t workspace_bytes, void* stream) {
+  if (n < 0) return fail("kgcn_dot_f32: n < 0");
+  if (!out) return fail("kgcn_dot_f32: out is NULL");
+  hipStream_t s = as_stream(stream);
+  if (n == 0) {
+    (void)hipMemsetAsync(out, 0, 4, s);
+    return 0;
+  }
+  if (!a || !b) return fail("kgcn_dot_f32: NULL operand");
+  if (!workspace || workspace_bytes < kgcn_dot_workspace_bytes(n))
+    return fail("kgcn_dot_f32: workspace too small");
+  long blocks = (n + 255) / 256;
+  if (blocks > kDotBlocks) blocks = kDotBlocks;
+  float* part = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(dot_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, b, (long)n,
+                     part);
+  if (int rc = check_launch("dot_partial_kernel")) return rc;
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, s, part, (int)blocks, out);
+  return check_launch("dot_final_kernel");
+}

@@ -1,0 +1,325 @@
+// Batched sparse x dense aggregation for gfx950 (MI355X):  out[t] = beta*out[t] + A[t] @ rhs[t].
+//
+// Replaces the reference's custom ops Bspmm / Bspmdt / Bconv (kgcn/bspmm_call.py:16,
+// kgcn/batched_call.py:27, kgcn/bconv_call.py:23) and the default-branch
+// tf.sparse_tensor_dense_matmul loop (kgcn/layers.py:105-116).  The op is HBM-bound
+// (~0.7 flop/B): the design goal is to touch every rhs/out byte exactly once with 16-byte
+// coalesced accesses and to keep all irregular (gather) traffic inside LDS.
+//
+// Two kernels:
+//  * spmm_tile_kernel   -- small graphs (the molecular case): ONE WAVE PER GRAPH.  The graph's
+//    rhs block [K x d] is streamed HBM -> LDS with 1 KiB-per-instruction dwordx4 loads, its CSR
+//    slice (rowptr + interleaved col/val pairs) is staged next to it, then 64/LPR rows are
+//    aggregated concurrently (LPR lanes x float4 cover one row), neighbours gathered from LDS
+//    with conflict-free ds_read_b128, and 64/LPR consecutive output rows leave as ONE fully
+//    coalesced dwordx4 store instruction.  A one-wave workgroup needs no cross-wave barrier.
+//  * spmm_gather_kernel -- any shape (big graphs, the block-diagonal [sumN x sumN] matrix of
+//    kgcn/data_util.py:698-845, d not a multiple of 4): classic CSR-vector, LPR lanes per row,
+//    neighbours gathered through L1/L2.
+#include "kgcn_common.h"
+
+namespace kgcn {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// ------------------------------------------------------------------------------------------------
+// LDS-staged tile kernel: one wave (= one 64-thread workgroup) per graph.
+// LDS layout: tile[K*d] | ecv[max_nnz] (int2) | rp[M+1]
+// ------------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(64) void spmm_tile_kernel(
+    const int* __restrict__ rowptr, const int2* __restrict__ cv, const float* __restrict__ rhs,
+    long rhs_ld, long rhs_gs, float* __restrict__ out, long out_ld, long out_gs, int M, int K,
+    int d, int max_nnz, float beta, const float* __restrict__ self_scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* tile = reinterpret_cast<float*>(smem);
+  int2* ecv = reinterpret_cast<int2*>(tile + (size_t)K * d);
+  int* rp = reinterpret_cast<int*>(ecv + max_nnz);
+
+  const int t = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int* grp = rowptr + (long)t * M;
+  const int base = grp[0];
+  const int cnt = grp[M] - base;
+
+  // ---- stage: rhs block (dwordx4, fully coalesced), CSR slice ---------------------------------
+  const float* rb = rhs + (long)t * rhs_gs;
+  const int d4 = d >> 2;
+  const int n4 = K * d4;
+  if (rhs_ld == d) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(rb);
+    f32x4* dst = reinterpret_cast<f32x4*>(tile);
+#pragma unroll 4
+    for (int i = lane; i < n4; i += 64) dst[i] = src[i];
+  } else {
+    for (int i = lane; i < n4; i += 64) {
+      int r = i / d4, c = i - r * d4;
+      st4(tile + (size_t)i * 4, ld4(rb + (long)r * rhs_ld + c * 4));
+    }
+  }
+  for (int i = lane; i < cnt; i += 64) ecv[i] = cv[base + i];
+  for (int i = lane; i <= M; i += 64) rp[i] = grp[i] - base;
+  __syncthreads();  // single-wave workgroup: orders the LDS writes before the gathers
+
+  // ---- aggregate: 64/LPR rows at a time, LPR lanes x float4 per row ---------------------------
+  constexpr int RPW = 64 / LPR;
+  const int sub = lane / LPR;
+  const int cl = lane % LPR;
+  const bool col_ok = cl * 4 < d;
+  const float sscale = self_scale ? self_scale[0] : 0.f;
+  float* ob = out + (long)t * out_gs;
+  for (int r0 = 0; r0 < M; r0 += RPW) {
+    const int r = r0 + sub;
+    if (r < M && col_ok) {
+      const int s = rp[r], e = rp[r + 1];
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int k = s; k < e; ++k) {
+        const int2 p = ecv[k];
+        const float v = __int_as_float(p.y);
+        const f32x4 x = ld4(tile + (size_t)p.x * d + cl * 4);
+        acc += v * x;
+      }
+      if (self_scale) acc += sscale * ld4(tile + (size_t)r * d + cl * 4);
+      float* o = ob + (long)r * out_ld + cl * 4;
+      if (beta != 0.f) acc += ld4(o);
+      st4(o, acc);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic CSR-vector gather kernel: LPR = 2^lpr_log2 lanes per row, VEC floats per lane
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void spmm_gather_kernel(
+    const int* __restrict__ rowptr, const int2* __restrict__ cv, const float* __restrict__ rhs,
+    long rhs_ld, long rhs_gs, float* __restrict__ out, long out_ld, long out_gs, int M,
+    long total_rows, int d, int lpr_log2, float beta, const float* __restrict__ self_scale) {
+  const int lpr = 1 << lpr_log2;
+  const int cl = threadIdx.x & (lpr - 1);
+  const long nworkers = ((long)gridDim.x * 256) >> lpr_log2;
+  const float sscale = self_scale ? self_scale[0] : 0.f;
+  for (long row = ((long)blockIdx.x * 256 + threadIdx.x) >> lpr_log2; row < total_rows;
+       row += nworkers) {
+    const long t = row / M;
+    const int r = (int)(row - t * M);
+    const int s = rowptr[row], e = rowptr[row + 1];
+    const float* rb = rhs + t * rhs_gs;
+    float* o = out + t * out_gs + (long)r * out_ld;
+    for (int c0 = cl * VEC; c0 < d; c0 += lpr * VEC) {
+      float acc[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+      for (int k = s; k < e; ++k) {
+        const int2 p = cv[k];
+        const float v = __int_as_float(p.y);
+        const float* src = rb + (long)p.x * rhs_ld + c0;
+        if constexpr (VEC == 4) {
+          const f32x4 x = ld4(src);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] += v * x[j];
+        } else {
+          acc[0] += v * src[0];
+        }
+      }
+      if (self_scale) {
+        const float* src = rb + (long)r * rhs_ld + c0;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += sscale * src[j];
+      }
+      if (beta != 0.f) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += o[c0 + j];
+      }
+      if constexpr (VEC == 4) {
+        f32x4 v4 = {acc[0], acc[1], acc[2], acc[3]};
+        st4(o + c0, v4);
+      } else {
+        o[c0] = acc[0];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// d values[e] = <grad[row_e, :], rhs[col_e, :]>   (kgcn/bspmm_call.py:50-55)
+// LPR lanes cooperate on one row's entries; butterfly reduction inside the lane group.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spmm_values_grad_kernel(
+    const int* __restrict__ rowptr, const int2* __restrict__ cv, const float* __restrict__ grad,
+    long g_ld, long g_gs, const float* __restrict__ rhs, long rhs_ld, long rhs_gs,
+    float* __restrict__ dval, int M, long total_rows, int d, int lpr_log2) {
+  const int lpr = 1 << lpr_log2;
+  const int cl = threadIdx.x & (lpr - 1);
+  const long nworkers = ((long)gridDim.x * 256) >> lpr_log2;
+  // all lanes of a group run the same trip counts, so the shuffles below are convergent
+  for (long row = ((long)blockIdx.x * 256 + threadIdx.x) >> lpr_log2; row < total_rows;
+       row += nworkers) {
+    const long t = row / M;
+    const int r = (int)(row - t * M);
+    const int s = rowptr[row], e = rowptr[row + 1];
+    const float* g = grad + t * g_gs + (long)r * g_ld;
+    const float* rb = rhs + t * rhs_gs;
+    for (int k = s; k < e; ++k) {
+      const int2 p = cv[k];
+      const float* src = rb + (long)p.x * rhs_ld;
+      float part = 0.f;
+      for (int c = cl; c < d; c += lpr) part += g[c] * src[c];
+      for (int off = lpr >> 1; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+      if (cl == 0) dval[k] = part;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side dispatch
+// ------------------------------------------------------------------------------------------------
+static int ilog2_ceil(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+// LDS bytes the tile kernel needs for one graph
+static size_t tile_lds_bytes(int M, int K, int d, int max_nnz) {
+  return (size_t)K * d * 4 + (size_t)max_nnz * 8 + (size_t)(M + 1) * 4;
+}
+
+// Tile kernel is used when one graph's working set leaves >= 8 waves per CU resident.
+static bool tile_ok(const kgcn_csr_batch* a, const float* rhs, long rhs_ld, long rhs_gs, int d,
+                    const float* out, long out_ld, long out_gs) {
+  if (d % 4 != 0 || d > 256 || d <= 0) return false;
+  if (rhs_ld % 4 || rhs_gs % 4 || out_ld % 4 || out_gs % 4) return false;
+  if (!aligned16(rhs) || !aligned16(out)) return false;
+  if (a->rows <= 0 || a->cols <= 0) return false;
+  return tile_lds_bytes(a->rows, a->cols, d, a->max_nnz_per_graph) <= 20 * 1024;
+}
+
+int launch_spmm(const kgcn_csr_batch* a, const float* rhs, long rhs_ld, long rhs_gs, int d,
+                float* out, long out_ld, long out_gs, float beta, const float* self_scale,
+                hipStream_t stream) {
+  const int T = a->num_graphs, M = a->rows, K = a->cols;
+  if (T == 0 || M == 0 || d == 0) return 0;
+  const int2* cv = reinterpret_cast<const int2*>(a->cv);
+  if (tile_ok(a, rhs, rhs_ld, rhs_gs, d, out, out_ld, out_gs)) {
+    const size_t lds = tile_lds_bytes(M, K, d, a->max_nnz_per_graph);
+    const int lanes = d / 4;
+#define KGCN_TILE(LPR)                                                                        \
+  hipLaunchKernelGGL((spmm_tile_kernel<LPR>), dim3(T), dim3(64), lds, stream, a->rowptr, cv,  \
+                     rhs, rhs_ld, rhs_gs, out, out_ld, out_gs, M, K, d,                       \
+                     a->max_nnz_per_graph, beta, self_scale)
+    if (lanes <= 8) KGCN_TILE(8);
+    else if (lanes <= 16) KGCN_TILE(16);
+    else if (lanes <= 32) KGCN_TILE(32);
+    else KGCN_TILE(64);
+#undef KGCN_TILE
+    return check_launch("spmm_tile_kernel");
+  }
+  const long total_rows = (long)T * M;
+  const bool vec4 = (d % 4 == 0) && (rhs_ld % 4 == 0) && (rhs_gs % 4 == 0) && (out_ld % 4 == 0) &&
+                    (out_gs % 4 == 0) && aligned16(rhs) && aligned16(out);
+  const int per_row = vec4 ? d / 4 : d;
+  int lpr_log2 = ilog2_ceil(per_row);
+  if (lpr_log2 > 6) lpr_log2 = 6;
+  long blocks = ((total_rows << lpr_log2) + 255) / 256;
+  const long max_blocks = (long)kNumCU * 64;
+  if (blocks > max_blocks) blocks = max_blocks;
+  if (blocks < 1) blocks = 1;
+  if (vec4)
+    hipLaunchKernelGGL((spmm_gather_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                       a->rowptr, cv, rhs, rhs_ld, rhs_gs, out, out_ld, out_gs, M, total_rows, d,
+                       lpr_log2, beta, self_scale);
+  else
+    hipLaunchKernelGGL((spmm_gather_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                       a->rowptr, cv, rhs, rhs_ld, rhs_gs, out, out_ld, out_gs, M, total_rows, d,
+                       lpr_log2, beta, self_scale);
+  return check_launch("spmm_gather_kernel");
+}
+
+}  // namespace kgcn
+
+using namespace kgcn;
+
+extern "C" int kgcn_bspmm_f32(const kgcn_csr_batch* a, const float* rhs, int64_t rhs_ld,
+                              int64_t rhs_graph_stride, int32_t d, float* out, int64_t out_ld,
+                              int64_t out_graph_stride, float beta, void* stream) {
+  if (int rc = validate_csr(a, "kgcn_bspmm_f32")) return rc;
+  if (d < 0) return fail("kgcn_bspmm_f32: d=%d < 0", d);
+  if (a->num_graphs == 0 || a->rows == 0 || d == 0) return 0;
+  if (!rhs || !out) return fail("kgcn_bspmm_f32: rhs/out is NULL");
+  if (rhs_ld < d || out_ld < d) return fail("kgcn_bspmm_f32: leading dimension smaller than d");
+  if (beta != 0.f && beta != 1.f) return fail("kgcn_bspmm_f32: beta must be 0 or 1");
+  return launch_spmm(a, rhs, rhs_ld, rhs_graph_stride, d, out, out_ld, out_graph_stride, beta,
+                     nullptr, as_stream(stream));
+}
+
+extern "C" int kgcn_bconv_f32(const kgcn_csr_batch* a_ch, int32_t num_channels, const float* rhs,
+                              int64_t rhs_ld, int64_t rhs_graph_stride,
+                              int64_t rhs_channel_stride, int32_t d, float* out, int64_t out_ld,
+                              int64_t out_graph_stride, void* stream) {
+  if (num_channels <= 0) return fail("kgcn_bconv_f32: num_channels=%d", num_channels);
+  if (!a_ch) return fail("kgcn_bconv_f32: a_ch is NULL");
+  for (int c = 0; c < num_channels; ++c) {
+    if (int rc = validate_csr(a_ch + c, "kgcn_bconv_f32")) return rc;
+    if (a_ch[c].num_graphs != a_ch[0].num_graphs || a_ch[c].rows != a_ch[0].rows ||
+        a_ch[c].cols != a_ch[0].cols)
+      return fail("kgcn_bconv_f32: channel %d has a different batch shape", c);
+  }
+  if (a_ch[0].num_graphs == 0 || a_ch[0].rows == 0 || d == 0) return 0;
+  if (!rhs || !out) return fail("kgcn_bconv_f32: rhs/out is NULL");
+  if (rhs_ld < d || out_ld < d) return fail("kgcn_bconv_f32: leading dimension smaller than d");
+  // channel add-n (tf.add_n, kgcn/layers.py:115): channel 0 overwrites, the others accumulate
+  for (int c = 0; c < num_channels; ++c) {
+    int rc = launch_spmm(a_ch + c, rhs + c * rhs_channel_stride, rhs_ld, rhs_graph_stride, d, out,
+                         out_ld, out_graph_stride, c == 0 ? 0.f : 1.f, nullptr, as_stream(stream));
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int kgcn_gin_aggregate_f32(const kgcn_csr_batch* a_ch, int32_t num_channels,
+                                      const float* x, int32_t d, const float* eps, float* out,
+                                      void* stream) {
+  if (num_channels <= 0) return fail("kgcn_gin_aggregate_f32: num_channels=%d", num_channels);
+  if (!a_ch) return fail("kgcn_gin_aggregate_f32: a_ch is NULL");
+  for (int c = 0; c < num_channels; ++c) {
+    if (int rc = validate_csr(a_ch + c, "kgcn_gin_aggregate_f32")) return rc;
+    if (a_ch[c].rows != a_ch[c].cols)
+      return fail("kgcn_gin_aggregate_f32: adjacency must be square (M=%d K=%d)", a_ch[c].rows,
+                  a_ch[c].cols);
+    if (a_ch[c].num_graphs != a_ch[0].num_graphs || a_ch[c].rows != a_ch[0].rows)
+      return fail("kgcn_gin_aggregate_f32: channel %d has a different batch shape", c);
+  }
+  if (a_ch[0].num_graphs == 0 || a_ch[0].rows == 0 || d == 0) return 0;
+  if (!x || !out) return fail("kgcn_gin_aggregate_f32: x/out is NULL");
+  const long gs = (long)a_ch[0].rows * d;
+  for (int c = 0; c < num_channels; ++c) {
+    int rc = launch_spmm(a_ch + c, x, d, gs, d, out, d, gs, c == 0 ? 0.f : 1.f,
+                         eps ? eps + c : nullptr, as_stream(stream));
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int kgcn_spmm_values_grad_f32(const kgcn_csr_batch* a, const float* grad,
+                                         int64_t grad_ld, int64_t grad_graph_stride,
+                                         const float* rhs, int64_t rhs_ld,
+                                         int64_t rhs_graph_stride, int32_t d, float* dval,
+                                         void* stream) {
+  if (int rc = validate_csr(a, "kgcn_spmm_values_grad_f32")) return rc;
+  if (a->nnz == 0 || a->num_graphs == 0 || a->rows == 0) return 0;
+  if (!grad || !rhs || !dval) return fail("kgcn_spmm_values_grad_f32: NULL operand");
+  if (d <= 0) return fail("kgcn_spmm_values_grad_f32: d=%d", d);
+  int lpr_log2 = ilog2_ceil(d);
+  if (lpr_log2 > 6) lpr_log2 = 6;
+  const long total_rows = (long)a->num_graphs * a->rows;
+  long blocks = ((total_rows << lpr_log2) + 255) / 256;
+  const long max_blocks = (long)kNumCU * 64;
+  if (blocks > max_blocks) blocks = max_blocks;
+  hipLaunchKernelGGL(spmm_values_grad_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     as_stream(stream), a->rowptr, reinterpret_cast<const int2*>(a->cv), grad,
+                     grad_ld, grad_graph_stride, rhs, rhs_ld, rhs_graph_stride, dval, a->rows,
+                     total_rows, d, lpr_log2);
+  return check_launch("spmm_values_grad_kernel");
+}

@@ -1,0 +1,297 @@
+"""Functional ops of the hot path on torch (ROCm) tensors, each a torch.autograd.Function whose
+forward and backward are calls into libkgcn_hip.so through the C ABI.  No arithmetic of the
+path is done by torch here: torch provides device memory, the stream and the autograd tape.
+
+Gradients follow the reference's registered gradients:
+  Bspmm  kgcn/bspmm_call.py:22-57   d rhs = A^T g ; d values[e] = <g[row_e], rhs[col_e]>
+  Bconv  kgcn/bconv_call.py:30-70   the output gradient fans out to every channel
+  Bspmdt kgcn/batched_call.py:33-75 d rhs is the stacked [T*K, D] tensor
+and TF's MatMul / BiasAdd gradients for the dense part.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, lib, ptr, require_gpu
+from .batched_csr import BatchedAdjacency, BatchedCSR
+
+
+def _f32c(t, name):
+    require_gpu(t, name)
+    if t.dtype != torch.float32:
+        raise _lib.KgcnHipError("%s must be float32 (the path computes in fp32), got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
+# -------------------------------------------------------------------------------------------------
+# raw (non-differentiable) launches
+# -------------------------------------------------------------------------------------------------
+def bspmm_raw(csr, rhs2d, d, out2d, rhs_ld=None, rhs_gs=None, out_ld=None, out_gs=None, beta=0.0,
+              rhs_col=0, out_col=0):
+    """out[t] = beta*out[t] + A[t] @ rhs[t] on strided views of 2-D tensors.
+    rhs2d: [T*K, rhs_ld] (block t starts at row t*K), columns rhs_col .. rhs_col+d."""
+    rhs_ld = rhs2d.stride(0) if rhs_ld is None else rhs_ld
+    out_ld = out2d.stride(0) if out_ld is None else out_ld
+    rhs_gs = csr.cols * rhs_ld if rhs_gs is None else rhs_gs
+    out_gs = csr.rows * out_ld if out_gs is None else out_gs
+    check(lib.kgcn_bspmm_f32(csr.desc(), rhs2d.data_ptr() + 4 * rhs_col, rhs_ld, rhs_gs, d,
+                             out2d.data_ptr() + 4 * out_col, out_ld, out_gs, float(beta),
+                             current_stream()), "kgcn_bspmm_f32")
+    return out2d
+
+
+# -------------------------------------------------------------------------------------------------
+# Bspmm / Bspmdt
+# -------------------------------------------------------------------------------------------------
+class _SpMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rhs, values, csr):
+        # rhs: [T*K, D] contiguous.  values: None or differentiable [nnz] (CSR order)
+        rhs = _f32c(rhs, "rhs")
+        if values is not None:
+            csr = csr.with_values(_f32c(values, "values"))
+        T, M, K = csr.num_graphs, csr.rows, csr.cols
+        if rhs.dim() != 2 or rhs.shape[0] != T * K:
+            raise _lib.KgcnHipError("rhs must be [T*K, D] = [%d, D], got %s" % (T * K, tuple(rhs.shape)))
+        d = rhs.shape[1]
+        out = torch.empty((T * M, d), device=rhs.device, dtype=torch.float32)
+        bspmm_raw(csr, rhs, d, out)
+        ctx.csr = csr
+        ctx.has_values = values is not None
+        ctx.save_for_backward(rhs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (rhs,) = ctx.saved_tensors
+        csr = ctx.csr
+        g = _f32c(g, "grad")
+        d = rhs.shape[1]
+        d_rhs = d_val = None
+        if ctx.needs_input_grad[0]:
+            d_rhs = torch.empty_like(rhs)
+            bspmm_raw(csr.transpose(), g, d, d_rhs)
+        if ctx.has_values and ctx.needs_input_grad[1]:
+            d_val = torch.empty((csr.nnz,), device=rhs.device, dtype=torch.float32)
+            check(lib.kgcn_spmm_values_grad_f32(csr.desc(), ptr(g), d, csr.rows * d, ptr(rhs), d,
+                                                csr.cols * d, d, ptr(d_val), current_stream()),
+                  "kgcn_spmm_values_grad_f32")
+        return d_rhs, d_val, None
+
+
+def bspmm(csr, rhs, values=None):
+    """Batched SpMM.  rhs [T, K, D] or [T*K, D] -> same rank ([T, M, D] or [T*M, D])."""
+    if rhs.dim() == 3:
+        T, K, D = rhs.shape
+        return _SpMM.apply(rhs.reshape(T * K, D), values, csr).reshape(T, csr.rows, D)
+    return _SpMM.apply(rhs, values, csr)
+
+
+# -------------------------------------------------------------------------------------------------
+# Bconv: out[t] = sum_c A_c[t] @ rhs_c[t], rhs given as ONE [T*K, C*D] tensor (channel c = columns
+# c*D..(c+1)*D) -- exactly what one GEMM with the concatenated kernels produces.
+# -------------------------------------------------------------------------------------------------
+class _BConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rhs, adj, d):
+        rhs = _f32c(rhs, "rhs")
+        C = adj.num_channels
+        T, M, K = adj.num_graphs, adj.n_nodes, adj.channels[0].cols
+        if rhs.shape != (T * K, C * d):
+            raise _lib.KgcnHipError("rhs must be [T*K, C*D] = [%d, %d], got %s" % (T * K, C * d, tuple(rhs.shape)))
+        out = torch.empty((T * M, d), device=rhs.device, dtype=torch.float32)
+        check(lib.kgcn_bconv_f32(adj.desc_array(False), C, ptr(rhs), C * d, K * C * d, d, d,
+                                 ptr(out), d, M * d, current_stream()), "kgcn_bconv_f32")
+        ctx.adj, ctx.d = adj, d
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        adj, d = ctx.adj, ctx.d
+        g = _f32c(g, "grad")
+        C = adj.num_channels
+        T, M, K = adj.num_graphs, adj.n_nodes, adj.channels[0].cols
+        d_rhs = torch.empty((T * K, C * d), device=g.device, dtype=torch.float32)
+        for c, ch in enumerate(adj.channels):        # addn_grad: g fans out to every channel
+            bspmm_raw(ch.transpose(), g, d, d_rhs, out_ld=C * d, out_gs=K * C * d, out_col=c * d)
+        return d_rhs, None, None
+
+
+def bconv(adj, rhs_cat, d):
+    return _BConv.apply(rhs_cat, adj, d)
+
+
+# -------------------------------------------------------------------------------------------------
+# dense contraction
+# -------------------------------------------------------------------------------------------------
+class _Dense(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2d, w, bias):
+        x2d, w = _f32c(x2d, "x"), _f32c(w, "w")
+        m, din = x2d.shape
+        dout = w.shape[1]
+        if w.shape[0] != din:
+            raise _lib.KgcnHipError("kernel is %s but inputs have %d features" % (tuple(w.shape), din))
+        b = None if bias is None else _f32c(bias, "bias").reshape(-1)
+        if b is not None and b.numel() != dout:
+            raise _lib.KgcnHipError("bias has %d elements, expected %d" % (b.numel(), dout))
+        y = torch.empty((m, dout), device=x2d.device, dtype=torch.float32)
+        check(lib.kgcn_dense_fwd_f32(ptr(x2d), m, din, din, ptr(w), dout, 0, ptr(b), ptr(y), dout,
+                                     dout, current_stream()), "kgcn_dense_fwd_f32")
+        ctx.save_for_backward(x2d, w)
+        ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2d, w = ctx.saved_tensors
+        gy = _f32c(gy, "grad")
+        m, din = x2d.shape
+        dout = w.shape[1]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x2d)
+            # dx = gy @ w^T : w [din, dout] used transposed
+            check(lib.kgcn_dense_fwd_f32(ptr(gy), m, dout, dout, ptr(w), dout, 1, None, ptr(dx),
+                                         din, din, current_stream()), "kgcn_dense_fwd_f32(dx)")
+        need_w = ctx.needs_input_grad[1]
+        need_b = ctx.bias_shape is not None and ctx.needs_input_grad[2]
+        if need_w or need_b:
+            wsb = lib.kgcn_dense_wgrad_workspace_bytes(m, din, dout)
+            wsp = torch.empty((max(wsb, 4) // 4,), device=gy.device, dtype=torch.float32)
+            dw = torch.empty_like(w) if need_w else None
+            db = torch.empty((dout,), device=gy.device, dtype=torch.float32) if need_b else None
+            check(lib.kgcn_dense_wgrad_f32(ptr(x2d), din, ptr(gy), dout, m, din, dout, ptr(dw),
+                                           ptr(db), ptr(wsp), wsb, current_stream()),
+                  "kgcn_dense_wgrad_f32")
+            if db is not None:
+                db = db.reshape(ctx.bias_shape)
+        return dx, dw, db
+
+
+def dense(x2d, w, bias=None):
+    return _Dense.apply(x2d, w, bias)
+
+
+# -------------------------------------------------------------------------------------------------
+# fused GraphConv (one channel)
+# -------------------------------------------------------------------------------------------------
+def graphconv_fused_supported(csr, din, dout):
+    return bool(lib.kgcn_graphconv_fused_supported(csr.rows, din, dout, csr.max_nnz)) and \
+        csr.rows == csr.cols
+
+
+class _GraphConvFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, csr):
+        x, w = _f32c(x, "inputs"), _f32c(w, "kernel")
+        T, N, din = x.shape
+        dout = w.shape[1]
+        b = _f32c(bias, "bias").reshape(-1)
+        out = torch.empty((T, N, dout), device=x.device, dtype=torch.float32)
+        check(lib.kgcn_graphconv_fwd_f32(csr.desc(), ptr(x), ptr(w), ptr(b), din, dout, ptr(out),
+                                         current_stream()), "kgcn_graphconv_fwd_f32")
+        ctx.csr = csr
+        ctx.bias_shape = tuple(bias.shape)
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = _f32c(g, "grad")
+        T, N, din = x.shape
+        dout = w.shape[1]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        db = torch.empty((dout,), device=x.device, dtype=torch.float32)
+        wsb = lib.kgcn_graphconv_bwd_workspace_bytes(T, din, dout)
+        wsp = torch.empty((max(wsb, 4) // 4,), device=x.device, dtype=torch.float32)
+        check(lib.kgcn_graphconv_bwd_f32(ctx.csr.transpose().desc(), ptr(x), ptr(w), ptr(g), din,
+                                         dout, ptr(dx), ptr(dw), ptr(db), ptr(wsp), wsb,
+                                         current_stream()), "kgcn_graphconv_bwd_f32")
+        return dx, dw, db.reshape(ctx.bias_shape), None
+
+
+def graphconv_fused(x, w, bias, csr):
+    return _GraphConvFused.apply(x, w, bias, csr)
+
+
+# -------------------------------------------------------------------------------------------------
+# GINAggregate
+# -------------------------------------------------------------------------------------------------
+class _GinAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps, adj):
+        x = _f32c(x, "inputs")
+        T, N, d = x.shape
+        if (T, N) != (adj.num_graphs, adj.n_nodes):
+            raise _lib.KgcnHipError("inputs %s do not match the adjacency batch (%d graphs x %d nodes)"
+                                    % (tuple(x.shape), adj.num_graphs, adj.n_nodes))
+        e = None if eps is None else _f32c(eps, "epsilon").reshape(-1)
+        out = torch.empty_like(x)
+        check(lib.kgcn_gin_aggregate_f32(adj.desc_array(False), adj.num_channels, ptr(x), d, ptr(e),
+                                         ptr(out), current_stream()), "kgcn_gin_aggregate_f32")
+        ctx.adj = adj
+        ctx.save_for_backward(x, e if e is not None else x.new_empty(0))
+        ctx.has_eps = e is not None
+        ctx.eps_shape = None if eps is None else tuple(eps.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, e = ctx.saved_tensors
+        adj = ctx.adj
+        g = _f32c(g, "grad")
+        T, N, d = x.shape
+        dx = deps = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.kgcn_gin_aggregate_f32(adj.desc_array(True), adj.num_channels, ptr(g), d,
+                                             ptr(e) if ctx.has_eps else None, ptr(dx),
+                                             current_stream()), "kgcn_gin_aggregate_f32(bwd)")
+        if ctx.has_eps and ctx.needs_input_grad[1]:
+            # d eps_c = <g, x> for every channel (same inner product, kgcn/layers.py:469)
+            n = x.numel()
+            wsb = lib.kgcn_dot_workspace_bytes(n)
+            wsp = torch.empty((wsb // 4,), device=x.device, dtype=torch.float32)
+            one = torch.empty((1,), device=x.device, dtype=torch.float32)
+            check(lib.kgcn_dot_f32(ptr(g), ptr(x), n, ptr(one), ptr(wsp), wsb, current_stream()),
+                  "kgcn_dot_f32")
+            deps = one.expand(adj.num_channels).reshape(ctx.eps_shape).clone()
+        return dx, deps, None
+
+
+def gin_aggregate(x, eps, adj):
+    return _GinAggregate.apply(x, eps, adj)
+
+
+# -------------------------------------------------------------------------------------------------
+# GraphGather
+# -------------------------------------------------------------------------------------------------
+class _Gather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x, "inputs")
+        B, N, d = x.shape
+        out = torch.empty((B, d), device=x.device, dtype=torch.float32)
+        check(lib.kgcn_graph_gather_fwd_f32(ptr(x), B, N, d, ptr(out), current_stream()),
+              "kgcn_graph_gather_fwd_f32")
+        ctx.shape = (B, N, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, d = ctx.shape
+        g = _f32c(g, "grad")
+        dx = torch.empty((B, N, d), device=g.device, dtype=torch.float32)
+        check(lib.kgcn_graph_gather_bwd_f32(ptr(g), B, N, d, ptr(dx), current_stream()),
+              "kgcn_graph_gather_bwd_f32")
+        return dx
+
+
+def graph_gather(x):
+    return _Gather.apply(x)
+
+
+__all__ = ["BatchedCSR", "BatchedAdjacency", "bspmm", "bspmm_raw", "bconv", "dense",
+           "graphconv_fused", "graphconv_fused_supported", "gin_aggregate", "graph_gather"]

@@ -1,0 +1,86 @@
+"""CPU-side checks of the drop-in boundary: libkgcn_hip.so loads (no GPU needed), exports every
+symbol include/kgcn_hip.h declares, the Python binding lists exactly those symbols, shape queries
+answer, and argument validation fails loudly (no compute launches here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "kgcn_hip.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(kgcn_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_header_declares_the_path():
+    names = declared_functions()
+    for must in ("kgcn_bspmm_f32", "kgcn_bconv_f32", "kgcn_spmm_values_grad_f32", "kgcn_dense_fwd_f32",
+                 "kgcn_dense_wgrad_f32", "kgcn_graphconv_fwd_f32", "kgcn_graphconv_bwd_f32",
+                 "kgcn_gin_aggregate_f32", "kgcn_graph_gather_fwd_f32", "kgcn_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from kgcn_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), "libkgcn_hip.so does not export %s" % name
+    assert sorted(_lib.SIGNATURES) == declared_functions(), "binding and header disagree"
+    assert _lib.lib.kgcn_abi_version() == 1
+    assert _lib.lib.kgcn_build_arch() == b"gfx950"
+
+
+def test_code_object_is_gfx950_only():
+    from kgcn_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"sm_90", b"nvptx"):
+        assert other not in blob
+
+
+def test_shape_queries_and_validation():
+    from kgcn_amd import _lib
+    lib = _lib.lib
+    assert lib.kgcn_graphconv_fused_supported(32, 64, 64, 100) == 1
+    assert lib.kgcn_graphconv_fused_supported(10, 4, 52, 24) == 1
+    assert lib.kgcn_graphconv_fused_supported(10, 3, 50, 24) == 0       # din not a multiple of 4
+    assert lib.kgcn_graphconv_fused_supported(50, 64, 64, 160) == 0      # N > 32
+    assert lib.kgcn_graphconv_fused_supported(32, 128, 64, 100) == 0
+    assert lib.kgcn_dense_wgrad_workspace_bytes(3_200_000, 64, 64) > 0
+    assert lib.kgcn_graphconv_bwd_workspace_bytes(100_000, 64, 64) >= 2048 * (64 * 64 + 64) * 4
+    assert lib.kgcn_dot_workspace_bytes(10) > 0
+    # validation happens before any launch: NULL descriptor / bad sizes -> status + message
+    rc = lib.kgcn_bspmm_f32(None, None, 0, 0, 4, None, 0, 0, 0.0, None)
+    assert rc != 0 and b"NULL" in lib.kgcn_last_error()
+    d = _lib.CsrBatch(-1, 4, 4, 0, 0, None, None)
+    assert lib.kgcn_bspmm_f32(ctypes.byref(d), None, 4, 16, 4, None, 4, 16, 0.0, None) != 0
+    d = _lib.CsrBatch(2, 4, 4, 0, 0, 1, None)                            # fake non-NULL rowptr
+    assert lib.kgcn_bspmm_f32(ctypes.byref(d), None, 4, 16, 4, None, 4, 16, 0.0, None) != 0
+    assert b"NULL" in lib.kgcn_last_error()
+    assert lib.kgcn_bspmm_f32(ctypes.byref(d), 16, 2, 16, 4, 16, 4, 16, 0.0, None) != 0   # ld < d
+    assert lib.kgcn_bspmm_f32(ctypes.byref(d), 16, 4, 16, 4, 16, 4, 16, 0.5, None) != 0   # beta
+    with pytest.raises(_lib.KgcnHipError):
+        _lib.check(lib.kgcn_dense_fwd_f32(None, 10, 0, 0, None, 0, 0, None, None, 4, 4, None), "dense")
+    rc = lib.kgcn_graphconv_fwd_f32(ctypes.byref(_lib.CsrBatch(1, 50, 50, 10, 0, 1, None)), None, None,
+                                    None, 64, 64, None, None)
+    assert rc != 0 and b"not supported" in lib.kgcn_last_error()
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    from kgcn_amd import _lib, layers
+    layer = layers.GraphConv(8, 1)
+    adjs = [[([[0, 0]], [1.0], [4, 4])] for _ in range(2)]
+    with pytest.raises((_lib.KgcnHipError, RuntimeError, AssertionError)):
+        layer(torch.zeros((2, 4, 4)), adj=adjs)                          # CPU tensors are refused
+    # nothing under kgcn_amd/ imports the oracle
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "kgcn_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read(), f

@@ -1,0 +1,443 @@
+"""Parity of the HIP path (through the C ABI, via kgcn_amd) against the oracle, on the MI355X.
+
+Tolerance: north_star states 1e-5 (fp32) against the reference CPU path.  Forward activations and
+per-batch gradients at cfg1-like sizes are held to max-abs 1e-5 against the fp64 oracle; sums
+over >= 10^3 graphs (dW, dbias at benchmark sizes) to 1e-5 * max|ref| (hard parts).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, unflatten_adjs
+from oracle import kgcn_oracle as K
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X box"
+    return torch.device("cuda:0")
+
+
+def t32(a):
+    return torch.as_tensor(np.asarray(a, np.float32), device=dev())
+
+
+def close(got, ref, atol=ATOL, rel=0.0, what=""):
+    got = got.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(got) else np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    tol = atol + rel * np.abs(ref).max()
+    err = np.abs(got - ref).max() if ref.size else 0.0
+    assert err <= tol, "%s: max abs err %.3e > %.3e" % (what, err, tol)
+    return err
+
+
+def synthetic_batch(kind="b30", channels="plain"):
+    z = load_golden("g3_synthetic_feed_%s.npz" % kind)
+    adjs = unflatten_adjs(z, "adj_")
+    x = z["features"]
+    if channels != "plain":
+        raw = load_golden("g1_synthetic_raw.npz")
+        full, _, _ = K.build_adjs({"dense_adj": raw["dense_adj"].astype(np.int64), "max_node_num": 10},
+                                  split_adj_flag=(channels in ("split", "split_norm")),
+                                  normalize_adj_flag=(channels in ("norm", "split_norm")))
+        adjs = K.feed_batch(list(z["batch_idx"]), 30, full)["adjs"]
+    return x, adjs
+
+
+def random_graphs(rng, T, N, density=0.12, empty_every=0, dup=False):
+    adjs = []
+    for t in range(T):
+        if empty_every and t % empty_every == empty_every - 1:
+            adjs.append([(np.zeros((0, 2), np.int32), np.zeros((0,), np.float32), [N, N])])
+            continue
+        a = (rng.random((N, N)) < density) * rng.standard_normal((N, N))
+        a[rng.integers(0, N)] = 0                      # an all-zero row
+        idx, val, shp = K.dense_to_sparse(a)
+        idx = np.asarray(idx).reshape(-1, 2)
+        if dup and len(val):
+            idx = np.concatenate([idx, idx[:3]])       # duplicated entries accumulate
+            val = np.concatenate([val, val[:3]])
+            p = rng.permutation(len(val))              # and unsorted COO order
+            idx, val = idx[p], val[p]
+        adjs.append([(idx.astype(np.int32), val.astype(np.float32), [N, N])])
+    return adjs
+
+
+# ---------------------------------------------------------------------------------------------
+# Bspmm / Bspmdt / Bconv / values gradient
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D", [1, 3, 50, 64, 128, 200, 256])
+def test_bspmm_synthetic_jbl(D):
+    from kgcn_amd import BatchedCSR, ops
+    x, adjs = synthetic_batch()
+    rng = np.random.default_rng(D)
+    rhs = rng.standard_normal((30, 10, D)).astype(np.float32)
+    csr = BatchedCSR.from_coo_list([a[0] for a in adjs], device=dev())
+    assert (csr.num_graphs, csr.rows, csr.cols) == (30, 10, 10)
+    out = ops.bspmm(csr, t32(rhs))
+    ref = np.stack(K.bspmm([a[0] for a in adjs], list(rhs)))
+    close(out, ref, what="bspmm")
+    assert torch.all(out[10:] == 0)                    # dummy graphs -> zeros
+    outT = ops.bspmm(csr.transpose(), t32(rhs))
+    refT = np.stack(K.bspmm([a[0] for a in adjs], list(rhs), adjoint_a=True))
+    close(outT, refT, what="bspmm^T")
+
+
+@pytest.mark.parametrize("N,D,dup", [(32, 64, False), (32, 64, True), (50, 128, False), (7, 12, True),
+                                     (64, 32, False), (200, 64, False), (33, 8, True)])
+def test_bspmm_random(N, D, dup):
+    from kgcn_amd import BatchedCSR, ops
+    rng = np.random.default_rng(N * 1000 + D)
+    T = 37
+    adjs = random_graphs(rng, T, N, empty_every=5, dup=dup)
+    rhs = rng.standard_normal((T, N, D)).astype(np.float32)
+    csr = BatchedCSR.from_coo_list([a[0] for a in adjs], rows=N, cols=N, device=dev())
+    ref = np.stack(K.bspmm([a[0] for a in adjs], list(rhs)))
+    close(ops.bspmm(csr, t32(rhs)), ref, rel=2e-6, what="bspmm")
+    refT = np.stack(K.bspmm([a[0] for a in adjs], list(rhs), adjoint_a=True))
+    close(ops.bspmm(csr.transpose(), t32(rhs)), refT, rel=2e-6, what="bspmm^T")
+
+
+def test_bspmm_rectangular_and_block_diagonal():
+    """M != K, and the config-3 shape: ONE [sumN x sumN] block-diagonal matrix with batch 1
+    (kgcn/data_util.py:698-845, example_model/sparse.py:65-69)."""
+    from kgcn_amd import BatchedCSR, ops
+    rng = np.random.default_rng(5)
+    a = (rng.random((9, 13)) < 0.3) * rng.standard_normal((9, 13))
+    idx, val, _ = K.dense_to_sparse(a)
+    csr = BatchedCSR.from_coo_list([(idx, val, [9, 13])] * 3, device=dev())
+    rhs = rng.standard_normal((3, 13, 20)).astype(np.float32)
+    close(ops.bspmm(csr, t32(rhs)), np.stack([a @ rhs[i] for i in range(3)]), what="rect")
+    # block diagonal: 128 graphs x 50 nodes, D = 128
+    adjs = K.synth_mol_graphs(rng, 128, 50, 5, normalize=True)
+    big = K.block_diag_csr(adjs, 0, 50).tocoo()
+    csr = BatchedCSR.from_arrays(np.zeros(big.nnz, np.int64), big.row, big.col, big.data, 1, 6400, 6400,
+                                 device=dev())
+    x = rng.standard_normal((6400, 128)).astype(np.float32)
+    close(ops.bspmm(csr, t32(x)), big.tocsr() @ x.astype(np.float64), what="blockdiag")
+
+
+def test_bspmm_autograd_and_values_grad():
+    from kgcn_amd import BatchedCSR, ops
+    x, adjs = synthetic_batch("full30", "norm")
+    rng = np.random.default_rng(7)
+    al = [a[0] for a in adjs]
+    rhs = rng.standard_normal((30, 10, 24)).astype(np.float32)
+    g = rng.standard_normal((30, 10, 24)).astype(np.float32)
+    csr = BatchedCSR.from_coo_list(al, device=dev())
+    r = t32(rhs).requires_grad_(True)
+    v = csr.values.clone().requires_grad_(True)
+    out = ops.bspmm(csr, r, v)
+    out.backward(t32(g))
+    vg, rg = K.bspmm_grad(al, list(rhs), list(g))
+    close(r.grad, np.stack(rg), what="d rhs")
+    close(v.grad, np.concatenate(vg), what="d values")      # COO already row-major -> same order
+
+
+def test_op_wrappers_api():
+    """Reference call conventions: kgcn/bspmm_call.py:11-16, bconv_call.py:11-23,
+    batched_call.py:18-27 (lists in, lists out)."""
+    from kgcn_amd.bspmm_call import BatchedSpMM
+    from kgcn_amd.bconv_call import BatchedConv
+    from kgcn_amd.batched_call import BatchedSpMDT
+    import collections
+    SparseTensorValue = collections.namedtuple("SparseTensorValue", ["indices", "values", "dense_shape"])
+    x, adjs = synthetic_batch("b30", "split")
+    rng = np.random.default_rng(8)
+    B, C, D = 30, 6, 16
+    sp = [[SparseTensorValue(*a) for a in row] for row in adjs]
+    dense = [[rng.standard_normal((10, D)).astype(np.float32) for _ in range(C)] for _ in range(B)]
+    td = [[t32(d) for d in row] for row in dense]
+    o = BatchedSpMM().call([sp[b][2] for b in range(B)], [td[b][2] for b in range(B)])
+    assert isinstance(o, list) and len(o) == B and tuple(o[0].shape) == (10, D)
+    close(torch.stack(o), np.stack(K.bspmm([adjs[b][2] for b in range(B)], [dense[b][2] for b in range(B)])))
+    o = BatchedSpMM().call([sp[b][2] for b in range(B)], [td[b][2].t().contiguous() for b in range(B)],
+                           adjoint_a=True, adjoint_b=True)
+    close(torch.stack(o), np.stack(K.bspmm([adjs[b][2] for b in range(B)], [dense[b][2] for b in range(B)],
+                                           adjoint_a=True)))
+    o = BatchedConv().call(sp, td)
+    assert len(o) == B
+    close(torch.stack(o), np.stack(K.bconv(adjs, dense)), what="bconv")
+    stacked = np.concatenate([dense[b][3] for b in range(B)], 0)
+    o = BatchedSpMDT().call([sp[b][3] for b in range(B)], t32(stacked))
+    assert len(o) == B
+    close(torch.stack(o), np.stack(K.bspmdt([adjs[b][3] for b in range(B)], stacked)), what="bspmdt")
+    # differentiable .values through the wrapper (visualization's use, bspmm_call.py:50-55)
+    vals = [t32(adjs[b][3][1]).requires_grad_(True) for b in range(B)]
+    sp3 = [SparseTensorValue(adjs[b][3][0], vals[b], adjs[b][3][2]) for b in range(B)]
+    r = [t32(dense[b][3]).requires_grad_(True) for b in range(B)]
+    o = BatchedSpMM().call(sp3, r)
+    g = rng.standard_normal((B, 10, D)).astype(np.float32)
+    (torch.stack(o) * t32(g)).sum().backward()
+    vg, rg = K.bspmm_grad([adjs[b][3] for b in range(B)], [dense[b][3] for b in range(B)], list(g))
+    for b in range(B):
+        close(vals[b].grad, vg[b], what="d values[%d]" % b)
+        close(r[b].grad, rg[b], what="d rhs[%d]" % b)
+
+
+# ---------------------------------------------------------------------------------------------
+# dense contraction (GraphDense)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,din,dout", [(300, 3, 50), (300, 50, 50), (1000, 64, 64), (777, 81, 256),
+                                        (129, 256, 50), (5, 7, 2), (4096, 128, 128)])
+def test_dense_fwd_bwd(M, din, dout):
+    from kgcn_amd import ops
+    rng = np.random.default_rng(M + din)
+    x = rng.standard_normal((M, din)).astype(np.float32)
+    w = K.glorot_uniform(rng, din, dout)
+    b = rng.standard_normal((dout,)).astype(np.float32)
+    g = rng.standard_normal((M, dout)).astype(np.float32)
+    tx, tw, tb = t32(x).requires_grad_(True), t32(w).requires_grad_(True), t32(b).requires_grad_(True)
+    y = ops.dense(tx, tw, tb)
+    y.backward(t32(g))
+    x64, w64, g64 = x.astype(np.float64), w.astype(np.float64), g.astype(np.float64)
+    close(y, x64 @ w64 + b, rel=1e-6, what="dense fwd")
+    close(tx.grad, g64 @ w64.T, rel=1e-6, what="dense dx")
+    close(tw.grad, x64.T @ g64, rel=2e-6, what="dense dw")
+    close(tb.grad, g64.sum(0), rel=2e-6, what="dense db")
+
+
+# ---------------------------------------------------------------------------------------------
+# GraphConv layer: synthetic.jbl (cfg1), all dispatch variants, model.py layer stack
+# ---------------------------------------------------------------------------------------------
+def _set_variant(name):
+    from kgcn_amd import layers
+    import types
+    layers.load_bspmm(types.SimpleNamespace(batched=name == "batched", bspmm=name == "bspmm",
+                                            bconv=name == "bconv"))
+
+
+@pytest.mark.parametrize("variant", ["default", "bspmm", "bconv", "batched"])
+@pytest.mark.parametrize("channels", ["plain", "norm", "split"])
+def test_graphconv_layer_synthetic_jbl(variant, channels):
+    from kgcn_amd import layers
+    x, adjs = synthetic_batch("b30", channels)
+    C = len(adjs[0])
+    rng = np.random.default_rng(11)
+    try:
+        _set_variant(variant)
+        layer = layers.GraphConv(50, C)
+        tx = t32(x).requires_grad_(True)
+        out = layer(tx, adj=adjs)
+        assert tuple(out.shape) == (30, 10, 50) == tuple(layer.compute_output_shape((30, 10, 3)))
+        w = [p.detach().cpu().numpy() for p in layer.w]
+        assert all(tuple(p.shape) == (3, 50) for p in layer.w) and all(tuple(p.shape) == (1, 50) for p in layer.bias)
+        lim = np.sqrt(6.0 / 53)
+        assert all(np.abs(t).max() <= lim for t in w) and all(float(p.abs().max()) == 0 for p in layer.bias)
+        with torch.no_grad():
+            for p in layer.bias:
+                p.copy_(t32(rng.standard_normal((1, 50))))
+        b = [p.detach().cpu().numpy() for p in layer.bias]
+        out = layer(tx, adj=adjs)
+        ref = K.graphconv_fwd(x, adjs, w, b)
+        close(out, ref, what="graphconv fwd")
+        g = rng.standard_normal(ref.shape).astype(np.float32)
+        out.backward(t32(g))
+        dx, dw, db = K.graphconv_bwd(x, adjs, w, b, g)
+        close(tx.grad, dx, what="dX")
+        for c in range(C):
+            close(layer.w[c].grad, dw[c], what="dW%d" % c)
+            close(layer.bias[c].grad, db[c], what="dbias%d" % c)
+    finally:
+        _set_variant("default")
+
+
+def test_model_py_layer_stack():
+    """example_model/model.py:41-46: GraphConv(50) -> sigmoid -> GraphConv(50) -> sigmoid ->
+    GraphConv(50), checked layer by layer, then GraphDense(50) -> sigmoid -> GraphGather."""
+    from kgcn_amd import layers
+    x, adjs = synthetic_batch("full30", "plain")
+    convs = [layers.GraphConv(50, 1) for _ in range(3)]
+    dense = layers.GraphDense(50)
+    h = t32(x)
+    ref = x.astype(np.float64)
+    sig = lambda a: 1.0 / (1.0 + np.exp(-a))
+    for i, conv in enumerate(convs):
+        h = conv(h, adj=adjs)
+        w = [conv.w[0].detach().cpu().numpy()]
+        b = [conv.bias[0].detach().cpu().numpy()]
+        ref = K.graphconv_fwd(ref, adjs, w, b)
+        close(h, ref, what="layer %d" % i)
+        if i < 2:
+            h = torch.sigmoid(h)
+            ref = sig(ref)
+    h = torch.sigmoid(h)
+    ref = sig(ref)
+    h = dense(h)
+    ref = K.graphdense_fwd(ref, dense.kernel.detach().cpu().numpy(), dense.bias.detach().cpu().numpy())
+    close(h, ref, what="graphdense")
+    out = layers.GraphGather()(torch.sigmoid(h))
+    close(out, K.gather_fwd(sig(ref)), what="gather")
+    out.sum().backward()
+    assert convs[0].w[0].grad is not None and torch.isfinite(convs[0].w[0].grad).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# fused GraphConv kernels
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,din,dout,T", [(32, 64, 64, 300), (32, 64, 64, 5), (10, 4, 52, 30),
+                                          (20, 12, 36, 77), (32, 32, 64, 129), (17, 64, 8, 64),
+                                          (32, 64, 64, 3001)])
+def test_graphconv_fused(N, din, dout, T):
+    from kgcn_amd import BatchedCSR, ops
+    rng = np.random.default_rng(N + din + dout + T)
+    if N == 32:
+        adjs = K.synth_mol_graphs(rng, T, 32, 3, normalize=(T % 2 == 1))
+        if T > 4:
+            adjs[3] = [(np.zeros((0, 2), np.int32), np.zeros((0,), np.float32), [32, 32])]
+    else:
+        adjs = random_graphs(rng, T, N, density=0.2, empty_every=7, dup=True)
+    x = rng.standard_normal((T, N, din)).astype(np.float32)
+    w = K.glorot_uniform(rng, din, dout)
+    b = rng.standard_normal((1, dout)).astype(np.float32)
+    g = rng.standard_normal((T, N, dout)).astype(np.float32)
+    csr = BatchedCSR.from_coo_list([a[0] for a in adjs], rows=N, cols=N, device=dev())
+    assert ops.graphconv_fused_supported(csr, din, dout)
+    tx, tw, tb = t32(x).requires_grad_(True), t32(w).requires_grad_(True), t32(b).requires_grad_(True)
+    out = ops.graphconv_fused(tx, tw, tb, csr)
+    ref = K.graphconv_fwd_fast(x, adjs, [w], [b])
+    close(out, ref, rel=1e-6, what="fused fwd")
+    out.backward(t32(g))
+    dx, dw, db = K.graphconv_bwd_fast(x, adjs, [w], g)
+    close(tx.grad, dx, rel=1e-6, what="fused dX")
+    close(tw.grad, dw[0], rel=1e-5, what="fused dW")
+    close(tb.grad, db[0], rel=1e-5, what="fused dbias")
+    # the fused kernels and the unfused kernels are two HIP implementations of the same function
+    fw = ops.dense(t32(x).reshape(T * N, din), t32(w), t32(b))
+    out2 = ops.bspmm(csr, fw).reshape(T, N, dout)
+    close(out2, ref, rel=1e-6, what="unfused fwd")
+
+
+def test_graphconv_layer_uses_fused_and_matches():
+    from kgcn_amd import layers
+    rng = np.random.default_rng(3)
+    T = 64
+    adjs = K.synth_mol_graphs(rng, T, 32, 3)
+    x = rng.standard_normal((T, 32, 64)).astype(np.float32)
+    layer = layers.GraphConv(64, 1)
+    tx = t32(x).requires_grad_(True)
+    out = layer(tx, adjs)                                 # positional adj (example_model/sparse.py:69)
+    w = [layer.w[0].detach().cpu().numpy()]
+    b = [layer.bias[0].detach().cpu().numpy()]
+    close(out, K.graphconv_fwd(x, adjs, w, b), rel=1e-6)
+    assert out.grad_fn.__class__.__name__.startswith("_GraphConvFused")
+
+
+# ---------------------------------------------------------------------------------------------
+# GINAggregate, GraphGather, GraphDense ragged
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("channels,D", [("plain", 3), ("split", 64), ("norm", 256)])
+def test_gin_aggregate(channels, D):
+    from kgcn_amd import layers
+    _, adjs = synthetic_batch("b30", channels)
+    C = len(adjs[0])
+    rng = np.random.default_rng(D)
+    x = rng.standard_normal((30, 10, D)).astype(np.float32)
+    layer = layers.GINAggregate(C)
+    tx = t32(x).requires_grad_(True)
+    out = layer(tx, adj=adjs)
+    assert all(float(e) == 0 for e in layer.epsilon)
+    close(out, K.gin_fwd(x, adjs, [0.0] * C), what="gin eps=0")
+    eps = rng.standard_normal(C).astype(np.float32)
+    with torch.no_grad():
+        for e, v in zip(layer.epsilon, eps):
+            e.fill_(float(v))
+    out = layer(tx, adj=adjs)
+    close(out, K.gin_fwd(x, adjs, eps), what="gin fwd")
+    g = rng.standard_normal(x.shape).astype(np.float32)
+    out.backward(t32(g))
+    dx, deps = K.gin_bwd(x, adjs, eps, g)
+    close(tx.grad, dx, what="gin dx")
+    for c in range(C):
+        close(layer.epsilon[c].grad, deps[c], rel=1e-6, what="gin deps")
+    try:                                                   # quirk Q1: accelerated branches drop eps
+        _set_variant("bspmm")
+        close(layer(t32(x), adj=adjs), K.gin_fwd(x, adjs, eps, with_eps=False), what="gin no-eps")
+    finally:
+        _set_variant("default")
+
+
+def test_graph_gather_and_ragged_dense():
+    from kgcn_amd import layers
+    rng = np.random.default_rng(9)
+    for shape in [(30, 10, 50), (7, 32, 64), (3, 5, 1)]:
+        x = rng.standard_normal(shape).astype(np.float32)
+        tx = t32(x).requires_grad_(True)
+        out = layers.GraphGather()(tx)
+        close(out, K.gather_fwd(x), what="gather")
+        g = rng.standard_normal(out.shape).astype(np.float32)
+        out.backward(t32(g))
+        close(tx.grad, K.gather_bwd(g, shape[1]), what="gather bwd")
+    x = rng.standard_normal((6, 10, 8)).astype(np.float32)
+    en = np.array([10, 3, 0, 7, 1, 10])
+    d = layers.GraphDense(5)
+    y = d(t32(x), enabled_node_nums=en)
+    close(y, K.graphdense_ragged_fwd(x, d.kernel.detach().cpu().numpy(), d.bias.detach().cpu().numpy(), en))
+
+
+# ---------------------------------------------------------------------------------------------
+# error behaviour of the boundary
+# ---------------------------------------------------------------------------------------------
+def test_errors_are_loud():
+    from kgcn_amd import BatchedCSR, ops, _lib
+    with pytest.raises(ValueError):
+        BatchedCSR.from_coo_list([(np.array([[0, 11]]), np.array([1.0]), [10, 10])], device=dev())
+    csr = BatchedCSR.from_coo_list([(np.array([[0, 1]]), np.array([1.0]), [10, 10])], device=dev())
+    with pytest.raises(_lib.KgcnHipError):
+        ops.bspmm(csr, torch.zeros((10, 4)))               # CPU tensor: no CPU path
+    with pytest.raises(_lib.KgcnHipError):
+        ops.bspmm(csr, torch.zeros((12, 4), device=dev()))  # wrong number of rows
+    with pytest.raises(_lib.KgcnHipError):
+        ops.bspmm(csr, torch.zeros((10, 4), device=dev(), dtype=torch.float64))
+    with pytest.raises(_lib.KgcnHipError):
+        _lib.check(_lib.lib.kgcn_graphconv_fwd_f32(csr.desc(), None, None, None, 3, 50, None, None), "fused")
+    assert b"not supported" in _lib.lib.kgcn_last_error()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE size (cfg2: 100k graphs x 32 nodes x 64 features): size-independent properties
+# ---------------------------------------------------------------------------------------------
+def test_cfg2_full_size_properties():
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_cfg2
+    from kgcn_amd import ops
+    T = 100_000
+    wl = make_cfg2(T, dev(), seed=1234)
+    csr, x, w, b, g = wl["csr"], wl["x"], wl["w"], wl["bias"], wl["g"]
+    assert csr.nnz == 100 * T and csr.max_nnz == 100
+    # linearity of the aggregation: A(x + 2y) = Ax + 2Ay (bitwise-close in fp32)
+    y = torch.roll(x, 1, 0)
+    lhs = ops.bspmm(csr, x + 2 * y)
+    rhs = ops.bspmm(csr, x) + 2 * ops.bspmm(csr, y)
+    assert float((lhs - rhs).abs().max()) < 5e-5
+    # adjacency is symmetric in this workload: A^T g == A g
+    assert float((ops.bspmm(csr.transpose(), g) - ops.bspmm(csr, g)).abs().max()) < 1e-5
+    # <A x, g> == <x, A^T g>  (adjoint identity, a checksum over the whole batch, fp64 accumulate)
+    ax = ops.bspmm(csr, x)
+    atg = ops.bspmm(csr.transpose(), g)
+    l, r = float((ax.double() * g.double()).sum()), float((x.double() * atg.double()).sum())
+    assert abs(l - r) <= 1e-6 * max(abs(l), abs(r), 1.0)
+    # fused layer == dense + bspmm (two independent HIP implementations) at full size
+    xg, wg, bg = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    out_f = ops.graphconv_fused(xg, wg, bg, csr)
+    out_f.backward(g)
+    xu, wu, bu = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    out_u = ops.bspmm(csr, ops.dense(xu.reshape(-1, 64), wu, bu)).reshape(T, 32, 64)
+    out_u.backward(g)
+    assert float((out_f - out_u).abs().max()) < 2e-5
+    assert float((xg.grad - xu.grad).abs().max()) < 2e-5
+    sw = float(wu.grad.abs().max())
+    assert float((wg.grad - wu.grad).abs().max()) <= 2e-5 * sw
+    assert float((bg.grad - bu.grad).abs().max()) <= 2e-5 * float(bu.grad.abs().max())
+    # a random sample of graphs against the oracle
+    pick = np.random.default_rng(0).choice(T, 64, replace=False)
+    adjs = wl["adjs_of"](pick)
+    ref = K.graphconv_fwd_fast(x[pick].cpu().numpy(), adjs, [w.cpu().numpy()], [b.cpu().numpy()])
+    close(out_f[pick], ref, rel=1e-6, what="cfg2 sample fwd")
+    dxr, _, _ = K.graphconv_bwd_fast(x[pick].cpu().numpy(), adjs, [w.cpu().numpy()], g[pick].cpu().numpy())
+    close(xg.grad[pick], dxr, rel=1e-6, what="cfg2 sample dX")

@@ -1,0 +1,109 @@
+"""Host-side logic of the product (no GPU): batched-CSR packing against scipy and against the
+golden reference adjacency, transposition, padding of short batches, layer bookkeeping."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import load_golden, unflatten_adjs
+from kgcn_amd import BatchedAdjacency, BatchedCSR
+from kgcn_amd import layers
+
+
+def _dense_of(csr, t):
+    rp = csr.rowptr.numpy()
+    cv = csr.cv.numpy()
+    M = csr.rows
+    out = np.zeros((csr.rows, csr.cols), np.float64)
+    for r in range(M):
+        for e in range(rp[t * M + r], rp[t * M + r + 1]):
+            out[r, cv[e, 0]] += cv[e, 1:2].view(np.float32)[0]
+    return out
+
+
+@pytest.mark.parametrize("tag", ["plain", "norm", "split", "order2"])
+def test_pack_reference_adjacency(tag):
+    z = load_golden("g2_synthetic_adj_%s.npz" % tag)
+    adjs = unflatten_adjs(z)
+    adj = BatchedAdjacency.from_adjs(adjs, device="cpu")
+    assert adj.num_graphs == 200 and adj.n_nodes == 10 and adj.num_channels == int(z["num_channels"])
+    for ch, csr in enumerate(adj.channels):
+        assert csr.rowptr.dtype == torch.int32 and csr.cv.dtype == torch.int32
+        assert csr.nnz == sum(len(adjs[g][ch][1]) for g in range(200))
+        assert csr.max_nnz == max(len(adjs[g][ch][1]) for g in range(200))
+        for g in (0, 57, 199):
+            idx, val, shape = adjs[g][ch]
+            ref = np.zeros((10, 10))
+            np.add.at(ref, (idx[:, 0], idx[:, 1]), val)
+            assert np.array_equal(_dense_of(csr, g), ref)
+            assert np.array_equal(_dense_of(csr.transpose(), g), ref.T)
+        # row-major sorted reference COO is kept in place: CSR order == COO order
+        assert csr.perm is None
+        cat = np.concatenate([adjs[g][ch][1] for g in range(200)])
+        assert np.array_equal(csr.values.numpy(), cat)
+
+
+def test_pack_padded_batch_with_dummy_graphs():
+    z = load_golden("g3_synthetic_feed_b30.npz")
+    adjs = unflatten_adjs(z, "adj_")
+    csr = BatchedCSR.from_coo_list([a[0] for a in adjs], device="cpu")
+    rp = csr.rowptr.numpy()
+    assert csr.num_graphs == 30 and rp.shape == (301,)
+    assert np.all(np.diff(rp) >= 0) and np.all(rp[100:] == rp[100])     # graphs 10..29 are empty
+    assert csr.transpose().nnz == csr.nnz
+
+
+def test_pack_unsorted_duplicates_and_validation():
+    idx = np.array([[2, 1], [0, 0], [2, 1], [1, 2], [2, 0]], np.int32)
+    val = np.array([1, 2, 3, 4, 5], np.float32)
+    csr = BatchedCSR.from_coo_list([(idx, val, [3, 3]), (idx[:0], val[:0], [3, 3])], device="cpu")
+    assert csr.perm is not None and csr.nnz == 5 and csr.max_nnz == 5
+    d = _dense_of(csr, 0)
+    assert d[2, 1] == 4 and d[0, 0] == 2 and d[1, 2] == 4 and d[2, 0] == 5
+    # stable: the two (2,1) entries keep their input order (1 then 3), (2,0) stays after them
+    cv = csr.cv.numpy()
+    row2 = cv[csr.rowptr.numpy()[2]:csr.rowptr.numpy()[3]]
+    assert list(row2[:, 0]) == [1, 1, 0]
+    assert list(row2[:, 1].view(np.float32)) == [1.0, 3.0, 5.0]
+    assert np.array_equal(csr.perm.numpy(), [1, 3, 0, 2, 4])
+    with pytest.raises(ValueError):
+        BatchedCSR.from_coo_list([(np.array([[3, 0]]), np.array([1.0]), [3, 3])], device="cpu")
+    with pytest.raises(ValueError):
+        BatchedCSR.from_coo_list([(np.array([[0, 0]]), np.array([1.0, 2.0]), [3, 3])], device="cpu")
+    with pytest.raises(ValueError):
+        BatchedAdjacency([])
+
+
+def test_block_diagonal_pack_matches_scipy():
+    rng = np.random.default_rng(0)
+    a = sp.random(300, 300, density=0.02, random_state=1, format="coo", dtype=np.float32)
+    csr = BatchedCSR.from_arrays(np.zeros(a.nnz, np.int64), a.row, a.col, a.data, 1, 300, 300, device="cpu")
+    ref = a.tocsr()
+    ref.sort_indices()
+    assert np.array_equal(csr.rowptr.numpy(), ref.indptr)
+    x = rng.standard_normal((300, 4))
+    assert np.allclose(_dense_of(csr, 0) @ x, ref @ x)
+    assert csr.algorithmic_bytes() == 4 * 301 + 8 * a.nnz
+
+
+def test_layer_bookkeeping_and_flags():
+    import types
+    l = layers.GraphConv(50, 6, initializer="zeros")
+    l.build((30, 10, 3))
+    assert len(l.w) == 6 and tuple(l.w[0].shape) == (3, 50) and tuple(l.bias[5].shape) == (1, 50)
+    assert l.compute_output_shape((30, 10, 3)) == (30, 10, 50)
+    assert layers.GraphGather().compute_output_shape((30, 10, 3)) == (30, 3)
+    g = layers.GINAggregate(2)
+    g.build((4, 5, 6))
+    assert len(g.epsilon) == 2 and g.epsilon[0].shape == () and float(g.epsilon[0]) == 0.0
+    d = layers.GraphDense(7)
+    d.build((4, 5, 6))
+    assert tuple(d.kernel.shape) == (6, 7) and tuple(d.bias.shape) == (7,)
+    try:
+        for flags, expect in [((1, 1, 1), "batched"), ((0, 1, 1), "bspmm"), ((0, 0, 1), "bconv"),
+                              ((0, 0, 0), None)]:
+            layers.load_bspmm(types.SimpleNamespace(batched=flags[0], bspmm=flags[1], bconv=flags[2]))
+            got = [n for n in ("batched", "bspmm", "bconv") if getattr(layers, "enabled_" + n)]
+            assert got == ([expect] if expect else [])        # precedence of kgcn/layers.py:23-29
+    finally:
+        layers.load_bspmm(types.SimpleNamespace(batched=False, bspmm=False, bconv=False))

@@ -1,0 +1,74 @@
+"""World-size-2 data-parallel test on CPU (gloo): the shard + flat-bucket all-reduce logic of
+kgcn_amd.parallel.  Local gradients come from the ORACLE here (the product kernels need a GPU);
+what is tested is that mean-reduced shard gradients equal the single-process gradients of the
+concatenated batch, and that the shards tile the batch."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kgcn_amd.parallel import GradBucket, shard_range
+    from oracle import kgcn_oracle as K
+    rng = np.random.default_rng(0)                       # same data on every rank
+    T = 24
+    adjs = K.synth_mol_graphs(rng, T, 16, 2)
+    x = rng.standard_normal((T, 16, 8))
+    w = [rng.standard_normal((8, 12))]
+    b = [rng.standard_normal((1, 12))]
+    g = rng.standard_normal((T, 16, 12))
+    lo, hi = shard_range(T, rank, world)
+    _, dw, db = K.graphconv_bwd(x[lo:hi], adjs[lo:hi], w, b, g[lo:hi])
+    pw = torch.nn.Parameter(torch.tensor(w[0], dtype=torch.float32))
+    pb = torch.nn.Parameter(torch.tensor(b[0], dtype=torch.float32))
+    pw.grad = torch.tensor(dw[0], dtype=torch.float32)
+    pb.grad = torch.tensor(db[0], dtype=torch.float32)
+    GradBucket([pw, pb]).all_reduce_mean()
+    _, dw_all, db_all = K.graphconv_bwd(x, adjs, w, b, g)
+    ok = (np.allclose(pw.grad.numpy() * world, dw_all[0], rtol=1e-5, atol=1e-4)
+          and np.allclose(pb.grad.numpy() * world, db_all[0], rtol=1e-5, atol=1e-4))
+    with open(os.path.join(outdir, "rank%d.txt" % rank), "w") as f:
+        f.write("%d %d %d" % (int(ok), lo, hi))
+    dist.destroy_process_group()
+
+
+def test_dp_gradient_allreduce_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    spans = []
+    for r in range(world):
+        ok, lo, hi = open(tmp_path / ("rank%d.txt" % r)).read().split()
+        assert ok == "1", "rank %d: reduced gradients differ from the full-batch gradients" % r
+        spans.append((int(lo), int(hi)))
+    assert spans[0][0] == 0 and spans[0][1] == spans[1][0] and spans[1][1] == 24
+
+
+def test_shard_range_tiles_any_batch():
+    from kgcn_amd.parallel import shard_range
+    for n in (0, 1, 7, 8, 100_000, 100_003):
+        for w in (1, 2, 4, 8):
+            cuts = [shard_range(n, r, w) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
