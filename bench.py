@@ -118,8 +118,8 @@ def cpu_baseline(wl, budget_s=12.0, sample=20000):
     nnz = int(off[-1])
     idx = np.ascontiguousarray(wl["idx"][:nnz])
     val = np.ascontiguousarray(wl["val"][:nnz])
-    x = wl["x"][:T].cpu().numpy()
-    g = wl["g"][:T].cpu().numpy()
+    x = wl["x"][:T].detach().cpu().numpy()
+    g = wl["g"][:T].detach().cpu().numpy()
     w = wl["w"].cpu().numpy()
     b = wl["bias"].cpu().numpy()
     threads = ref_c.max_threads()

@@ -29,7 +29,7 @@ def close(got, ref, atol=ATOL, rel=0.0, what=""):
     got = got.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(got) else np.asarray(got, np.float64)
     ref = np.asarray(ref, np.float64)
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
-    tol = atol + rel * np.abs(ref).max()
+    tol = atol + rel * (np.abs(ref).max() if ref.size else 0.0)
     err = np.abs(got - ref).max() if ref.size else 0.0
     assert err <= tol, "%s: max abs err %.3e > %.3e" % (what, err, tol)
     return err
