@@ -173,22 +173,34 @@ __global__ __launch_bounds__(256) void dense_wgrad_kernel(
   }
 }
 
-// out[i] = sum_p part[p*n + i]   (deterministic second stage)
+// out[i] = sum_p part[p*n + i]   (deterministic second stage).  A workgroup owns 32 consecutive
+// outputs (128 contiguous bytes per partial); its 8 lane-groups stride over the partials with 8
+// independent loads in flight each, then combine through LDS in a fixed order.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part,
                                                               int nparts, long n,
                                                               float* __restrict__ out) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int p = 0;
-  for (; p + 3 < nparts; p += 4) {
-    s0 += part[(long)p * n + i];
-    s1 += part[(long)(p + 1) * n + i];
-    s2 += part[(long)(p + 2) * n + i];
-    s3 += part[(long)(p + 3) * n + i];
+  __shared__ float red[8][33];
+  const int oi = threadIdx.x & 31, pg = threadIdx.x >> 5;
+  const long o = (long)blockIdx.x * 32 + oi;
+  float s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s[u] = 0.f;
+  if (o < n) {
+    int p = pg;
+    for (; p + 56 < nparts; p += 64) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += part[(long)(p + 8 * u) * n + o];
+    }
+    for (; p < nparts; p += 8) s[0] += part[(long)p * n + o];
   }
-  for (; p < nparts; ++p) s0 += part[(long)p * n + i];
-  out[i] = (s0 + s1) + (s2 + s3);
+  red[pg][oi] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (pg == 0 && o < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q][oi];
+    out[o] = t;
+  }
 }
 
 static void wgrad_plan(long m, long* rows_per_chunk, int* nchunks) {
@@ -203,7 +215,7 @@ static void wgrad_plan(long m, long* rows_per_chunk, int* nchunks) {
 }
 
 int launch_reduce_partials(const float* part, int nparts, long n, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s,
                      part, nparts, n, out);
   return check_launch("reduce_partials_kernel");
 }

@@ -6,13 +6,17 @@
 //
 // The reference materialises FW = X.W + b per graph and channel (B*C tiny MatMul ops) and then
 // aggregates it with B*C sparse ops.  Here one persistent wave owns one graph at a time:
-//   * the graph's node-feature tile [N<=32 x D<=64] is streamed HBM -> LDS once (dwordx4),
+//   * the graph's node-feature tile [N<=32 x D<=64] is streamed HBM -> registers -> LDS once
+//     (dwordx4, all loads of a tile in flight together), and the NEXT graph's tile + CSR slice are
+//     already in flight (register prefetch) while the current graph is being computed,
 //   * the dense contraction runs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32)
 //     with the weight fragments resident in registers (forward) / in LDS (backward, W^T),
 //   * FW (resp. dFW) lives only in LDS, where the sparse aggregation gathers neighbour rows with
-//     conflict-free ds_read_b128 -- X.W and dFW never touch HBM,
-//   * dW / dbias accumulate in MFMA accumulators across ALL graphs a wave processes and leave the
-//     chip once per wave (deterministic second-stage reduction).
+//     conflict-free ds_read_b128, four entries per lane group in flight -- X.W and dFW never
+//     touch HBM,
+//   * dW / dbias accumulate in MFMA accumulators across ALL graphs a wave processes, are reduced
+//     across the workgroup's waves through LDS and leave the chip once per workgroup
+//     (deterministic second-stage reduction).
 // Algorithmic HBM bytes per graph (N=32, D=64, nnz=100): forward 17,316, backward 25,508.
 //
 // Shape support (kgcn_graphconv_fused_supported): N <= 32, din,dout <= 64 and multiples of 4.
@@ -27,6 +31,7 @@ constexpr int FN = 32;    // node tile (MFMA M)
 constexpr int FD = 64;    // feature tile (K of the forward GEMM, two 32-wide output tiles)
 constexpr int ALD = 68;   // padded row stride (floats) of tiles read as MFMA A fragments (b128)
 constexpr int MAX_WPB = 8;
+constexpr int ECV_PAD = 4;  // the 4-entry batched gather may read (not use) 3 entries past the end
 
 __device__ __forceinline__ void wave_sync() {
   // LDS operations of one wave execute in order; this only stops the compiler from moving LDS
@@ -36,18 +41,21 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 struct WaveSlice {
   float* a;     // [FN][ALD]  A-fragment source tile
-  float* b;     // [FN][FD]   gather source tile
-  int2* ecv;    // [max_nnz]
+  float* b;     // [FN+1][FD] gather source tile; row FN stays zero (target of masked gathers)
+  int2* ecv;    // [max_nnz + ECV_PAD]
   int* rp;      // [FN + 4]
 };
 
+__host__ __device__ inline size_t ecv_bytes(int max_nnz) {
+  return ((size_t)(max_nnz + ECV_PAD) * 8 + 15) & ~(size_t)15;
+}
+
 __host__ __device__ inline size_t slice_bytes(int max_nnz) {
-  size_t e = ((size_t)max_nnz * 8 + 15) & ~(size_t)15;
-  return (size_t)FN * ALD * 4 + (size_t)FN * FD * 4 + e + (FN + 4) * 4;
+  return (size_t)FN * ALD * 4 + (size_t)(FN + 1) * FD * 4 + ecv_bytes(max_nnz) + (FN + 4) * 4;
 }
 
 __device__ __forceinline__ WaveSlice carve(unsigned char* base, int wave, int max_nnz) {
@@ -55,40 +63,83 @@ __device__ __forceinline__ WaveSlice carve(unsigned char* base, int wave, int ma
   WaveSlice s;
   s.a = reinterpret_cast<float*>(p);
   s.b = s.a + FN * ALD;
-  s.ecv = reinterpret_cast<int2*>(s.b + FN * FD);
-  s.rp = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(s.ecv) +
-                                (((size_t)max_nnz * 8 + 15) & ~(size_t)15));
+  s.ecv = reinterpret_cast<int2*>(s.b + (FN + 1) * FD);
+  s.rp = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(s.ecv) + ecv_bytes(max_nnz));
   return s;
 }
 
-// stage one graph's CSR slice (rowptr rebased to 0, interleaved col/val pairs) into LDS
-__device__ __forceinline__ void stage_csr(const int* __restrict__ rowptr,
-                                          const int2* __restrict__ cv, int t, int N, int lane,
-                                          const WaveSlice& ws) {
-  const int* grp = rowptr + (long)t * N;
-  const int base = grp[0];
-  const int cnt = grp[N] - base;
-  for (int i = lane; i < cnt; i += 64) ws.ecv[i] = cv[base + i];
-  if (lane <= N) ws.rp[lane] = grp[lane] - base;
+// One graph's inputs in flight: the feature tile (<= 512 float4 = 8 per lane), the first 128 CSR
+// entries (2 per lane) and the row pointers (lane l holds rowptr[t*N + min(l, N)]).
+struct InFlight {
+  f32x4 tile[8];
+  int2 cv[2];
+};
+
+__device__ __forceinline__ void issue_tile(InFlight& f, const float* __restrict__ src, int n4,
+                                           int lane) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int i = lane + q * 64;
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f.tile[q] = (i < n4) ? ldv4(src + (long)i * 4) : z;
+  }
 }
 
-// out rows r0..r0+3 (16 lanes x float4 each) = sum of gathered rows of `src` (row stride FD)
+__device__ __forceinline__ void issue_cv(InFlight& f, const int2* __restrict__ cv, int base,
+                                         int cnt, int lane) {
+  const int2 z = {0, 0};
+  f.cv[0] = (lane < cnt) ? cv[base + lane] : z;
+  f.cv[1] = (lane + 64 < cnt) ? cv[base + lane + 64] : z;
+}
+
+// registers -> LDS: tile rows get row stride `ld` (floats); CSR slice rebased to 0
+__device__ __forceinline__ void land(const InFlight& f, float* tile, int ld, int n4, int d4,
+                                     const WaveSlice& ws, const int2* __restrict__ cv, int rp_val,
+                                     int base, int cnt, int N, int lane) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int i = lane + q * 64;
+    if (i < n4) {
+      const int r = i / d4, c4 = i - r * d4;
+      *reinterpret_cast<f32x4*>(tile + r * ld + c4 * 4) = f.tile[q];
+    }
+  }
+  if (lane < cnt) ws.ecv[lane] = f.cv[0];
+  if (lane + 64 < cnt) ws.ecv[lane + 64] = f.cv[1];
+  for (int i = 128 + lane; i < cnt; i += 64) ws.ecv[i] = cv[base + i];  // rare: > 128 entries
+  if (lane <= N) ws.rp[lane] = rp_val - base;
+}
+
+// Rows r0..r0+3 of the output (16 lanes x float4 each) = sum over the row's entries of
+// val * src[col].  Entries are consumed four at a time: 4 ds_read_b64 (col,val) + 4 ds_read_b128
+// in flight per lane instead of a dependent chain per entry.
 template <typename Sink>
-__device__ __forceinline__ void aggregate_rows(const WaveSlice& ws, const float* src, int N,
-                                               int dcols, int lane, Sink&& sink) {
+__device__ __forceinline__ void aggregate_rows(const WaveSlice& ws, const float* src, int src_ld,
+                                               int N, int dcols, int lane, Sink&& sink) {
   const int sub = lane >> 4, cl = lane & 15;
   const bool col_ok = cl * 4 < dcols;
+  const float* srcl = src + cl * 4;
   for (int r0 = 0; r0 < N; r0 += 4) {
     const int r = r0 + sub;
-    if (r < N && col_ok) {
-      const int s = ws.rp[r], e = ws.rp[r + 1];
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int k = s; k < e; ++k) {
-        const int2 p = ws.ecv[k];
-        acc += __int_as_float(p.y) * lds4(src + p.x * FD + cl * 4);
-      }
-      sink(r, cl, acc);
+    const bool ok = (r < N) && col_ok;
+    const int rr = ok ? r : 0;
+    const int s = ws.rp[rr];
+    const int e = ok ? ws.rp[rr + 1] : s;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    for (int k = s; k < e; k += 4) {
+      const int2 p0 = ws.ecv[k], p1 = ws.ecv[k + 1], p2 = ws.ecv[k + 2], p3 = ws.ecv[k + 3];
+      const bool h1 = k + 1 < e, h2 = k + 2 < e, h3 = k + 3 < e;
+      const f32x4 x0 = ldv4(srcl + p0.x * src_ld);
+      // masked slots gather the all-zero row FN with value 0 (0 * 0, never 0 * inf)
+      const f32x4 x1 = ldv4(srcl + (h1 ? p1.x : FN) * src_ld);
+      const f32x4 x2 = ldv4(srcl + (h2 ? p2.x : FN) * src_ld);
+      const f32x4 x3 = ldv4(srcl + (h3 ? p3.x : FN) * src_ld);
+      acc0 += __int_as_float(p0.y) * x0;
+      acc1 += (h1 ? __int_as_float(p1.y) : 0.f) * x1;
+      acc0 += (h2 ? __int_as_float(p2.y) : 0.f) * x2;
+      acc1 += (h3 ? __int_as_float(p3.y) : 0.f) * x3;
     }
+    if (ok) sink(r, cl, acc0 + acc1);
   }
 }
 
@@ -106,8 +157,13 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
   const int wpb = blockDim.x >> 6;
   WaveSlice ws = carve(smem, wave, max_nnz);
 
+  const int nwaves = gridDim.x * wpb;
+  int t = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
+  if (t >= T) return;  // no workgroup barrier below: idle waves may leave
+
   // zero the A tile once: padding rows (>= N) and columns (>= din) stay zero for every graph
   for (int i = lane; i < FN * ALD; i += 64) ws.a[i] = 0.f;
+  for (int i = lane; i < FD; i += 64) ws.b[FN * FD + i] = 0.f;
 
   // weight fragments: B[k][j] with k = hi*32 + s (the K permutation matches the A fragments)
   float wr0[32], wr1[32];
@@ -119,33 +175,54 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
   }
   const float b0 = (bias && li < dout) ? bias[li] : 0.f;
   const float b1 = (bias && 32 + li < dout) ? bias[32 + li] : 0.f;
-  wave_sync();
 
   const int din4 = din >> 2;
   const int n4 = N * din4;
-  const int nwaves = gridDim.x * wpb;
-  for (int t = blockIdx.x * wpb + wave; t < T; t += nwaves) {
-    // ---- stage x[t] (contiguous N*din floats) into the padded A tile, and the CSR slice ------
-    const float* xt = x + (long)t * N * din;
-    for (int i = lane; i < n4; i += 64) {
-      const int r = i / din4, c4 = i - r * din4;
-      *reinterpret_cast<f32x4*>(ws.a + r * ALD + c4 * 4) = lds4(xt + (long)i * 4);
-    }
-    stage_csr(rowptr, cv, t, N, lane, ws);
+  const int lrp = lane < N ? lane : N;
+
+  // ---- prologue: first graph's inputs, second graph's row pointers ---------------------------
+  InFlight fl;
+  int rp_cur = rowptr[(long)t * N + lrp];
+  int base = __builtin_amdgcn_readlane(rp_cur, 0);
+  int cnt = __builtin_amdgcn_readlane(rp_cur, N) - base;
+  issue_tile(fl, x + (long)t * N * din, n4, lane);
+  issue_cv(fl, cv, base, cnt, lane);
+  int tn = t + nwaves;
+  int rp_nxt = (tn < T) ? rowptr[(long)tn * N + lrp] : 0;
+  wave_sync();
+
+  for (;;) {
+    // ---- 1. graph t: registers -> LDS ----------------------------------------------------------
+    land(fl, ws.a, ALD, n4, din4, ws, cv, rp_cur, base, cnt, N, lane);
     wave_sync();
 
-    // ---- FW = x @ W + bias on the matrix cores ------------------------------------------------
-    f32x4 a4[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) a4[q] = lds4(ws.a + li * ALD + hi * 32 + q * 4);
+    // ---- 2. put graph t+nwaves in flight (lands while graph t is computed) ------------------
+    const bool has_next = tn < T;
+    int base_n = 0, cnt_n = 0;
+    if (has_next) {
+      base_n = __builtin_amdgcn_readlane(rp_nxt, 0);
+      cnt_n = __builtin_amdgcn_readlane(rp_nxt, N) - base_n;
+      issue_tile(fl, x + (long)tn * N * din, n4, lane);
+      issue_cv(fl, cv, base_n, cnt_n, lane);
+      rp_cur = rp_nxt;
+      const int tnn = tn + nwaves;
+      rp_nxt = (tnn < T) ? rowptr[(long)tnn * N + lrp] : 0;
+    }
+
+    // ---- 3. FW = x @ W + bias on the matrix cores ---------------------------------------------
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
+    {
+      f32x4 a4[8];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-      const float a = a4[s >> 2][s & 3];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr0[s], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr1[s], acc1, 0, 0, 0);
+      for (int q = 0; q < 8; ++q) a4[q] = ldv4(ws.a + li * ALD + hi * 32 + q * 4);
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        const float a = a4[s >> 2][s & 3];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr0[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr1[s], acc1, 0, 0, 0);
+      }
     }
     // C layout -> LDS gather tile (bank = column: conflict free)
 #pragma unroll
@@ -156,18 +233,29 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
     }
     wave_sync();
 
-    // ---- out[t] = A[t] @ FW : 4 rows per pass, 1 KiB coalesced store per pass ---------------
+    // ---- 4. out[t] = A[t] @ FW : 4 rows per pass, 1 KiB coalesced store per pass -------------
     float* ot = out + (long)t * N * dout;
-    aggregate_rows(ws, ws.b, N, dout, lane, [&](int r, int cl, f32x4 acc) {
+    aggregate_rows(ws, ws.b, FD, N, dout, lane, [&](int r, int cl, f32x4 acc) {
       *reinterpret_cast<f32x4*>(ot + (long)r * dout + cl * 4) = acc;
     });
     wave_sync();
+
+    if (!has_next) break;
+    t = tn;
+    tn += nwaves;
+    base = base_n;
+    cnt = cnt_n;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
+// dFW tile row stride in the backward: ODD, so that both MFMA operand patterns read it with
+// conflict-free ds_read_b32 (lanes along a column for dX's A operand, lanes along a row for dW's B
+// operand) and no A-fragment registers are needed.
+constexpr int BLD = 65;
+
 __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
     const int* __restrict__ rowptr_t, const int2* __restrict__ cv_t, const float* __restrict__ x,
     const float* __restrict__ w, const float* __restrict__ g, float* __restrict__ dx,
@@ -182,11 +270,11 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
   WaveSlice ws = carve(smem + FD * FD * 4, wave, max_nnz);
 
   for (int i = tid; i < FD * FD; i += blockDim.x) {
-    const int k = i >> 6, j = i & 63;  // coalesced over k for fixed j would be strided; W is tiny
+    const int k = i >> 6, j = i & 63;
     Wt[i] = (j < din && k < dout) ? w[(long)j * dout + k] : 0.f;
   }
   for (int i = lane; i < FN * ALD; i += 64) ws.a[i] = 0.f;
-  for (int i = lane; i < FN * FD; i += 64) ws.b[i] = 0.f;
+  for (int i = lane; i < (FN + 1) * FD; i += 64) ws.b[i] = 0.f;
   __syncthreads();
 
   f32x16 dw00, dw01, dw10, dw11;
@@ -197,97 +285,125 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
   const int din4 = din >> 2, dout4 = dout >> 2;
   const int nx4 = N * din4, ng4 = N * dout4;
   const int nwaves = gridDim.x * wpb;
-  for (int t = blockIdx.x * wpb + wave; t < T; t += nwaves) {
-    // ---- stage g[t] into the gather tile, CSR(A^T) slice ------------------------------------
-    const float* gt = g + (long)t * N * dout;
-    for (int i = lane; i < ng4; i += 64) {
-      const int r = i / dout4, c4 = i - r * dout4;
-      *reinterpret_cast<f32x4*>(ws.b + r * FD + c4 * 4) = lds4(gt + (long)i * 4);
-    }
-    stage_csr(rowptr_t, cv_t, t, N, lane, ws);
-    wave_sync();
+  const int lrp = lane < N ? lane : N;
+  int t = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
 
-    // ---- dFW = A^T @ g -> A tile (padded stride), dbias partial ------------------------------
-    aggregate_rows(ws, ws.b, N, dout, lane, [&](int r, int cl, f32x4 acc) {
-      *reinterpret_cast<f32x4*>(ws.a + r * ALD + cl * 4) = acc;
-      dbacc += acc;
-    });
-    wave_sync();
-
-    // ---- x[t] on its way (registers) while dX runs ---------------------------------------------
-    const float* xt = x + (long)t * N * din;
-    f32x4 xpf[8];
+  if (t < T) {
+    // ---- prologue: g, CSR(A^T) and x of the first graph in flight ------------------------------
+    InFlight fg;       // g tile + CSR entries
+    f32x4 fx[8];       // x tile
+    int rp_cur = rowptr_t[(long)t * N + lrp];
+    int base = __builtin_amdgcn_readlane(rp_cur, 0);
+    int cnt = __builtin_amdgcn_readlane(rp_cur, N) - base;
+    issue_tile(fg, g + (long)t * N * dout, ng4, lane);
+    issue_cv(fg, cv_t, base, cnt, lane);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int i = lane + q * 64;
       f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      xpf[q] = (i < nx4) ? lds4(xt + (long)i * 4) : z;
+      fx[q] = (i < nx4) ? ldv4(x + (long)t * N * din + (long)i * 4) : z;
     }
+    int tn = t + nwaves;
+    int rp_nxt = (tn < T) ? rowptr_t[(long)tn * N + lrp] : 0;
 
-    // ---- dX = dFW @ W^T ------------------------------------------------------------------------
-    if (dx) {
-      f32x4 a4[8];
+    for (;;) {
+      // ---- 1. g[t], CSR(A^T) slice: registers -> LDS ------------------------------------------
+      land(fg, ws.b, FD, ng4, dout4, ws, cv_t, rp_cur, base, cnt, N, lane);
+      wave_sync();
+
+      // ---- 2. dFW = A^T @ g -> dFW tile (odd stride), dbias partial ----------------------------
+      aggregate_rows(ws, ws.b, FD, N, dout, lane, [&](int r, int cl, f32x4 acc) {
+        float* d = ws.a + r * BLD + cl * 4;
+        d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2]; d[3] = acc[3];
+        dbacc += acc;
+      });
+      wave_sync();
+
+      // ---- 3. x[t] -> gather tile (g is dead) --------------------------------------------------
 #pragma unroll
-      for (int q = 0; q < 8; ++q) a4[q] = lds4(ws.a + li * ALD + hi * 32 + q * 4);
-      f32x16 c0, c1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
-#pragma unroll
-      for (int s = 0; s < 32; ++s) {
-        const float a = a4[s >> 2][s & 3];
-        const int k = hi * 32 + s;
-        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Wt[k * FD + li], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Wt[k * FD + 32 + li], c1, 0, 0, 0);
-      }
-      float* dxt = dx + (long)t * N * din;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (row < N) {
-          if (li < din) dxt[(long)row * din + li] = c0[r];
-          if (32 + li < din) dxt[(long)row * din + 32 + li] = c1[r];
+      for (int q = 0; q < 8; ++q) {
+        const int i = lane + q * 64;
+        if (i < nx4) {
+          const int r = i / din4, c4 = i - r * din4;
+          *reinterpret_cast<f32x4*>(ws.b + r * FD + c4 * 4) = fx[q];
         }
       }
-    }
 
-    // ---- x[t] -> gather tile (g is dead), then dW += x^T @ dFW ---------------------------------
-    wave_sync();
+      // ---- 4. next graph (g, CSR, x) in flight during the whole MFMA phase ---------------------
+      const bool has_next = tn < T;
+      int base_n = 0, cnt_n = 0;
+      if (has_next) {
+        base_n = __builtin_amdgcn_readlane(rp_nxt, 0);
+        cnt_n = __builtin_amdgcn_readlane(rp_nxt, N) - base_n;
+        issue_tile(fg, g + (long)tn * N * dout, ng4, lane);
+        issue_cv(fg, cv_t, base_n, cnt_n, lane);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int i = lane + q * 64;
-      if (i < nx4) {
-        const int r = i / din4, c4 = i - r * din4;
-        *reinterpret_cast<f32x4*>(ws.b + r * FD + c4 * 4) = xpf[q];
+        for (int q = 0; q < 8; ++q) {
+          const int i = lane + q * 64;
+          f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          fx[q] = (i < nx4) ? ldv4(x + (long)tn * N * din + (long)i * 4) : z;
+        }
+        rp_cur = rp_nxt;
+        const int tnn = tn + nwaves;
+        rp_nxt = (tnn < T) ? rowptr_t[(long)tnn * N + lrp] : 0;
       }
-    }
-    wave_sync();
+      wave_sync();
+
+      // ---- 5. dW += x^T @ dFW --------------------------------------------------------------------
+#pragma unroll 2
+      for (int s = 0; s < 16; ++s) {
+        const int n = hi * 16 + s;
+        const float a0 = ws.b[n * FD + li], a1 = ws.b[n * FD + 32 + li];
+        const float f0 = ws.a[n * BLD + li], f1 = ws.a[n * BLD + 32 + li];
+        dw00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, f0, dw00, 0, 0, 0);
+        dw01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, f1, dw01, 0, 0, 0);
+        dw10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f0, dw10, 0, 0, 0);
+        dw11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f1, dw11, 0, 0, 0);
+      }
+
+      // ---- 6. dX = dFW @ W^T (A operand straight from the odd-stride LDS tile) ------------------
+      if (dx) {
+        f32x16 c0, c1;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int n = hi * 16 + s;
-      const float a0 = ws.b[n * FD + li], a1 = ws.b[n * FD + 32 + li];
-      const float f0 = ws.a[n * ALD + li], f1 = ws.a[n * ALD + 32 + li];
-      dw00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, f0, dw00, 0, 0, 0);
-      dw01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, f1, dw01, 0, 0, 0);
-      dw10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f0, dw10, 0, 0, 0);
-      dw11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f1, dw11, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+#pragma unroll 4
+        for (int s = 0; s < 32; ++s) {
+          const int k = hi * 32 + s;
+          const float a = ws.a[li * BLD + k];
+          c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Wt[k * FD + li], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Wt[k * FD + 32 + li], c1, 0, 0, 0);
+        }
+        float* dxt = dx + (long)t * N * din;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (row < N) {
+            if (li < din) dxt[(long)row * din + li] = c0[r];
+            if (32 + li < din) dxt[(long)row * din + 32 + li] = c1[r];
+          }
+        }
+      }
+      wave_sync();
+
+      if (!has_next) break;
+      t = tn;
+      tn += nwaves;
+      base = base_n;
+      cnt = cnt_n;
     }
-    wave_sync();
   }
 
-  // ---- per-wave partials leave the chip once -----------------------------------------------------
-  const int gw = blockIdx.x * wpb + wave;
-  float* pw = part_dw + (long)gw * din * dout;
+  // ---- reduce the workgroup's waves through LDS; one partial per workgroup leaves the chip -----
+  // every wave parks its 64x64 dW tile (C layout -> row major) + dbias in its own slice
+  __syncthreads();
+  float* park = ws.a;  // a (8704 B) and b (8448 B) are contiguous: 4096 + 64 floats fit
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-    if (row < din) {
-      if (li < dout) pw[(long)row * dout + li] = dw00[r];
-      if (32 + li < dout) pw[(long)row * dout + 32 + li] = dw01[r];
-    }
-    if (32 + row < din) {
-      if (li < dout) pw[(long)(32 + row) * dout + li] = dw10[r];
-      if (32 + li < dout) pw[(long)(32 + row) * dout + 32 + li] = dw11[r];
-    }
+    park[row * FD + li] = dw00[r];
+    park[row * FD + 32 + li] = dw01[r];
+    park[(32 + row) * FD + li] = dw10[r];
+    park[(32 + row) * FD + 32 + li] = dw11[r];
   }
   // dbacc: lane (sub, cl) holds the column-4-group cl summed over rows == sub (mod 4)
 #pragma unroll
@@ -297,9 +413,21 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
     v += __shfl_xor(v, 32, 64);
     dbacc[j] = v;
   }
-  if (lane < 16 && lane * 4 < dout) {
-    float* pb = part_db + (long)gw * dout + lane * 4;
-    pb[0] = dbacc[0]; pb[1] = dbacc[1]; pb[2] = dbacc[2]; pb[3] = dbacc[3];
+  if (lane < 16) *reinterpret_cast<f32x4*>(park + FD * FD + lane * 4) = dbacc;
+  __syncthreads();
+  const size_t slice_f = slice_bytes(max_nnz) / 4;
+  const float* slice0 = reinterpret_cast<const float*>(smem + FD * FD * 4);
+  float* pw = part_dw + (long)blockIdx.x * din * dout;
+  for (int i = tid; i < FD * FD; i += blockDim.x) {
+    float s = 0.f;
+    for (int wv = 0; wv < wpb; ++wv) s += slice0[wv * slice_f + i];
+    const int row = i >> 6, col = i & 63;
+    if (row < din && col < dout) pw[(long)row * dout + col] = s;
+  }
+  if (tid < dout) {
+    float s = 0.f;
+    for (int wv = 0; wv < wpb; ++wv) s += slice0[wv * slice_f + FD * FD + tid];
+    part_db[(long)blockIdx.x * dout + tid] = s;
   }
 }
 
@@ -363,8 +491,8 @@ extern "C" int kgcn_graphconv_fwd_f32(const kgcn_csr_batch* a, const float* x, c
 extern "C" int64_t kgcn_graphconv_bwd_workspace_bytes(int32_t num_graphs, int32_t din,
                                                       int32_t dout) {
   if (num_graphs <= 0 || din <= 0 || dout <= 0) return 0;
-  // sized for the largest grid the launcher can pick (MAX_WPB waves x one workgroup per CU)
-  return (int64_t)kNumCU * MAX_WPB * ((int64_t)din * dout + dout) * 4;
+  // one partial per persistent workgroup (at most one workgroup per CU)
+  return (int64_t)kNumCU * ((int64_t)din * dout + dout) * 4;
 }
 
 extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, const float* w,
@@ -388,13 +516,12 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
     return fail("kgcn_graphconv_bwd_f32: tensors not 16-byte aligned");
   const int wpb = fused_wpb(at->max_nnz_per_graph, FD * FD * 4);
   const int blocks = fused_grid(at->num_graphs, wpb);
-  const int nparts = blocks * wpb;
-  const int64_t need = (int64_t)nparts * ((int64_t)din * dout + dout) * 4;
+  const int64_t need = (int64_t)blocks * ((int64_t)din * dout + dout) * 4;
   if (!workspace || workspace_bytes < need)
     return fail("kgcn_graphconv_bwd_f32: workspace %lld < %lld bytes", (long long)workspace_bytes,
                 (long long)need);
   float* part_dw = static_cast<float*>(workspace);
-  float* part_db = part_dw + (long)nparts * din * dout;
+  float* part_db = part_dw + (long)blocks * din * dout;
   const size_t lds = FD * FD * 4 + (size_t)wpb * slice_bytes(at->max_nnz_per_graph);
   static thread_local bool attr_set = false;
   if (!attr_set) {
@@ -406,6 +533,6 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
                      reinterpret_cast<const int2*>(at->cv), x, w, dout_grad, dx, part_dw, part_db,
                      at->num_graphs, at->rows, din, dout, at->max_nnz_per_graph);
   if (int rc = check_launch("graphconv_bwd_kernel")) return rc;
-  if (int rc = launch_reduce_partials(part_dw, nparts, (long)din * dout, dw, s)) return rc;
-  return launch_reduce_partials(part_db, nparts, dout, dbias, s);
+  if (int rc = launch_reduce_partials(part_dw, blocks, (long)din * dout, dw, s)) return rc;
+  return launch_reduce_partials(part_db, blocks, dout, dbias, s);
 }
