@@ -43,12 +43,21 @@ extern "C" {
 
 #define KGCN_HIP_ABI_VERSION 1
 
+/* Column index of the padding entries of a row-padded batch (see row_pad): they carry value 0 and
+ * gather an all-zero row the fused kernels keep in LDS, so they contribute exactly 0 (never 0*inf). */
+#define KGCN_PAD_COL 32
+
 typedef struct kgcn_csr_batch {
   int32_t num_graphs;        /* T */
   int32_t rows;              /* M: rows per graph (padded, uniform) */
   int32_t cols;              /* K: columns per graph = rows of each rhs block */
   int32_t max_nnz_per_graph; /* max over graphs of stored entries (sizes the LDS staging) */
-  int64_t nnz;               /* total stored entries */
+  int32_t row_pad;           /* 0: plain CSR.  4: every row holds a positive multiple of 4 entries,
+                                padded with (col = KGCN_PAD_COL, value = 0) -- the layout the fused
+                                GraphConv kernels read (mask-free 4-entry gathers); only those
+                                kernels accept it */
+  int32_t reserved_;
+  int64_t nnz;               /* total stored entries (including padding entries) */
   const int32_t* rowptr;     /* device, [T*M + 1], absolute offsets into cv (in entries) */
   const int32_t* cv;         /* device, [2*nnz], interleaved (local col, fp32 value bits) */
 } kgcn_csr_batch;
@@ -114,6 +123,7 @@ int kgcn_dense_wgrad_f32(const float* x, int64_t x_ld, const float* dy, int64_t 
  * Forward in ONE kernel (x tile -> LDS, fp32 MFMA, aggregation out of LDS; X.W never touches
  * HBM).  Supported fused shapes are reported by kgcn_graphconv_fused_supported(); other
  * shapes and multi-channel layers use kgcn_dense_* + kgcn_bconv_f32. */
+/* a / at of the fused entry points must be row-padded batches (row_pad == 4). */
 int kgcn_graphconv_fused_supported(int32_t n_nodes, int32_t din, int32_t dout,
                                    int32_t max_nnz_per_graph);
 int kgcn_graphconv_fwd_f32(const kgcn_csr_batch* a, const float* x, const float* w,

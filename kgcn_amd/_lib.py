@@ -22,6 +22,8 @@ class CsrBatch(ctypes.Structure):
         ("rows", c_i32),
         ("cols", c_i32),
         ("max_nnz_per_graph", c_i32),
+        ("row_pad", c_i32),
+        ("reserved_", c_i32),
         ("nnz", c_i64),
         ("rowptr", ctypes.c_void_p),
         ("cv", ctypes.c_void_p),

@@ -36,7 +36,10 @@ def _to_numpy(a):
 class BatchedCSR:
     """One adjacency channel of a batch of T graphs, device resident."""
 
-    def __init__(self, rowptr, cv, num_graphs, rows, cols, max_nnz, perm=None, host=None):
+    PAD_COL = 32        # KGCN_PAD_COL of include/kgcn_hip.h
+
+    def __init__(self, rowptr, cv, num_graphs, rows, cols, max_nnz, perm=None, host=None,
+                 row_pad=0):
         self.rowptr = rowptr            # torch int32 [T*M+1] (device)
         self.cv = cv                    # torch int32 [nnz,2] (device)
         self.num_graphs = int(num_graphs)
@@ -50,6 +53,8 @@ class BatchedCSR:
         self._desc = None
         self._struct_src = None         # set by with_values(): container owning the pattern
         self._vals = None
+        self.row_pad = int(row_pad)     # 0 plain CSR, 4 = rows padded to multiples of 4 entries
+        self._p4 = None
 
     # ---- construction -------------------------------------------------------------------------
     @classmethod
@@ -138,6 +143,47 @@ class BatchedCSR:
             self._t = t
         return self._t
 
+    def padded4(self):
+        """Row-padded copy for the fused GraphConv kernels (kgcn_csr_batch.row_pad = 4): every row
+        holds a positive multiple of 4 entries; padding entries are (col = PAD_COL, value = 0) and
+        gather an all-zero LDS row, so the kernels run mask-free 4-entry gathers.  Cached."""
+        if self.row_pad == 4:
+            return self
+        if self._p4 is None:
+            import torch
+            if self._host is None:
+                raise NotImplementedError("padded4() needs the host-side pattern (not available on "
+                                          "containers made by with_values())")
+            if self.rows > self.PAD_COL or self.cols > self.PAD_COL:
+                raise ValueError("row padding is only defined for graphs of at most %d nodes" % self.PAD_COL)
+            g, r, c, v = self._host
+            T, M = self.num_graphs, self.rows
+            nnz = g.shape[0]
+            key = g * M + r
+            counts = np.bincount(key, minlength=T * M) if nnz else np.zeros(T * M, np.int64)
+            padded = np.maximum(4, (counts + 3) // 4 * 4)
+            rp = np.zeros(T * M + 1, np.int64)
+            np.cumsum(counts, out=rp[1:])
+            rp4 = np.zeros(T * M + 1, np.int64)
+            np.cumsum(padded, out=rp4[1:])
+            n4 = int(rp4[-1])
+            if n4 >= 2 ** 31:
+                raise ValueError("batch too large for int32 offsets")
+            cv4 = np.empty((n4, 2), np.int32)
+            cv4[:, 0] = self.PAD_COL
+            cv4[:, 1] = 0
+            if nnz:
+                pos = rp4[key] + (np.arange(nnz) - rp[key])
+                cv4[pos, 0] = c
+                cv4[pos, 1] = v.view(np.int32)
+            per_graph = rp4[M::M] - rp4[:-1:M] if (T and M) else np.zeros(0, np.int64)
+            max_nnz = int(per_graph.max()) if per_graph.size else 0
+            dev = self.rowptr.device
+            self._p4 = BatchedCSR(torch.from_numpy(rp4.astype(np.int32)).to(dev),
+                                  torch.from_numpy(cv4).to(dev), T, M, self.cols, max_nnz,
+                                  row_pad=4)
+        return self._p4
+
     def with_values(self, values):
         """Same pattern, new values (device fp32 tensor [nnz] in CSR order).  Used when the
         adjacency values are themselves differentiable inputs (kgcn/bspmm_call.py:50-55)."""
@@ -162,7 +208,7 @@ class BatchedCSR:
         """ctypes struct kgcn_csr_batch pointing at the device arrays."""
         if self._desc is None:
             self._desc = _lib.CsrBatch(self.num_graphs, self.rows, self.cols, self.max_nnz,
-                                       self.nnz, self.rowptr.data_ptr(),
+                                       self.row_pad, 0, self.nnz, self.rowptr.data_ptr(),
                                        self.cv.data_ptr() if self.nnz else 0)
         return self._desc
 

@@ -8,19 +8,21 @@
 // aggregates it with B*C sparse ops.  Here one persistent wave owns one graph at a time:
 //   * the graph's node-feature tile [N<=32 x D<=64] is streamed HBM -> registers -> LDS once
 //     (dwordx4, all loads of a tile in flight together), and the NEXT graph's tile + CSR slice are
-//     already in flight (register prefetch) while the current graph is being computed,
+//     already in flight (register prefetch, branch-free) while the current graph is computed,
 //   * the dense contraction runs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32)
 //     with the weight fragments resident in registers (forward) / in LDS (backward, W^T),
 //   * FW (resp. dFW) lives only in LDS, where the sparse aggregation gathers neighbour rows with
-//     conflict-free ds_read_b128, four entries per lane group in flight -- X.W and dFW never
-//     touch HBM,
+//     conflict-free ds_read_b128 -- X.W and dFW never touch HBM,
 //   * dW / dbias accumulate in MFMA accumulators across ALL graphs a wave processes, are reduced
 //     across the workgroup's waves through LDS and leave the chip once per workgroup
 //     (deterministic second-stage reduction).
 // Algorithmic HBM bytes per graph (N=32, D=64, nnz=100): forward 17,316, backward 25,508.
 //
-// Shape support (kgcn_graphconv_fused_supported): N <= 32, din,dout <= 64 and multiples of 4.
-// Everything else goes through kgcn_dense_* + kgcn_bconv_f32.
+// Two instantiations of every kernel: FULL (N = 32, din = dout = 64: the benchmark shape; all
+// sizes are compile-time constants, the 8 aggregation passes are straight-line code) and generic
+// (N <= 32, din,dout <= 64 multiples of 4).  Other shapes use kgcn_dense_* + kgcn_bconv_f32.
+#include <type_traits>
+
 #include "kgcn_common.h"
 
 namespace kgcn {
@@ -29,123 +31,263 @@ int launch_reduce_partials(const float* part, int nparts, long n, float* out, hi
 
 constexpr int FN = 32;    // node tile (MFMA M)
 constexpr int FD = 64;    // feature tile (K of the forward GEMM, two 32-wide output tiles)
-constexpr int ALD = 68;   // padded row stride (floats) of tiles read as MFMA A fragments (b128)
+constexpr int ALD = 68;   // padded row stride (floats) of the forward's A-fragment tile (b128 reads)
+constexpr int BLD = 65;   // ODD row stride of the backward's dFW tile: conflict-free ds_read_b32 for
+                          // both MFMA operand patterns (down a column for dX, along a row for dW)
 constexpr int MAX_WPB = 8;
-constexpr int ECV_PAD = 4;  // the 4-entry batched gather may read (not use) 3 entries past the end
+
+
+// Phase probe (tools/phase_probe.py builds a second library with -DKGCN_PROBE): per-wave sums of
+// s_memtime deltas per phase, written to a device buffer.  Compiled out of the product library.
+#ifdef KGCN_PROBE
+__device__ long long* g_probe = nullptr;
+#define PROBE_DECL long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long pc_ = __builtin_readcyclecounter();
+#define PROBE(k) { const long long n_ = __builtin_readcyclecounter(); pt_[k] += n_ - pc_; pc_ = n_; }
+#define PROBE_FLUSH(gw) if (g_probe && lane == 0) { for (int k_ = 0; k_ < 8; ++k_) g_probe[(long)(gw) * 8 + k_] = pt_[k_]; }
+#else
+#define PROBE_DECL
+#define PROBE(k)
+#define PROBE_FLUSH(gw)
+#endif
 
 __device__ __forceinline__ void wave_sync() {
-  // LDS operations of one wave execute in order; this only stops the compiler from moving LDS
-  // accesses of different lanes across the hand-off point.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  // Hand-off of LDS data between lanes of ONE wave.  The LDS unit executes a wave's DS
+  // instructions in issue order, so no hardware wait is needed -- only the compiler must not move
+  // LDS accesses across this point.  Deliberately NOT an atomic fence: a release/acquire fence
+  // lowers to s_waitcnt vmcnt(0), which drains the next graph's prefetch loads the moment they
+  // are issued.
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
 }
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's int4 class type went
+                                                        // through scratch memory in selects
 
 __device__ __forceinline__ f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void stv4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 struct WaveSlice {
-  float* a;     // [FN][ALD]  A-fragment source tile
-  float* b;     // [FN+1][FD] gather source tile; row FN stays zero (target of masked gathers)
-  int2* ecv;    // [max_nnz + ECV_PAD]
-  int* rp;      // [FN + 4]
+  float* a;     // forward: x tile [FN][ALD] (A-fragment source); backward: dFW tile [FN][BLD]
+  float* b;     // [FN+1][FD] gather source tile; row FN (= KGCN_PAD_COL) stays zero
+  int2* ecv;    // [max_nnz] (col,val) pairs of the graph, row-padded layout (x2 when double buffered)
+  int* rp;      // [FN + 4] row pointers rebased to 0 (x2 when double buffered)
 };
 
-__host__ __device__ inline size_t ecv_bytes(int max_nnz) {
-  return ((size_t)(max_nnz + ECV_PAD) * 8 + 15) & ~(size_t)15;
+static_assert(KGCN_PAD_COL == FN, "padding entries must address the zero row of the gather tile");
+
+__host__ __device__ inline size_t ecv_bytes(int max_nnz) { return ((size_t)max_nnz * 8 + 15) & ~(size_t)15; }
+constexpr size_t RP_BYTES = (FN + 4) * 4;
+
+// a_floats: FN*ALD (forward) or FN*BLD rounded up to 16 bytes (backward); ncsr: 1 or 2 CSR buffers
+__host__ __device__ inline size_t slice_bytes(int max_nnz, int a_floats, int ncsr) {
+  return (((size_t)a_floats * 4 + 15) & ~(size_t)15) + (size_t)(FN + 1) * FD * 4 +
+         (size_t)ncsr * (ecv_bytes(max_nnz) + RP_BYTES);
 }
 
-__host__ __device__ inline size_t slice_bytes(int max_nnz) {
-  return (size_t)FN * ALD * 4 + (size_t)(FN + 1) * FD * 4 + ecv_bytes(max_nnz) + (FN + 4) * 4;
-}
-
-__device__ __forceinline__ WaveSlice carve(unsigned char* base, int wave, int max_nnz) {
-  unsigned char* p = base + (size_t)wave * slice_bytes(max_nnz);
+__device__ __forceinline__ WaveSlice carve(unsigned char* base, int wave, int max_nnz, int a_floats,
+                                           int ncsr) {
+  unsigned char* p = base + (size_t)wave * slice_bytes(max_nnz, a_floats, ncsr);
   WaveSlice s;
   s.a = reinterpret_cast<float*>(p);
-  s.b = s.a + FN * ALD;
+  s.b = reinterpret_cast<float*>(p + (((size_t)a_floats * 4 + 15) & ~(size_t)15));
   s.ecv = reinterpret_cast<int2*>(s.b + (FN + 1) * FD);
-  s.rp = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(s.ecv) + ecv_bytes(max_nnz));
+  s.rp = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(s.ecv) + (size_t)ncsr * ecv_bytes(max_nnz));
   return s;
 }
 
-// One graph's inputs in flight: the feature tile (<= 512 float4 = 8 per lane), the first 128 CSR
-// entries (2 per lane) and the row pointers (lane l holds rowptr[t*N + min(l, N)]).
-struct InFlight {
-  f32x4 tile[8];
-  int2 cv[2];
-};
+// One feature tile in flight (<= 512 float4 = 8 per lane) / the first 128 CSR entries (2 per lane)
+struct TileRegs { f32x4 v[8]; };
+struct CsrRegs { i32x4 e0, e1; };   // lane l: entries 2l, 2l+1 and 128+2l, 128+2l+1 (plain members:
+                                   // an array member ended up in scratch memory)
 
-__device__ __forceinline__ void issue_tile(InFlight& f, const float* __restrict__ src, int n4,
+template <bool FULL>
+__device__ __forceinline__ void issue_tile(TileRegs& f, const float* __restrict__ src, int n4,
                                            int lane) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int i = lane + q * 64;
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f.tile[q] = (i < n4) ? ldv4(src + (long)i * 4) : z;
+    if constexpr (FULL) {
+      f.v[q] = ldv4(src + (long)i * 4);
+    } else {
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      f.v[q] = (i < n4) ? ldv4(src + (long)i * 4) : z;
+    }
   }
 }
 
-__device__ __forceinline__ void issue_cv(InFlight& f, const int2* __restrict__ cv, int base,
-                                         int cnt, int lane) {
-  const int2 z = {0, 0};
-  f.cv[0] = (lane < cnt) ? cv[base + lane] : z;
-  f.cv[1] = (lane + 64 < cnt) ? cv[base + lane + 64] : z;
+// Row-padded layout: the graph's entry count is a multiple of 4 and its first entry index too, so
+// entries can be moved two at a time as aligned 16-byte words.
+__device__ __forceinline__ void issue_cv(CsrRegs& f, const int2* __restrict__ cv, int base, int cnt,
+                                         int lane) {
+  const i32x4 z = {0, 0, 0, 0};
+  const i32x4* src = reinterpret_cast<const i32x4*>(cv + base);
+  f.e0 = (2 * lane < cnt) ? src[lane] : z;
+  f.e1 = (128 + 2 * lane < cnt) ? src[64 + lane] : z;
 }
 
-// registers -> LDS: tile rows get row stride `ld` (floats); CSR slice rebased to 0
-__device__ __forceinline__ void land(const InFlight& f, float* tile, int ld, int n4, int d4,
-                                     const WaveSlice& ws, const int2* __restrict__ cv, int rp_val,
-                                     int base, int cnt, int N, int lane) {
+// registers -> LDS tile with row stride `ld` floats (d4 = float4 per source row)
+template <bool FULL>
+__device__ __forceinline__ void land_tile(const TileRegs& f, float* tile, int ld, int n4, int d4,
+                                          int lane) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int i = lane + q * 64;
-    if (i < n4) {
-      const int r = i / d4, c4 = i - r * d4;
-      *reinterpret_cast<f32x4*>(tile + r * ld + c4 * 4) = f.tile[q];
+    if constexpr (FULL) {
+      stv4(tile + (i >> 4) * ld + (i & 15) * 4, f.v[q]);
+    } else {
+      if (i < n4) {
+        const int r = i / d4, c4 = i - r * d4;
+        stv4(tile + r * ld + c4 * 4, f.v[q]);
+      }
     }
   }
-  if (lane < cnt) ws.ecv[lane] = f.cv[0];
-  if (lane + 64 < cnt) ws.ecv[lane + 64] = f.cv[1];
-  for (int i = 128 + lane; i < cnt; i += 64) ws.ecv[i] = cv[base + i];  // rare: > 128 entries
-  if (lane <= N) ws.rp[lane] = rp_val - base;
 }
 
-// Rows r0..r0+3 of the output (16 lanes x float4 each) = sum over the row's entries of
-// val * src[col].  Entries are consumed four at a time: 4 ds_read_b64 (col,val) + 4 ds_read_b128
-// in flight per lane instead of a dependent chain per entry.
-template <typename Sink>
-__device__ __forceinline__ void aggregate_rows(const WaveSlice& ws, const float* src, int src_ld,
-                                               int N, int dcols, int lane, Sink&& sink) {
-  const int sub = lane >> 4, cl = lane & 15;
-  const bool col_ok = cl * 4 < dcols;
-  const float* srcl = src + cl * 4;
-  for (int r0 = 0; r0 < N; r0 += 4) {
-    const int r = r0 + sub;
-    const bool ok = (r < N) && col_ok;
-    const int rr = ok ? r : 0;
-    const int s = ws.rp[rr];
-    const int e = ok ? ws.rp[rr + 1] : s;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-    for (int k = s; k < e; k += 4) {
-      const int2 p0 = ws.ecv[k], p1 = ws.ecv[k + 1], p2 = ws.ecv[k + 2], p3 = ws.ecv[k + 3];
-      const bool h1 = k + 1 < e, h2 = k + 2 < e, h3 = k + 3 < e;
-      const f32x4 x0 = ldv4(srcl + p0.x * src_ld);
-      // masked slots gather the all-zero row FN with value 0 (0 * 0, never 0 * inf)
-      const f32x4 x1 = ldv4(srcl + (h1 ? p1.x : FN) * src_ld);
-      const f32x4 x2 = ldv4(srcl + (h2 ? p2.x : FN) * src_ld);
-      const f32x4 x3 = ldv4(srcl + (h3 ? p3.x : FN) * src_ld);
-      acc0 += __int_as_float(p0.y) * x0;
-      acc1 += (h1 ? __int_as_float(p1.y) : 0.f) * x1;
-      acc0 += (h2 ? __int_as_float(p2.y) : 0.f) * x2;
-      acc1 += (h3 ? __int_as_float(p3.y) : 0.f) * x3;
+__device__ __forceinline__ void land_csr(const CsrRegs& f, int2* ecv, int* rp,
+                                         const int2* __restrict__ cv, int rp_val, int base, int cnt,
+                                         int N, int lane) {
+  i32x4* dst = reinterpret_cast<i32x4*>(ecv);
+  if (2 * lane < cnt) dst[lane] = f.e0;
+  if (128 + 2 * lane < cnt) dst[64 + lane] = f.e1;
+  for (int i = 256 + lane; i < cnt; i += 64) ecv[i] = cv[base + i];  // rare: > 256 entries
+  if (lane <= N) rp[lane] = rp_val - base;
+}
+
+// Gather of the four entries k..k+3 of one CSR row (k is a multiple of 4 in the row-padded layout):
+// 2 ds_read_b128 fetch the (col,val) pairs, 4 ds_read_b128 the neighbour rows.  Padding entries
+// are (col = FN, val = 0): they read the all-zero row, 0 * 0, never 0 * inf -- no masks.
+__device__ __forceinline__ f32x4 gather4(const int2* ecv, const float* srcl, int k) {
+  const i32x4 q0 = *reinterpret_cast<const i32x4*>(ecv + k);
+  const i32x4 q1 = *reinterpret_cast<const i32x4*>(ecv + k + 2);
+  const f32x4 x0 = ldv4(srcl + q0.x * FD);
+  const f32x4 x1 = ldv4(srcl + q0.z * FD);
+  const f32x4 x2 = ldv4(srcl + q1.x * FD);
+  const f32x4 x3 = ldv4(srcl + q1.z * FD);
+  f32x4 a0 = __int_as_float(q0.y) * x0;
+  f32x4 a1 = __int_as_float(q0.w) * x1;
+  a0 += __int_as_float(q1.y) * x2;
+  a1 += __int_as_float(q1.w) * x3;
+  return a0 + a1;
+}
+
+// One aggregation "group" = passes 2h and 2h+1 (rows 8h + sub and 8h + 4 + sub) of a 32-row graph:
+// straight-line code (2 x 6 LDS reads in flight), then a rarely taken wave-uniform tail for rows
+// with more than 4 entries (degree + self loop > 4), then emit(row, column group, value).
+template <typename Emit>
+__device__ __forceinline__ void aggregate_group(const int2* ecv, const int* rp, const float* srcl,
+                                                int h, int sub, int cl, Emit&& emit) {
+  const int r0 = 8 * h + sub, r1 = r0 + 4;
+  const int s0 = rp[r0], e0 = rp[r0 + 1];
+  const int s1 = rp[r1], e1 = rp[r1 + 1];
+  f32x4 a0 = gather4(ecv, srcl, s0);
+  f32x4 a1 = gather4(ecv, srcl, s1);
+  if (__builtin_amdgcn_ballot_w64((s0 + 4 < e0) | (s1 + 4 < e1))) {
+    for (int k = s0 + 4; __builtin_amdgcn_ballot_w64(k < e0); k += 4)
+      if (k < e0) a0 += gather4(ecv, srcl, k);
+    for (int k = s1 + 4; __builtin_amdgcn_ballot_w64(k < e1); k += 4)
+      if (k < e1) a1 += gather4(ecv, srcl, k);
+  }
+  emit(r0, cl, a0);
+  emit(r1, cl, a1);
+}
+
+// One aggregation pass (4 rows: r = 4p + sub) cut into micro-steps, so that the forward kernel can
+// place one step behind every MFMA pair of the dense contraction (the compiler keeps MFMAs in one
+// clump otherwise, and an in-order wave cannot overlap a clump with what follows it):
+//   rp() -> ecv() -> tile() -> fma() -> [tail()] -> a ready
+struct PassSteps {
+  int s, e;
+  i32x4 q0, q1;
+  f32x4 x0, x1, x2, x3;
+  f32x4 a;
+  __device__ __forceinline__ void rp(const int* rp_, int r) { s = rp_[r]; e = rp_[r + 1]; }
+  __device__ __forceinline__ void ecv(const int2* ecv_) {
+    q0 = *reinterpret_cast<const i32x4*>(ecv_ + s);
+    q1 = *reinterpret_cast<const i32x4*>(ecv_ + s + 2);
+  }
+  __device__ __forceinline__ void tile(const float* srcl) {
+    x0 = ldv4(srcl + q0.x * FD); x1 = ldv4(srcl + q0.z * FD);
+    x2 = ldv4(srcl + q1.x * FD); x3 = ldv4(srcl + q1.z * FD);
+  }
+  __device__ __forceinline__ void fma() {
+    f32x4 u = __int_as_float(q0.y) * x0, v = __int_as_float(q0.w) * x1;
+    u += __int_as_float(q1.y) * x2; v += __int_as_float(q1.w) * x3;
+    a = u + v;
+  }
+  __device__ __forceinline__ void tail(const int2* ecv_, const float* srcl) {
+    if (__builtin_amdgcn_ballot_w64(s + 4 < e)) {   // rows with > 4 entries: rare for molecules
+      for (int k = s + 4; __builtin_amdgcn_ballot_w64(k < e); k += 4)
+        if (k < e) a += gather4(ecv_, srcl, k);
     }
-    if (ok) sink(r, cl, acc0 + acc1);
+  }
+};
+
+// Sparse aggregation of one graph out of the gather tile ws.b (row stride FD): lane (sub, cl)
+// produces the float4 [4cl, 4cl+4) of rows r = 4p + sub.  emit(r, cl, acc) receives every row once.
+template <bool FULL, typename Emit>
+__device__ __forceinline__ void aggregate_rows(const int2* ecv, const int* rp, const float* tile,
+                                               int N, int dcols, int lane, Emit&& emit) {
+  const int sub = lane >> 4, cl = lane & 15;
+  const float* srcl = tile + cl * 4;
+  if constexpr (FULL) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      aggregate_group(ecv, rp, srcl, h, sub, cl, emit);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    const bool col_ok = cl * 4 < dcols;
+    for (int r0 = 0; r0 < N; r0 += 4) {
+      const int r = r0 + sub;
+      const bool ok = (r < N) && col_ok;
+      const int rr = ok ? r : 0;
+      const int s = rp[rr];
+      const int e = ok ? rp[rr + 1] : s;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int k = s; __builtin_amdgcn_ballot_w64(k < e); k += 4)
+        if (k < e) acc += gather4(ecv, srcl, k);
+      if (ok) emit(r, cl, acc);
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+constexpr int A_FWD = FN * ALD;   // floats of the forward's A tile
+constexpr int A_BWD = FN * BLD;   // floats of the backward's dFW tile
+
+// weight fragments: B[k][j] with k = hi*32 + s (the K permutation matches the A fragments)
+template <bool FULL>
+__device__ __forceinline__ void load_w_frags(float (&wr0)[32], float (&wr1)[32],
+                                             const float* __restrict__ w, int din, int dout, int li,
+                                             int hi) {
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    const int k = hi * 32 + s;
+    if constexpr (FULL) {
+      wr0[s] = w[k * FD + li];
+      wr1[s] = w[k * FD + 32 + li];
+    } else {
+      wr0[s] = (k < din && li < dout) ? w[(long)k * dout + li] : 0.f;
+      wr1[s] = (k < din && 32 + li < dout) ? w[(long)k * dout + 32 + li] : 0.f;
+    }
+  }
+}
+
+// MFMA C layout (two 32x32 tiles) -> gather tile, bank = column: conflict free
+__device__ __forceinline__ void store_c_tiles(float* tile, const f32x16& c0, const f32x16& c1, int li,
+                                              int hi) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    tile[row * FD + li] = c0[r];
+    tile[row * FD + 32 + li] = c1[r];
+  }
+}
+
+// Generic shapes (N <= 32, din/dout <= 64 multiples of 4): prefetch + phase-sequential per graph.
 __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
     const int* __restrict__ rowptr, const int2* __restrict__ cv, const float* __restrict__ x,
     const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out, int T,
@@ -155,24 +297,18 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, hi = lane >> 5;
   const int wpb = blockDim.x >> 6;
-  WaveSlice ws = carve(smem, wave, max_nnz);
+  WaveSlice ws = carve(smem, wave, max_nnz, A_FWD, 1);
 
   const int nwaves = gridDim.x * wpb;
   int t = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
   if (t >= T) return;  // no workgroup barrier below: idle waves may leave
 
   // zero the A tile once: padding rows (>= N) and columns (>= din) stay zero for every graph
-  for (int i = lane; i < FN * ALD; i += 64) ws.a[i] = 0.f;
+  for (int i = lane; i < A_FWD; i += 64) ws.a[i] = 0.f;
   for (int i = lane; i < FD; i += 64) ws.b[FN * FD + i] = 0.f;
 
-  // weight fragments: B[k][j] with k = hi*32 + s (the K permutation matches the A fragments)
   float wr0[32], wr1[32];
-#pragma unroll
-  for (int s = 0; s < 32; ++s) {
-    const int k = hi * 32 + s;
-    wr0[s] = (k < din && li < dout) ? w[(long)k * dout + li] : 0.f;
-    wr1[s] = (k < din && 32 + li < dout) ? w[(long)k * dout + 32 + li] : 0.f;
-  }
+  load_w_frags<false>(wr0, wr1, w, din, dout, li, hi);
   const float b0 = (bias && li < dout) ? bias[li] : 0.f;
   const float b1 = (bias && 32 + li < dout) ? bias[32 + li] : 0.f;
 
@@ -180,36 +316,39 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
   const int n4 = N * din4;
   const int lrp = lane < N ? lane : N;
 
-  // ---- prologue: first graph's inputs, second graph's row pointers ---------------------------
-  InFlight fl;
+  TileRegs fx;
+  CsrRegs fc;
   int rp_cur = rowptr[(long)t * N + lrp];
   int base = __builtin_amdgcn_readlane(rp_cur, 0);
   int cnt = __builtin_amdgcn_readlane(rp_cur, N) - base;
-  issue_tile(fl, x + (long)t * N * din, n4, lane);
-  issue_cv(fl, cv, base, cnt, lane);
+  issue_tile<false>(fx, x + (long)t * N * din, n4, lane);
+  issue_cv(fc, cv, base, cnt, lane);
   int tn = t + nwaves;
-  int rp_nxt = (tn < T) ? rowptr[(long)tn * N + lrp] : 0;
+  // unconditional (index clamped): a conditional load becomes a phi whose copy forces
+  // s_waitcnt vmcnt(0) right behind the prefetch
+  int rp_nxt = rowptr[(long)(tn < T ? tn : t) * N + lrp];
   wave_sync();
 
   for (;;) {
-    // ---- 1. graph t: registers -> LDS ----------------------------------------------------------
-    land(fl, ws.a, ALD, n4, din4, ws, cv, rp_cur, base, cnt, N, lane);
+    land_tile<false>(fx, ws.a, ALD, n4, din4, lane);
+    land_csr(fc, ws.ecv, ws.rp, cv, rp_cur, base, cnt, N, lane);
     wave_sync();
 
-    // ---- 2. put graph t+nwaves in flight (lands while graph t is computed) ------------------
+    // next graph in flight while this one is computed.  Branch-free on purpose: values defined
+    // under `if (has_next)` become phis whose copies make the compiler wait (vmcnt(0)) for the
+    // prefetch right after issuing it; on the last iteration the current graph is re-read (L2 hit).
     const bool has_next = tn < T;
-    int base_n = 0, cnt_n = 0;
-    if (has_next) {
-      base_n = __builtin_amdgcn_readlane(rp_nxt, 0);
-      cnt_n = __builtin_amdgcn_readlane(rp_nxt, N) - base_n;
-      issue_tile(fl, x + (long)tn * N * din, n4, lane);
-      issue_cv(fl, cv, base_n, cnt_n, lane);
-      rp_cur = rp_nxt;
+    const int tp = has_next ? tn : t;
+    const int base_n = __builtin_amdgcn_readlane(rp_nxt, 0);
+    const int cnt_n = __builtin_amdgcn_readlane(rp_nxt, N) - base_n;
+    issue_tile<false>(fx, x + (long)tp * N * din, n4, lane);
+    issue_cv(fc, cv, base_n, cnt_n, lane);
+    rp_cur = rp_nxt;
+    {
       const int tnn = tn + nwaves;
-      rp_nxt = (tnn < T) ? rowptr[(long)tnn * N + lrp] : 0;
+      rp_nxt = rowptr[(long)(tnn < T ? tnn : tp) * N + lrp];
     }
 
-    // ---- 3. FW = x @ W + bias on the matrix cores ---------------------------------------------
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
@@ -224,19 +363,12 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr1[s], acc1, 0, 0, 0);
       }
     }
-    // C layout -> LDS gather tile (bank = column: conflict free)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      ws.b[row * FD + li] = acc0[r];
-      ws.b[row * FD + 32 + li] = acc1[r];
-    }
+    store_c_tiles(ws.b, acc0, acc1, li, hi);
     wave_sync();
 
-    // ---- 4. out[t] = A[t] @ FW : 4 rows per pass, 1 KiB coalesced store per pass -------------
     float* ot = out + (long)t * N * dout;
-    aggregate_rows(ws, ws.b, FD, N, dout, lane, [&](int r, int cl, f32x4 acc) {
-      *reinterpret_cast<f32x4*>(ot + (long)r * dout + cl * 4) = acc;
+    aggregate_rows<false>(ws.ecv, ws.rp, ws.b, N, dout, lane, [&](int r, int cl, f32x4 acc) {
+      stv4(ot + (long)r * dout + cl * 4, acc);
     });
     wave_sync();
 
@@ -248,32 +380,177 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
   }
 }
 
+// FULL shape (N = 32, din = dout = 64), software pipelined inside the wave: while the matrix cores
+// run FW(t) = x[t] @ W + b (64 MFMAs = 4096 cycles), the SAME instruction stream aggregates graph
+// t - nwaves out of the gather tile and stores it; FW(t) then replaces the tile.  Each of the four
+// aggregation groups shares a basic block with 16 MFMAs so the scheduler fills the MFMA shadows
+// with the gather's LDS/VALU work -- the SIMD is issue bound otherwise (phase probe: 4.1k MFMA
+// cycles + 8k aggregation cycles per graph when run back to back).  CSR slices are double buffered.
+__global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
+    const int* __restrict__ rowptr, const int2* __restrict__ cv, const float* __restrict__ x,
+    const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out, int T,
+    int max_nnz) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int N = FN, D = FD;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, hi = lane >> 5;
+  const int sub = lane >> 4, cl = lane & 15;
+  const int wpb = blockDim.x >> 6;
+  WaveSlice ws = carve(smem, wave, max_nnz, A_FWD, 2);
+  const size_t ecv_stride = ecv_bytes(max_nnz) / 8;   // int2 elements between the two CSR buffers
+
+  const int nwaves = gridDim.x * wpb;
+  int t = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
+  if (t >= T) return;
+
+  for (int i = lane; i < D; i += 64) ws.b[FN * FD + i] = 0.f;   // zero row for padding entries
+
+  float wr0[32], wr1[32];
+  load_w_frags<true>(wr0, wr1, w, D, D, li, hi);
+  const float b0 = bias ? bias[li] : 0.f;
+  const float b1 = bias ? bias[32 + li] : 0.f;
+  const int lrp = lane < N ? lane : N;
+  const float* srcl = ws.b + cl * 4;
+
+  // ---- prologue ------------------------------------------------------------------------------
+  TileRegs fx;
+  CsrRegs fc;
+  int rp_cur = rowptr[(long)t * N + lrp];
+  int base = __builtin_amdgcn_readlane(rp_cur, 0);
+  int cnt = __builtin_amdgcn_readlane(rp_cur, N) - base;
+  issue_tile<true>(fx, x + (long)t * N * D, 512, lane);
+  issue_cv(fc, cv, base, cnt, lane);
+  int tn = t + nwaves;
+  int rp_nxt = rowptr[(long)(tn < T ? tn : t) * N + lrp];
+  wave_sync();
+
+  // One pipeline step: land graph t (registers -> LDS), put graph t+nwaves in flight, run FW(t)
+  // on the matrix cores -- with AGG, interleaved with the aggregation of graph t_prev whose FW
+  // sits in the gather tile (CSR buffer pb^1) -- and finally replace the gather tile by FW(t).
+  int pb = 0;          // CSR buffer of the graph being multiplied (t)
+  int t_prev = t;      // graph whose FW sits in the gather tile (valid from the second step on)
+  bool has_next = true;
+  PROBE_DECL
+  auto step = [&](auto agg_tag) __attribute__((always_inline)) {
+    constexpr bool AGG = decltype(agg_tag)::value;
+    PROBE(0)
+    int2* ecv_t = ws.ecv + pb * ecv_stride;
+    int* rp_t = ws.rp + pb * (FN + 4);
+    const int2* ecv_p = ws.ecv + (pb ^ 1) * ecv_stride;
+    const int* rp_p = ws.rp + (pb ^ 1) * (FN + 4);
+
+    // ---- 1. graph t: registers -> LDS (x tile, CSR slice into buffer pb) -----------------------
+    land_tile<true>(fx, ws.a, ALD, 512, 16, lane);
+    land_csr(fc, ecv_t, rp_t, cv, rp_cur, base, cnt, N, lane);
+    wave_sync();
+    PROBE(1)
+
+    // ---- 2. graph t + nwaves in flight.  Branch-free on purpose: values defined under
+    // `if (has_next)` become phis whose copies make the compiler wait (vmcnt(0)) for the prefetch
+    // right after issuing it; on the last step the current graph is re-read (L2 hit), unused.
+    has_next = tn < T;
+    const int tp = has_next ? tn : t;
+    const int base_n = __builtin_amdgcn_readlane(rp_nxt, 0);
+    const int cnt_n = __builtin_amdgcn_readlane(rp_nxt, N) - base_n;
+    issue_tile<true>(fx, x + (long)tp * N * D, 512, lane);
+    issue_cv(fc, cv, base_n, cnt_n, lane);
+    rp_cur = rp_nxt;
+    {
+      const int tnn = tn + nwaves;
+      rp_nxt = rowptr[(long)(tnn < T ? tnn : tp) * N + lrp];
+    }
+    PROBE(2)
+
+    // ---- 3. FW(t) on the matrix cores || aggregation of graph t_prev ---------------------------
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
+    float* ot = out + (long)t_prev * N * D;
+    PassSteps ps;
+#pragma unroll
+    for (int p8 = 0; p8 < 8; ++p8) {      // 8 passes x 4 MFMA pairs
+      const f32x4 a4 = ldv4(ws.a + li * ALD + hi * 32 + p8 * 4);
+      const int r = 4 * p8 + sub;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int sidx = p8 * 4 + s4;
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s4], wr0[sidx], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s4], wr1[sidx], acc1, 0, 0, 0);
+        if constexpr (AGG) {
+          // one micro-step of the previous graph's aggregation in the shadow of this MFMA pair
+          if (s4 == 0) {
+            if (p8 > 0) stv4(ot + (r - 4) * D + cl * 4, ps.a);   // previous pass: 1 KiB store
+            ps.rp(rp_p, r);
+          } else if (s4 == 1) {
+            ps.ecv(ecv_p);
+          } else if (s4 == 2) {
+            ps.tile(srcl);
+          } else {
+            ps.fma();
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if constexpr (AGG) {
+        ps.tail(ecv_p, srcl);
+        if (p8 == 7) stv4(ot + r * D + cl * 4, ps.a);
+      }
+    }
+    PROBE(3)
+    // ---- 4. FW(t) replaces the gather tile ------------------------------------------------------
+    wave_sync();
+    store_c_tiles(ws.b, acc0, acc1, li, hi);
+    wave_sync();
+    PROBE(4)
+
+    t_prev = t;
+    pb ^= 1;
+    t = tn;
+    tn += nwaves;
+    base = base_n;
+    cnt = cnt_n;
+  };
+
+  step(std::false_type{});                       // first graph: nothing to aggregate yet
+  while (has_next) step(std::true_type{});
+  // ---- epilogue: aggregate the last graph (CSR buffer pb^1, FW in the gather tile) --------------
+  {
+    const int2* ecv_p = ws.ecv + (pb ^ 1) * ecv_stride;
+    const int* rp_p = ws.rp + (pb ^ 1) * (FN + 4);
+    float* ot = out + (long)t_prev * N * D;
+    aggregate_rows<true>(ecv_p, rp_p, ws.b, N, D, lane, [&](int r, int c4, f32x4 v) {
+      stv4(ot + r * D + c4 * 4, v);
+    });
+  }
+  PROBE_FLUSH(blockIdx.x * wpb + wave)
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-// dFW tile row stride in the backward: ODD, so that both MFMA operand patterns read it with
-// conflict-free ds_read_b32 (lanes along a column for dX's A operand, lanes along a row for dW's B
-// operand) and no A-fragment registers are needed.
-constexpr int BLD = 65;
-
+template <bool FULL>
 __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
     const int* __restrict__ rowptr_t, const int2* __restrict__ cv_t, const float* __restrict__ x,
     const float* __restrict__ w, const float* __restrict__ g, float* __restrict__ dx,
-    float* __restrict__ part_dw, float* __restrict__ part_db, int T, int N, int din, int dout,
+    float* __restrict__ part_dw, float* __restrict__ part_db, int T, int N_, int din_, int dout_,
     int max_nnz) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int N = FULL ? FN : N_;
+  const int din = FULL ? FD : din_;
+  const int dout = FULL ? FD : dout_;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, hi = lane >> 5;
   const int wpb = blockDim.x >> 6;
   float* Wt = reinterpret_cast<float*>(smem);  // [FD][FD]: Wt[k][j] = W[j][k] (zero padded)
-  WaveSlice ws = carve(smem + FD * FD * 4, wave, max_nnz);
+  WaveSlice ws = carve(smem + FD * FD * 4, wave, max_nnz, A_BWD, 1);
 
   for (int i = tid; i < FD * FD; i += blockDim.x) {
     const int k = i >> 6, j = i & 63;
     Wt[i] = (j < din && k < dout) ? w[(long)j * dout + k] : 0.f;
   }
-  for (int i = lane; i < FN * ALD; i += 64) ws.a[i] = 0.f;
+  for (int i = lane; i < A_BWD; i += 64) ws.a[i] = 0.f;
   for (int i = lane; i < (FN + 1) * FD; i += 64) ws.b[i] = 0.f;
   __syncthreads();
 
@@ -290,64 +567,54 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
 
   if (t < T) {
     // ---- prologue: g, CSR(A^T) and x of the first graph in flight ------------------------------
-    InFlight fg;       // g tile + CSR entries
-    f32x4 fx[8];       // x tile
+    TileRegs fg, fx;
+    CsrRegs fc;
     int rp_cur = rowptr_t[(long)t * N + lrp];
     int base = __builtin_amdgcn_readlane(rp_cur, 0);
     int cnt = __builtin_amdgcn_readlane(rp_cur, N) - base;
-    issue_tile(fg, g + (long)t * N * dout, ng4, lane);
-    issue_cv(fg, cv_t, base, cnt, lane);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int i = lane + q * 64;
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      fx[q] = (i < nx4) ? ldv4(x + (long)t * N * din + (long)i * 4) : z;
-    }
+    issue_tile<FULL>(fg, g + (long)t * N * dout, ng4, lane);
+    issue_cv(fc, cv_t, base, cnt, lane);
+    issue_tile<FULL>(fx, x + (long)t * N * din, nx4, lane);
     int tn = t + nwaves;
-    int rp_nxt = (tn < T) ? rowptr_t[(long)tn * N + lrp] : 0;
+    int rp_nxt = rowptr_t[(long)(tn < T ? tn : t) * N + lrp];
 
+    PROBE_DECL
     for (;;) {
+      PROBE(0)
       // ---- 1. g[t], CSR(A^T) slice: registers -> LDS ------------------------------------------
-      land(fg, ws.b, FD, ng4, dout4, ws, cv_t, rp_cur, base, cnt, N, lane);
+      land_tile<FULL>(fg, ws.b, FD, ng4, dout4, lane);
+      land_csr(fc, ws.ecv, ws.rp, cv_t, rp_cur, base, cnt, N, lane);
       wave_sync();
+      PROBE(1)
 
       // ---- 2. dFW = A^T @ g -> dFW tile (odd stride), dbias partial ----------------------------
-      aggregate_rows(ws, ws.b, FD, N, dout, lane, [&](int r, int cl, f32x4 acc) {
+      aggregate_rows<FULL>(ws.ecv, ws.rp, ws.b, N, dout, lane, [&](int r, int cl, f32x4 acc) {
         float* d = ws.a + r * BLD + cl * 4;
         d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2]; d[3] = acc[3];
         dbacc += acc;
       });
       wave_sync();
+      PROBE(2)
 
       // ---- 3. x[t] -> gather tile (g is dead) --------------------------------------------------
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int i = lane + q * 64;
-        if (i < nx4) {
-          const int r = i / din4, c4 = i - r * din4;
-          *reinterpret_cast<f32x4*>(ws.b + r * FD + c4 * 4) = fx[q];
-        }
-      }
+      land_tile<FULL>(fx, ws.b, FD, nx4, din4, lane);
 
       // ---- 4. next graph (g, CSR, x) in flight during the whole MFMA phase ---------------------
+      // (branch-free, see the forward kernel)
       const bool has_next = tn < T;
-      int base_n = 0, cnt_n = 0;
-      if (has_next) {
-        base_n = __builtin_amdgcn_readlane(rp_nxt, 0);
-        cnt_n = __builtin_amdgcn_readlane(rp_nxt, N) - base_n;
-        issue_tile(fg, g + (long)tn * N * dout, ng4, lane);
-        issue_cv(fg, cv_t, base_n, cnt_n, lane);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int i = lane + q * 64;
-          f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          fx[q] = (i < nx4) ? ldv4(x + (long)tn * N * din + (long)i * 4) : z;
-        }
-        rp_cur = rp_nxt;
+      const int tp = has_next ? tn : t;
+      const int base_n = __builtin_amdgcn_readlane(rp_nxt, 0);
+      const int cnt_n = __builtin_amdgcn_readlane(rp_nxt, N) - base_n;
+      issue_tile<FULL>(fg, g + (long)tp * N * dout, ng4, lane);
+      issue_cv(fc, cv_t, base_n, cnt_n, lane);
+      issue_tile<FULL>(fx, x + (long)tp * N * din, nx4, lane);
+      rp_cur = rp_nxt;
+      {
         const int tnn = tn + nwaves;
-        rp_nxt = (tnn < T) ? rowptr_t[(long)tnn * N + lrp] : 0;
+        rp_nxt = rowptr_t[(long)(tnn < T ? tnn : tp) * N + lrp];
       }
       wave_sync();
+      PROBE(3)
 
       // ---- 5. dW += x^T @ dFW --------------------------------------------------------------------
 #pragma unroll 2
@@ -360,6 +627,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
         dw10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f0, dw10, 0, 0, 0);
         dw11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f1, dw11, 0, 0, 0);
       }
+      PROBE(4)
 
       // ---- 6. dX = dFW @ W^T (A operand straight from the odd-stride LDS tile) ------------------
       if (dx) {
@@ -373,17 +641,26 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
           c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Wt[k * FD + li], c0, 0, 0, 0);
           c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Wt[k * FD + 32 + li], c1, 0, 0, 0);
         }
+        // C layout -> LDS (the x tile is dead) -> whole rows as dwordx4 (1 KiB per instruction)
+        wave_sync();
+        store_c_tiles(ws.b, c0, c1, li, hi);
+        wave_sync();
         float* dxt = dx + (long)t * N * din;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (row < N) {
-            if (li < din) dxt[(long)row * din + li] = c0[r];
-            if (32 + li < din) dxt[(long)row * din + 32 + li] = c1[r];
+        for (int q = 0; q < 8; ++q) {
+          const int i = lane + q * 64;
+          if constexpr (FULL) {
+            stv4(dxt + (long)i * 4, ldv4(ws.b + i * 4));
+          } else {
+            if (i < nx4) {
+              const int r = i / din4, c4 = i - r * din4;
+              stv4(dxt + (long)i * 4, ldv4(ws.b + r * FD + c4 * 4));
+            }
           }
         }
       }
       wave_sync();
+      PROBE(5)
 
       if (!has_next) break;
       t = tn;
@@ -391,12 +668,14 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
       base = base_n;
       cnt = cnt_n;
     }
+    PROBE_FLUSH(blockIdx.x * wpb + wave)
   }
 
   // ---- reduce the workgroup's waves through LDS; one partial per workgroup leaves the chip -----
   // every wave parks its 64x64 dW tile (C layout -> row major) + dbias in its own slice
   __syncthreads();
-  float* park = ws.a;  // a (8704 B) and b (8448 B) are contiguous: 4096 + 64 floats fit
+  float* park = ws.a;  // dFW tile (8320 B) and gather tile (8448 B) are contiguous: 4160 floats fit
+  static_assert(((A_BWD * 4 + 15) & ~15) + (FN + 1) * FD * 4 >= (FD * FD + FD) * 4, "park area");
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -413,9 +692,9 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
     v += __shfl_xor(v, 32, 64);
     dbacc[j] = v;
   }
-  if (lane < 16) *reinterpret_cast<f32x4*>(park + FD * FD + lane * 4) = dbacc;
+  if (lane < 16) stv4(park + FD * FD + lane * 4, dbacc);
   __syncthreads();
-  const size_t slice_f = slice_bytes(max_nnz) / 4;
+  const size_t slice_f = slice_bytes(max_nnz, A_BWD, 1) / 4;
   const float* slice0 = reinterpret_cast<const float*>(smem + FD * FD * 4);
   float* pw = part_dw + (long)blockIdx.x * din * dout;
   for (int i = tid; i < FD * FD; i += blockDim.x) {
@@ -432,9 +711,8 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
 }
 
 // waves per block that fit the LDS budget (0 = does not fit at all)
-static int fused_wpb(int max_nnz, size_t shared_bytes) {
-  const size_t per = slice_bytes(max_nnz);
-  long fit = ((long)kLdsBytes - (long)shared_bytes) / (long)per;
+static int fused_wpb(size_t per_wave, size_t shared_bytes) {
+  long fit = ((long)kLdsBytes - (long)shared_bytes) / (long)per_wave;
   if (fit > MAX_WPB) fit = MAX_WPB;
   return fit < 1 ? 0 : (int)fit;
 }
@@ -445,46 +723,84 @@ static int fused_grid(int T, int wpb) {
   return blocks < 1 ? 1 : blocks;
 }
 
+static bool is_full(int n, int din, int dout) { return n == FN && din == FD && dout == FD; }
+
+// LDS per wave of the forward / backward kernel for a (row-padded) batch
+static size_t fwd_slice(int n, int din, int dout, int max_nnz) {
+  return slice_bytes(max_nnz, A_FWD, is_full(n, din, dout) ? 2 : 1);
+}
+static size_t bwd_slice(int max_nnz) { return slice_bytes(max_nnz, A_BWD, 1); }
+
 static bool fused_shape_ok(int n, int din, int dout, int max_nnz) {
   if (n <= 0 || n > FN) return false;
   if (din <= 0 || din > FD || (din & 3)) return false;
   if (dout <= 0 || dout > FD || (dout & 3)) return false;
-  if (max_nnz < 0) return false;
-  return fused_wpb(max_nnz, FD * FD * 4) >= 4;
+  if (max_nnz < 0 || (max_nnz & 3)) return false;
+  return fused_wpb(fwd_slice(n, din, dout, max_nnz), 0) >= 4 &&
+         fused_wpb(bwd_slice(max_nnz), FD * FD * 4) >= 4;
+}
+
+template <typename K>
+static void allow_big_lds(K kernel) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+}
+
+static int check_padded(const kgcn_csr_batch* a, const char* who) {
+  if (int rc = validate_csr(a, who, true)) return rc;
+  if (a->row_pad != 4)
+    return fail("%s: the fused kernels read the row-padded layout (row_pad = 4), got row_pad=%d", who,
+                a->row_pad);
+  if (a->rows != a->cols) return fail("%s: adjacency must be square", who);
+  return 0;
 }
 
 }  // namespace kgcn
 
 using namespace kgcn;
 
+#ifdef KGCN_PROBE
+extern "C" int kgcn_probe_set(void* buf) {
+  long long* p = static_cast<long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_probe), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 extern "C" int kgcn_graphconv_fused_supported(int32_t n_nodes, int32_t din, int32_t dout,
                                               int32_t max_nnz_per_graph) {
-  return fused_shape_ok(n_nodes, din, dout, max_nnz_per_graph) ? 1 : 0;
+  // max_nnz_per_graph of the ROW-PADDED batch (a multiple of 4); rounded up here for convenience
+  return fused_shape_ok(n_nodes, din, dout, (max_nnz_per_graph + 3) & ~3) ? 1 : 0;
 }
 
 extern "C" int kgcn_graphconv_fwd_f32(const kgcn_csr_batch* a, const float* x, const float* w,
                                       const float* bias, int32_t din, int32_t dout, float* out,
                                       void* stream) {
-  if (int rc = validate_csr(a, "kgcn_graphconv_fwd_f32")) return rc;
-  if (a->rows != a->cols) return fail("kgcn_graphconv_fwd_f32: adjacency must be square");
+  if (int rc = check_padded(a, "kgcn_graphconv_fwd_f32")) return rc;
   if (!fused_shape_ok(a->rows, din, dout, a->max_nnz_per_graph))
     return fail("kgcn_graphconv_fwd_f32: shape N=%d din=%d dout=%d max_nnz=%d not supported by the "
                 "fused kernel (use kgcn_dense_fwd_f32 + kgcn_bconv_f32)",
                 a->rows, din, dout, a->max_nnz_per_graph);
   if (a->num_graphs == 0) return 0;
   if (!x || !w || !out) return fail("kgcn_graphconv_fwd_f32: NULL operand");
-  if (!aligned16(x) || !aligned16(out)) return fail("kgcn_graphconv_fwd_f32: x/out not 16-byte aligned");
-  const int wpb = fused_wpb(a->max_nnz_per_graph, 0);
-  const size_t lds = (size_t)wpb * slice_bytes(a->max_nnz_per_graph);
+  if (!aligned16(x) || !aligned16(out) || !aligned16(a->cv))
+    return fail("kgcn_graphconv_fwd_f32: x/out/cv not 16-byte aligned");
+  const size_t per = fwd_slice(a->rows, din, dout, a->max_nnz_per_graph);
+  const int wpb = fused_wpb(per, 0);
+  const size_t lds = (size_t)wpb * per;
   static thread_local bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(graphconv_fwd_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    allow_big_lds(graphconv_fwd_full_kernel);
+    allow_big_lds(graphconv_fwd_kernel);
     attr_set = true;
   }
-  hipLaunchKernelGGL(graphconv_fwd_kernel, dim3(fused_grid(a->num_graphs, wpb)), dim3(64 * wpb),
-                     lds, as_stream(stream), a->rowptr, reinterpret_cast<const int2*>(a->cv), x, w,
-                     bias, out, a->num_graphs, a->rows, din, dout, a->max_nnz_per_graph);
+  const dim3 grid(fused_grid(a->num_graphs, wpb)), block(64 * wpb);
+  const int2* cv = reinterpret_cast<const int2*>(a->cv);
+  if (is_full(a->rows, din, dout))
+    hipLaunchKernelGGL(graphconv_fwd_full_kernel, grid, block, lds, as_stream(stream), a->rowptr, cv,
+                       x, w, bias, out, a->num_graphs, a->max_nnz_per_graph);
+  else
+    hipLaunchKernelGGL(graphconv_fwd_kernel, grid, block, lds, as_stream(stream), a->rowptr, cv, x,
+                       w, bias, out, a->num_graphs, a->rows, din, dout, a->max_nnz_per_graph);
   return check_launch("graphconv_fwd_kernel");
 }
 
@@ -499,8 +815,7 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
                                       const float* dout_grad, int32_t din, int32_t dout, float* dx,
                                       float* dw, float* dbias, void* workspace,
                                       int64_t workspace_bytes, void* stream) {
-  if (int rc = validate_csr(at, "kgcn_graphconv_bwd_f32")) return rc;
-  if (at->rows != at->cols) return fail("kgcn_graphconv_bwd_f32: adjacency must be square");
+  if (int rc = check_padded(at, "kgcn_graphconv_bwd_f32")) return rc;
   if (!fused_shape_ok(at->rows, din, dout, at->max_nnz_per_graph))
     return fail("kgcn_graphconv_bwd_f32: shape N=%d din=%d dout=%d max_nnz=%d not supported by the "
                 "fused kernel", at->rows, din, dout, at->max_nnz_per_graph);
@@ -512,9 +827,10 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
     return 0;
   }
   if (!x || !w || !dout_grad) return fail("kgcn_graphconv_bwd_f32: NULL operand");
-  if (!aligned16(x) || !aligned16(dout_grad) || (dx && !aligned16(dx)))
+  if (!aligned16(x) || !aligned16(dout_grad) || (dx && !aligned16(dx)) || !aligned16(at->cv))
     return fail("kgcn_graphconv_bwd_f32: tensors not 16-byte aligned");
-  const int wpb = fused_wpb(at->max_nnz_per_graph, FD * FD * 4);
+  const size_t per = bwd_slice(at->max_nnz_per_graph);
+  const int wpb = fused_wpb(per, FD * FD * 4);
   const int blocks = fused_grid(at->num_graphs, wpb);
   const int64_t need = (int64_t)blocks * ((int64_t)din * dout + dout) * 4;
   if (!workspace || workspace_bytes < need)
@@ -522,16 +838,22 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
                 (long long)need);
   float* part_dw = static_cast<float*>(workspace);
   float* part_db = part_dw + (long)blocks * din * dout;
-  const size_t lds = FD * FD * 4 + (size_t)wpb * slice_bytes(at->max_nnz_per_graph);
+  const size_t lds = FD * FD * 4 + (size_t)wpb * per;
   static thread_local bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(graphconv_bwd_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    allow_big_lds(graphconv_bwd_kernel<true>);
+    allow_big_lds(graphconv_bwd_kernel<false>);
     attr_set = true;
   }
-  hipLaunchKernelGGL(graphconv_bwd_kernel, dim3(blocks), dim3(64 * wpb), lds, s, at->rowptr,
-                     reinterpret_cast<const int2*>(at->cv), x, w, dout_grad, dx, part_dw, part_db,
-                     at->num_graphs, at->rows, din, dout, at->max_nnz_per_graph);
+  const int2* cv = reinterpret_cast<const int2*>(at->cv);
+  if (is_full(at->rows, din, dout))
+    hipLaunchKernelGGL(graphconv_bwd_kernel<true>, dim3(blocks), dim3(64 * wpb), lds, s, at->rowptr,
+                       cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs, at->rows, din,
+                       dout, at->max_nnz_per_graph);
+  else
+    hipLaunchKernelGGL(graphconv_bwd_kernel<false>, dim3(blocks), dim3(64 * wpb), lds, s,
+                       at->rowptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
+                       at->rows, din, dout, at->max_nnz_per_graph);
   if (int rc = check_launch("graphconv_bwd_kernel")) return rc;
   if (int rc = launch_reduce_partials(part_dw, blocks, (long)din * dout, dw, s)) return rc;
   return launch_reduce_partials(part_db, blocks, dout, dbias, s);

@@ -24,8 +24,11 @@ inline int check_launch(const char* what) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-inline int validate_csr(const kgcn_csr_batch* a, const char* who) {
+inline int validate_csr(const kgcn_csr_batch* a, const char* who, bool allow_row_pad = false) {
   if (!a) return fail("%s: csr descriptor is NULL", who);
+  if (a->row_pad != 0 && !(allow_row_pad && a->row_pad == 4))
+    return fail("%s: row_pad=%d batches are only accepted by the fused GraphConv kernels", who,
+                a->row_pad);
   if (a->num_graphs < 0 || a->rows < 0 || a->cols < 0 || a->nnz < 0)
     return fail("%s: negative size in csr descriptor (T=%d M=%d K=%d nnz=%lld)", who,
                 a->num_graphs, a->rows, a->cols, (long long)a->nnz);

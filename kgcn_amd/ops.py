@@ -176,8 +176,12 @@ def dense(x2d, w, bias=None):
 # fused GraphConv (one channel)
 # -------------------------------------------------------------------------------------------------
 def graphconv_fused_supported(csr, din, dout):
-    return bool(lib.kgcn_graphconv_fused_supported(csr.rows, din, dout, csr.max_nnz)) and \
-        csr.rows == csr.cols
+    """Shape test of the fused kernels; they read the row-padded layout (BatchedCSR.padded4()),
+    whose per-graph entry count is bounded by max_nnz + 4 * rows."""
+    if csr.rows != csr.cols or csr.rows > BatchedCSR.PAD_COL:
+        return False
+    bound = csr._p4.max_nnz if csr._p4 is not None else csr.max_nnz + 4 * csr.rows
+    return bool(lib.kgcn_graphconv_fused_supported(csr.rows, din, dout, bound))
 
 
 class _GraphConvFused(torch.autograd.Function):
@@ -188,8 +192,8 @@ class _GraphConvFused(torch.autograd.Function):
         dout = w.shape[1]
         b = _f32c(bias, "bias").reshape(-1)
         out = torch.empty((T, N, dout), device=x.device, dtype=torch.float32)
-        check(lib.kgcn_graphconv_fwd_f32(csr.desc(), ptr(x), ptr(w), ptr(b), din, dout, ptr(out),
-                                         current_stream()), "kgcn_graphconv_fwd_f32")
+        check(lib.kgcn_graphconv_fwd_f32(csr.padded4().desc(), ptr(x), ptr(w), ptr(b), din, dout,
+                                         ptr(out), current_stream()), "kgcn_graphconv_fwd_f32")
         ctx.csr = csr
         ctx.bias_shape = tuple(bias.shape)
         ctx.save_for_backward(x, w)
@@ -206,9 +210,9 @@ class _GraphConvFused(torch.autograd.Function):
         db = torch.empty((dout,), device=x.device, dtype=torch.float32)
         wsb = lib.kgcn_graphconv_bwd_workspace_bytes(T, din, dout)
         wsp = torch.empty((max(wsb, 4) // 4,), device=x.device, dtype=torch.float32)
-        check(lib.kgcn_graphconv_bwd_f32(ctx.csr.transpose().desc(), ptr(x), ptr(w), ptr(g), din,
-                                         dout, ptr(dx), ptr(dw), ptr(db), ptr(wsp), wsb,
-                                         current_stream()), "kgcn_graphconv_bwd_f32")
+        check(lib.kgcn_graphconv_bwd_f32(ctx.csr.transpose().padded4().desc(), ptr(x), ptr(w),
+                                         ptr(g), din, dout, ptr(dx), ptr(dw), ptr(db), ptr(wsp),
+                                         wsb, current_stream()), "kgcn_graphconv_bwd_f32")
         return dx, dw, db.reshape(ctx.bias_shape), None
 
 

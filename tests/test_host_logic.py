@@ -74,6 +74,27 @@ def test_pack_unsorted_duplicates_and_validation():
         BatchedAdjacency([])
 
 
+def test_row_padded_layout_for_fused_kernels():
+    z = load_golden("g3_synthetic_feed_b30.npz")
+    adjs = unflatten_adjs(z, "adj_")
+    csr = BatchedCSR.from_coo_list([a[0] for a in adjs], device="cpu")
+    p4 = csr.padded4()
+    assert p4.row_pad == 4 and p4.padded4() is p4 and csr.padded4() is p4
+    rp, rp4 = csr.rowptr.numpy(), p4.rowptr.numpy()
+    cnt, cnt4 = np.diff(rp), np.diff(rp4)
+    assert np.all(cnt4 % 4 == 0) and np.all(cnt4 >= 4) and np.all(cnt4 >= cnt) and np.all(cnt4 - cnt < 8)
+    cv, cv4 = csr.cv.numpy(), p4.cv.numpy()
+    for row in range(300):
+        real = cv4[rp4[row]:rp4[row] + cnt[row]]
+        pad = cv4[rp4[row] + cnt[row]:rp4[row + 1]]
+        assert np.array_equal(real, cv[rp[row]:rp[row + 1]])
+        assert np.all(pad[:, 0] == BatchedCSR.PAD_COL) and np.all(pad[:, 1] == 0)
+    assert p4.max_nnz == int((rp4[10::10] - rp4[:-1:10]).max())
+    assert p4.desc().row_pad == 4 and csr.desc().row_pad == 0
+    with pytest.raises(ValueError):
+        BatchedCSR.from_coo_list([(np.array([[0, 40]]), np.array([1.0]), [50, 50])], device="cpu").padded4()
+
+
 def test_block_diagonal_pack_matches_scipy():
     rng = np.random.default_rng(0)
     a = sp.random(300, 300, density=0.02, random_state=1, format="coo", dtype=np.float32)
