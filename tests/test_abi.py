@@ -53,7 +53,7 @@ def test_shape_queries_and_validation():
     assert lib.kgcn_graphconv_fused_supported(50, 64, 64, 160) == 0      # N > 32
     assert lib.kgcn_graphconv_fused_supported(32, 128, 64, 100) == 0
     assert lib.kgcn_dense_wgrad_workspace_bytes(3_200_000, 64, 64) > 0
-    assert lib.kgcn_graphconv_bwd_workspace_bytes(100_000, 64, 64) >= 2048 * (64 * 64 + 64) * 4
+    assert lib.kgcn_graphconv_bwd_workspace_bytes(100_000, 64, 64) >= 256 * (64 * 64 + 64) * 4   # one partial per CU
     assert lib.kgcn_dot_workspace_bytes(10) > 0
     # validation happens before any launch: NULL descriptor / bad sizes -> status + message
     rc = lib.kgcn_bspmm_f32(None, None, 0, 0, 4, None, 0, 0, 0.0, None)
