@@ -60,6 +60,13 @@ typedef struct kgcn_csr_batch {
   int64_t nnz;               /* total stored entries (including padding entries) */
   const int32_t* rowptr;     /* device, [T*M + 1], absolute offsets into cv (in entries) */
   const int32_t* cv;         /* device, [2*nnz], interleaved (local col, fp32 value bits) */
+  /* row_pad == 4 only (NULL otherwise): */
+  const int32_t* slots;      /* device, [T*M]: per graph its M rows ordered by DEcreasing entry count,
+                                slot = (offset of the row's first entry inside the graph) |
+                                (entry count << 16) | (row index << 24).  A 4-row aggregation pass
+                                reads 4 consecutive slots, so rows longer than 4 entries share the
+                                first pass(es) and the others never branch */
+  const int32_t* graph_ptr;  /* device, [T + 1]: graph_ptr[t] = rowptr[t*M] */
 } kgcn_csr_batch;
 
 /* -- library info ------------------------------------------------------------------------ */

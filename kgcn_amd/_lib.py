@@ -27,6 +27,8 @@ class CsrBatch(ctypes.Structure):
         ("nnz", c_i64),
         ("rowptr", ctypes.c_void_p),
         ("cv", ctypes.c_void_p),
+        ("slots", ctypes.c_void_p),
+        ("graph_ptr", ctypes.c_void_p),
     ]
 
 

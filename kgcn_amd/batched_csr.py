@@ -55,6 +55,8 @@ class BatchedCSR:
         self._vals = None
         self.row_pad = int(row_pad)     # 0 plain CSR, 4 = rows padded to multiples of 4 entries
         self._p4 = None
+        self.slots = None               # row_pad == 4: int32 [T*M] slot table (see include/kgcn_hip.h)
+        self.graph_ptr = None           # row_pad == 4: int32 [T+1]
 
     # ---- construction -------------------------------------------------------------------------
     @classmethod
@@ -178,10 +180,25 @@ class BatchedCSR:
                 cv4[pos, 1] = v.view(np.int32)
             per_graph = rp4[M::M] - rp4[:-1:M] if (T and M) else np.zeros(0, np.int64)
             max_nnz = int(per_graph.max()) if per_graph.size else 0
+            if max_nnz >= 65536 or (padded.size and padded.max() > 252):
+                raise ValueError("graph too dense for the packed slot table of the fused kernels")
+            # slot table: per graph, rows by decreasing (padded) length, stable
+            gptr = rp4[::M] if M else np.zeros(T + 1, np.int64)
+            if T and M:
+                plen = padded.reshape(T, M)
+                order = np.argsort(-plen, axis=1, kind="stable")                 # [T, M] row ids
+                start = (rp4[:-1].reshape(T, M) - gptr[:-1, None])               # local offsets
+                so = np.take_along_axis(start, order, 1)
+                lo = np.take_along_axis(plen, order, 1)
+                slots = (so | (lo << 16) | (order << 24)).astype(np.uint32).view(np.int32).reshape(-1)
+            else:
+                slots = np.zeros(0, np.int32)
             dev = self.rowptr.device
             self._p4 = BatchedCSR(torch.from_numpy(rp4.astype(np.int32)).to(dev),
                                   torch.from_numpy(cv4).to(dev), T, M, self.cols, max_nnz,
                                   row_pad=4)
+            self._p4.slots = torch.from_numpy(np.ascontiguousarray(slots)).to(dev)
+            self._p4.graph_ptr = torch.from_numpy(gptr.astype(np.int32)).to(dev)
         return self._p4
 
     def with_values(self, values):
@@ -209,7 +226,9 @@ class BatchedCSR:
         if self._desc is None:
             self._desc = _lib.CsrBatch(self.num_graphs, self.rows, self.cols, self.max_nnz,
                                        self.row_pad, 0, self.nnz, self.rowptr.data_ptr(),
-                                       self.cv.data_ptr() if self.nnz else 0)
+                                       self.cv.data_ptr() if self.nnz else 0,
+                                       self.slots.data_ptr() if self.slots is not None else 0,
+                                       self.graph_ptr.data_ptr() if self.graph_ptr is not None else 0)
         return self._desc
 
     def algorithmic_bytes(self):

@@ -144,14 +144,35 @@ __device__ __forceinline__ void land_tile(const TileRegs& f, float* tile, int ld
   }
 }
 
-__device__ __forceinline__ void land_csr(const CsrRegs& f, int2* ecv, int* rp,
-                                         const int2* __restrict__ cv, int rp_val, int base, int cnt,
+__device__ __forceinline__ void land_csr(const CsrRegs& f, int2* ecv, int* tab,
+                                         const int2* __restrict__ cv, int slot_val, int base, int cnt,
                                          int N, int lane) {
   i32x4* dst = reinterpret_cast<i32x4*>(ecv);
   if (2 * lane < cnt) dst[lane] = f.e0;
   if (128 + 2 * lane < cnt) dst[64 + lane] = f.e1;
   for (int i = 256 + lane; i < cnt; i += 64) ecv[i] = cv[base + i];  // rare: > 256 entries
-  if (lane <= N) rp[lane] = rp_val - base;
+  if (lane < N) tab[lane] = slot_val;   // slot table of the graph (offsets are graph-local already)
+}
+
+// Per-graph metadata in flight: lane l < N holds slots[t*N + l]; `gp` holds graph_ptr[t + (l & 1)]
+// (lane 0: first entry of the graph, lane 1: one past its last entry).
+struct MetaRegs { int slot, gp; };
+__device__ __forceinline__ void issue_meta(MetaRegs& m, const int* __restrict__ slots,
+                                           const int* __restrict__ gptr, int t, int N, int lane) {
+  m.slot = slots[(long)t * N + (lane < N ? lane : N - 1)];
+  m.gp = gptr[t + (lane & 1)];
+}
+__device__ __forceinline__ int meta_base(const MetaRegs& m) { return __builtin_amdgcn_readlane(m.gp, 0); }
+__device__ __forceinline__ int meta_cnt(const MetaRegs& m) {
+  return __builtin_amdgcn_readlane(m.gp, 1) - __builtin_amdgcn_readlane(m.gp, 0);
+}
+
+// slot = (offset of the row's first entry inside the graph) | (entry count << 16) | (row << 24)
+__device__ __forceinline__ void unpack_slot(int v, int& s, int& len, int& row) {
+  const unsigned u = (unsigned)v;
+  s = (int)(u & 0xffffu);
+  len = (int)((u >> 16) & 0xffu);
+  row = (int)(u >> 24);
 }
 
 // Gather of the four entries k..k+3 of one CSR row (k is a multiple of 4 in the row-padded layout):
@@ -171,37 +192,18 @@ __device__ __forceinline__ f32x4 gather4(const int2* ecv, const float* srcl, int
   return a0 + a1;
 }
 
-// One aggregation "group" = passes 2h and 2h+1 (rows 8h + sub and 8h + 4 + sub) of a 32-row graph:
-// straight-line code (2 x 6 LDS reads in flight), then a rarely taken wave-uniform tail for rows
-// with more than 4 entries (degree + self loop > 4), then emit(row, column group, value).
-template <typename Emit>
-__device__ __forceinline__ void aggregate_group(const int2* ecv, const int* rp, const float* srcl,
-                                                int h, int sub, int cl, Emit&& emit) {
-  const int r0 = 8 * h + sub, r1 = r0 + 4;
-  const int s0 = rp[r0], e0 = rp[r0 + 1];
-  const int s1 = rp[r1], e1 = rp[r1 + 1];
-  f32x4 a0 = gather4(ecv, srcl, s0);
-  f32x4 a1 = gather4(ecv, srcl, s1);
-  if (__builtin_amdgcn_ballot_w64((s0 + 4 < e0) | (s1 + 4 < e1))) {
-    for (int k = s0 + 4; __builtin_amdgcn_ballot_w64(k < e0); k += 4)
-      if (k < e0) a0 += gather4(ecv, srcl, k);
-    for (int k = s1 + 4; __builtin_amdgcn_ballot_w64(k < e1); k += 4)
-      if (k < e1) a1 += gather4(ecv, srcl, k);
-  }
-  emit(r0, cl, a0);
-  emit(r1, cl, a1);
-}
-
-// One aggregation pass (4 rows: r = 4p + sub) cut into micro-steps, so that the forward kernel can
-// place one step behind every MFMA pair of the dense contraction (the compiler keeps MFMAs in one
-// clump otherwise, and an in-order wave cannot overlap a clump with what follows it):
-//   rp() -> ecv() -> tile() -> fma() -> [tail()] -> a ready
+// One aggregation pass (4 slots j = 4p + sub of the graph's slot table, i.e. 4 rows) cut into
+// micro-steps, so that the FULL kernels can place one step behind every MFMA pair of the dense
+// contraction (the compiler keeps MFMAs in one clump otherwise, and an in-order wave cannot overlap
+// a clump with what follows it):   slot() -> ecv() -> tile() -> fma() -> [tail()] -> a / row ready.
+// Rows are ordered by decreasing length in the slot table, so tail() (rows with more than 4
+// entries) fires only in the first pass or two of a graph.
 struct PassSteps {
-  int s, e;
+  int s, len, row;
   i32x4 q0, q1;
   f32x4 x0, x1, x2, x3;
   f32x4 a;
-  __device__ __forceinline__ void rp(const int* rp_, int r) { s = rp_[r]; e = rp_[r + 1]; }
+  __device__ __forceinline__ void slot(const int* tab, int j) { unpack_slot(tab[j], s, len, row); }
   __device__ __forceinline__ void ecv(const int2* ecv_) {
     q0 = *reinterpret_cast<const i32x4*>(ecv_ + s);
     q1 = *reinterpret_cast<const i32x4*>(ecv_ + s + 2);
@@ -216,38 +218,84 @@ struct PassSteps {
     a = u + v;
   }
   __device__ __forceinline__ void tail(const int2* ecv_, const float* srcl) {
-    if (__builtin_amdgcn_ballot_w64(s + 4 < e)) {   // rows with > 4 entries: rare for molecules
-      for (int k = s + 4; __builtin_amdgcn_ballot_w64(k < e); k += 4)
-        if (k < e) a += gather4(ecv_, srcl, k);
+    if (__builtin_amdgcn_ballot_w64(len > 4)) {
+      for (int k = 4; __builtin_amdgcn_ballot_w64(k < len); k += 4)
+        if (k < len) a += gather4(ecv_, srcl, s + k);
     }
   }
 };
 
-// Sparse aggregation of one graph out of the gather tile ws.b (row stride FD): lane (sub, cl)
-// produces the float4 [4cl, 4cl+4) of rows r = 4p + sub.  emit(r, cl, acc) receives every row once.
+// Micro-step m (0..31) of one graph's aggregation for the MFMA-interleaved kernels.  Two passes are
+// in flight, skewed by one step, so that every LDS-dependent step comes two steps (>= 2 MFMA pairs,
+// >= 256 cycles) after its producer -- with dependent steps only one MFMA apart the in-order wave
+// stalls on every s_waitcnt:
+//   w = m % 8:   0: emit(A) A.slot   1: emit(B) B.slot   2: A.ecv   3: B.ecv
+//                4: A.tile           5: B.tile           6: A.fma   7: B.fma
+// A handles passes 0,2,4,6 (slots 8*pp + sub), B passes 1,3,5,7 (slots 8*pp + 4 + sub).
+// agg_tail(m, ...) must follow outside the sched_barrier'ed region (rare branch); after step 31,
+// emit(A) and emit(B) once more.
+template <typename Emit>
+__device__ __forceinline__ void agg_step(int m, PassSteps& A, PassSteps& B, const int* tab,
+                                         const int2* ecv, const float* srcl, int sub, Emit&& emit) {
+  const int pp = m >> 3, w = m & 7;
+  if (w == 0) {
+    if (pp > 0) emit(A);
+    A.slot(tab, 8 * pp + sub);
+  } else if (w == 1) {
+    if (pp > 0) emit(B);
+    B.slot(tab, 8 * pp + 4 + sub);
+  } else if (w == 2) {
+    A.ecv(ecv);
+  } else if (w == 3) {
+    B.ecv(ecv);
+  } else if (w == 4) {
+    A.tile(srcl);
+  } else if (w == 5) {
+    B.tile(srcl);
+  } else if (w == 6) {
+    A.fma();
+  } else {
+    B.fma();
+  }
+}
+__device__ __forceinline__ void agg_tail(int m, PassSteps& A, PassSteps& B, const int2* ecv,
+                                         const float* srcl) {
+  if ((m & 7) == 6) A.tail(ecv, srcl);
+  if ((m & 7) == 7) B.tail(ecv, srcl);
+}
+
+// Sparse aggregation of one graph out of a gather tile (row stride FD) without MFMA overlap: lane
+// (sub, cl) produces the float4 [4cl, 4cl+4) of the rows of slots j = 4p + sub.
+// emit(row, cl, acc) receives every row exactly once.
 template <bool FULL, typename Emit>
-__device__ __forceinline__ void aggregate_rows(const int2* ecv, const int* rp, const float* tile,
+__device__ __forceinline__ void aggregate_rows(const int2* ecv, const int* tab, const float* tile,
                                                int N, int dcols, int lane, Emit&& emit) {
   const int sub = lane >> 4, cl = lane & 15;
   const float* srcl = tile + cl * 4;
   if constexpr (FULL) {
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      aggregate_group(ecv, rp, srcl, h, sub, cl, emit);
+    for (int p8 = 0; p8 < 8; ++p8) {
+      PassSteps ps;
+      ps.slot(tab, 4 * p8 + sub);
+      ps.ecv(ecv);
+      ps.tile(srcl);
+      ps.fma();
+      ps.tail(ecv, srcl);
+      emit(ps.row, cl, ps.a);
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {
     const bool col_ok = cl * 4 < dcols;
-    for (int r0 = 0; r0 < N; r0 += 4) {
-      const int r = r0 + sub;
-      const bool ok = (r < N) && col_ok;
-      const int rr = ok ? r : 0;
-      const int s = rp[rr];
-      const int e = ok ? rp[rr + 1] : s;
+    for (int j0 = 0; j0 < N; j0 += 4) {
+      const int j = j0 + sub;
+      const bool ok = (j < N) && col_ok;
+      int s_, len, row;
+      unpack_slot(tab[ok ? j : 0], s_, len, row);
+      if (!ok) len = 0;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int k = s; __builtin_amdgcn_ballot_w64(k < e); k += 4)
-        if (k < e) acc += gather4(ecv, srcl, k);
-      if (ok) emit(r, cl, acc);
+      for (int k = 0; __builtin_amdgcn_ballot_w64(k < len); k += 4)
+        if (k < len) acc += gather4(ecv, srcl, s_ + k);
+      if (ok) emit(row, cl, acc);
     }
   }
 }
@@ -289,9 +337,9 @@ __device__ __forceinline__ void store_c_tiles(float* tile, const f32x16& c0, con
 
 // Generic shapes (N <= 32, din/dout <= 64 multiples of 4): prefetch + phase-sequential per graph.
 __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
-    const int* __restrict__ rowptr, const int2* __restrict__ cv, const float* __restrict__ x,
-    const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out, int T,
-    int N, int din, int dout, int max_nnz) {
+    const int* __restrict__ slots, const int* __restrict__ gptr, const int2* __restrict__ cv,
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, int T, int N, int din, int dout, int max_nnz) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -314,24 +362,23 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
 
   const int din4 = din >> 2;
   const int n4 = N * din4;
-  const int lrp = lane < N ? lane : N;
 
   TileRegs fx;
   CsrRegs fc;
-  int rp_cur = rowptr[(long)t * N + lrp];
-  int base = __builtin_amdgcn_readlane(rp_cur, 0);
-  int cnt = __builtin_amdgcn_readlane(rp_cur, N) - base;
+  MetaRegs m_cur, m_nxt;
+  issue_meta(m_cur, slots, gptr, t, N, lane);
+  int base = meta_base(m_cur), cnt = meta_cnt(m_cur);
   issue_tile<false>(fx, x + (long)t * N * din, n4, lane);
   issue_cv(fc, cv, base, cnt, lane);
   int tn = t + nwaves;
   // unconditional (index clamped): a conditional load becomes a phi whose copy forces
   // s_waitcnt vmcnt(0) right behind the prefetch
-  int rp_nxt = rowptr[(long)(tn < T ? tn : t) * N + lrp];
+  issue_meta(m_nxt, slots, gptr, tn < T ? tn : t, N, lane);
   wave_sync();
 
   for (;;) {
     land_tile<false>(fx, ws.a, ALD, n4, din4, lane);
-    land_csr(fc, ws.ecv, ws.rp, cv, rp_cur, base, cnt, N, lane);
+    land_csr(fc, ws.ecv, ws.rp, cv, m_cur.slot, base, cnt, N, lane);
     wave_sync();
 
     // next graph in flight while this one is computed.  Branch-free on purpose: values defined
@@ -339,14 +386,13 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
     // prefetch right after issuing it; on the last iteration the current graph is re-read (L2 hit).
     const bool has_next = tn < T;
     const int tp = has_next ? tn : t;
-    const int base_n = __builtin_amdgcn_readlane(rp_nxt, 0);
-    const int cnt_n = __builtin_amdgcn_readlane(rp_nxt, N) - base_n;
+    const int base_n = meta_base(m_nxt), cnt_n = meta_cnt(m_nxt);
     issue_tile<false>(fx, x + (long)tp * N * din, n4, lane);
     issue_cv(fc, cv, base_n, cnt_n, lane);
-    rp_cur = rp_nxt;
+    m_cur = m_nxt;
     {
       const int tnn = tn + nwaves;
-      rp_nxt = rowptr[(long)(tnn < T ? tnn : tp) * N + lrp];
+      issue_meta(m_nxt, slots, gptr, tnn < T ? tnn : tp, N, lane);
     }
 
     f32x16 acc0, acc1;
@@ -382,14 +428,14 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
 
 // FULL shape (N = 32, din = dout = 64), software pipelined inside the wave: while the matrix cores
 // run FW(t) = x[t] @ W + b (64 MFMAs = 4096 cycles), the SAME instruction stream aggregates graph
-// t - nwaves out of the gather tile and stores it; FW(t) then replaces the tile.  Each of the four
-// aggregation groups shares a basic block with 16 MFMAs so the scheduler fills the MFMA shadows
-// with the gather's LDS/VALU work -- the SIMD is issue bound otherwise (phase probe: 4.1k MFMA
-// cycles + 8k aggregation cycles per graph when run back to back).  CSR slices are double buffered.
+// t - nwaves out of the gather tile and stores it; FW(t) then replaces the tile.  Every aggregation
+// pass is cut into micro-steps pinned behind MFMA pairs (sched_barrier) -- the SIMD is issue bound
+// otherwise (phase probe: 4.1k MFMA cycles + 8k aggregation cycles per graph when run back to
+// back).  CSR slices are double buffered.
 __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
-    const int* __restrict__ rowptr, const int2* __restrict__ cv, const float* __restrict__ x,
-    const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out, int T,
-    int max_nnz) {
+    const int* __restrict__ slots, const int* __restrict__ gptr, const int2* __restrict__ cv,
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, int T, int max_nnz) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int N = FN, D = FD;
   const int tid = threadIdx.x;
@@ -410,19 +456,18 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
   load_w_frags<true>(wr0, wr1, w, D, D, li, hi);
   const float b0 = bias ? bias[li] : 0.f;
   const float b1 = bias ? bias[32 + li] : 0.f;
-  const int lrp = lane < N ? lane : N;
   const float* srcl = ws.b + cl * 4;
 
   // ---- prologue ------------------------------------------------------------------------------
   TileRegs fx;
   CsrRegs fc;
-  int rp_cur = rowptr[(long)t * N + lrp];
-  int base = __builtin_amdgcn_readlane(rp_cur, 0);
-  int cnt = __builtin_amdgcn_readlane(rp_cur, N) - base;
+  MetaRegs m_cur, m_nxt;
+  issue_meta(m_cur, slots, gptr, t, N, lane);
+  int base = meta_base(m_cur), cnt = meta_cnt(m_cur);
   issue_tile<true>(fx, x + (long)t * N * D, 512, lane);
   issue_cv(fc, cv, base, cnt, lane);
   int tn = t + nwaves;
-  int rp_nxt = rowptr[(long)(tn < T ? tn : t) * N + lrp];
+  issue_meta(m_nxt, slots, gptr, tn < T ? tn : t, N, lane);
   wave_sync();
 
   // One pipeline step: land graph t (registers -> LDS), put graph t+nwaves in flight, run FW(t)
@@ -436,13 +481,13 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
     constexpr bool AGG = decltype(agg_tag)::value;
     PROBE(0)
     int2* ecv_t = ws.ecv + pb * ecv_stride;
-    int* rp_t = ws.rp + pb * (FN + 4);
+    int* tab_t = ws.rp + pb * (FN + 4);
     const int2* ecv_p = ws.ecv + (pb ^ 1) * ecv_stride;
-    const int* rp_p = ws.rp + (pb ^ 1) * (FN + 4);
+    const int* tab_p = ws.rp + (pb ^ 1) * (FN + 4);
 
     // ---- 1. graph t: registers -> LDS (x tile, CSR slice into buffer pb) -----------------------
     land_tile<true>(fx, ws.a, ALD, 512, 16, lane);
-    land_csr(fc, ecv_t, rp_t, cv, rp_cur, base, cnt, N, lane);
+    land_csr(fc, ecv_t, tab_t, cv, m_cur.slot, base, cnt, N, lane);
     wave_sync();
     PROBE(1)
 
@@ -451,14 +496,13 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
     // right after issuing it; on the last step the current graph is re-read (L2 hit), unused.
     has_next = tn < T;
     const int tp = has_next ? tn : t;
-    const int base_n = __builtin_amdgcn_readlane(rp_nxt, 0);
-    const int cnt_n = __builtin_amdgcn_readlane(rp_nxt, N) - base_n;
+    const int base_n = meta_base(m_nxt), cnt_n = meta_cnt(m_nxt);
     issue_tile<true>(fx, x + (long)tp * N * D, 512, lane);
     issue_cv(fc, cv, base_n, cnt_n, lane);
-    rp_cur = rp_nxt;
+    m_cur = m_nxt;
     {
       const int tnn = tn + nwaves;
-      rp_nxt = rowptr[(long)(tnn < T ? tnn : tp) * N + lrp];
+      issue_meta(m_nxt, slots, gptr, tnn < T ? tnn : tp, N, lane);
     }
     PROBE(2)
 
@@ -467,11 +511,12 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
     float* ot = out + (long)t_prev * N * D;
+    // single pass in flight (the dual, skewed schedule of the backward needs ~28 more VGPRs than
+    // this 2-waves-per-SIMD kernel has: 19 spills, 1.5x slower)
     PassSteps ps;
 #pragma unroll
     for (int p8 = 0; p8 < 8; ++p8) {      // 8 passes x 4 MFMA pairs
       const f32x4 a4 = ldv4(ws.a + li * ALD + hi * 32 + p8 * 4);
-      const int r = 4 * p8 + sub;
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         const int sidx = p8 * 4 + s4;
@@ -480,8 +525,8 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
         if constexpr (AGG) {
           // one micro-step of the previous graph's aggregation in the shadow of this MFMA pair
           if (s4 == 0) {
-            if (p8 > 0) stv4(ot + (r - 4) * D + cl * 4, ps.a);   // previous pass: 1 KiB store
-            ps.rp(rp_p, r);
+            if (p8 > 0) stv4(ot + ps.row * D + cl * 4, ps.a);   // previous pass: 4 rows x 256 B
+            ps.slot(tab_p, 4 * p8 + sub);
           } else if (s4 == 1) {
             ps.ecv(ecv_p);
           } else if (s4 == 2) {
@@ -494,7 +539,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
       }
       if constexpr (AGG) {
         ps.tail(ecv_p, srcl);
-        if (p8 == 7) stv4(ot + r * D + cl * 4, ps.a);
+        if (p8 == 7) stv4(ot + ps.row * D + cl * 4, ps.a);
       }
     }
     PROBE(3)
@@ -517,9 +562,9 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
   // ---- epilogue: aggregate the last graph (CSR buffer pb^1, FW in the gather tile) --------------
   {
     const int2* ecv_p = ws.ecv + (pb ^ 1) * ecv_stride;
-    const int* rp_p = ws.rp + (pb ^ 1) * (FN + 4);
+    const int* tab_p = ws.rp + (pb ^ 1) * (FN + 4);
     float* ot = out + (long)t_prev * N * D;
-    aggregate_rows<true>(ecv_p, rp_p, ws.b, N, D, lane, [&](int r, int c4, f32x4 v) {
+    aggregate_rows<true>(ecv_p, tab_p, ws.b, N, D, lane, [&](int r, int c4, f32x4 v) {
       stv4(ot + r * D + c4 * 4, v);
     });
   }
@@ -527,18 +572,14 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward
+// backward, generic shapes: prefetch + phase-sequential per graph, 2 waves per SIMD
 // ------------------------------------------------------------------------------------------------
-template <bool FULL>
 __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
-    const int* __restrict__ rowptr_t, const int2* __restrict__ cv_t, const float* __restrict__ x,
-    const float* __restrict__ w, const float* __restrict__ g, float* __restrict__ dx,
-    float* __restrict__ part_dw, float* __restrict__ part_db, int T, int N_, int din_, int dout_,
-    int max_nnz) {
+    const int* __restrict__ slots_t, const int* __restrict__ gptr_t, const int2* __restrict__ cv_t,
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ g,
+    float* __restrict__ dx, float* __restrict__ part_dw, float* __restrict__ part_db, int T, int N,
+    int din, int dout, int max_nnz) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int N = FULL ? FN : N_;
-  const int din = FULL ? FD : din_;
-  const int dout = FULL ? FD : dout_;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, hi = lane >> 5;
@@ -562,59 +603,50 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
   const int din4 = din >> 2, dout4 = dout >> 2;
   const int nx4 = N * din4, ng4 = N * dout4;
   const int nwaves = gridDim.x * wpb;
-  const int lrp = lane < N ? lane : N;
   int t = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
 
   if (t < T) {
-    // ---- prologue: g, CSR(A^T) and x of the first graph in flight ------------------------------
     TileRegs fg, fx;
     CsrRegs fc;
-    int rp_cur = rowptr_t[(long)t * N + lrp];
-    int base = __builtin_amdgcn_readlane(rp_cur, 0);
-    int cnt = __builtin_amdgcn_readlane(rp_cur, N) - base;
-    issue_tile<FULL>(fg, g + (long)t * N * dout, ng4, lane);
+    MetaRegs m_cur, m_nxt;
+    issue_meta(m_cur, slots_t, gptr_t, t, N, lane);
+    int base = meta_base(m_cur), cnt = meta_cnt(m_cur);
+    issue_tile<false>(fg, g + (long)t * N * dout, ng4, lane);
     issue_cv(fc, cv_t, base, cnt, lane);
-    issue_tile<FULL>(fx, x + (long)t * N * din, nx4, lane);
+    issue_tile<false>(fx, x + (long)t * N * din, nx4, lane);
     int tn = t + nwaves;
-    int rp_nxt = rowptr_t[(long)(tn < T ? tn : t) * N + lrp];
+    issue_meta(m_nxt, slots_t, gptr_t, tn < T ? tn : t, N, lane);
 
-    PROBE_DECL
     for (;;) {
-      PROBE(0)
       // ---- 1. g[t], CSR(A^T) slice: registers -> LDS ------------------------------------------
-      land_tile<FULL>(fg, ws.b, FD, ng4, dout4, lane);
-      land_csr(fc, ws.ecv, ws.rp, cv_t, rp_cur, base, cnt, N, lane);
+      land_tile<false>(fg, ws.b, FD, ng4, dout4, lane);
+      land_csr(fc, ws.ecv, ws.rp, cv_t, m_cur.slot, base, cnt, N, lane);
       wave_sync();
-      PROBE(1)
 
       // ---- 2. dFW = A^T @ g -> dFW tile (odd stride), dbias partial ----------------------------
-      aggregate_rows<FULL>(ws.ecv, ws.rp, ws.b, N, dout, lane, [&](int r, int cl, f32x4 acc) {
+      aggregate_rows<false>(ws.ecv, ws.rp, ws.b, N, dout, lane, [&](int r, int cl, f32x4 acc) {
         float* d = ws.a + r * BLD + cl * 4;
         d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2]; d[3] = acc[3];
         dbacc += acc;
       });
       wave_sync();
-      PROBE(2)
 
       // ---- 3. x[t] -> gather tile (g is dead) --------------------------------------------------
-      land_tile<FULL>(fx, ws.b, FD, nx4, din4, lane);
+      land_tile<false>(fx, ws.b, FD, nx4, din4, lane);
 
-      // ---- 4. next graph (g, CSR, x) in flight during the whole MFMA phase ---------------------
-      // (branch-free, see the forward kernel)
+      // ---- 4. next graph (g, CSR, x) in flight during the whole MFMA phase (branch-free) --------
       const bool has_next = tn < T;
       const int tp = has_next ? tn : t;
-      const int base_n = __builtin_amdgcn_readlane(rp_nxt, 0);
-      const int cnt_n = __builtin_amdgcn_readlane(rp_nxt, N) - base_n;
-      issue_tile<FULL>(fg, g + (long)tp * N * dout, ng4, lane);
+      const int base_n = meta_base(m_nxt), cnt_n = meta_cnt(m_nxt);
+      issue_tile<false>(fg, g + (long)tp * N * dout, ng4, lane);
       issue_cv(fc, cv_t, base_n, cnt_n, lane);
-      issue_tile<FULL>(fx, x + (long)tp * N * din, nx4, lane);
-      rp_cur = rp_nxt;
+      issue_tile<false>(fx, x + (long)tp * N * din, nx4, lane);
+      m_cur = m_nxt;
       {
         const int tnn = tn + nwaves;
-        rp_nxt = rowptr_t[(long)(tnn < T ? tnn : tp) * N + lrp];
+        issue_meta(m_nxt, slots_t, gptr_t, tnn < T ? tnn : tp, N, lane);
       }
       wave_sync();
-      PROBE(3)
 
       // ---- 5. dW += x^T @ dFW --------------------------------------------------------------------
 #pragma unroll 2
@@ -627,7 +659,6 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
         dw10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f0, dw10, 0, 0, 0);
         dw11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f1, dw11, 0, 0, 0);
       }
-      PROBE(4)
 
       // ---- 6. dX = dFW @ W^T (A operand straight from the odd-stride LDS tile) ------------------
       if (dx) {
@@ -641,7 +672,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
           c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Wt[k * FD + li], c0, 0, 0, 0);
           c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Wt[k * FD + 32 + li], c1, 0, 0, 0);
         }
-        // C layout -> LDS (the x tile is dead) -> whole rows as dwordx4 (1 KiB per instruction)
+        // C layout -> LDS (the x tile is dead) -> whole rows as dwordx4
         wave_sync();
         store_c_tiles(ws.b, c0, c1, li, hi);
         wave_sync();
@@ -649,18 +680,13 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int i = lane + q * 64;
-          if constexpr (FULL) {
-            stv4(dxt + (long)i * 4, ldv4(ws.b + i * 4));
-          } else {
-            if (i < nx4) {
-              const int r = i / din4, c4 = i - r * din4;
-              stv4(dxt + (long)i * 4, ldv4(ws.b + r * FD + c4 * 4));
-            }
+          if (i < nx4) {
+            const int r = i / din4, c4 = i - r * din4;
+            stv4(dxt + (long)i * 4, ldv4(ws.b + r * FD + c4 * 4));
           }
         }
       }
       wave_sync();
-      PROBE(5)
 
       if (!has_next) break;
       t = tn;
@@ -668,11 +694,9 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
       base = base_n;
       cnt = cnt_n;
     }
-    PROBE_FLUSH(blockIdx.x * wpb + wave)
   }
 
   // ---- reduce the workgroup's waves through LDS; one partial per workgroup leaves the chip -----
-  // every wave parks its 64x64 dW tile (C layout -> row major) + dbias in its own slice
   __syncthreads();
   float* park = ws.a;  // dFW tile (8320 B) and gather tile (8448 B) are contiguous: 4160 floats fit
   static_assert(((A_BWD * 4 + 15) & ~15) + (FN + 1) * FD * 4 >= (FD * FD + FD) * 4, "park area");
@@ -684,7 +708,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
     park[(32 + row) * FD + li] = dw10[r];
     park[(32 + row) * FD + 32 + li] = dw11[r];
   }
-  // dbacc: lane (sub, cl) holds the column-4-group cl summed over rows == sub (mod 4)
+  // dbacc: lane (sub, cl) holds the column-4-group cl summed over its rows
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float v = dbacc[j];
@@ -707,6 +731,295 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
     float s = 0.f;
     for (int wv = 0; wv < wpb; ++wv) s += slice0[wv * slice_f + FD * FD + tid];
     part_db[(long)blockIdx.x * dout + tid] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, FULL shape, software pipelined: ONE wave per SIMD (4 waves per CU, up to 512 VGPRs and
+// 36 KB LDS each).  The 128 MFMAs of graph i (dW then dX, 8192 cycles on the SIMD's matrix pipe) are
+// the backbone of the instruction stream; everything else is cut into micro-steps pinned behind
+// MFMA pairs:
+//   phase A (64 MFMAs, dW(i) += x(i)^T dFW(i)):  aggregation of graph i+1 (dFW(i+1) = A^T g(i+1),
+//            32 micro-steps, into the other dFW buffer) and the 32 row stores of dX(i-1);
+//   phase B (64 MFMAs, dX(i) = dFW(i) W^T):      x(i+1), g(i+2), CSR(i+2) registers -> LDS and the
+//            global loads of x(i+2), g(i+3), CSR(i+3) (a full iteration of flight time).
+// MFMA operands are read from LDS one (phase A) / two (phase B) k-steps ahead.
+// LDS per wave: dFW[2] (odd stride), x tile, g tile (+ zero row), CSR[2].
+// ------------------------------------------------------------------------------------------------
+constexpr int BWD_FULL_WPB = 4;
+
+__host__ __device__ inline size_t bwd_full_slice_bytes(int max_nnz) {
+  return 2 * (((size_t)A_BWD * 4 + 15) & ~(size_t)15) + (size_t)FN * FD * 4 + (size_t)(FN + 1) * FD * 4 +
+         2 * (ecv_bytes(max_nnz) + RP_BYTES);
+}
+
+__global__ __launch_bounds__(256, 1) void graphconv_bwd_full_kernel(
+    const int* __restrict__ slots_t, const int* __restrict__ gptr_t, const int2* __restrict__ cv_t,
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ g,
+    float* __restrict__ dx, float* __restrict__ part_dw, float* __restrict__ part_db, int T,
+    int max_nnz) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int N = FN, D = FD;
+  constexpr size_t DFW_B = ((size_t)A_BWD * 4 + 15) & ~(size_t)15;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, hi = lane >> 5;
+  const int sub = lane >> 4, cl = lane & 15;
+  float* Wt = reinterpret_cast<float*>(smem);  // [D][D]: Wt[k][j] = W[j][k]
+  unsigned char* sl = smem + D * D * 4 + (size_t)wave * bwd_full_slice_bytes(max_nnz);
+  float* dfw0 = reinterpret_cast<float*>(sl);
+  float* dfw1 = reinterpret_cast<float*>(sl + DFW_B);
+  float* xt = reinterpret_cast<float*>(sl + 2 * DFW_B);
+  float* gt = xt + FN * FD;                                   // [FN+1][FD], row FN stays zero
+  int2* ecv0 = reinterpret_cast<int2*>(gt + (FN + 1) * FD);
+  const size_t ecv_stride = ecv_bytes(max_nnz) / 8;
+  int* tab0 = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(ecv0) + 2 * ecv_bytes(max_nnz));
+
+  for (int i = tid; i < D * D; i += blockDim.x) Wt[i] = w[(i & 63) * D + (i >> 6)];
+  for (int i = lane; i < D; i += 64) gt[FN * FD + i] = 0.f;
+  __syncthreads();
+
+  f32x16 dw00, dw01, dw10, dw11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dw00[r] = 0.f; dw01[r] = 0.f; dw10[r] = 0.f; dw11[r] = 0.f; }
+  f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
+
+  const int nwaves = gridDim.x * BWD_FULL_WPB;
+  const int t0 = __builtin_amdgcn_readfirstlane(blockIdx.x * BWD_FULL_WPB + wave);
+  if (t0 < T) {
+    const int cntw = (T - 1 - t0) / nwaves + 1;              // graphs of this wave
+    const int tl = t0 + (cntw - 1) * nwaves;                  // its last graph
+    auto gidx = [&](int k) { const int t = t0 + k * nwaves; return t < tl ? t : tl; };  // clamped
+    const float* srcl = gt + cl * 4;
+
+    TileRegs gpf, xpf;
+    CsrRegs cpf;
+    MetaRegs m_a, m_b;   // m_a: graph whose g/CSR are in flight; m_b: the one after it
+    // ---- prologue: graph 0 aggregated without overlap; the pipeline state of iteration 0 -------
+    issue_meta(m_a, slots_t, gptr_t, gidx(0), N, lane);
+    int base_a = meta_base(m_a), cnt_a = meta_cnt(m_a);
+    issue_tile<true>(gpf, g + (long)gidx(0) * N * D, 512, lane);
+    issue_cv(cpf, cv_t, base_a, cnt_a, lane);
+    issue_tile<true>(xpf, x + (long)gidx(0) * N * D, 512, lane);
+    issue_meta(m_b, slots_t, gptr_t, gidx(1), N, lane);
+    land_tile<true>(gpf, gt, FD, 512, 16, lane);
+    land_csr(cpf, ecv0, tab0, cv_t, m_a.slot, base_a, cnt_a, N, lane);
+    wave_sync();
+    // g(1), CSR(1) in flight
+    m_a = m_b;
+    base_a = meta_base(m_a);
+    cnt_a = meta_cnt(m_a);
+    issue_tile<true>(gpf, g + (long)gidx(1) * N * D, 512, lane);
+    issue_cv(cpf, cv_t, base_a, cnt_a, lane);
+    issue_meta(m_b, slots_t, gptr_t, gidx(2), N, lane);
+    aggregate_rows<true>(ecv0, tab0, gt, N, D, lane, [&](int r, int c4, f32x4 acc) {
+      float* d = dfw0 + r * BLD + c4 * 4;
+      d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2]; d[3] = acc[3];
+      dbacc += acc;
+    });
+    wave_sync();
+    // x(0) -> xt, x(1) in flight; g(1), CSR(1) -> LDS (buffer 1); g(2), CSR(2) in flight
+    land_tile<true>(xpf, xt, FD, 512, 16, lane);
+    issue_tile<true>(xpf, x + (long)gidx(1) * N * D, 512, lane);
+    land_tile<true>(gpf, gt, FD, 512, 16, lane);
+    land_csr(cpf, ecv0 + ecv_stride, tab0 + (FN + 4), cv_t, m_a.slot, base_a, cnt_a, N, lane);
+    m_a = m_b;
+    base_a = meta_base(m_a);
+    cnt_a = meta_cnt(m_a);
+    issue_tile<true>(gpf, g + (long)gidx(2) * N * D, 512, lane);
+    issue_cv(cpf, cv_t, base_a, cnt_a, lane);
+    issue_meta(m_b, slots_t, gptr_t, gidx(3), N, lane);
+    wave_sync();
+
+    f32x16 c0, c1;   // dX accumulators of the previous graph, stored during the next phase A
+    int cur = 0;     // dFW / CSR buffer of the MFMA graph i; the aggregated graph i+1 uses cur^1
+
+    // ---- phase A: dW(i) MFMAs  ||  aggregation of graph i+1  ||  stores of dX(i-1) ---------------
+    auto phase_a = [&](auto agg_tag, auto st_tag, int i) __attribute__((always_inline)) {
+      constexpr bool AGG = decltype(agg_tag)::value, ST = decltype(st_tag)::value;
+      const float* dfc = cur ? dfw1 : dfw0;
+      float* dfn = cur ? dfw0 : dfw1;
+      const int2* ecv_n = ecv0 + (cur ^ 1) * ecv_stride;
+      const int* tab_n = tab0 + (cur ^ 1) * (FN + 4);
+      float* dxp = dx + (long)gidx(i - 1) * N * D;
+      PassSteps qa, qb;
+      auto emit = [&](const PassSteps& q) {   // finished pass -> dFW(i+1) tile (odd stride), dbias
+        float* d = dfn + q.row * BLD + cl * 4;
+        d[0] = q.a[0]; d[1] = q.a[1]; d[2] = q.a[2]; d[3] = q.a[3];
+        dbacc += q.a;
+      };
+      // MFMA operands are read one k-step ahead (the order of everything below is pinned by
+      // sched_barriers, so the compiler cannot hoist these LDS reads itself)
+      float a0n = xt[(hi * 16) * FD + li], a1n = xt[(hi * 16) * FD + 32 + li];
+      float f0n = dfc[(hi * 16) * BLD + li], f1n = dfc[(hi * 16) * BLD + 32 + li];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {          // k-step: node n = hi*16 + s
+        const float a0 = a0n, a1 = a1n, f0 = f0n, f1 = f1n;
+        if (s < 15) {
+          const int n1 = hi * 16 + s + 1;
+          a0n = xt[n1 * FD + li]; a1n = xt[n1 * FD + 32 + li];
+          f0n = dfc[n1 * BLD + li]; f1n = dfc[n1 * BLD + 32 + li];
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {         // two MFMA pairs per k-step, one micro-step each
+          if (m == 0) {
+            dw00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, f0, dw00, 0, 0, 0);
+            dw01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, f1, dw01, 0, 0, 0);
+          } else {
+            dw10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f0, dw10, 0, 0, 0);
+            dw11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f1, dw11, 0, 0, 0);
+          }
+          const int step = 2 * s + m;         // 0..31
+          if constexpr (AGG) agg_step(step, qa, qb, tab_n, ecv_n, srcl, sub, emit);
+          if constexpr (ST) {
+            // dX(i-1): rows leave from the C layout, all 32 stores in the first half of the phase so
+            // that they have retired before phase B waits for its prefetched tiles
+            if (step < 16) {
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                const int rr = 2 * (step & 7) + u;          // accumulator register 0..15
+                const int row = (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+                if (step < 8) dxp[row * D + li] = c0[rr];
+                else dxp[row * D + 32 + li] = c1[rr];
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (AGG) agg_tail(step, qa, qb, ecv_n, srcl);
+        }
+      }
+      if constexpr (AGG) {
+        emit(qa);
+        emit(qb);
+      }
+      wave_sync();
+    };
+
+    // ---- phase B: dX(i) MFMAs  ||  x(i+1), g(i+2), CSR(i+2) -> LDS  ||  loads of i+2 / i+3 -------
+    auto phase_b = [&](auto mv_tag, int i) __attribute__((always_inline)) {
+      constexpr bool MV = decltype(mv_tag)::value;
+      const float* dfc = cur ? dfw1 : dfw0;
+      int2* ecv_c = ecv0 + cur * ecv_stride;     // CSR(i) is dead: receives CSR(i+2)
+      int* tab_c = tab0 + cur * (FN + 4);
+      const float* xsrc = x + (long)gidx(i + 2) * N * D;
+      const float* gsrc = g + (long)gidx(i + 3) * N * D;
+      int base_n = 0, cnt_n = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+      // operands two k-steps ahead (a k-step is only one MFMA pair = 128 cycles)
+      float pa[3], pb0[3], pb1[3];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int k = hi * 32 + u;
+        pa[u] = dfc[li * BLD + k]; pb0[u] = Wt[k * FD + li]; pb1[u] = Wt[k * FD + 32 + li];
+      }
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        if (s + 2 < 32) {
+          const int k2 = hi * 32 + s + 2;
+          pa[(s + 2) % 3] = dfc[li * BLD + k2];
+          pb0[(s + 2) % 3] = Wt[k2 * FD + li];
+          pb1[(s + 2) % 3] = Wt[k2 * FD + 32 + li];
+        }
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s % 3], pb0[s % 3], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s % 3], pb1[s % 3], c1, 0, 0, 0);
+        if constexpr (MV) {
+          if (s < 8) {                         // x(i+1): registers -> x tile, then x(i+2) in flight
+            const int idx = lane + s * 64;
+            stv4(xt + idx * 4, xpf.v[s]);
+            xpf.v[s] = ldv4(xsrc + (long)idx * 4);
+          } else if (s < 16) {                 // g(i+2): registers -> gather tile
+            const int q = s - 8, idx = lane + q * 64;
+            stv4(gt + idx * 4, gpf.v[q]);
+          } else if (s == 16) {                // CSR(i+2) -> the buffer graph i used
+            land_csr(cpf, ecv_c, tab_c, cv_t, m_a.slot, base_a, cnt_a, N, lane);
+          } else if (s == 17) {                // metadata of i+3 has landed: CSR(i+3) in flight
+            base_n = meta_base(m_b);
+            cnt_n = meta_cnt(m_b);
+            issue_cv(cpf, cv_t, base_n, cnt_n, lane);
+          } else if (s >= 18 && s < 26) {      // g(i+3) in flight
+            const int q = s - 18, idx = lane + q * 64;
+            gpf.v[q] = ldv4(gsrc + (long)idx * 4);
+          } else if (s == 26) {
+            m_a = m_b;
+            issue_meta(m_b, slots_t, gptr_t, gidx(i + 4), N, lane);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if constexpr (MV) {
+        base_a = base_n;
+        cnt_a = cnt_n;
+      }
+      wave_sync();
+    };
+
+    // iterations: MFMA graph i, aggregated graph i+1
+    PROBE_DECL
+    if (cntw > 1) {
+      phase_a(std::true_type{}, std::false_type{}, 0);
+      phase_b(std::true_type{}, 0);
+      cur ^= 1;
+      PROBE(0)
+      for (int i = 1; i < cntw - 1; ++i) {
+        phase_a(std::true_type{}, std::true_type{}, i);
+        PROBE(1)
+        phase_b(std::true_type{}, i);
+        PROBE(2)
+        cur ^= 1;
+      }
+      // last graph: its dFW is ready, nothing left to aggregate or prefetch
+      phase_a(std::false_type{}, std::true_type{}, cntw - 1);
+      phase_b(std::false_type{}, cntw - 1);
+    } else {
+      phase_a(std::false_type{}, std::false_type{}, 0);
+      phase_b(std::false_type{}, 0);
+    }
+    PROBE_FLUSH(blockIdx.x * BWD_FULL_WPB + wave)
+    {                                           // dX of the last graph
+      float* dxp = dx + (long)tl * N * D;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        dxp[row * D + li] = c0[r];
+        dxp[row * D + 32 + li] = c1[r];
+      }
+    }
+  }
+
+  // ---- reduce the workgroup's 4 waves through LDS; one partial per workgroup ---------------------
+  __syncthreads();
+  float* park = reinterpret_cast<float*>(sl);   // dFW[2] = 16,640 B >= (4096 + 64) floats
+  static_assert(2 * (((size_t)A_BWD * 4 + 15) & ~(size_t)15) >= (FD * FD + FD) * 4, "park area");
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    park[row * FD + li] = dw00[r];
+    park[row * FD + 32 + li] = dw01[r];
+    park[(32 + row) * FD + li] = dw10[r];
+    park[(32 + row) * FD + 32 + li] = dw11[r];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float v = dbacc[j];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    dbacc[j] = v;
+  }
+  if (lane < 16) stv4(park + FD * FD + lane * 4, dbacc);
+  __syncthreads();
+  const size_t slice_f = bwd_full_slice_bytes(max_nnz) / 4;
+  const float* slice0 = reinterpret_cast<const float*>(smem + D * D * 4);
+  float* pw = part_dw + (long)blockIdx.x * D * D;
+  for (int i = tid; i < D * D; i += blockDim.x) {
+    float s = 0.f;
+    for (int wv = 0; wv < BWD_FULL_WPB; ++wv) s += slice0[wv * slice_f + i];
+    pw[i] = s;
+  }
+  if (tid < D) {
+    float s = 0.f;
+    for (int wv = 0; wv < BWD_FULL_WPB; ++wv) s += slice0[wv * slice_f + D * D + tid];
+    part_db[(long)blockIdx.x * D + tid] = s;
   }
 }
 
@@ -751,6 +1064,8 @@ static int check_padded(const kgcn_csr_batch* a, const char* who) {
   if (a->row_pad != 4)
     return fail("%s: the fused kernels read the row-padded layout (row_pad = 4), got row_pad=%d", who,
                 a->row_pad);
+  if (a->num_graphs > 0 && (!a->slots || !a->graph_ptr))
+    return fail("%s: row-padded batch without slots / graph_ptr", who);
   if (a->rows != a->cols) return fail("%s: adjacency must be square", who);
   return 0;
 }
@@ -796,11 +1111,12 @@ extern "C" int kgcn_graphconv_fwd_f32(const kgcn_csr_batch* a, const float* x, c
   const dim3 grid(fused_grid(a->num_graphs, wpb)), block(64 * wpb);
   const int2* cv = reinterpret_cast<const int2*>(a->cv);
   if (is_full(a->rows, din, dout))
-    hipLaunchKernelGGL(graphconv_fwd_full_kernel, grid, block, lds, as_stream(stream), a->rowptr, cv,
-                       x, w, bias, out, a->num_graphs, a->max_nnz_per_graph);
+    hipLaunchKernelGGL(graphconv_fwd_full_kernel, grid, block, lds, as_stream(stream), a->slots,
+                       a->graph_ptr, cv, x, w, bias, out, a->num_graphs, a->max_nnz_per_graph);
   else
-    hipLaunchKernelGGL(graphconv_fwd_kernel, grid, block, lds, as_stream(stream), a->rowptr, cv, x,
-                       w, bias, out, a->num_graphs, a->rows, din, dout, a->max_nnz_per_graph);
+    hipLaunchKernelGGL(graphconv_fwd_kernel, grid, block, lds, as_stream(stream), a->slots,
+                       a->graph_ptr, cv, x, w, bias, out, a->num_graphs, a->rows, din, dout,
+                       a->max_nnz_per_graph);
   return check_launch("graphconv_fwd_kernel");
 }
 
@@ -829,8 +1145,10 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
   if (!x || !w || !dout_grad) return fail("kgcn_graphconv_bwd_f32: NULL operand");
   if (!aligned16(x) || !aligned16(dout_grad) || (dx && !aligned16(dx)) || !aligned16(at->cv))
     return fail("kgcn_graphconv_bwd_f32: tensors not 16-byte aligned");
-  const size_t per = bwd_slice(at->max_nnz_per_graph);
-  const int wpb = fused_wpb(per, FD * FD * 4);
+  const bool full = dx != nullptr && is_full(at->rows, din, dout) &&
+                    FD * FD * 4 + BWD_FULL_WPB * bwd_full_slice_bytes(at->max_nnz_per_graph) <= (size_t)kLdsBytes;
+  const size_t per = full ? bwd_full_slice_bytes(at->max_nnz_per_graph) : bwd_slice(at->max_nnz_per_graph);
+  const int wpb = full ? BWD_FULL_WPB : fused_wpb(per, FD * FD * 4);
   const int blocks = fused_grid(at->num_graphs, wpb);
   const int64_t need = (int64_t)blocks * ((int64_t)din * dout + dout) * 4;
   if (!workspace || workspace_bytes < need)
@@ -841,18 +1159,18 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
   const size_t lds = FD * FD * 4 + (size_t)wpb * per;
   static thread_local bool attr_set = false;
   if (!attr_set) {
-    allow_big_lds(graphconv_bwd_kernel<true>);
-    allow_big_lds(graphconv_bwd_kernel<false>);
+    allow_big_lds(graphconv_bwd_full_kernel);
+    allow_big_lds(graphconv_bwd_kernel);
     attr_set = true;
   }
   const int2* cv = reinterpret_cast<const int2*>(at->cv);
-  if (is_full(at->rows, din, dout))
-    hipLaunchKernelGGL(graphconv_bwd_kernel<true>, dim3(blocks), dim3(64 * wpb), lds, s, at->rowptr,
-                       cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs, at->rows, din,
-                       dout, at->max_nnz_per_graph);
+  if (full)
+    hipLaunchKernelGGL(graphconv_bwd_full_kernel, dim3(blocks), dim3(64 * wpb), lds, s, at->slots,
+                       at->graph_ptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
+                       at->max_nnz_per_graph);
   else
-    hipLaunchKernelGGL(graphconv_bwd_kernel<false>, dim3(blocks), dim3(64 * wpb), lds, s,
-                       at->rowptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
+    hipLaunchKernelGGL(graphconv_bwd_kernel, dim3(blocks), dim3(64 * wpb), lds, s, at->slots,
+                       at->graph_ptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
                        at->rows, din, dout, at->max_nnz_per_graph);
   if (int rc = check_launch("graphconv_bwd_kernel")) return rc;
   if (int rc = launch_reduce_partials(part_dw, blocks, (long)din * dout, dw, s)) return rc;

@@ -58,19 +58,19 @@ def test_shape_queries_and_validation():
     # validation happens before any launch: NULL descriptor / bad sizes -> status + message
     rc = lib.kgcn_bspmm_f32(None, None, 0, 0, 4, None, 0, 0, 0.0, None)
     assert rc != 0 and b"NULL" in lib.kgcn_last_error()
-    d = _lib.CsrBatch(-1, 4, 4, 0, 0, 0, 0, None, None)
+    d = _lib.CsrBatch(-1, 4, 4, 0, 0, 0, 0, None, None, None, None)
     assert lib.kgcn_bspmm_f32(ctypes.byref(d), None, 4, 16, 4, None, 4, 16, 0.0, None) != 0
-    d = _lib.CsrBatch(2, 4, 4, 0, 0, 0, 0, 1, None)                            # fake non-NULL rowptr
+    d = _lib.CsrBatch(2, 4, 4, 0, 0, 0, 0, 1, None, None, None)                            # fake non-NULL rowptr
     assert lib.kgcn_bspmm_f32(ctypes.byref(d), None, 4, 16, 4, None, 4, 16, 0.0, None) != 0
     assert b"NULL" in lib.kgcn_last_error()
     assert lib.kgcn_bspmm_f32(ctypes.byref(d), 16, 2, 16, 4, 16, 4, 16, 0.0, None) != 0   # ld < d
     assert lib.kgcn_bspmm_f32(ctypes.byref(d), 16, 4, 16, 4, 16, 4, 16, 0.5, None) != 0   # beta
-    pd = _lib.CsrBatch(2, 4, 4, 16, 4, 0, 32, 1, 1)                        # row-padded batch
+    pd = _lib.CsrBatch(2, 4, 4, 16, 4, 0, 32, 1, 1, 1, 1)                        # row-padded batch
     assert lib.kgcn_bspmm_f32(ctypes.byref(pd), 16, 4, 16, 4, 16, 4, 16, 0.0, None) != 0
     assert b"row_pad" in lib.kgcn_last_error()                            # plain kernels refuse it
     with pytest.raises(_lib.KgcnHipError):
         _lib.check(lib.kgcn_dense_fwd_f32(None, 10, 0, 0, None, 0, 0, None, None, 4, 4, None), "dense")
-    rc = lib.kgcn_graphconv_fwd_f32(ctypes.byref(_lib.CsrBatch(1, 50, 50, 10, 4, 0, 0, 1, None)), None, None,
+    rc = lib.kgcn_graphconv_fwd_f32(ctypes.byref(_lib.CsrBatch(1, 50, 50, 12, 4, 0, 0, 1, None, 1, 1)), None, None,
                                     None, 64, 64, None, None)
     assert rc != 0 and b"not supported" in lib.kgcn_last_error()
 

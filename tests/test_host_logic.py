@@ -90,6 +90,17 @@ def test_row_padded_layout_for_fused_kernels():
         assert np.array_equal(real, cv[rp[row]:rp[row + 1]])
         assert np.all(pad[:, 0] == BatchedCSR.PAD_COL) and np.all(pad[:, 1] == 0)
     assert p4.max_nnz == int((rp4[10::10] - rp4[:-1:10]).max())
+    # slot table: per graph the rows by decreasing padded length; packed offset | len<<16 | row<<24
+    slots = p4.slots.numpy().view(np.uint32).reshape(30, 10)
+    gptr = p4.graph_ptr.numpy()
+    assert np.array_equal(gptr, rp4[::10])
+    for t in (0, 5, 9, 10, 29):
+        off, ln, row = slots[t] & 0xFFFF, (slots[t] >> 16) & 0xFF, slots[t] >> 24
+        assert sorted(row.tolist()) == list(range(10))
+        assert np.all(np.diff(ln.astype(int)) <= 0)
+        for j in range(10):
+            r = t * 10 + int(row[j])
+            assert int(ln[j]) == cnt4[r] and int(off[j]) == rp4[r] - gptr[t]
     assert p4.desc().row_pad == 4 and csr.desc().row_pad == 0
     with pytest.raises(ValueError):
         BatchedCSR.from_coo_list([(np.array([[0, 40]]), np.array([1.0]), [50, 50])], device="cpu").padded4()

@@ -36,11 +36,12 @@ db = torch.empty(64, device=dev)
 wsb = lib.kgcn_graphconv_bwd_workspace_bytes(T, 64, 64)
 wsp = torch.empty(wsb // 4, device=dev)
 probe = torch.zeros(2048 * 8, dtype=torch.int64, device=dev)
+NW = {'fwd': 2048.0, 'bwd': 1024.0}
 assert lib.kgcn_probe_set(ctypes.c_void_p(probe.data_ptr())) == 0
 s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 names_f = ["loop-top(wait)", "land", "issue-prefetch", "mfma(t) || aggregate(t-1)+store", "FW->LDS"]
-names_b = ["loop-top", "land g", "aggregate(A^T g)", "land x + issue-prefetch", "dW mfma", "dX mfma+store"]
+names_b = ["prologue+iter0", "phase A: dW mfma || aggregate(i+1) || dX(i-1) stores", "phase B: dX mfma || land/issue next tiles"]
 for which in ("fwd", "bwd"):
     for rep in range(3):
         probe.zero_()
@@ -56,7 +57,8 @@ for which in ("fwd", "bwd"):
         torch.cuda.synchronize()
         assert rc == 0
     pr = probe.cpu().numpy().reshape(2048, 8).astype(np.float64)
-    graphs_per_wave = T / 2048.0
+    graphs_per_wave = T / NW[which]
+    pr = pr[:int(NW[which])]
     tot = pr.sum(1).mean() / graphs_per_wave
     print("%s: %.1f us/launch (probe build), per graph per wave: %.0f cycles (s_memtime ticks @100MHz? see ratio)"
           % (which, e0.elapsed_time(e1) * 1e3, tot))
