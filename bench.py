@@ -220,6 +220,13 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
+        traffic_bwd = traffic_fwd = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_cfg2.json")
+        if os.path.exists(tpath) and not args.unfused:
+            tj = json.load(open(tpath))
+            if tj.get("graphs_per_launch") == T:      # PMC-measured HBM bytes of the same launch shape
+                traffic_bwd = tj["graphconv_bwd_full_kernel"]["bytes"]
+                traffic_fwd = tj["graphconv_fwd_full_kernel"]["bytes"]
         fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
         bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
         ab = algorithmic_bytes(N_NODES, FEAT, FEAT, wl["nnz_per_graph"])
@@ -246,12 +253,15 @@ def main():
                        "adjacency_values": "kipf" if args.normalize else "ones"},
             "roofline": {"bound": "hbm",
                          "kernel": "dense_wgrad+bspmm (unfused)" if args.unfused else
-                                   "graphconv_bwd_kernel (+2 reduce_partials launches in the event bracket)",
+                                   "graphconv_bwd_full_kernel (+2 reduce_partials launches, ~10 us, in the event bracket)",
                          "achieved": bwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": bwd_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": bwd_gbs / HBM_PEAK_GBS, "traffic": traffic_bwd,
+                         "traffic_note": "HBM bytes per launch, rocprofv3 PMC (profiles/traffic_cfg2.json); "
+                                         "algorithmic bytes per launch = %d" % int(ab["bwd"] * T),
                          "algorithmic_bytes_per_graph": ab["bwd"], "avg_launch_ms": bwd_ms,
                          "fwd_kernel": {"achieved": fwd_gbs, "frac": fwd_gbs / HBM_PEAK_GBS,
-                                        "algorithmic_bytes_per_graph": ab["fwd"], "avg_launch_ms": fwd_ms},
+                                        "algorithmic_bytes_per_graph": ab["fwd"], "avg_launch_ms": fwd_ms,
+                                        "traffic": traffic_fwd},
                          "layer_frac_of_hbm_peak": ab["layer"] * T / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -67,6 +67,20 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's
 __device__ __forceinline__ f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void stv4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// acc += v * x, component by component as plain v_fma_f32.  Beside f32 MFMAs the packed forms
+// (v_pk_fma_f32 / v_pk_mul_f32, which hipcc forms from float4 arithmetic) cost ~22-26 extra cycles
+// each (MI355X_MICROARCH.md, "price of one filler beside MFMAs"); the file is built with
+// -fno-slp-vectorize so these stay scalar.
+__device__ __forceinline__ void fma4(f32x4& acc, float v, const f32x4& x) {
+  acc[0] = __builtin_fmaf(v, x[0], acc[0]);
+  acc[1] = __builtin_fmaf(v, x[1], acc[1]);
+  acc[2] = __builtin_fmaf(v, x[2], acc[2]);
+  acc[3] = __builtin_fmaf(v, x[3], acc[3]);
+}
+__device__ __forceinline__ void add4(f32x4& acc, const f32x4& x) {
+  acc[0] += x[0]; acc[1] += x[1]; acc[2] += x[2]; acc[3] += x[3];
+}
+
 struct WaveSlice {
   float* a;     // forward: x tile [FN][ALD] (A-fragment source); backward: dFW tile [FN][BLD]
   float* b;     // [FN+1][FD] gather source tile; row FN (= KGCN_PAD_COL) stays zero
@@ -185,11 +199,12 @@ __device__ __forceinline__ f32x4 gather4(const int2* ecv, const float* srcl, int
   const f32x4 x1 = ldv4(srcl + q0.z * FD);
   const f32x4 x2 = ldv4(srcl + q1.x * FD);
   const f32x4 x3 = ldv4(srcl + q1.z * FD);
-  f32x4 a0 = __int_as_float(q0.y) * x0;
-  f32x4 a1 = __int_as_float(q0.w) * x1;
-  a0 += __int_as_float(q1.y) * x2;
-  a1 += __int_as_float(q1.w) * x3;
-  return a0 + a1;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f};
+  fma4(a0, __int_as_float(q0.y), x0);
+  fma4(a0, __int_as_float(q0.w), x1);
+  fma4(a0, __int_as_float(q1.y), x2);
+  fma4(a0, __int_as_float(q1.w), x3);
+  return a0;
 }
 
 // One aggregation pass (4 slots j = 4p + sub of the graph's slot table, i.e. 4 rows) cut into
@@ -213,55 +228,57 @@ struct PassSteps {
     x2 = ldv4(srcl + q1.x * FD); x3 = ldv4(srcl + q1.z * FD);
   }
   __device__ __forceinline__ void fma() {
-    f32x4 u = __int_as_float(q0.y) * x0, v = __int_as_float(q0.w) * x1;
-    u += __int_as_float(q1.y) * x2; v += __int_as_float(q1.w) * x3;
-    a = u + v;
+    a[0] = __int_as_float(q0.y) * x0[0]; a[1] = __int_as_float(q0.y) * x0[1];
+    a[2] = __int_as_float(q0.y) * x0[2]; a[3] = __int_as_float(q0.y) * x0[3];
+    fma4(a, __int_as_float(q0.w), x1);
+    fma4(a, __int_as_float(q1.y), x2);
+    fma4(a, __int_as_float(q1.w), x3);
   }
   __device__ __forceinline__ void tail(const int2* ecv_, const float* srcl) {
     if (__builtin_amdgcn_ballot_w64(len > 4)) {
       for (int k = 4; __builtin_amdgcn_ballot_w64(k < len); k += 4)
-        if (k < len) a += gather4(ecv_, srcl, s + k);
+        if (k < len) add4(a, gather4(ecv_, srcl, s + k));
     }
   }
 };
 
-// Micro-step m (0..31) of one graph's aggregation for the MFMA-interleaved kernels.  Two passes are
-// in flight, skewed by one step, so that every LDS-dependent step comes two steps (>= 2 MFMA pairs,
-// >= 256 cycles) after its producer -- with dependent steps only one MFMA apart the in-order wave
-// stalls on every s_waitcnt:
-//   w = m % 8:   0: emit(A) A.slot   1: emit(B) B.slot   2: A.ecv   3: B.ecv
-//                4: A.tile           5: B.tile           6: A.fma   7: B.fma
-// A handles passes 0,2,4,6 (slots 8*pp + sub), B passes 1,3,5,7 (slots 8*pp + 4 + sub).
-// agg_tail(m, ...) must follow outside the sched_barrier'ed region (rare branch); after step 31,
-// emit(A) and emit(B) once more.
+// Filler schedule of one graph's aggregation for the MFMA-interleaved kernels.  The matrix pipe
+// holds ONE MFMA: the next MFMA of the stream blocks the in-order wave until the pipe frees, so only
+// the instructions placed directly behind an MFMA run in its shadow (64 cycles, ~10 issue slots).
+// Hence one small "half step" behind EVERY MFMA, and LDS-dependent half steps of a pass at least two
+// MFMAs behind their producer.
+//   halves of a pass: 0 emit(previous pass)  1 slot  2 ecv0  3 ecv1  4 tile0  5 tile1  6 fma0  7 fma1
+// Dual schedule (backward, 64 MFMAs per phase): passes A (even) and B (odd) alternate MFMA by MFMA:
+//   j = 0..63: group gq = j>>4 handles slots 8gq+sub (A, even j) and 8gq+4+sub (B, odd j), half (j&15)>>1.
 template <typename Emit>
-__device__ __forceinline__ void agg_step(int m, PassSteps& A, PassSteps& B, const int* tab,
-                                         const int2* ecv, const float* srcl, int sub, Emit&& emit) {
-  const int pp = m >> 3, w = m & 7;
-  if (w == 0) {
-    if (pp > 0) emit(A);
-    A.slot(tab, 8 * pp + sub);
-  } else if (w == 1) {
-    if (pp > 0) emit(B);
-    B.slot(tab, 8 * pp + 4 + sub);
-  } else if (w == 2) {
-    A.ecv(ecv);
-  } else if (w == 3) {
-    B.ecv(ecv);
-  } else if (w == 4) {
-    A.tile(srcl);
-  } else if (w == 5) {
-    B.tile(srcl);
-  } else if (w == 6) {
-    A.fma();
+__device__ __forceinline__ void pass_half(PassSteps& P, int h, bool do_emit, const int* tab, int j,
+                                          const int2* ecv, const float* srcl, Emit&& emit) {
+  if (h == 0) { if (do_emit) emit(P); }
+  else if (h == 1) P.slot(tab, j);
+  else if (h == 2) P.q0 = *reinterpret_cast<const i32x4*>(ecv + P.s);
+  else if (h == 3) P.q1 = *reinterpret_cast<const i32x4*>(ecv + P.s + 2);
+  else if (h == 4) { P.x0 = ldv4(srcl + P.q0.x * FD); P.x1 = ldv4(srcl + P.q0.z * FD); }
+  else if (h == 5) { P.x2 = ldv4(srcl + P.q1.x * FD); P.x3 = ldv4(srcl + P.q1.z * FD); }
+  else if (h == 6) {
+    const float v = __int_as_float(P.q0.y);
+    P.a[0] = v * P.x0[0]; P.a[1] = v * P.x0[1]; P.a[2] = v * P.x0[2]; P.a[3] = v * P.x0[3];
+    fma4(P.a, __int_as_float(P.q0.w), P.x1);
   } else {
-    B.fma();
+    fma4(P.a, __int_as_float(P.q1.y), P.x2);
+    fma4(P.a, __int_as_float(P.q1.w), P.x3);
   }
 }
-__device__ __forceinline__ void agg_tail(int m, PassSteps& A, PassSteps& B, const int2* ecv,
-                                         const float* srcl) {
-  if ((m & 7) == 6) A.tail(ecv, srcl);
-  if ((m & 7) == 7) B.tail(ecv, srcl);
+template <typename Emit>
+__device__ __forceinline__ void agg_dual_half(int j, PassSteps& A, PassSteps& B, const int* tab,
+                                              const int2* ecv, const float* srcl, int sub, Emit&& emit) {
+  const int gq = j >> 4, w = j & 15;
+  if ((w & 1) == 0) pass_half(A, w >> 1, gq > 0, tab, 8 * gq + sub, ecv, srcl, emit);
+  else pass_half(B, w >> 1, gq > 0, tab, 8 * gq + 4 + sub, ecv, srcl, emit);
+}
+__device__ __forceinline__ void agg_dual_tail(int j, PassSteps& A, PassSteps& B, const int2* ecv,
+                                              const float* srcl) {
+  if ((j & 15) == 14) A.tail(ecv, srcl);
+  if ((j & 15) == 15) B.tail(ecv, srcl);
 }
 
 // Sparse aggregation of one graph out of a gather tile (row stride FD) without MFMA overlap: lane
@@ -294,7 +311,7 @@ __device__ __forceinline__ void aggregate_rows(const int2* ecv, const int* tab, 
       if (!ok) len = 0;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       for (int k = 0; __builtin_amdgcn_ballot_w64(k < len); k += 4)
-        if (k < len) acc += gather4(ecv, srcl, s_ + k);
+        if (k < len) add4(acc, gather4(ecv, srcl, s_ + k));
       if (ok) emit(row, cl, acc);
     }
   }
@@ -426,12 +443,10 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
   }
 }
 
-// FULL shape (N = 32, din = dout = 64), software pipelined inside the wave: while the matrix cores
-// run FW(t) = x[t] @ W + b (64 MFMAs = 4096 cycles), the SAME instruction stream aggregates graph
-// t - nwaves out of the gather tile and stores it; FW(t) then replaces the tile.  Every aggregation
-// pass is cut into micro-steps pinned behind MFMA pairs (sched_barrier) -- the SIMD is issue bound
-// otherwise (phase probe: 4.1k MFMA cycles + 8k aggregation cycles per graph when run back to
-// back).  CSR slices are double buffered.
+// FULL shape (N = 32, din = dout = 64): all sizes compile-time, straight-line aggregation, one
+// graph of lag between the contraction and the aggregation (FW(t) is produced while graph
+// t - nwaves is aggregated out of the gather tile; CSR slices double buffered) so that a wave's
+// LDS/global latencies always have independent work queued behind them.
 __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
     const int* __restrict__ slots, const int* __restrict__ gptr, const int2* __restrict__ cv,
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
@@ -441,7 +456,6 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, hi = lane >> 5;
-  const int sub = lane >> 4, cl = lane & 15;
   const int wpb = blockDim.x >> 6;
   WaveSlice ws = carve(smem, wave, max_nnz, A_FWD, 2);
   const size_t ecv_stride = ecv_bytes(max_nnz) / 8;   // int2 elements between the two CSR buffers
@@ -456,7 +470,6 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
   load_w_frags<true>(wr0, wr1, w, D, D, li, hi);
   const float b0 = bias ? bias[li] : 0.f;
   const float b1 = bias ? bias[32 + li] : 0.f;
-  const float* srcl = ws.b + cl * 4;
 
   // ---- prologue ------------------------------------------------------------------------------
   TileRegs fx;
@@ -510,37 +523,26 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
-    float* ot = out + (long)t_prev * N * D;
-    // single pass in flight (the dual, skewed schedule of the backward needs ~28 more VGPRs than
-    // this 2-waves-per-SIMD kernel has: 19 spills, 1.5x slower)
-    PassSteps ps;
+    // The 64 MFMAs stay in ONE cluster: on gfx950 the f32-input MFMA executes on the vector ALU
+    // datapath -- nothing VALU hides behind it (tools/mfma_shadow.hip: 64 cycles alone, 90 with two
+    // v_fma behind it, +4 per further VALU op) and every MFMA<->VALU switch costs ~18 cycles.  The
+    // aggregation of the previous graph follows as one VALU/LDS cluster; the second wave of the SIMD
+    // covers its LDS latency.
 #pragma unroll
-    for (int p8 = 0; p8 < 8; ++p8) {      // 8 passes x 4 MFMA pairs
+    for (int p8 = 0; p8 < 8; ++p8) {
       const f32x4 a4 = ldv4(ws.a + li * ALD + hi * 32 + p8 * 4);
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         const int sidx = p8 * 4 + s4;
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s4], wr0[sidx], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s4], wr1[sidx], acc1, 0, 0, 0);
-        if constexpr (AGG) {
-          // one micro-step of the previous graph's aggregation in the shadow of this MFMA pair
-          if (s4 == 0) {
-            if (p8 > 0) stv4(ot + ps.row * D + cl * 4, ps.a);   // previous pass: 4 rows x 256 B
-            ps.slot(tab_p, 4 * p8 + sub);
-          } else if (s4 == 1) {
-            ps.ecv(ecv_p);
-          } else if (s4 == 2) {
-            ps.tile(srcl);
-          } else {
-            ps.fma();
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
       }
-      if constexpr (AGG) {
-        ps.tail(ecv_p, srcl);
-        if (p8 == 7) stv4(ot + ps.row * D + cl * 4, ps.a);
-      }
+    }
+    if constexpr (AGG) {
+      float* ot = out + (long)t_prev * N * D;
+      aggregate_rows<true>(ecv_p, tab_p, ws.b, N, D, lane, [&](int r, int c4, f32x4 v) {
+        stv4(ot + r * D + c4 * 4, v);
+      });
     }
     PROBE(3)
     // ---- 4. FW(t) replaces the gather tile ------------------------------------------------------
@@ -735,15 +737,15 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward, FULL shape, software pipelined: ONE wave per SIMD (4 waves per CU, up to 512 VGPRs and
-// 36 KB LDS each).  The 128 MFMAs of graph i (dW then dX, 8192 cycles on the SIMD's matrix pipe) are
-// the backbone of the instruction stream; everything else is cut into micro-steps pinned behind
-// MFMA pairs:
-//   phase A (64 MFMAs, dW(i) += x(i)^T dFW(i)):  aggregation of graph i+1 (dFW(i+1) = A^T g(i+1),
-//            32 micro-steps, into the other dFW buffer) and the 32 row stores of dX(i-1);
-//   phase B (64 MFMAs, dX(i) = dFW(i) W^T):      x(i+1), g(i+2), CSR(i+2) registers -> LDS and the
-//            global loads of x(i+2), g(i+3), CSR(i+3) (a full iteration of flight time).
-// MFMA operands are read from LDS one (phase A) / two (phase B) k-steps ahead.
+// backward, FULL shape: ONE wave per SIMD (4 waves per CU, up to 512 VGPRs and 36 KB LDS each), a
+// two-graph-deep software pipeline so that nothing the wave needs is ever in flight when it needs it:
+//   phase A: 64 MFMAs dW(i) += x(i)^T dFW(i), then the aggregation dFW(i+1) = A^T g(i+1) into the
+//            other dFW buffer (two passes in flight, skewed, for LDS latency);
+//   phase B: 64 MFMAs dX(i) = dFW(i) W^T, then the 32 row stores of dX(i-1) (alternating accumulator
+//            sets), x(i+1), g(i+2), CSR(i+2) registers -> LDS and the global loads of x(i+2),
+//            g(i+3), CSR(i+3) (a full iteration of flight time).
+// MFMAs are kept in clusters: the f32-input MFMA shares the VALU datapath on gfx950 (nothing hides
+// behind it, ~18 cycles per MFMA<->VALU switch; tools/mfma_shadow.hip).
 // LDS per wave: dFW[2] (odd stride), x tile, g tile (+ zero row), CSR[2].
 // ------------------------------------------------------------------------------------------------
 constexpr int BWD_FULL_WPB = 4;
@@ -831,122 +833,97 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_full_kernel(
     issue_meta(m_b, slots_t, gptr_t, gidx(3), N, lane);
     wave_sync();
 
-    f32x16 c0, c1;   // dX accumulators of the previous graph, stored during the next phase A
+    // dX accumulators: two sets alternate by graph parity, so that dX(i-1) can leave the chip from
+    // one set (32 row stores spread over phase B) while dX(i) accumulates in the other
+    f32x16 ce0, ce1, co0 = {}, co1 = {};
     int cur = 0;     // dFW / CSR buffer of the MFMA graph i; the aggregated graph i+1 uses cur^1
 
-    // ---- phase A: dW(i) MFMAs  ||  aggregation of graph i+1  ||  stores of dX(i-1) ---------------
-    auto phase_a = [&](auto agg_tag, auto st_tag, int i) __attribute__((always_inline)) {
-      constexpr bool AGG = decltype(agg_tag)::value, ST = decltype(st_tag)::value;
+    // ---- phase A: dW(i) MFMAs  ||  aggregation of graph i+1 (one half step per MFMA) -------------
+    auto phase_a = [&](auto agg_tag) __attribute__((always_inline)) {
+      constexpr bool AGG = decltype(agg_tag)::value;
       const float* dfc = cur ? dfw1 : dfw0;
       float* dfn = cur ? dfw0 : dfw1;
       const int2* ecv_n = ecv0 + (cur ^ 1) * ecv_stride;
       const int* tab_n = tab0 + (cur ^ 1) * (FN + 4);
-      float* dxp = dx + (long)gidx(i - 1) * N * D;
       PassSteps qa, qb;
       auto emit = [&](const PassSteps& q) {   // finished pass -> dFW(i+1) tile (odd stride), dbias
         float* d = dfn + q.row * BLD + cl * 4;
         d[0] = q.a[0]; d[1] = q.a[1]; d[2] = q.a[2]; d[3] = q.a[3];
-        dbacc += q.a;
+        add4(dbacc, q.a);
       };
-      // MFMA operands are read one k-step ahead (the order of everything below is pinned by
-      // sched_barriers, so the compiler cannot hoist these LDS reads itself)
-      float a0n = xt[(hi * 16) * FD + li], a1n = xt[(hi * 16) * FD + 32 + li];
-      float f0n = dfc[(hi * 16) * BLD + li], f1n = dfc[(hi * 16) * BLD + 32 + li];
+      // MFMA cluster first (the f32 MFMA runs on the VALU datapath: nothing hides behind it and
+      // every MFMA<->VALU switch costs ~18 cycles), then the aggregation as one VALU/LDS cluster
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {          // k-step: node n = hi*16 + s
-        const float a0 = a0n, a1 = a1n, f0 = f0n, f1 = f1n;
-        if (s < 15) {
-          const int n1 = hi * 16 + s + 1;
-          a0n = xt[n1 * FD + li]; a1n = xt[n1 * FD + 32 + li];
-          f0n = dfc[n1 * BLD + li]; f1n = dfc[n1 * BLD + 32 + li];
-        }
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {         // two MFMA pairs per k-step, one micro-step each
-          if (m == 0) {
-            dw00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, f0, dw00, 0, 0, 0);
-            dw01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, f1, dw01, 0, 0, 0);
-          } else {
-            dw10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f0, dw10, 0, 0, 0);
-            dw11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f1, dw11, 0, 0, 0);
-          }
-          const int step = 2 * s + m;         // 0..31
-          if constexpr (AGG) agg_step(step, qa, qb, tab_n, ecv_n, srcl, sub, emit);
-          if constexpr (ST) {
-            // dX(i-1): rows leave from the C layout, all 32 stores in the first half of the phase so
-            // that they have retired before phase B waits for its prefetched tiles
-            if (step < 16) {
-#pragma unroll
-              for (int u = 0; u < 2; ++u) {
-                const int rr = 2 * (step & 7) + u;          // accumulator register 0..15
-                const int row = (rr & 3) + 8 * (rr >> 2) + 4 * hi;
-                if (step < 8) dxp[row * D + li] = c0[rr];
-                else dxp[row * D + 32 + li] = c1[rr];
-              }
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if constexpr (AGG) agg_tail(step, qa, qb, ecv_n, srcl);
-        }
+      for (int s = 0; s < 16; ++s) {          // k-step: node n = hi*16 + s, 4 MFMAs
+        const int n = hi * 16 + s;
+        const float a0 = xt[n * FD + li], a1 = xt[n * FD + 32 + li];
+        const float f0 = dfc[n * BLD + li], f1 = dfc[n * BLD + 32 + li];
+        dw00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, f0, dw00, 0, 0, 0);
+        dw01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, f1, dw01, 0, 0, 0);
+        dw10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f0, dw10, 0, 0, 0);
+        dw11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f1, dw11, 0, 0, 0);
       }
+#ifndef KGCN_ABL_NO_AGG
       if constexpr (AGG) {
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {        // two passes in flight, skewed (LDS latency covered)
+          agg_dual_half(j, qa, qb, tab_n, ecv_n, srcl, sub, emit);
+          agg_dual_tail(j, qa, qb, ecv_n, srcl);
+        }
         emit(qa);
         emit(qb);
       }
+#endif
       wave_sync();
     };
 
-    // ---- phase B: dX(i) MFMAs  ||  x(i+1), g(i+2), CSR(i+2) -> LDS  ||  loads of i+2 / i+3 -------
-    auto phase_b = [&](auto mv_tag, int i) __attribute__((always_inline)) {
-      constexpr bool MV = decltype(mv_tag)::value;
+    // ---- phase B: dX(i) MFMAs into set `c`  ||  stores of dX(i-1) from set `p`  ||
+    //      x(i+1), g(i+2), CSR(i+2) -> LDS  ||  loads of x(i+2), g(i+3), CSR(i+3) --------------------
+    auto phase_b = [&](auto mv_tag, auto st_tag, f32x16& c0, f32x16& c1, const f32x16& p0,
+                       const f32x16& p1, int i) __attribute__((always_inline)) {
+      constexpr bool MV = decltype(mv_tag)::value, ST = decltype(st_tag)::value;
       const float* dfc = cur ? dfw1 : dfw0;
       int2* ecv_c = ecv0 + cur * ecv_stride;     // CSR(i) is dead: receives CSR(i+2)
       int* tab_c = tab0 + cur * (FN + 4);
       const float* xsrc = x + (long)gidx(i + 2) * N * D;
       const float* gsrc = g + (long)gidx(i + 3) * N * D;
+      float* dxp = dx + (long)gidx(i - 1) * N * D;
       int base_n = 0, cnt_n = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
-      // operands two k-steps ahead (a k-step is only one MFMA pair = 128 cycles)
-      float pa[3], pb0[3], pb1[3];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int k = hi * 32 + u;
-        pa[u] = dfc[li * BLD + k]; pb0[u] = Wt[k * FD + li]; pb1[u] = Wt[k * FD + 32 + li];
+      for (int s = 0; s < 32; ++s) {           // MFMA cluster
+        const int k = hi * 32 + s;
+        const float a = dfc[li * BLD + k];
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Wt[k * FD + li], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Wt[k * FD + 32 + li], c1, 0, 0, 0);
       }
+#ifndef KGCN_ABL_NO_ST
+      if constexpr (ST) {                      // dX(i-1) leaves from the other accumulator set
 #pragma unroll
-      for (int s = 0; s < 32; ++s) {
-        if (s + 2 < 32) {
-          const int k2 = hi * 32 + s + 2;
-          pa[(s + 2) % 3] = dfc[li * BLD + k2];
-          pb0[(s + 2) % 3] = Wt[k2 * FD + li];
-          pb1[(s + 2) % 3] = Wt[k2 * FD + 32 + li];
-        }
-        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s % 3], pb0[s % 3], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s % 3], pb1[s % 3], c1, 0, 0, 0);
-        if constexpr (MV) {
-          if (s < 8) {                         // x(i+1): registers -> x tile, then x(i+2) in flight
-            const int idx = lane + s * 64;
-            stv4(xt + idx * 4, xpf.v[s]);
-            xpf.v[s] = ldv4(xsrc + (long)idx * 4);
-          } else if (s < 16) {                 // g(i+2): registers -> gather tile
-            const int q = s - 8, idx = lane + q * 64;
-            stv4(gt + idx * 4, gpf.v[q]);
-          } else if (s == 16) {                // CSR(i+2) -> the buffer graph i used
-            land_csr(cpf, ecv_c, tab_c, cv_t, m_a.slot, base_a, cnt_a, N, lane);
-          } else if (s == 17) {                // metadata of i+3 has landed: CSR(i+3) in flight
-            base_n = meta_base(m_b);
-            cnt_n = meta_cnt(m_b);
-            issue_cv(cpf, cv_t, base_n, cnt_n, lane);
-          } else if (s >= 18 && s < 26) {      // g(i+3) in flight
-            const int q = s - 18, idx = lane + q * 64;
-            gpf.v[q] = ldv4(gsrc + (long)idx * 4);
-          } else if (s == 26) {
-            m_a = m_b;
-            issue_meta(m_b, slots_t, gptr_t, gidx(i + 4), N, lane);
-          }
-          __builtin_amdgcn_sched_barrier(0);
+        for (int rr = 0; rr < 16; ++rr) {
+          const int row = (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+          dxp[row * D + li] = p0[rr];
+          dxp[row * D + 32 + li] = p1[rr];
         }
       }
+#endif
+#ifndef KGCN_ABL_NO_MV
+      if constexpr (MV) {
+        // x(i+1): registers -> x tile, x(i+2) in flight; g(i+2), CSR(i+2) -> LDS; g(i+3), CSR(i+3)
+        // in flight (a full iteration of flight time)
+        land_tile<true>(xpf, xt, FD, 512, 16, lane);
+        issue_tile<true>(xpf, xsrc, 512, lane);
+        land_tile<true>(gpf, gt, FD, 512, 16, lane);
+        land_csr(cpf, ecv_c, tab_c, cv_t, m_a.slot, base_a, cnt_a, N, lane);
+        base_n = meta_base(m_b);
+        cnt_n = meta_cnt(m_b);
+        issue_cv(cpf, cv_t, base_n, cnt_n, lane);
+        issue_tile<true>(gpf, gsrc, 512, lane);
+        m_a = m_b;
+        issue_meta(m_b, slots_t, gptr_t, gidx(i + 4), N, lane);
+      }
+#endif
       if constexpr (MV) {
         base_a = base_n;
         cnt_a = cnt_n;
@@ -954,35 +931,51 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_full_kernel(
       wave_sync();
     };
 
-    // iterations: MFMA graph i, aggregated graph i+1
+    // iterations: MFMA graph i (dX into set i&1), aggregated graph i+1, stores of dX(i-1)
+    using Y = std::true_type;
+    using Nn = std::false_type;
     PROBE_DECL
     if (cntw > 1) {
-      phase_a(std::true_type{}, std::false_type{}, 0);
-      phase_b(std::true_type{}, 0);
+      phase_a(Y{});
+      phase_b(Y{}, Nn{}, ce0, ce1, co0, co1, 0);
       cur ^= 1;
       PROBE(0)
-      for (int i = 1; i < cntw - 1; ++i) {
-        phase_a(std::true_type{}, std::true_type{}, i);
+      int i = 1;
+      for (; i + 1 < cntw - 1; i += 2) {       // two graphs per trip: odd set, then even set
+        phase_a(Y{});
         PROBE(1)
-        phase_b(std::true_type{}, i);
+        phase_b(Y{}, Y{}, co0, co1, ce0, ce1, i);
+        PROBE(2)
+        cur ^= 1;
+        phase_a(Y{});
+        PROBE(1)
+        phase_b(Y{}, Y{}, ce0, ce1, co0, co1, i + 1);
         PROBE(2)
         cur ^= 1;
       }
-      // last graph: its dFW is ready, nothing left to aggregate or prefetch
-      phase_a(std::false_type{}, std::true_type{}, cntw - 1);
-      phase_b(std::false_type{}, cntw - 1);
+      if (i < cntw - 1) {                      // one more full iteration (odd set)
+        phase_a(Y{});
+        phase_b(Y{}, Y{}, co0, co1, ce0, ce1, i);
+        cur ^= 1;
+        ++i;
+      }
+      // last graph i = cntw-1: its dFW is ready, nothing left to aggregate or prefetch
+      phase_a(Nn{});
+      if (i & 1) phase_b(Nn{}, Y{}, co0, co1, ce0, ce1, i);
+      else phase_b(Nn{}, Y{}, ce0, ce1, co0, co1, i);
     } else {
-      phase_a(std::false_type{}, std::false_type{}, 0);
-      phase_b(std::false_type{}, 0);
+      phase_a(Nn{});
+      phase_b(Nn{}, Nn{}, ce0, ce1, co0, co1, 0);
     }
     PROBE_FLUSH(blockIdx.x * BWD_FULL_WPB + wave)
-    {                                           // dX of the last graph
+    {                                           // dX of the last graph (set of parity (cntw-1)&1)
       float* dxp = dx + (long)tl * N * D;
+      const bool odd = (cntw - 1) & 1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        dxp[row * D + li] = c0[r];
-        dxp[row * D + 32 + li] = c1[r];
+        dxp[row * D + li] = odd ? co0[r] : ce0[r];
+        dxp[row * D + 32 + li] = odd ? co1[r] : ce1[r];
       }
     }
   }

@@ -15,7 +15,8 @@ sys.path.insert(0, ROOT)
 out = os.path.join(ROOT, "gpurun_out", "libkgcn_probe.so")
 src = [os.path.join(ROOT, "kgcn_amd", "csrc", f) for f in ("misc.hip", "spmm.hip", "dense.hip", "fused.hip")]
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                       "-DKGCN_PROBE", "-o", out] + src)
+                       "-DKGCN_PROBE", "-fno-slp-vectorize", "-o", out] + [a for a in sys.argv[1:] if a.startswith("-D")] + src)
+sys.argv = [a for a in sys.argv if not a.startswith("-D")]
 import kgcn_amd._lib as L
 L.LIB_PATH = out
 lib = ctypes.CDLL(out)
