@@ -1,0 +1,212 @@
+"""Host-side input producers of the hot path, vectorised over the WHOLE dataset.
+
+The reference builds adjacency graph by graph in Python loops (kgcn/data_util.py:40-45 dense ->
+COO, :58-73 powers, :76-122 degree split, :125-140 Kipf normalisation, :396-420 build_data) and
+assembles every mini-batch entry by entry (kgcn/feed.py:112-133).  Here one adjacency channel of
+the whole dataset is four flat arrays (graph, row, col, val) in the reference's stored-entry
+order; every transformation is a handful of numpy array operations over all graphs at once, and a
+mini-batch (including the reference's empty dummy graphs that pad a short batch,
+kgcn/feed.py:123-126) is a slice-gather of those arrays straight into a device BatchedCSR.
+
+Results are pinned bit-exactly against the reference's own outputs for the shipped datasets
+(tests/test_product_loaders.py, fixtures tests/golden/g2*, g3*, g4*).
+"""
+import numpy as np
+import scipy.sparse as sp
+
+from .batched_csr import BatchedAdjacency, BatchedCSR
+
+
+class FlatAdjacency:
+    """One adjacency channel of G graphs: entries sorted by graph, stored order inside a graph."""
+
+    def __init__(self, graph, row, col, val, num_graphs, n_rows, n_cols=None):
+        self.graph = np.asarray(graph, np.int64)
+        self.row = np.asarray(row, np.int32)
+        self.col = np.asarray(col, np.int32)
+        self.val = np.asarray(val, np.float32)
+        self.num_graphs = int(num_graphs)
+        self.n_rows = int(n_rows)
+        self.n_cols = int(n_rows if n_cols is None else n_cols)
+        self.ptr = np.zeros(self.num_graphs + 1, np.int64)
+        np.cumsum(np.bincount(self.graph, minlength=self.num_graphs), out=self.ptr[1:])
+
+    # -- construction -------------------------------------------------------------------------
+    @classmethod
+    def from_dense(cls, dense_adj):
+        """dense [G,N,N] -> COO in row-major order of the non-zeros (kgcn/data_util.py:40-45)."""
+        a = np.asarray(dense_adj)
+        g, r, c = np.nonzero(a)
+        return cls(g, r, c, a[g, r, c].astype(np.float32), a.shape[0], a.shape[1], a.shape[2])
+
+    @classmethod
+    def from_coo_list(cls, mats, n_nodes=None):
+        """mats[g] = (idx [nnz,2], val [nnz], shape) -- the "adj" key of a .jbl file."""
+        gs, rs, cs, vs = [], [], [], []
+        n = 0
+        for g, m in enumerate(mats):
+            idx = np.asarray(m[0]).reshape(-1, 2)
+            gs.append(np.full(idx.shape[0], g, np.int64))
+            rs.append(idx[:, 0])
+            cs.append(idx[:, 1])
+            vs.append(np.asarray(m[1], np.float32).reshape(-1))
+            n = max(n, int(m[2][0]))
+        cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
+        return cls(cat(gs, np.int64), cat(rs, np.int32), cat(cs, np.int32), cat(vs, np.float32),
+                   len(mats), n_nodes if n_nodes is not None else n)
+
+    # -- views ----------------------------------------------------------------------------------
+    def to_list(self, shape=None):
+        """Back to the reference's per-graph layout adjs[g] = (idx int32 [nnz,2], val f32, shape)."""
+        shp = [self.n_rows, self.n_cols] if shape is None else shape
+        idx = np.stack([self.row, self.col], axis=1).astype(np.int32)
+        return [(idx[self.ptr[g]:self.ptr[g + 1]], self.val[self.ptr[g]:self.ptr[g + 1]], shp)
+                for g in range(self.num_graphs)]
+
+    def key(self):
+        return (self.graph * self.n_rows + self.row) * self.n_cols + self.col
+
+    def batch(self, batch_idx, batch_size=None, device="cuda"):
+        """Mini-batch as a device BatchedCSR: graphs `batch_idx` in order, padded with empty graphs
+        up to batch_size (kgcn/feed.py:112-126)."""
+        batch_idx = np.asarray(batch_idx, np.int64)
+        nb = batch_idx.shape[0]
+        T = nb if batch_size is None else int(batch_size)
+        lo, hi = self.ptr[batch_idx], self.ptr[batch_idx + 1]
+        cnt = hi - lo
+        total = int(cnt.sum())
+        # concatenated ranges lo[i]..hi[i]
+        start = np.zeros(nb + 1, np.int64)
+        np.cumsum(cnt, out=start[1:])
+        sel = np.arange(total, dtype=np.int64) - np.repeat(start[:-1], cnt) + np.repeat(lo, cnt)
+        newg = np.repeat(np.arange(nb, dtype=np.int64), cnt)
+        return BatchedCSR.from_arrays(newg, self.row[sel], self.col[sel], self.val[sel], T, self.n_rows,
+                                      self.n_cols, device=device)
+
+
+# -------------------------------------------------------------------------------------------------
+# transformations (whole dataset at once)
+# -------------------------------------------------------------------------------------------------
+def normalize_adj(fa):
+    """Kipf normalisation (kgcn/data_util.py:125-140): binarise positive values, scale by
+    D^-1/2 on both sides with D = COLUMN sums (0 -> 1); float32 arithmetic as the reference's
+    expression evaluates (two multiplications by the float32 reciprocal square root).  Pattern in
+    canonical row-major order with duplicates summed; explicit zeros are kept."""
+    v = fa.val.copy()
+    v[v > 0] = 1
+    key = fa.key()
+    order = np.argsort(key, kind="stable")
+    ks, vs = key[order], v[order]
+    first = np.ones(ks.shape[0], bool)
+    first[1:] = ks[1:] != ks[:-1]
+    seg = np.cumsum(first) - 1
+    vsum = np.zeros(int(first.sum()), np.float32)
+    np.add.at(vsum, seg, vs)
+    ku = ks[first]
+    col = (ku % fa.n_cols).astype(np.int32)
+    gr = ku // fa.n_cols
+    row = (gr % fa.n_rows).astype(np.int32)
+    g = gr // fa.n_rows
+    deg = np.zeros(fa.num_graphs * fa.n_cols, np.float32)
+    np.add.at(deg, g * fa.n_cols + col, vsum)
+    deg[deg == 0] = 1
+    recip = (1.0 / np.sqrt(deg)).astype(np.float32)
+    # A / sqrt(d)[:,None] / sqrt(d): the row factor is indexed by the ROW index into the same
+    # (column-sum) degree vector, exactly like the reference's broadcasting does
+    out = (vsum * recip[g * fa.n_cols + row]) * recip[g * fa.n_cols + col]
+    return FlatAdjacency(g, row, col, out.astype(np.float32), fa.num_graphs, fa.n_rows, fa.n_cols)
+
+
+def split_adj(fa, min_deg=1, max_deg=5):
+    """Degree split (kgcn/data_util.py:76-122): off-diagonal entries go to the channel of their
+    row's entry count (clamped at max_deg), diagonal entries to the last channel.  Every channel
+    of every graph starts with an explicit (0,0)->0.0 entry, dropped only when the channel's
+    first real entry is itself at (0,0)."""
+    nch = (max_deg - min_deg + 1) + 1
+    G, N = fa.num_graphs, fa.n_rows
+    deg = np.bincount(fa.graph * N + fa.row, minlength=G * N)
+    ch = np.minimum(deg[fa.graph * N + fa.row], max_deg) - min_deg
+    ch = np.where(fa.row == fa.col, nch - 1, ch)
+    out = []
+    pos = np.arange(fa.graph.shape[0])
+    for k in range(nch):
+        m = ch == k
+        g, r, c, v, p = fa.graph[m], fa.row[m], fa.col[m], fa.val[m], pos[m]
+        # first real entry of every graph in this channel
+        has = np.zeros(G, bool)
+        has[g] = True
+        firstpos = np.full(G, np.iinfo(np.int64).max)
+        np.minimum.at(firstpos, g, p)
+        first_is_origin = np.zeros(G, bool)
+        sel = has.nonzero()[0]
+        fp = firstpos[sel]
+        first_is_origin[sel] = (fa.row[fp] == 0) & (fa.col[fp] == 0)
+        dummy_g = np.nonzero(~first_is_origin)[0]            # graphs that keep the dummy entry
+        gg = np.concatenate([dummy_g, g])
+        rr = np.concatenate([np.zeros(dummy_g.shape[0], np.int32), r])
+        cc = np.concatenate([np.zeros(dummy_g.shape[0], np.int32), c])
+        vv = np.concatenate([np.zeros(dummy_g.shape[0], np.float32), v])
+        pp = np.concatenate([np.full(dummy_g.shape[0], -1, np.int64), p])   # dummy first
+        order = np.lexsort((pp, gg))
+        out.append(FlatAdjacency(gg[order], rr[order], cc[order], vv[order], G, N, fa.n_cols))
+    return out
+
+
+def high_order_adj(fa, order):
+    """Pattern of A^order with unit values, indices sorted (kgcn/data_util.py:58-73), computed on
+    the block-diagonal matrix of the whole dataset."""
+    if order <= 1:
+        return fa
+    n = fa.num_graphs * fa.n_rows
+    a = sp.csr_matrix((fa.val, (fa.graph * fa.n_rows + fa.row, fa.graph * fa.n_rows + fa.col)), shape=(n, n))
+    b = a
+    for _ in range(order - 1):
+        b = b.dot(a)
+    b = b.tocoo()
+    k = np.sort(b.row.astype(np.int64) * n + b.col)
+    r, c = k // n, k % n
+    return FlatAdjacency(r // fa.n_rows, r % fa.n_rows, c % fa.n_rows, np.ones(k.shape[0], np.float32),
+                         fa.num_graphs, fa.n_rows, fa.n_cols)
+
+
+def build_adjs(data, normalize_adj_flag=False, split_adj_flag=False, order=1):
+    """Dataset dict (.jbl content) -> list of adjacency channels (FlatAdjacency), following
+    build_data (kgcn/data_util.py:396-420): "dense_adj" | "adj" (+ "max_node_num") |
+    "multi_dense_adj"; powers 1..order are separate channels; then split, then normalise.
+    Returns (channels, enabled_node_nums)."""
+    if "multi_dense_adj" in data:
+        mats = data["multi_dense_adj"]
+        nch = len(mats[0])
+        chans = [FlatAdjacency.from_dense(np.stack([np.asarray(m[c]) for m in mats])) for c in range(nch)]
+        enabled = np.array([max(len(x) for x in m) for m in mats], np.int32)
+    else:
+        max_n = int(data["max_node_num"])
+        if "adj" in data:
+            base = FlatAdjacency.from_coo_list(data["adj"], n_nodes=max_n)
+            enabled = np.array([int(m[2][0]) for m in data["adj"]], np.int32)
+        else:
+            dense = np.asarray(data["dense_adj"])
+            base = FlatAdjacency.from_dense(dense)
+            enabled = np.full(dense.shape[0], dense.shape[1], np.int32)
+            base.n_rows = base.n_cols = max_n                # align_size, kgcn/data_util.py:30-37
+        chans = [high_order_adj(base, o) for o in range(1, order + 1)]
+    if split_adj_flag:
+        chans = [c for ch in chans for c in split_adj(ch)]
+    if normalize_adj_flag:
+        chans = [normalize_adj(ch) for ch in chans]
+    return chans, enabled
+
+
+def batch_adjacency(channels, batch_idx, batch_size=None, device="cuda"):
+    """All channels of one mini-batch as a BatchedAdjacency (what GraphConv/GINAggregate take)."""
+    return BatchedAdjacency([c.batch(batch_idx, batch_size, device) for c in channels])
+
+
+def batch_features(features, batch_idx, batch_size=None, device="cuda"):
+    """kgcn/feed.py:127-133: float32 features of the batch, zero rows for the padding graphs."""
+    import torch
+    batch_idx = np.asarray(batch_idx, np.int64)
+    T = batch_idx.shape[0] if batch_size is None else int(batch_size)
+    out = np.zeros((T,) + tuple(features.shape[1:]), np.float32)
+    out[:batch_idx.shape[0]] = features[batch_idx]
+    return torch.from_numpy(out).to(device)

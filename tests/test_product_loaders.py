@@ -1,0 +1,82 @@
+"""The product's vectorised loaders / batch assembly (kgcn_amd/data_util.py) must reproduce, bit
+for bit, the reference's own kgcn/data_util.py + kgcn/feed.py outputs (golden fixtures G2-G4),
+and their batches must equal the containers packed from the reference's per-graph lists."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, unflatten_adjs
+from kgcn_amd import BatchedCSR
+from kgcn_amd import data_util as D
+
+
+def _raw():
+    z = load_golden("g1_synthetic_raw.npz")
+    return {"feature": z["feature"], "dense_adj": z["dense_adj"].astype(np.int64),
+            "max_node_num": int(z["max_node_num"])}
+
+
+def _same(channels, ref):
+    assert len(channels) == len(ref[0])
+    for ch, fa in enumerate(channels):
+        mine = fa.to_list()
+        assert len(mine) == len(ref)
+        for g in range(len(ref)):
+            mi, mv, ms = mine[g]
+            ri, rv, rs = ref[g][ch]
+            assert mi.shape == ri.reshape(-1, 2).shape and np.array_equal(mi, ri.reshape(-1, 2)), (ch, g)
+            assert mv.tobytes() == rv.astype(np.float32).tobytes(), (ch, g, mv, rv)
+            assert [int(a) for a in ms] == [int(a) for a in rs], (ch, g)
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("plain", {}), ("norm", {"normalize_adj_flag": True}), ("split", {"split_adj_flag": True}),
+    ("split_norm", {"split_adj_flag": True, "normalize_adj_flag": True}), ("order2", {"order": 2})])
+def test_build_adjs_matches_reference(tag, kw):
+    z = load_golden("g2_synthetic_adj_%s.npz" % tag)
+    chans, enabled = D.build_adjs(_raw(), **kw)
+    assert len(chans) == int(z["adj_channel_num"])
+    assert np.array_equal(enabled, z["enabled_node_nums"])
+    _same(chans, unflatten_adjs(z))
+
+
+def test_multi_dense_adj_and_sparse_coo_inputs():
+    z = load_golden("g2_sample_multiadj.npz")
+    chans, enabled = D.build_adjs({"multi_dense_adj": list(z["multi_dense_adj"])})
+    assert np.array_equal(enabled, z["enabled_node_nums"])
+    _same(chans, unflatten_adjs(z))
+    z = load_golden("g4_synthetic_sparse_loader.npz")
+    raw_in = unflatten_adjs(z, "in_")
+    chans, enabled = D.build_adjs({"adj": [a[0] for a in raw_in], "max_node_num": int(z["in_max_node_num"])})
+    assert np.array_equal(enabled, z["enabled_node_nums"])
+    _same(chans, unflatten_adjs(z))
+
+
+@pytest.mark.parametrize("name", ["g3_synthetic_feed_b30.npz", "g3_synthetic_feed_full30.npz"])
+def test_batches_match_reference_feed(name):
+    z = load_golden(name)
+    raw = _raw()
+    chans, _ = D.build_adjs(raw)
+    bidx, B = list(z["batch_idx"]), int(z["batch_size"])
+    mine = chans[0].batch(bidx, B, device="cpu")
+    ref = BatchedCSR.from_coo_list([a[0] for a in unflatten_adjs(z, "adj_")], rows=10, cols=10, device="cpu")
+    assert (mine.num_graphs, mine.rows, mine.cols, mine.nnz, mine.max_nnz) == \
+           (ref.num_graphs, ref.rows, ref.cols, ref.nnz, ref.max_nnz)
+    assert torch.equal(mine.rowptr, ref.rowptr) and torch.equal(mine.cv, ref.cv)
+    f = D.batch_features(raw["feature"], bidx, B, device="cpu")
+    assert f.dtype == torch.float32 and f.numpy().tobytes() == z["features"].tobytes()
+    adj = D.batch_adjacency(chans, bidx, B, device="cpu")
+    assert adj.num_graphs == B and adj.n_nodes == 10 and adj.num_channels == 1
+
+
+def test_split_channels_batch_equals_list_packing():
+    z = load_golden("g2_synthetic_adj_split.npz")
+    ref = unflatten_adjs(z)
+    chans, _ = D.build_adjs(_raw(), split_adj_flag=True)
+    bidx = [3, 199, 0, 57]
+    for ch in range(6):
+        mine = chans[ch].batch(bidx, 6, device="cpu")
+        want = BatchedCSR.from_coo_list([ref[g][ch] for g in bidx] +
+                                        [(np.zeros((0, 2), np.int32), np.zeros(0, np.float32), [10, 10])] * 2,
+                                        rows=10, cols=10, device="cpu")
+        assert torch.equal(mine.rowptr, want.rowptr) and torch.equal(mine.cv, want.cv), ch
