@@ -203,6 +203,227 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent variants (the fast path): one workgroup per CU, 8 waves, every wave owns whole 32-row
+// tiles.  The weight panel [din x 64] of the block's 64 output columns lives in LDS for the whole
+// launch, the next x tile is already in flight (registers) while the current one is multiplied,
+// MFMAs stay in clusters (the f32 MFMA shares the VALU datapath, see fused.hip).
+// ------------------------------------------------------------------------------------------------
+constexpr int PT_LD = 68;                 // padded row stride of the per-wave x tile (b128 A reads)
+constexpr int PT_FLOATS = 32 * PT_LD;
+constexpr int P_WAVES = 8;
+
+// one [32 rows x 64 cols] chunk of x in flight: VEC: 8 float4 per lane, else 32 floats per lane
+template <bool VEC>
+struct XChunk { f32x4 v[8]; };
+template <>
+struct XChunk<false> { float v[32]; };
+
+template <bool VEC>
+__device__ __forceinline__ void issue_xchunk(XChunk<VEC>& f, const float* __restrict__ x, long m,
+                                             int din, long x_ld, long row0, int k0, int lane) {
+  if constexpr (VEC) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = lane + q * 64, r = i >> 4, c = (i & 15) * 4;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      f.v[q] = (row0 + r < m && k0 + c < din) ? *reinterpret_cast<const f32x4*>(x + (row0 + r) * x_ld + k0 + c) : z;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      const int i = lane + q * 64, r = i >> 6, c = i & 63;
+      f.v[q] = (row0 + r < m && k0 + c < din) ? x[(row0 + r) * x_ld + k0 + c] : 0.f;
+    }
+  }
+}
+template <bool VEC>
+__device__ __forceinline__ void land_xchunk(const XChunk<VEC>& f, float* tile, int ld, int lane) {
+  if constexpr (VEC) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = lane + q * 64, r = i >> 4, c = (i & 15) * 4;
+      *reinterpret_cast<f32x4*>(tile + r * ld + c) = f.v[q];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      const int i = lane + q * 64, r = i >> 6, c = i & 63;
+      tile[r * ld + c] = f.v[q];
+    }
+  }
+}
+
+__device__ __forceinline__ void lds_handoff() {   // intra-wave LDS hand-off: compiler barrier only
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(512, 2) void dense_fwd_persist_kernel(
+    const float* __restrict__ x, long m, int din, long x_ld, const float* __restrict__ w, long w_ld,
+    int trans_w, const float* __restrict__ bias, float* __restrict__ y, int dout, long y_ld, int kp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  float* Wp = reinterpret_cast<float*>(dsm);                      // [kp][64], zero padded
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, hi = lane >> 5;
+  float* xs = Wp + (size_t)kp * 64 + (size_t)wave * PT_FLOATS;    // this wave's x tile
+  const int n0 = blockIdx.y * 64;
+  for (int i = tid; i < kp * 64; i += blockDim.x) {
+    const int k = i >> 6, j = n0 + (i & 63);
+    float v = 0.f;
+    if (k < din && j < dout) v = trans_w ? w[(long)j * w_ld + k] : w[(long)k * w_ld + j];
+    Wp[i] = v;
+  }
+  __syncthreads();
+  const int c0 = n0 + li, c1 = n0 + 32 + li;
+  const float b0 = (bias && c0 < dout) ? bias[c0] : 0.f;
+  const float b1 = (bias && c1 < dout) ? bias[c1] : 0.f;
+
+  const long ntiles = (m + 31) / 32;
+  const int nkc = kp >> 6;
+  const long nwaves = (long)gridDim.x * P_WAVES;
+  long tile = (long)blockIdx.x * P_WAVES + wave;
+  if (tile >= ntiles) return;
+  // flattened (tile, k chunk) sequence with one chunk of lookahead
+  XChunk<VEC> fx;
+  issue_xchunk<VEC>(fx, x, m, din, x_ld, tile * 32, 0, lane);
+  f32x16 acc0, acc1;
+  int kc = 0;
+  for (;;) {
+    land_xchunk<VEC>(fx, xs, PT_LD, lane);
+    lds_handoff();
+    // next chunk (same tile, or first chunk of the wave's next tile; clamped on the last step)
+    const bool last_kc = (kc + 1 == nkc);
+    const long tn = last_kc ? tile + nwaves : tile;
+    const bool more = tn < ntiles;
+    issue_xchunk<VEC>(fx, x, m, din, x_ld, (more ? tn : tile) * 32, more ? (last_kc ? 0 : (kc + 1) * 64) : kc * 64, lane);
+    if (kc == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
+    }
+    {
+      f32x4 a4[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a4[q] = *reinterpret_cast<const f32x4*>(xs + li * PT_LD + hi * 32 + q * 4);
+      const float* wb = Wp + (size_t)(kc * 64 + hi * 32) * 64 + li;
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        const float a = a4[s >> 2][s & 3];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[s * 64], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[s * 64 + 32], acc1, 0, 0, 0);
+      }
+    }
+    lds_handoff();
+    if (last_kc) {
+      const long row0 = tile * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (row < m) {
+          if (c0 < dout) y[row * y_ld + c0] = acc0[r];
+          if (c1 < dout) y[row * y_ld + c1] = acc1[r];
+        }
+      }
+      if (!more) break;
+      tile = tn;
+      kc = 0;
+    } else {
+      ++kc;
+    }
+  }
+}
+
+// dW[64x64 block] / dbias partials: every wave owns whole 32-row tiles and all four 32x32 output
+// tiles (64 accumulator registers live across the wave's whole row range), rows are the MFMA K.
+template <bool VEC>
+__global__ __launch_bounds__(512, 2) void dense_wgrad_persist_kernel(
+    const float* __restrict__ x, long x_ld, const float* __restrict__ dy, long dy_ld, long m, int din,
+    int dout, float* __restrict__ part_dw, float* __restrict__ part_db) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, hi = lane >> 5;
+  float* xs = reinterpret_cast<float*>(dsm) + (size_t)wave * (2 * 32 * 64);   // [32][64]
+  float* gs = xs + 32 * 64;                                                    // [32][64]
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.z * 64;
+
+  f32x16 d00, d01, d10, d11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { d00[r] = 0.f; d01[r] = 0.f; d10[r] = 0.f; d11[r] = 0.f; }
+  float cs0 = 0.f, cs1 = 0.f;
+
+  const long ntiles = (m + 31) / 32;
+  const long nwaves = (long)gridDim.x * P_WAVES;
+  long tile = (long)blockIdx.x * P_WAVES + wave;
+  if (tile < ntiles) {
+    XChunk<VEC> fx, fg;
+    issue_xchunk<VEC>(fx, x, m, din, x_ld, tile * 32, i0, lane);
+    issue_xchunk<VEC>(fg, dy, m, dout, dy_ld, tile * 32, j0, lane);
+    for (;;) {
+      land_xchunk<VEC>(fx, xs, 64, lane);
+      land_xchunk<VEC>(fg, gs, 64, lane);
+      lds_handoff();
+      const long tn = tile + nwaves;
+      const bool more = tn < ntiles;
+      issue_xchunk<VEC>(fx, x, m, din, x_ld, (more ? tn : tile) * 32, i0, lane);
+      issue_xchunk<VEC>(fg, dy, m, dout, dy_ld, (more ? tn : tile) * 32, j0, lane);
+#pragma unroll 4
+      for (int s = 0; s < 16; ++s) {
+        const int n = hi * 16 + s;
+        const float a0 = xs[n * 64 + li], a1 = xs[n * 64 + 32 + li];
+        const float f0 = gs[n * 64 + li], f1 = gs[n * 64 + 32 + li];
+        d00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, f0, d00, 0, 0, 0);
+        d01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, f1, d01, 0, 0, 0);
+        d10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f0, d10, 0, 0, 0);
+        d11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f1, d11, 0, 0, 0);
+        cs0 += f0;
+        cs1 += f1;
+      }
+      lds_handoff();
+      if (!more) break;
+      tile = tn;
+    }
+  }
+  // reduce the 8 waves through LDS (each wave parks 64x64 + 64 floats in its own 16 KB + ...)
+  __syncthreads();
+  float* park = reinterpret_cast<float*>(dsm) + (size_t)wave * (64 * 64 + 64);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    park[row * 64 + li] = d00[r];
+    park[row * 64 + 32 + li] = d01[r];
+    park[(32 + row) * 64 + li] = d10[r];
+    park[(32 + row) * 64 + 32 + li] = d11[r];
+  }
+  cs0 += __shfl_xor(cs0, 32, 64);
+  cs1 += __shfl_xor(cs1, 32, 64);
+  if (hi == 0) { park[64 * 64 + li] = cs0; park[64 * 64 + 32 + li] = cs1; }
+  __syncthreads();
+  const float* base = reinterpret_cast<const float*>(dsm);
+  float* pw = part_dw + (long)blockIdx.x * din * dout;
+  for (int i = tid; i < 64 * 64; i += blockDim.x) {
+    float sum = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < P_WAVES; ++wv) sum += base[(size_t)wv * (64 * 64 + 64) + i];
+    const int row = i0 + (i >> 6), col = j0 + (i & 63);
+    if (row < din && col < dout) pw[(long)row * dout + col] = sum;
+  }
+  if (part_db && blockIdx.y == 0 && tid < 64) {
+    float sum = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < P_WAVES; ++wv) sum += base[(size_t)wv * (64 * 64 + 64) + 64 * 64 + tid];
+    if (j0 + tid < dout) part_db[(long)blockIdx.x * dout + j0 + tid] = sum;
+  }
+}
+
+static int persist_blocks(long m) {
+  long tiles = (m + 31) / 32;
+  long b = (tiles + P_WAVES - 1) / P_WAVES;
+  if (b > kNumCU) b = kNumCU;
+  return b < 1 ? 1 : (int)b;
+}
+
 static void wgrad_plan(long m, long* rows_per_chunk, int* nchunks) {
   // ~4 workgroups per CU worth of row chunks, each a multiple of WG_ROWS rows
   long target = (long)kNumCU * 4;
@@ -233,6 +454,33 @@ extern "C" int kgcn_dense_fwd_f32(const float* x, int64_t m, int32_t din, int64_
   if (!x || !w || !y) return fail("kgcn_dense_fwd_f32: NULL operand");
   if (x_ld < din || y_ld < dout) return fail("kgcn_dense_fwd_f32: leading dimension too small");
   if (w_ld < (trans_w ? din : dout)) return fail("kgcn_dense_fwd_f32: w_ld too small");
+  {
+    // fast path: weight panel [din_pad x 64] resident in LDS next to 8 per-wave x tiles
+    const int kp = ((din + 63) / 64) * 64;
+    const size_t lds = (size_t)kp * 64 * 4 + (size_t)P_WAVES * PT_FLOATS * 4;
+    if (lds <= (size_t)kLdsBytes) {
+      const bool vec = (din % 4 == 0) && (x_ld % 4 == 0) && aligned16(x);
+      static thread_local bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_fwd_persist_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_fwd_persist_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        attr_set = true;
+      }
+      // two workgroups per CU when the panel is small enough (4 waves per SIMD in total)
+      int blocks = persist_blocks(m);
+      if (2 * lds <= (size_t)kLdsBytes && blocks == kNumCU) blocks = 2 * kNumCU;
+      dim3 grid((unsigned)blocks, (unsigned)((dout + 63) / 64));
+      if (vec)
+        hipLaunchKernelGGL(dense_fwd_persist_kernel<true>, grid, dim3(64 * P_WAVES), lds, as_stream(stream), x,
+                           (long)m, din, (long)x_ld, w, (long)w_ld, trans_w, bias, y, dout, (long)y_ld, kp);
+      else
+        hipLaunchKernelGGL(dense_fwd_persist_kernel<false>, grid, dim3(64 * P_WAVES), lds, as_stream(stream), x,
+                           (long)m, din, (long)x_ld, w, (long)w_ld, trans_w, bias, y, dout, (long)y_ld, kp);
+      return check_launch("dense_fwd_persist_kernel");
+    }
+  }
   const long gx = (m + BM - 1) / BM;
   if (gx > 0x7fffffffL) return fail("kgcn_dense_fwd_f32: m too large");
   dim3 grid((unsigned)gx, (unsigned)((dout + BN - 1) / BN));
@@ -246,6 +494,7 @@ extern "C" int64_t kgcn_dense_wgrad_workspace_bytes(int64_t m, int32_t din, int3
   long rpc;
   int nchunks;
   wgrad_plan(m, &rpc, &nchunks);
+  if (nchunks < kNumCU) nchunks = kNumCU;   // the persistent kernel writes one partial per workgroup
   return (int64_t)nchunks * ((int64_t)din * dout + dout) * 4;
 }
 
@@ -268,6 +517,38 @@ extern "C" int kgcn_dense_wgrad_f32(const float* x, int64_t x_ld, const float* d
                 (long long)need);
   long rpc;
   int nchunks;
+  {
+    // persistent kernel: one workgroup (8 waves) per CU and per 64x64 output block
+    nchunks = persist_blocks(m);
+    const size_t lds = (size_t)P_WAVES * (2 * 32 * 64) * 4;      // >= P_WAVES * (64*64+64)*4 ? no: park needs more
+    const size_t lds_park = (size_t)P_WAVES * (64 * 64 + 64) * 4;
+    const size_t lds_use = lds > lds_park ? lds : lds_park;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wgrad_persist_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wgrad_persist_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+      attr_set = true;
+    }
+    float* part_dw = static_cast<float*>(workspace);
+    float* part_db = part_dw + (long)nchunks * din * dout;
+    const bool vec = (din % 4 == 0) && (dout % 4 == 0) && (x_ld % 4 == 0) && (dy_ld % 4 == 0) &&
+                     aligned16(x) && aligned16(dy);
+    dim3 grid((unsigned)nchunks, (unsigned)((din + 63) / 64), (unsigned)((dout + 63) / 64));
+    if (vec)
+      hipLaunchKernelGGL(dense_wgrad_persist_kernel<true>, grid, dim3(64 * P_WAVES), lds_use, s, x, (long)x_ld, dy,
+                         (long)dy_ld, (long)m, din, dout, part_dw, part_db);
+    else
+      hipLaunchKernelGGL(dense_wgrad_persist_kernel<false>, grid, dim3(64 * P_WAVES), lds_use, s, x, (long)x_ld, dy,
+                         (long)dy_ld, (long)m, din, dout, part_dw, part_db);
+    if (int rc = check_launch("dense_wgrad_persist_kernel")) return rc;
+    if (dw)
+      if (int rc = launch_reduce_partials(part_dw, nchunks, (long)din * dout, dw, s)) return rc;
+    if (dbias)
+      if (int rc = launch_reduce_partials(part_db, nchunks, dout, dbias, s)) return rc;
+    return 0;
+  }
   wgrad_plan(m, &rpc, &nchunks);
   float* part_dw = static_cast<float*>(workspace);
   float* part_db = part_dw + (long)nchunks * din * dout;

@@ -52,7 +52,7 @@ def test_model_py_gradients_and_adam_trajectory(batch):
         cost_opt.backward()
         if step == 0:
             close(logits, c["logits"], atol=2e-5, what="logits")
-            assert abs(float(cost_opt) - c["cost_opt"]) < 1e-6 and abs(float(cost_sum) - c["cost_sum"]) < 1e-5
+            assert abs(float(cost_opt) - c["cost_opt"]) < 5e-6 and abs(float(cost_sum) - c["cost_sum"]) < 1e-4
             for k, t in _named(model).items():
                 ref = g[k][0] if isinstance(g[k], list) else g[k]
                 close(t.grad, np.asarray(ref).reshape(tuple(t.shape)), atol=1e-6, rel=1e-5, what="grad " + k)
