@@ -152,6 +152,21 @@ int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, const float
 int kgcn_gin_aggregate_f32(const kgcn_csr_batch* a_ch, int32_t num_channels, const float* x,
                            int32_t d, const float* eps, float* out, void* stream);
 
+/* -- GraphMaxPooling ------------------------------------------------------------------------ */
+/* kgcn/layers.py:122-150 (one adjacency channel per call; beta = 1 accumulates the channel add-n):
+ *   out[t,i,k] = beta*out[t,i,k] + max_j dense(A[t] .* x[t][:,k])[i,j]
+ * = the maximum of a_ij * x[t][j,k] over the stored entries of row i, with 0 as a candidate unless
+ * the row stores all `cols` entries (absent entries of the densified row are zeros). */
+int kgcn_graph_maxpool_fwd_f32(const kgcn_csr_batch* a, const float* x, int32_t d, float* out,
+                               float beta, void* stream);
+/* Gradient as TF builds it (reduce_max splits the gradient equally among ALL maximal elements of
+ * the densified row, implicit zeros included):  dx[t,j,k] = beta*dx + sum_i a_ij * share(i,j,k).
+ * at = batched CSR of A^T (same value per entry); workspace >= kgcn_graph_maxpool_bwd_workspace_bytes. */
+int64_t kgcn_graph_maxpool_bwd_workspace_bytes(int32_t num_graphs, int32_t rows, int32_t d);
+int kgcn_graph_maxpool_bwd_f32(const kgcn_csr_batch* a, const kgcn_csr_batch* at, const float* x,
+                               const float* dout_grad, int32_t d, float* dx, float beta,
+                               void* workspace, int64_t workspace_bytes, void* stream);
+
 /* -- GraphGather ---------------------------------------------------------------------------- */
 /* kgcn/layers.py:163-164: out[b, :] = sum_n x[b, n, :] (padding rows included). */
 int kgcn_graph_gather_fwd_f32(const float* x, int64_t batch, int32_t n_nodes, int32_t d,

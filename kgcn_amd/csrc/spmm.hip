@@ -173,6 +173,77 @@ __global__ __launch_bounds__(256) void spmm_values_grad_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// GraphMaxPooling (kgcn/layers.py:122-150): the segmented-max twin of the gather kernel.
+//   fwd:    out[row,k] (+)= max( {a_e * x[col_e,k]} , 0 if the row stores fewer than K entries )
+//   count:  m[row,k] = that maximum, inv[row,k] = 1 / #maximal elements of the densified row
+//   bwd:    dx[j,k] (+)= sum over entries (i,j) of A^T's row j:  a * [a*x[j,k] == m[i,k]] * g[i,k]*inv[i,k]
+// ------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(
+    const int* __restrict__ rowptr, const int2* __restrict__ cv, const float* __restrict__ x,
+    float* __restrict__ out, float* __restrict__ mm, float* __restrict__ inv, int M, int K,
+    long total_rows, int d, int lpr_log2, float beta) {
+  const int lpr = 1 << lpr_log2;
+  const int cl = threadIdx.x & (lpr - 1);
+  const long nworkers = ((long)gridDim.x * 256) >> lpr_log2;
+  for (long row = ((long)blockIdx.x * 256 + threadIdx.x) >> lpr_log2; row < total_rows;
+       row += nworkers) {
+    const long t = row / M;
+    const int s = rowptr[row], e = rowptr[row + 1];
+    const float* xb = x + t * (long)K * d;
+    const bool has_zero = (e - s) < K;            // the densified row contains implicit zeros
+    for (int c = cl; c < d; c += lpr) {
+      float m = has_zero ? 0.f : -INFINITY;
+      for (int k = s; k < e; ++k) {
+        const int2 p = cv[k];
+        m = fmaxf(m, __int_as_float(p.y) * xb[(long)p.x * d + c]);
+      }
+      if constexpr (COUNT) {
+        int cnt = (has_zero && m == 0.f) ? K - (e - s) : 0;
+        for (int k = s; k < e; ++k) {
+          const int2 p = cv[k];
+          cnt += (__int_as_float(p.y) * xb[(long)p.x * d + c] == m) ? 1 : 0;
+        }
+        mm[row * d + c] = m;
+        inv[row * d + c] = 1.0f / (float)cnt;
+      } else {
+        float* o = out + row * d + c;
+        *o = (beta != 0.f ? *o : 0.f) + m;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(
+    const int* __restrict__ rowptr_t, const int2* __restrict__ cv_t, const float* __restrict__ x,
+    const float* __restrict__ g, const float* __restrict__ mm, const float* __restrict__ inv,
+    float* __restrict__ dx, int M, int K, long total_cols, int d, int lpr_log2, float beta) {
+  // rows of A^T = columns j of A: K per graph; entries (j, i) carry a_ij
+  const int lpr = 1 << lpr_log2;
+  const int cl = threadIdx.x & (lpr - 1);
+  const long nworkers = ((long)gridDim.x * 256) >> lpr_log2;
+  for (long col = ((long)blockIdx.x * 256 + threadIdx.x) >> lpr_log2; col < total_cols;
+       col += nworkers) {
+    const long t = col / K;
+    const int s = rowptr_t[col], e = rowptr_t[col + 1];
+    const float* xr = x + col * d;                 // x[t][j,:]
+    const long rbase = t * (long)M;
+    for (int c = cl; c < d; c += lpr) {
+      const float xv = xr[c];
+      float acc = 0.f;
+      for (int k = s; k < e; ++k) {
+        const int2 p = cv_t[k];                    // p.x = original row i
+        const float av = __int_as_float(p.y);
+        const long ri = (rbase + p.x) * d + c;
+        if (av * xv == mm[ri]) acc += av * (g[ri] * inv[ri]);
+      }
+      float* o = dx + col * d + c;
+      *o = (beta != 0.f ? *o : 0.f) + acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------
 static int ilog2_ceil(int v) {
@@ -322,4 +393,62 @@ extern "C" int kgcn_spmm_values_grad_f32(const kgcn_csr_batch* a, const float* g
                      grad_ld, grad_graph_stride, rhs, rhs_ld, rhs_graph_stride, dval, a->rows,
                      total_rows, d, lpr_log2);
   return check_launch("spmm_values_grad_kernel");
+}
+
+extern "C" int kgcn_graph_maxpool_fwd_f32(const kgcn_csr_batch* a, const float* x, int32_t d,
+                                          float* out, float beta, void* stream) {
+  if (int rc = validate_csr(a, "kgcn_graph_maxpool_fwd_f32")) return rc;
+  if (a->num_graphs == 0 || a->rows == 0 || d <= 0) return 0;
+  if (!x || !out) return fail("kgcn_graph_maxpool_fwd_f32: NULL operand");
+  if (beta != 0.f && beta != 1.f) return fail("kgcn_graph_maxpool_fwd_f32: beta must be 0 or 1");
+  int lpr_log2 = ilog2_ceil(d);
+  if (lpr_log2 > 6) lpr_log2 = 6;
+  const long total_rows = (long)a->num_graphs * a->rows;
+  long blocks = ((total_rows << lpr_log2) + 255) / 256;
+  if (blocks > (long)kNumCU * 64) blocks = (long)kNumCU * 64;
+  hipLaunchKernelGGL((maxpool_fwd_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                     a->rowptr, reinterpret_cast<const int2*>(a->cv), x, out, nullptr, nullptr, a->rows,
+                     a->cols, total_rows, d, lpr_log2, beta);
+  return check_launch("maxpool_fwd_kernel");
+}
+
+extern "C" int64_t kgcn_graph_maxpool_bwd_workspace_bytes(int32_t num_graphs, int32_t rows, int32_t d) {
+  if (num_graphs <= 0 || rows <= 0 || d <= 0) return 0;
+  return (int64_t)2 * num_graphs * rows * d * 4;
+}
+
+extern "C" int kgcn_graph_maxpool_bwd_f32(const kgcn_csr_batch* a, const kgcn_csr_batch* at,
+                                          const float* x, const float* dout_grad, int32_t d, float* dx,
+                                          float beta, void* workspace, int64_t workspace_bytes,
+                                          void* stream) {
+  if (int rc = validate_csr(a, "kgcn_graph_maxpool_bwd_f32")) return rc;
+  if (int rc = validate_csr(at, "kgcn_graph_maxpool_bwd_f32")) return rc;
+  if (at->num_graphs != a->num_graphs || at->rows != a->cols || at->cols != a->rows || at->nnz != a->nnz)
+    return fail("kgcn_graph_maxpool_bwd_f32: `at` is not the transposed batch of `a`");
+  if (a->num_graphs == 0 || a->rows == 0 || a->cols == 0 || d <= 0) return 0;
+  if (!x || !dout_grad || !dx) return fail("kgcn_graph_maxpool_bwd_f32: NULL operand");
+  if (beta != 0.f && beta != 1.f) return fail("kgcn_graph_maxpool_bwd_f32: beta must be 0 or 1");
+  const int64_t need = kgcn_graph_maxpool_bwd_workspace_bytes(a->num_graphs, a->rows, d);
+  if (!workspace || workspace_bytes < need)
+    return fail("kgcn_graph_maxpool_bwd_f32: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                (long long)need);
+  float* mm = static_cast<float*>(workspace);
+  float* inv = mm + (long)a->num_graphs * a->rows * d;
+  int lpr_log2 = ilog2_ceil(d);
+  if (lpr_log2 > 6) lpr_log2 = 6;
+  hipStream_t s = as_stream(stream);
+  const long total_rows = (long)a->num_graphs * a->rows;
+  long blocks = ((total_rows << lpr_log2) + 255) / 256;
+  if (blocks > (long)kNumCU * 64) blocks = (long)kNumCU * 64;
+  hipLaunchKernelGGL((maxpool_fwd_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, a->rowptr,
+                     reinterpret_cast<const int2*>(a->cv), x, nullptr, mm, inv, a->rows, a->cols, total_rows,
+                     d, lpr_log2, 0.f);
+  if (int rc = check_launch("maxpool_fwd_kernel<count>")) return rc;
+  const long total_cols = (long)at->num_graphs * at->rows;
+  blocks = ((total_cols << lpr_log2) + 255) / 256;
+  if (blocks > (long)kNumCU * 64) blocks = (long)kNumCU * 64;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, at->rowptr,
+                     reinterpret_cast<const int2*>(at->cv), x, dout_grad, mm, inv, dx, a->rows, a->cols,
+                     total_cols, d, lpr_log2, beta);
+  return check_launch("maxpool_bwd_kernel");
 }

@@ -197,6 +197,25 @@ class GINAggregate(nn.Module):
         return ops.gin_aggregate(inputs, eps, a)
 
 
+class GraphMaxPooling(nn.Module):
+    """kgcn/layers.py:122-153: out[b,i,k] = sum_c max_j dense(A[b][c] .* X[b][:,k])[i,j] -- the maximum
+    of a_ij * x_jk over node i's stored neighbours (0 is a candidate unless the row is full)."""
+
+    def __init__(self, adj_channel_num, **kwargs):
+        super().__init__()
+        self.adj_channel_num = int(adj_channel_num)
+
+    def compute_output_shape(self, input_shape):
+        return input_shape
+
+    def forward(self, inputs, adj=None):
+        a = _pack(adj, inputs)
+        if a.num_channels != self.adj_channel_num:
+            raise ValueError("layer has %d adjacency channels, adj has %d"
+                             % (self.adj_channel_num, a.num_channels))
+        return ops.graph_maxpool(inputs, a)
+
+
 class GraphGather(nn.Module):
     """kgcn/layers.py:156-167: reduce_sum over the node axis (padding rows included, quirk Q4)."""
 
@@ -207,5 +226,5 @@ class GraphGather(nn.Module):
         return ops.graph_gather(inputs)
 
 
-__all__ = ["GraphConv", "GraphDense", "GINAggregate", "GraphGather", "load_bspmm",
+__all__ = ["GraphConv", "GraphDense", "GINAggregate", "GraphGather", "GraphMaxPooling", "load_bspmm",
            "BatchedAdjacency"]

@@ -270,6 +270,44 @@ def gin_aggregate(x, eps, adj):
 
 
 # -------------------------------------------------------------------------------------------------
+# GraphMaxPooling
+# -------------------------------------------------------------------------------------------------
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, adj):
+        x = _f32c(x, "inputs")
+        T, N, d = x.shape
+        if (T, N) != (adj.num_graphs, adj.channels[0].cols):
+            raise _lib.KgcnHipError("inputs %s do not match the adjacency batch" % (tuple(x.shape),))
+        out = torch.empty((T, adj.n_nodes, d), device=x.device, dtype=torch.float32)
+        for c, ch in enumerate(adj.channels):            # tf.add_n over the channels
+            check(lib.kgcn_graph_maxpool_fwd_f32(ch.desc(), ptr(x), d, ptr(out), 0.0 if c == 0 else 1.0,
+                                                 current_stream()), "kgcn_graph_maxpool_fwd_f32")
+        ctx.adj = adj
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        adj = ctx.adj
+        g = _f32c(g, "grad")
+        T, N, d = x.shape
+        dx = torch.empty_like(x)
+        wsb = lib.kgcn_graph_maxpool_bwd_workspace_bytes(T, adj.n_nodes, d)
+        wsp = torch.empty((max(wsb, 4) // 4,), device=x.device, dtype=torch.float32)
+        for c, ch in enumerate(adj.channels):
+            check(lib.kgcn_graph_maxpool_bwd_f32(ch.desc(), ch.transpose().desc(), ptr(x), ptr(g), d, ptr(dx),
+                                                 0.0 if c == 0 else 1.0, ptr(wsp), wsb, current_stream()),
+                  "kgcn_graph_maxpool_bwd_f32")
+        return dx, None
+
+
+def graph_maxpool(x, adj):
+    return _MaxPool.apply(x, adj)
+
+
+# -------------------------------------------------------------------------------------------------
 # GraphGather
 # -------------------------------------------------------------------------------------------------
 class _Gather(torch.autograd.Function):
@@ -298,4 +336,5 @@ def graph_gather(x):
 
 
 __all__ = ["BatchedCSR", "BatchedAdjacency", "bspmm", "bspmm_raw", "bconv", "dense",
-           "graphconv_fused", "graphconv_fused_supported", "gin_aggregate", "graph_gather"]
+           "graphconv_fused", "graphconv_fused_supported", "gin_aggregate", "graph_gather",
+           "graph_maxpool"]

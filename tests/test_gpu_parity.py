@@ -379,6 +379,31 @@ def test_graph_gather_and_ragged_dense():
     close(y, K.graphdense_ragged_fwd(x, d.kernel.detach().cpu().numpy(), d.bias.detach().cpu().numpy(), en))
 
 
+@pytest.mark.parametrize("channels,D", [("plain", 3), ("split", 50), ("norm", 64)])
+def test_graph_maxpooling(channels, D):
+    """kgcn/layers.py:122-153 (row N3): values on a coarse grid so that ties -- between entries and
+    with the implicit zeros of the densified row -- really occur; fp32 oracle for exact tie sets."""
+    from kgcn_amd import layers
+    _, adjs = synthetic_batch("b30", channels)
+    C = len(adjs[0])
+    rng = np.random.default_rng(D + C)
+    x = (rng.integers(-2, 3, size=(30, 10, D)) * 0.5).astype(np.float32)
+    layer = layers.GraphMaxPooling(C)
+    tx = t32(x).requires_grad_(True)
+    out = layer(tx, adj=adjs)
+    assert tuple(out.shape) == (30, 10, D) == tuple(layer.compute_output_shape((30, 10, D)))
+    close(out, K.graph_maxpool_fwd(x, adjs, dtype=np.float32), atol=0, what="maxpool fwd")
+    g = rng.standard_normal(x.shape).astype(np.float32)
+    out.backward(t32(g))
+    close(tx.grad, K.graph_maxpool_bwd(x, adjs, g, dtype=np.float32), atol=2e-6, what="maxpool bwd")
+    x2 = rng.standard_normal((30, 10, D)).astype(np.float32)        # generic values, fp64 oracle
+    t2 = t32(x2).requires_grad_(True)
+    o2 = layer(t2, adj=adjs)
+    close(o2, K.graph_maxpool_fwd(x2, adjs), what="maxpool fwd (random)")
+    o2.backward(t32(g))
+    close(t2.grad, K.graph_maxpool_bwd(x2, adjs, g), what="maxpool bwd (random)")
+
+
 # ---------------------------------------------------------------------------------------------
 # error behaviour of the boundary
 # ---------------------------------------------------------------------------------------------

@@ -181,3 +181,55 @@ def test_synth_generator_cfg2():
         d[idx[:, 0], idx[:, 1]] = val
         assert np.array_equal(d, d.T) and np.all(np.diag(d) == 1)
         assert np.all(np.diff(idx[:, 0] * 32 + idx[:, 1]) > 0)      # row-major sorted
+
+
+def test_graph_maxpool_matches_densified_definition_and_fd():
+    """kgcn/layers.py:122-150 restated literally (densify A .* x_k, reduce_max over columns) vs the
+    sparse form of the oracle; gradient against central finite differences."""
+    rng = np.random.default_rng(5)
+    B, N, D = 3, 6, 4
+    adjs = []
+    for b in range(B):
+        chans = []
+        for c in range(2):
+            dense = (rng.random((N, N)) < 0.4) * rng.standard_normal((N, N))
+            if b == 0 and c == 0:
+                dense[2] = rng.standard_normal(N)            # a FULL row: no implicit zero candidate
+            idx = np.argwhere(dense != 0).astype(np.int32)
+            chans.append((idx, dense[dense != 0].astype(np.float32), [N, N]))
+        adjs.append(chans)
+    x = rng.standard_normal((B, N, D))
+    out = K.graph_maxpool_fwd(x, adjs)
+    ref = np.zeros_like(out)
+    for b in range(B):
+        for c in range(2):
+            idx, val, _ = adjs[b][c]
+            dense = np.zeros((N, N))
+            dense[idx[:, 0], idx[:, 1]] = val
+            for k in range(D):
+                ref[b, :, k] += (dense * x[b, :, k][None, :]).max(axis=1)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-12)
+    g = rng.standard_normal(out.shape)
+    dx = K.graph_maxpool_bwd(x, adjs, g)
+    eps = 1e-6
+    for _ in range(10):
+        i = tuple(rng.integers(0, s) for s in x.shape)
+        xp, xm = x.copy(), x.copy()
+        xp[i] += eps
+        xm[i] -= eps
+        fd = ((K.graph_maxpool_fwd(xp, adjs) - K.graph_maxpool_fwd(xm, adjs)) * g).sum() / (2 * eps)
+        assert abs(fd - dx[i]) < 1e-6
+
+
+def test_graph_maxpool_tie_split():
+    """tf.reduce_max's gradient divides equally among all maximal elements of the densified row,
+    the implicit zeros included."""
+    N = 4
+    adj = [[(np.array([[0, 1], [0, 2], [1, 0]], np.int32), np.array([1.0, 1.0, 1.0], np.float32), [N, N])]]
+    x = np.array([[[5.0], [2.0], [2.0], [7.0]]])            # row 0: two entries tie at 2 > 0
+    g = np.ones((1, N, 1))
+    dx = K.graph_maxpool_bwd(x, adj, g)
+    np.testing.assert_allclose(dx[0, :, 0], [1.0, 0.5, 0.5, 0.0])
+    x0 = np.array([[[-1.0], [0.0], [-3.0], [7.0]]])         # row 0: entry value 0 ties with 2 implicit zeros
+    dx0 = K.graph_maxpool_bwd(x0, adj, g)
+    np.testing.assert_allclose(dx0[0, :, 0], [0.0, 1.0 / 3.0, 0.0, 0.0])
