@@ -210,3 +210,64 @@ def batch_features(features, batch_idx, batch_size=None, device="cuda"):
     out = np.zeros((T,) + tuple(features.shape[1:]), np.float32)
     out[:batch_idx.shape[0]] = features[batch_idx]
     return torch.from_numpy(out).to(device)
+
+
+# -------------------------------------------------------------------------------------------------
+# block-diagonal batch (kgcn-sparse path, BASELINE config 3)
+# -------------------------------------------------------------------------------------------------
+class BlockDiagonalBatch:
+    """What construct_batched_adjacency_and_feature_matrices returns, device resident:
+    adjacency = BatchedAdjacency of C channels with ONE [sumN x sumN] graph each, features
+    torch [sumN, input_dim], plus the molecule -> node-range indicator used by the read-out
+    (example_model/sparse.py:83-94)."""
+
+    def __init__(self, adjacency, features, sizes, segments):
+        self.adjacency = adjacency
+        self.features = features
+        self.sizes = sizes
+        self.segments = segments        # BatchedCSR [1 graph, B rows, sumN cols] of ones
+
+
+def block_diagonal_batch(size, adj_row, adj_column, adj_values, adj_elem_len, adj_degrees, feature_row,
+                         feature_column, feature_values, feature_elem_len, input_dim, max_degree=5,
+                         normalize=True, split_adj=False, device="cuda"):
+    """kgcn/data_util.py:698-845 without the per-molecule tf.scan (which builds a [B, nnz_total]
+    padded index tensor): molecule offsets are ONE np.repeat over the concatenated entries.
+    Same argument list and channel semantics as the reference function (normalise: values /
+    sqrt(colsum)[col] / sqrt(colsum)[row] in float32; split: channels by clipped per-entry degree
+    1..max_degree + identity channel)."""
+    import torch
+    size = np.asarray(size, np.int64).reshape(-1)
+    total = int(size.sum())
+    nmol = size.shape[0]
+    offset = np.zeros(nmol, np.int64)
+    np.cumsum(size[:-1], out=offset[1:])
+    elem = np.asarray(adj_elem_len, np.int64).reshape(-1)
+    eoff = np.repeat(offset, elem)
+    drow = np.asarray(adj_row, np.int64) + eoff
+    dcol = np.asarray(adj_column, np.int64) + eoff
+    vals = np.asarray(adj_values, np.float32)
+    zeros = lambda n: np.zeros(n, np.int64)
+    if normalize:
+        deg = np.zeros(total, np.float32)
+        np.add.at(deg, dcol, vals)
+        sq = np.sqrt(deg).astype(np.float32)
+        v = ((vals / sq[dcol]).astype(np.float32) / sq[drow]).astype(np.float32)
+        chans = [(drow, dcol, v)]
+    elif split_adj:
+        d = np.clip(np.asarray(adj_degrees, np.int64), 0, max_degree)
+        chans = [(drow[d == k], dcol[d == k], vals[d == k]) for k in range(1, max_degree + 1)]
+        eye = np.arange(total, dtype=np.int64)
+        chans.append((eye, eye, np.ones(total, np.float32)))
+    else:
+        chans = [(drow, dcol, vals)]
+    adjacency = BatchedAdjacency([BatchedCSR.from_arrays(zeros(r.shape[0]), r, c, v, 1, total, total, device=device)
+                                  for r, c, v in chans])
+    felem = np.asarray(feature_elem_len, np.int64).reshape(-1)
+    net = np.zeros((total, int(input_dim)), np.float32)
+    net[np.asarray(feature_row, np.int64) + np.repeat(offset, felem), np.asarray(feature_column, np.int64)] = \
+        np.asarray(feature_values, np.float32)
+    node = np.arange(total, dtype=np.int64)
+    segments = BatchedCSR.from_arrays(zeros(total), np.repeat(np.arange(nmol, dtype=np.int64), size), node,
+                                      np.ones(total, np.float32), 1, nmol, total, device=device)
+    return BlockDiagonalBatch(adjacency, torch.from_numpy(net).to(device), size, segments)

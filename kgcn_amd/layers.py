@@ -216,6 +216,35 @@ class GraphMaxPooling(nn.Module):
         return ops.graph_maxpool(inputs, a)
 
 
+class GraphBatchNormalization(nn.Module):
+    """kgcn/layers.py:170-220 with Keras' learning phase at its TF1 default (quirk Q6): the wrapped
+    BatchNormalization normalises with its moving statistics (mean 0, variance 1, epsilon 1e-3):
+        y = gamma * x / sqrt(1 + 1e-3) + beta
+    on the valid node rows (the first enabled_node_nums[b] of every graph, :196-210; all rows when
+    enabled_node_nums is None, :211-216) and zero on the padding rows."""
+
+    def __init__(self, bn_name=None, eps=1e-3, **kwargs):
+        super().__init__()
+        self.bn_name = bn_name
+        self.eps = eps
+        self.gamma = None
+        self.beta = None
+
+    def compute_output_shape(self, input_shape):
+        return input_shape
+
+    def forward(self, x, enabled_node_nums=None, shape=None, max_node_num=None, training=True):
+        if self.gamma is None:
+            self.gamma = nn.Parameter(torch.ones(x.shape[-1], device=x.device))
+            self.beta = nn.Parameter(torch.zeros(x.shape[-1], device=x.device))
+        y = x * (self.gamma / math.sqrt(1.0 + self.eps)) + self.beta
+        if enabled_node_nums is not None:
+            n = x.shape[1]
+            en = torch.as_tensor(enabled_node_nums, device=x.device).reshape(-1, 1)
+            y = y * (torch.arange(n, device=x.device).reshape(1, n) < en).to(y.dtype).unsqueeze(-1)
+        return y
+
+
 class GraphGather(nn.Module):
     """kgcn/layers.py:156-167: reduce_sum over the node axis (padding rows included, quirk Q4)."""
 
@@ -226,5 +255,6 @@ class GraphGather(nn.Module):
         return ops.graph_gather(inputs)
 
 
-__all__ = ["GraphConv", "GraphDense", "GINAggregate", "GraphGather", "GraphMaxPooling", "load_bspmm",
+__all__ = ["GraphConv", "GraphDense", "GINAggregate", "GraphGather", "GraphMaxPooling",
+           "GraphBatchNormalization", "load_bspmm",
            "BatchedAdjacency"]

@@ -4,12 +4,15 @@ activations, the loss and the BatchNorm affine are elementwise torch ops around 
 
   GCN  -- example_model/model.py:41-61      GraphConv(50) x3, BN, GraphDense(50), GraphGather, Dense(2)
   GIN  -- example_model/model_gin.py:40-67  2 x [GINAggregate, GraphDense(50) x2], Gather x2, Dense(2)
+  MultitaskGCN -- example_model/model_multitask.py:45-101  GraphConv 256/256, GraphDense 256, GraphConv 50, BN,
+                  GraphDense 50, Gather, Dense(label_dim); masked (weighted) sigmoid cross entropy
+  SparseGCN    -- example_model/sparse.py:45-134  block-diagonal batch of one: 3 x [GraphConv(256) relu],
+                  GraphDense(256), BN, relu, per-molecule sum, tanh, Dense(num_classes); summed sparse softmax CE
 
 Keras learning-phase semantics (quirk Q6): the reference calls BatchNormalization / Dropout
 without `training=`; under TF1 graph mode that is inference behaviour -- BN normalises with its
 moving statistics (0, 1) and Dropout is the identity.  That is what is implemented here
-(GraphBatchNormalization: y = gamma * x / sqrt(1 + 1e-3) + beta on the valid node rows, zero on the
-padding rows, kgcn/layers.py:196-215).
+(layers.GraphBatchNormalization).
 """
 import math
 
@@ -19,25 +22,7 @@ from torch import nn
 from . import layers, ops
 
 
-class GraphBatchNormalization(nn.Module):
-    """kgcn/layers.py:170-220 in inference mode (moving mean 0, variance 1, epsilon 1e-3)."""
-
-    def __init__(self, eps=1e-3):
-        super().__init__()
-        self.eps = eps
-        self.gamma = None
-        self.beta = None
-
-    def forward(self, x, max_node_num=None, enabled_node_nums=None):
-        if self.gamma is None:
-            self.gamma = nn.Parameter(torch.ones(x.shape[-1], device=x.device))
-            self.beta = nn.Parameter(torch.zeros(x.shape[-1], device=x.device))
-        y = x * (self.gamma / math.sqrt(1.0 + self.eps)) + self.beta
-        if enabled_node_nums is not None:       # valid rows only; padding rows are zero
-            n = x.shape[1]
-            en = torch.as_tensor(enabled_node_nums, device=x.device).reshape(-1, 1)
-            y = y * (torch.arange(n, device=x.device).reshape(1, n) < en).to(y.dtype).unsqueeze(-1)
-        return y
+GraphBatchNormalization = layers.GraphBatchNormalization
 
 
 class KerasDense(nn.Module):
@@ -112,3 +97,79 @@ class GIN(nn.Module):
             outs.append(layer)
         read_out = [self.gather(o) for o in outs]
         return self.out(torch.cat(read_out, dim=1))
+
+
+def masked_sigmoid_ce(logits, labels, mask, mask_label, pos_weight=None):
+    """model_multitask.py:66-79: cost = mask * sum_tasks mask_label * (weighted) sigmoid cross entropy;
+    cost_opt = reduce_mean over the padded batch, cost_sum = reduce_sum.  Formulas of
+    tf.nn.sigmoid_cross_entropy_with_logits / tf.nn.weighted_cross_entropy_with_logits."""
+    x, z = logits, labels.to(logits.dtype)
+    sp = torch.log1p(torch.exp(-x.abs()))
+    if pos_weight is None:
+        ce = torch.clamp(x, min=0) - x * z + sp
+    else:
+        ce = (1 - z) * x + (1 + (pos_weight - 1) * z) * (sp + torch.clamp(-x, min=0))
+    cost = mask * (mask_label * ce).sum(dim=1)
+    return cost.mean(), cost.sum()
+
+
+def sparse_softmax_ce_sum(logits, labels):
+    """sparse.py:112-113: loss_to_minimize = reduce_sum(sparse_softmax_cross_entropy_with_logits)."""
+    logp = torch.log_softmax(logits, dim=1)
+    return -logp.gather(1, labels.reshape(-1, 1).long()).sum()
+
+
+class MultitaskGCN(nn.Module):
+    """example_model/model_multitask.py:32-101."""
+
+    def __init__(self, adj_channel_num=1, label_dim=12):
+        super().__init__()
+        self.conv1 = layers.GraphConv(256, adj_channel_num)
+        self.conv2 = layers.GraphConv(256, adj_channel_num)
+        self.dense1 = layers.GraphDense(256)
+        self.conv3 = layers.GraphConv(50, adj_channel_num)
+        self.bn = layers.GraphBatchNormalization()
+        self.dense2 = layers.GraphDense(50)
+        self.gather = layers.GraphGather()
+        self.out = KerasDense(label_dim)
+
+    def forward(self, features, adjs, enabled_node_nums=None):
+        layer = torch.sigmoid(self.conv1(features, adj=adjs))
+        layer = torch.sigmoid(self.conv2(layer, adj=adjs))
+        layer = torch.sigmoid(self.dense1(layer))
+        layer = self.conv3(layer, adj=adjs)
+        layer = self.bn(layer, max_node_num=features.shape[1], enabled_node_nums=enabled_node_nums)
+        layer = torch.sigmoid(layer)
+        layer = torch.sigmoid(self.dense2(layer))
+        layer = self.gather(layer)
+        return self.out(layer)                      # prediction = sigmoid(logits)
+
+
+class SparseGCN(nn.Module):
+    """example_model/sparse.py:45-134 (params of build(): out_dims [256,256,256], dense_dim 256,
+    batch_normalize False, max_pool False; both optional layers are available as flags)."""
+
+    def __init__(self, num_classes, adj_channel_num=1, out_dims=(256, 256, 256), dense_dim=256,
+                 batch_normalize=False, max_pool=False):
+        super().__init__()
+        self.convs = nn.ModuleList([layers.GraphConv(o, adj_channel_num) for o in out_dims])
+        self.pools = nn.ModuleList([layers.GraphMaxPooling(adj_channel_num) for _ in out_dims]) if max_pool else None
+        self.bns = nn.ModuleList([layers.GraphBatchNormalization() for _ in out_dims]) if batch_normalize else None
+        self.dense = layers.GraphDense(dense_dim)
+        self.bn = layers.GraphBatchNormalization()
+        self.out = KerasDense(num_classes)
+
+    def forward(self, batch):
+        """batch: kgcn_amd.data_util.BlockDiagonalBatch."""
+        net = batch.features.unsqueeze(0)                       # tf.expand_dims(net, 0)
+        for i, conv in enumerate(self.convs):
+            net = conv(net, batch.adjacency)                    # positional adj, sparse.py:69
+            if self.pools is not None:
+                net = self.pools[i](net, batch.adjacency)
+            if self.bns is not None:
+                net = self.bns[i](net)
+            net = torch.relu(net)
+        net = torch.relu(self.bn(self.dense(net)))[0]
+        net = ops.bspmm(batch.segments, net.unsqueeze(0))       # per-molecule node sum (:83-94)
+        net = torch.tanh(net.reshape(len(batch.sizes), -1))
+        return self.out(net)                                    # probabilities = softmax(logits)

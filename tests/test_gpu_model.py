@@ -92,3 +92,99 @@ def test_short_training_run_on_synthetic_jbl(kind):
             tot += cs
         epoch_cost.append(tot / 160)
     assert np.isfinite(epoch_cost).all() and epoch_cost[-1] < epoch_cost[0] - 0.02, epoch_cost
+
+
+# ---- example_model/model_multitask.py (BASELINE config 4) and example_model/sparse.py (config 3) ------
+from oracle import kgcn_nets_oracle as NETS
+from oracle import kgcn_oracle as K
+
+
+def _copy_conv(conv, w, b):
+    with torch.no_grad():
+        for c in range(len(w)):
+            conv.w[c].copy_(t32(w[c])); conv.bias[c].copy_(t32(b[c]))
+
+
+def _grad_of(t, ref, what, rel=2e-5):
+    close(t.grad, np.asarray(ref).reshape(tuple(t.shape)), atol=2e-6, rel=rel, what="grad " + what)
+
+
+@pytest.mark.parametrize("pos_weight", [None, 2.5])
+def test_model_multitask_tox21_shaped(pos_weight):
+    """12 tasks, N = 50 padded with variable true sizes, F = 81, widths 256/256/256/50/50, masked labels,
+    a dummy graph in the batch; logits, loss and every gradient vs the fp64 oracle."""
+    from kgcn_amd import models
+    from test_oracle_model import tox21_like_batch
+    rng = np.random.default_rng(44)
+    x, adjs, labels, mask, mask_label, sizes = tox21_like_batch(rng, B=24, N=50, F=81, T=12)
+    p = NETS.multitask_init(rng, 81, 12)
+    for k in ("b1", "b2", "b4"):
+        p[k] = [rng.standard_normal(p[k][0].shape) * 0.1]
+    c = NETS.multitask_forward(p, x, adjs, labels, mask, mask_label, sizes, pos_weight)
+    g = NETS.multitask_backward(p, c, x, adjs, labels, mask, mask_label, pos_weight)
+    model = models.MultitaskGCN(1, 12).to(dev())
+    tx = t32(x).requires_grad_(True)
+    en = torch.as_tensor(sizes)
+    model(tx, adjs, enabled_node_nums=en)
+    _copy_conv(model.conv1, p["w1"], p["b1"]); _copy_conv(model.conv2, p["w2"], p["b2"])
+    _copy_conv(model.conv3, p["w4"], p["b4"])
+    with torch.no_grad():
+        model.dense1.kernel.copy_(t32(p["k3"])); model.dense1.bias.copy_(t32(p["c3"]))
+        model.dense2.kernel.copy_(t32(p["k5"])); model.dense2.bias.copy_(t32(p["c5"]))
+        model.out.kernel.copy_(t32(p["ok"])); model.out.bias.copy_(t32(p["ob"]))
+    logits = model(tx, adjs, enabled_node_nums=en)
+    close(logits, c["logits"], atol=5e-5, what="multitask logits")
+    cost_opt, cost_sum = models.masked_sigmoid_ce(logits, t32(labels), t32(mask), t32(mask_label), pos_weight)
+    assert abs(float(cost_opt) - c["cost_opt"]) < 1e-5 * max(1.0, abs(c["cost_opt"]))
+    assert abs(float(cost_sum) - c["cost_sum"]) < 1e-5 * max(1.0, abs(c["cost_sum"]))
+    cost_opt.backward()
+    _grad_of(tx, g["dx"], "x")
+    for name, t, ref in [("w1", model.conv1.w[0], g["w1"][0]), ("b1", model.conv1.bias[0], g["b1"][0]),
+                         ("w2", model.conv2.w[0], g["w2"][0]), ("k3", model.dense1.kernel, g["k3"]),
+                         ("c3", model.dense1.bias, g["c3"]), ("w4", model.conv3.w[0], g["w4"][0]),
+                         ("b4", model.conv3.bias[0], g["b4"][0]), ("gamma", model.bn.gamma, g["gamma"]),
+                         ("beta", model.bn.beta, g["beta"]), ("k5", model.dense2.kernel, g["k5"]),
+                         ("ok", model.out.kernel, g["ok"]), ("ob", model.out.bias, g["ob"])]:
+        _grad_of(t, ref, name)
+
+
+@pytest.mark.parametrize("mode", ["normalize", "split"])
+def test_model_sparse_block_diagonal(mode):
+    """kgcn-sparse: records -> product block-diagonal builder -> SparseGCN (batch of ONE [sumN x sumN] graph,
+    1 channel Kipf-normalised or max_degree+1 = 6 split channels) vs the oracle built from the
+    per-molecule restatement; relu masks of the oracle chain rule taken from the GPU activations."""
+    from kgcn_amd import data_util as D, models
+    from test_oracle_model import _construct, _sparse_batch
+    rng = np.random.default_rng(33)
+    F, ncls = 40, 5
+    f, sizes = _sparse_batch(rng, nmol=24, F=F)
+    kw = dict(max_degree=0, normalize=True) if mode == "normalize" else dict(max_degree=5, normalize=False, split_adj=True)
+    chans, net = _construct(f, F, **kw)
+    batch = D.block_diagonal_batch(f["size"][:, 0], f["adj_row"], f["adj_column"], f["adj_values"], f["adj_elem_len"],
+                                   f["adj_degrees"], f["feature_row"], f["feature_column"], f["feature_values"],
+                                   f["feature_elem_len"], F, device=dev(), **kw)
+    labels = rng.integers(0, ncls, size=len(sizes))
+    C = len(chans)
+    p = NETS.sparse_init(rng, F, ncls, channels=C, out_dims=(256, 256, 256), dense_dim=256)
+    for i in (1, 2, 3):
+        p["b%d" % i] = [rng.standard_normal(b.shape) * 0.05 for b in p["b%d" % i]]
+    model = models.SparseGCN(ncls, adj_channel_num=C).to(dev())
+    model(batch)
+    for i, conv in enumerate(model.convs, 1):
+        _copy_conv(conv, p["w%d" % i], p["b%d" % i])
+    with torch.no_grad():
+        model.dense.kernel.copy_(t32(p["dk"])); model.dense.bias.copy_(t32(p["dc"]))
+        model.out.kernel.copy_(t32(p["ok"])); model.out.bias.copy_(t32(p["ob"]))
+    logits = model(batch)
+    c = NETS.sparse_forward(p, net, chans, sizes, labels)
+    close(logits, c["logits"], atol=5e-5, what="sparse logits")
+    loss = models.sparse_softmax_ce_sum(logits, torch.as_tensor(labels, device=dev()))
+    assert abs(float(loss) - c["loss"]) < 1e-5 * max(1.0, abs(c["loss"]))
+    loss.backward()
+    g = NETS.sparse_backward(p, c, chans, sizes, labels)
+    for i, conv in enumerate(model.convs, 1):
+        for ch in range(C):
+            _grad_of(conv.w[ch], g["w%d" % i][ch], "w%d[%d]" % (i, ch), rel=5e-5)
+            _grad_of(conv.bias[ch], g["b%d" % i][ch], "b%d[%d]" % (i, ch), rel=5e-5)
+    _grad_of(model.dense.kernel, g["dk"], "dk", rel=5e-5); _grad_of(model.out.kernel, g["ok"], "ok", rel=5e-5)
+    _grad_of(model.bn.gamma, g["gamma"], "gamma", rel=5e-5); _grad_of(model.bn.beta, g["beta"], "beta", rel=5e-5)

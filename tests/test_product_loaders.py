@@ -80,3 +80,33 @@ def test_split_channels_batch_equals_list_packing():
                                         [(np.zeros((0, 2), np.int32), np.zeros(0, np.float32), [10, 10])] * 2,
                                         rows=10, cols=10, device="cpu")
         assert torch.equal(mine.rowptr, want.rowptr) and torch.equal(mine.cv, want.cv), ch
+
+
+@pytest.mark.parametrize("mode", ["plain", "normalize", "split"])
+def test_block_diagonal_batch_matches_oracle(mode):
+    """Product builder (one np.repeat) vs the per-molecule restatement of kgcn/data_util.py:698-845:
+    channel patterns, float32 values and the dense feature matrix, bit for bit."""
+    from kgcn_amd import data_util as D
+    from test_oracle_model import _construct, _sparse_batch
+    rng = np.random.default_rng(8)
+    F = 9
+    f, sizes = _sparse_batch(rng, nmol=7, F=F)
+    kw = {"plain": dict(normalize=False), "normalize": dict(normalize=True),
+          "split": dict(normalize=False, split_adj=True, max_degree=3)}[mode]
+    chans, net = _construct(f, F, **kw)
+    b = D.block_diagonal_batch(f["size"][:, 0], f["adj_row"], f["adj_column"], f["adj_values"], f["adj_elem_len"],
+                               f["adj_degrees"], f["feature_row"], f["feature_column"], f["feature_values"],
+                               f["feature_elem_len"], F, device="cpu", **kw)
+    assert b.adjacency.num_channels == len(chans) and b.adjacency.num_graphs == 1
+    total = int(sizes.sum())
+    for ch, (idx, val, shape) in zip(b.adjacency.channels, chans):
+        assert (ch.rows, ch.cols) == (total, total) == tuple(shape)
+        rp, cv = ch.rowptr.numpy(), ch.cv.numpy()
+        np.testing.assert_array_equal(rp, np.concatenate([[0], np.cumsum(np.bincount(idx[:, 0], minlength=total))]))
+        order = np.argsort(idx[:, 0], kind="stable")          # CSR keeps the COO order inside a row
+        np.testing.assert_array_equal(cv[:, 0], idx[order, 1])
+        np.testing.assert_array_equal(cv[:, 1].view(np.float32), val[order])
+    np.testing.assert_array_equal(b.features.numpy(), net)
+    seg = b.segments
+    assert (seg.rows, seg.cols, seg.nnz) == (len(sizes), total, total)
+    np.testing.assert_array_equal(np.diff(seg.rowptr.numpy()), sizes)
