@@ -152,6 +152,20 @@ int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, const float
 int kgcn_gin_aggregate_f32(const kgcn_csr_batch* a_ch, int32_t num_channels, const float* x,
                            int32_t d, const float* eps, float* out, void* stream);
 
+/* -- mini-batch assembly on the device ---------------------------------------------------------- */
+/* kgcn/feed.py:112-126 without the host: `src` is the container of the WHOLE dataset (resident in HBM),
+ * sel[t] (device, int32[num_sel]) the dataset index of batch graph t or -1 for an empty dummy graph.
+ * Writes the batch container: dst_rowptr[num_sel*rows + 1], dst_cv[2 * total entries] (capacity in
+ * ENTRIES; exact total or worst case num_sel * max_nnz_per_graph), dst_graph_ptr[num_sel + 1]
+ * (graph_ptr[num_sel] = total entries) and, for a row-padded source, dst_slots[num_sel*rows] (dummy
+ * graphs become rows of 4 padding entries).  sel values must be < src->num_graphs (not checked: device
+ * data).  workspace >= kgcn_csr_gather_workspace_bytes(num_sel). */
+int64_t kgcn_csr_gather_workspace_bytes(int32_t num_sel);
+int kgcn_csr_gather_graphs(const kgcn_csr_batch* src, const int32_t* sel, int32_t num_sel,
+                           int32_t* dst_rowptr, int32_t* dst_cv, int64_t dst_cv_capacity,
+                           int32_t* dst_slots, int32_t* dst_graph_ptr, void* workspace,
+                           int64_t workspace_bytes, void* stream);
+
 /* -- GraphMaxPooling ------------------------------------------------------------------------ */
 /* kgcn/layers.py:122-150 (one adjacency channel per call; beta = 1 accumulates the channel add-n):
  *   out[t,i,k] = beta*out[t,i,k] + max_j dense(A[t] .* x[t][:,k])[i,j]

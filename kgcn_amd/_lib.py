@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkgcn_hip.so")
 
 c_f32p = ctypes.c_void_p
+c_i32p = ctypes.c_void_p
 c_i64 = ctypes.c_int64
 c_i32 = ctypes.c_int32
 
@@ -61,6 +62,9 @@ SIGNATURES = {
                                               ctypes.c_void_p]),
     "kgcn_gin_aggregate_f32": (ctypes.c_int, [_CSRP, c_i32, c_f32p, c_i32, c_f32p, c_f32p,
                                               ctypes.c_void_p]),
+    "kgcn_csr_gather_workspace_bytes": (c_i64, [c_i32]),
+    "kgcn_csr_gather_graphs": (ctypes.c_int, [_CSRP, c_i32p, c_i32, c_i32p, c_i32p, c_i64, c_i32p, c_i32p,
+                                              ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_graph_maxpool_fwd_f32": (ctypes.c_int, [_CSRP, c_f32p, c_i32, c_f32p, ctypes.c_float,
                                                   ctypes.c_void_p]),
     "kgcn_graph_maxpool_bwd_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),

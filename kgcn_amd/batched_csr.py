@@ -55,6 +55,9 @@ class BatchedCSR:
         self._vals = None
         self.row_pad = int(row_pad)     # 0 plain CSR, 4 = rows padded to multiples of 4 entries
         self._p4 = None
+        self._make_t = None             # thunks set by gather(): build A^T / the padded copy on demand
+        self._make_p4 = None
+        self._graph_counts = None       # host int64 [T]: stored entries per graph
         self.slots = None               # row_pad == 4: int32 [T*M] slot table (see include/kgcn_hip.h)
         self.graph_ptr = None           # row_pad == 4: int32 [T+1]
 
@@ -132,6 +135,9 @@ class BatchedCSR:
     def transpose(self):
         """Batched CSR of A[t]^T (cached).  Entry order inside a transposed row follows the
         original row-major order, i.e. ascending original row."""
+        if self._t is None and self._make_t is not None:
+            self._t = self._make_t()
+            self._t._t = self
         if self._t is None:
             if self._struct_src is not None:
                 bt = self._struct_src.transpose()          # pattern of A^T (cached there)
@@ -151,6 +157,8 @@ class BatchedCSR:
         gather an all-zero LDS row, so the kernels run mask-free 4-entry gathers.  Cached."""
         if self.row_pad == 4:
             return self
+        if self._p4 is None and self._make_p4 is not None:
+            self._p4 = self._make_p4()
         if self._p4 is None:
             import torch
             if self._host is None:
@@ -199,7 +207,61 @@ class BatchedCSR:
                                   row_pad=4)
             self._p4.slots = torch.from_numpy(np.ascontiguousarray(slots)).to(dev)
             self._p4.graph_ptr = torch.from_numpy(gptr.astype(np.int32)).to(dev)
+            self._p4._graph_counts = np.diff(gptr).astype(np.int64)
         return self._p4
+
+    def graph_counts(self):
+        """Host int64 [T]: stored entries per graph (padding entries included for row_pad = 4)."""
+        if self._graph_counts is None:
+            if self._host is not None:
+                self._graph_counts = np.bincount(self._host[0], minlength=self.num_graphs).astype(np.int64)
+            else:
+                rp = self.rowptr[::self.rows].cpu().numpy().astype(np.int64) if self.rows else \
+                    np.zeros(self.num_graphs + 1, np.int64)
+                self._graph_counts = np.diff(rp)
+        return self._graph_counts
+
+    def gather(self, sel):
+        """Mini-batch assembly ON THE DEVICE (kgcn_csr_gather_graphs): `self` is the container of the
+        whole dataset, sel[t] the dataset index of batch graph t (-1 = empty dummy graph padding a short
+        batch, kgcn/feed.py:123-126).  The host only adds up the selected graphs' entry counts (to size
+        the output); rowptr / cv / slots never leave HBM.  A^T and the row-padded copy of the batch are
+        gathered lazily from the dataset's own A^T / padded containers."""
+        import torch
+        if self.rowptr.device.type != "cuda":
+            raise _lib.KgcnHipError("gather(): device-side batch assembly needs a device-resident container")
+        sel = np.asarray(sel, np.int64).reshape(-1)
+        T, M = sel.shape[0], self.rows
+        if T and (sel.max() >= self.num_graphs or sel.min() < -1):
+            raise ValueError("graph index out of range for a dataset of %d graphs" % self.num_graphs)
+        counts = self.graph_counts()
+        dummy = 4 * M if self.row_pad else 0
+        per = np.where(sel >= 0, counts[np.maximum(sel, 0)], dummy) if T else np.zeros(0, np.int64)
+        total = int(per.sum())
+        if T * M + 1 >= 2 ** 31 or total >= 2 ** 31:
+            raise ValueError("batch too large for int32 offsets")
+        dev = self.rowptr.device
+        i32 = dict(device=dev, dtype=torch.int32)
+        sel_d = torch.from_numpy(sel.astype(np.int32)).to(dev)
+        rowptr = torch.empty(T * M + 1, **i32)
+        cv = torch.empty((total, 2), **i32)
+        gptr = torch.empty(T + 1, **i32)
+        slots = torch.empty(T * M, **i32) if self.row_pad else None
+        wsb = _lib.lib.kgcn_csr_gather_workspace_bytes(T)
+        ws = torch.empty(max(wsb, 4) // 4, **i32)
+        _lib.check(_lib.lib.kgcn_csr_gather_graphs(
+            self.desc(), sel_d.data_ptr(), T, rowptr.data_ptr(), cv.data_ptr() if total else 0, total,
+            slots.data_ptr() if slots is not None else 0, gptr.data_ptr(), ws.data_ptr(), wsb,
+            _lib.current_stream()), "kgcn_csr_gather_graphs")
+        out = BatchedCSR(rowptr, cv, T, M, self.cols, int(per.max()) if T else 0, row_pad=self.row_pad)
+        out._graph_counts = per.astype(np.int64)
+        if self.row_pad:
+            out.slots, out.graph_ptr = slots, gptr
+        else:
+            src = self
+            out._make_t = lambda: src.transpose().gather(sel)
+            out._make_p4 = lambda: src.padded4().gather(sel)
+        return out
 
     def with_values(self, values):
         """Same pattern, new values (device fp32 tensor [nnz] in CSR order).  Used when the

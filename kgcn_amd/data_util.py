@@ -212,6 +212,37 @@ def batch_features(features, batch_idx, batch_size=None, device="cuda"):
     return torch.from_numpy(out).to(device)
 
 
+class DeviceGraphDataset:
+    """The whole dataset resident in HBM: every adjacency channel as ONE batched-CSR
+    container over all G graphs (plus, built lazily, its transpose and the row-padded copies the fused
+    kernels read), features as one [G, N, F] tensor.  batch() assembles a mini-batch on the device:
+    adjacency by kgcn_csr_gather_graphs (segmented copies, no host loops, no per-step upload of the
+    adjacency like kgcn/core.py:267-269 does), features by one index_select; short batches are padded
+    with empty dummy graphs / zero feature rows exactly like kgcn/feed.py:112-133."""
+
+    def __init__(self, channels, features=None, device="cuda"):
+        import torch
+        self.num_graphs = channels[0].num_graphs
+        all_idx = np.arange(self.num_graphs)
+        self.channels = [c.batch(all_idx, device=device) for c in channels]
+        self.features = None if features is None else \
+            torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).to(device)
+
+    def batch(self, batch_idx, batch_size=None):
+        import torch
+        batch_idx = np.asarray(batch_idx, np.int64).reshape(-1)
+        T = batch_idx.shape[0] if batch_size is None else int(batch_size)
+        sel = np.full(T, -1, np.int64)
+        sel[:batch_idx.shape[0]] = batch_idx
+        adj = BatchedAdjacency([c.gather(sel) for c in self.channels])
+        if self.features is None:
+            return adj, None
+        idx = torch.from_numpy(batch_idx).to(self.features.device)
+        feat = self.features.new_zeros((T,) + tuple(self.features.shape[1:]))
+        feat[:batch_idx.shape[0]] = self.features.index_select(0, idx)
+        return adj, feat
+
+
 # -------------------------------------------------------------------------------------------------
 # block-diagonal batch (kgcn-sparse path, BASELINE config 3)
 # -------------------------------------------------------------------------------------------------

@@ -83,6 +83,15 @@ wsp2 = torch.empty(wsb2 // 4, device=dev)
 add("graphconv_bwd fused (+2 reduce launches)",
     lambda: check(lib.kgcn_graphconv_bwd_f32(p4t.desc(), ptr(x), ptr(w), ptr(g), D, D, ptr(dx), ptr(dw), ptr(db),
                                              ptr(wsp2), wsb2, current_stream())), ab["bwd"], 4 * N * D * D + 2 * NNZ * D)
+# device-side mini-batch assembly: T graphs gathered (shuffled) out of a resident dataset of T graphs;
+# bytes = read + write of rowptr and cv
+sel = np.random.default_rng(0).permutation(T)
+csr.graph_counts()
+gather_bytes = 2 * (4 * N + 8 * NNZ)
+add("batch assembly A (kgcn_csr_gather_graphs)", lambda: csr.gather(sel), gather_bytes)
+p4.graph_counts()
+p4_bytes = 2 * (8 * N + 8 * (p4.nnz // T))
+add("batch assembly A row-padded + slots", lambda: p4.gather(sel), p4_bytes)
 # achievable HBM copy bandwidth on this box (float4 copy of 2 x 819 MB), the practical ceiling
 src, dst = x.reshape(-1), torch.empty_like(x).reshape(-1)
 t = timeit(lambda: dst.copy_(src))
