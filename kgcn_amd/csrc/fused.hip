@@ -9,8 +9,10 @@
 //   * the graph's node-feature tile [N<=32 x D<=64] is streamed HBM -> registers -> LDS once
 //     (dwordx4, all loads of a tile in flight together), and the NEXT graph's tile + CSR slice are
 //     already in flight (register prefetch, branch-free) while the current graph is computed,
-//   * the dense contraction runs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32)
-//     with the weight fragments resident in registers (forward) / in LDS (backward, W^T),
+//   * the dense contraction of the forward runs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) with
+//     the weight fragments resident in registers; the two contractions of the backward run on the bf16
+//     matrix pipe with an exact 3-way split of the fp32 operands (six v_mfma_f32_32x32x16_bf16 products
+//     per k-step, fp32-accurate -- see split_pair below),
 //   * FW (resp. dFW) lives only in LDS, where the sparse aggregation gathers neighbour rows with
 //     conflict-free ds_read_b128 -- X.W and dFW never touch HBM,
 //   * dW / dbias accumulate in MFMA accumulators across ALL graphs a wave processes, are reduced
@@ -22,6 +24,7 @@
 // sizes are compile-time constants, the 8 aggregation passes are straight-line code) and generic
 // (N <= 32, din,dout <= 64 multiples of 4).  Other shapes use kgcn_dense_* + kgcn_bconv_f32.
 #include <type_traits>
+#include <utility>
 
 #include "kgcn_common.h"
 
@@ -80,6 +83,54 @@ __device__ __forceinline__ void fma4(f32x4& acc, float v, const f32x4& x) {
 __device__ __forceinline__ void add4(f32x4& acc, const f32x4& x) {
   acc[0] += x[0]; acc[1] += x[1]; acc[2] += x[2]; acc[3] += x[3];
 }
+
+// ---- fp32 contraction on the bf16 matrix pipe: exact 3-way split ------------------------------------
+// gfx950 runs v_mfma_f32_32x32x2_f32 at the VALU rate AND on the VALU datapath (nothing overlaps it:
+// tools/mfma_shadow.hip), while v_mfma_f32_32x32x16_bf16 is 16x faster per flop and runs beside VALU
+// work (tools/mfma_shadow_bf16.hip).  An fp32 value is the EXACT sum of three bf16 values obtained by
+// truncation -- v = p1 + p2 + p3, 24 significand bits = 8 + 8 + 8 -- and bf16 x bf16 products are exact
+// in the fp32 accumulator, so  a*b = sum_{i+j<=4} a_i b_j + O(2^-23 |ab|): six bf16 MFMAs replace eight
+// f32 MFMAs (K = 16 vs 2) at fp32 accuracy (the dropped terms a2b3 + a3b2 + a3b3 are below one fp32 ulp
+// of the product).
+template <typename Fn, int... I>
+__device__ __forceinline__ void static_for_impl(Fn&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): straight-line code with compile-time
+// indices (register arrays indexed inside `#pragma unroll` loops ended up in scratch memory)
+template <int N, typename Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Frag3 { u32x4 p1, p2, p3; };   // 8 k-values of one MFMA operand row/column, three bf16 pieces
+
+__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& q1, unsigned& q2, unsigned& q3) {
+  const unsigned m = 0xffff0000u;
+  const float h0 = __uint_as_float(__float_as_uint(v0) & m), h1 = __uint_as_float(__float_as_uint(v1) & m);
+  const float r0 = v0 - h0, r1 = v1 - h1;                     // exact: the low 16 significand bits
+  const float g0 = __uint_as_float(__float_as_uint(r0) & m), g1 = __uint_as_float(__float_as_uint(r1) & m);
+  const float s0 = r0 - g0, s1 = r1 - g1;                     // exact, <= 8 significant bits: a bf16 value
+  q1 = __builtin_amdgcn_perm(__float_as_uint(v1), __float_as_uint(v0), 0x07060302u);   // high halves
+  q2 = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+  q3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+__device__ __forceinline__ void split8(const float* v, Frag3& f) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned q1, q2, q3;
+    split_pair(v[2 * j], v[2 * j + 1], q1, q2, q3);
+    f.p1[j] = q1; f.p2[j] = q2; f.p3[j] = q3;
+  }
+}
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
+                                                 0, 0, 0);
+}
+// the six products of one (A fragment, B fragment) pair, smallest terms first
+#define KGCN_SPLIT_PRODUCTS(F) F(p3, p1) F(p2, p2) F(p1, p3) F(p2, p1) F(p1, p2) F(p1, p1)
 
 struct WaveSlice {
   float* a;     // forward: x tile [FN][ALD] (A-fragment source); backward: dFW tile [FN][BLD]
@@ -581,6 +632,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ g,
     float* __restrict__ dx, float* __restrict__ part_dw, float* __restrict__ part_db, int T, int N,
     int din, int dout, int max_nnz) {
+  constexpr bool FULL = false;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -613,61 +665,81 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
     MetaRegs m_cur, m_nxt;
     issue_meta(m_cur, slots_t, gptr_t, t, N, lane);
     int base = meta_base(m_cur), cnt = meta_cnt(m_cur);
-    issue_tile<false>(fg, g + (long)t * N * dout, ng4, lane);
+    issue_tile<FULL>(fg, g + (long)t * N * dout, ng4, lane);
     issue_cv(fc, cv_t, base, cnt, lane);
-    issue_tile<false>(fx, x + (long)t * N * din, nx4, lane);
+    issue_tile<FULL>(fx, x + (long)t * N * din, nx4, lane);
     int tn = t + nwaves;
     issue_meta(m_nxt, slots_t, gptr_t, tn < T ? tn : t, N, lane);
 
+    PROBE_DECL
     for (;;) {
+      PROBE(0)
       // ---- 1. g[t], CSR(A^T) slice: registers -> LDS ------------------------------------------
-      land_tile<false>(fg, ws.b, FD, ng4, dout4, lane);
+      land_tile<FULL>(fg, ws.b, FD, ng4, dout4, lane);
       land_csr(fc, ws.ecv, ws.rp, cv_t, m_cur.slot, base, cnt, N, lane);
       wave_sync();
 
+      PROBE(1)
       // ---- 2. dFW = A^T @ g -> dFW tile (odd stride), dbias partial ----------------------------
-      aggregate_rows<false>(ws.ecv, ws.rp, ws.b, N, dout, lane, [&](int r, int cl, f32x4 acc) {
+      aggregate_rows<FULL>(ws.ecv, ws.rp, ws.b, N, dout, lane, [&](int r, int cl, f32x4 acc) {
         float* d = ws.a + r * BLD + cl * 4;
         d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2]; d[3] = acc[3];
         dbacc += acc;
       });
       wave_sync();
+      PROBE(2)
 
       // ---- 3. x[t] -> gather tile (g is dead) --------------------------------------------------
-      land_tile<false>(fx, ws.b, FD, nx4, din4, lane);
+      land_tile<FULL>(fx, ws.b, FD, nx4, din4, lane);
 
-      // ---- 4. next graph (g, CSR, x) in flight during the whole MFMA phase (branch-free) --------
+      wave_sync();
+      PROBE(3)
+      // ---- 4. dW += x^T @ dFW on the bf16 matrix pipe (exact 3-way split, 6 products) ------------------
+      // lane (li, hi): columns li / 32+li of x and dFW over its 16 nodes n = hi*16 + s; bf16 k-step ks
+      // takes nodes hi*16 + 8ks .. +7 (the same node set for both operands).  The second wave of the
+      // SIMD runs its VALU/LDS phases beside these MFMAs.
+      static_for<2>([&](auto ksc) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ksc)::value;
+        u32x4 F[4][3];                             // [operand: x lo, x hi, dFW lo, dFW hi][piece]
+        static_for<16>([&](auto qc) __attribute__((always_inline)) {
+          constexpr int Q = decltype(qc)::value, OP = Q >> 2, J = Q & 3;
+          const int n = hi * 16 + 8 * ks + 2 * J;
+          const float* src = (OP < 2 ? ws.b + n * FD : ws.a + n * BLD) + (OP & 1) * 32 + li;
+          unsigned q1, q2, q3;
+          split_pair(src[0], src[OP < 2 ? FD : BLD], q1, q2, q3);
+          F[OP][0][J] = q1; F[OP][1][J] = q2; F[OP][2][J] = q3;
+        });
+        static_for<6>([&](auto pc) __attribute__((always_inline)) {
+          constexpr int pr = decltype(pc)::value;
+          constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
+          dw00 = mfma_bf16(F[0][PA[pr]], F[2][PB[pr]], dw00);
+          dw01 = mfma_bf16(F[0][PA[pr]], F[3][PB[pr]], dw01);
+          dw10 = mfma_bf16(F[1][PA[pr]], F[2][PB[pr]], dw10);
+          dw11 = mfma_bf16(F[1][PA[pr]], F[3][PB[pr]], dw11);
+        });
+      });
+
+      // ---- 5. next graph (g, CSR, x) in flight during the dX phase and the other wave's work (issued
+      // AFTER the dW phase: its 72 registers would not fit beside the split fragments) ---------------
       const bool has_next = tn < T;
       const int tp = has_next ? tn : t;
       const int base_n = meta_base(m_nxt), cnt_n = meta_cnt(m_nxt);
-      issue_tile<false>(fg, g + (long)tp * N * dout, ng4, lane);
+      issue_tile<FULL>(fg, g + (long)tp * N * dout, ng4, lane);
       issue_cv(fc, cv_t, base_n, cnt_n, lane);
-      issue_tile<false>(fx, x + (long)tp * N * din, nx4, lane);
+      issue_tile<FULL>(fx, x + (long)tp * N * din, nx4, lane);
       m_cur = m_nxt;
       {
         const int tnn = tn + nwaves;
         issue_meta(m_nxt, slots_t, gptr_t, tnn < T ? tnn : tp, N, lane);
       }
-      wave_sync();
 
-      // ---- 5. dW += x^T @ dFW --------------------------------------------------------------------
-#pragma unroll 2
-      for (int s = 0; s < 16; ++s) {
-        const int n = hi * 16 + s;
-        const float a0 = ws.b[n * FD + li], a1 = ws.b[n * FD + 32 + li];
-        const float f0 = ws.a[n * BLD + li], f1 = ws.a[n * BLD + 32 + li];
-        dw00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, f0, dw00, 0, 0, 0);
-        dw01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, f1, dw01, 0, 0, 0);
-        dw10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f0, dw10, 0, 0, 0);
-        dw11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f1, dw11, 0, 0, 0);
-      }
-
+      PROBE(4)
       // ---- 6. dX = dFW @ W^T (A operand straight from the odd-stride LDS tile) ------------------
-      if (dx) {
+      if (FULL || dx) {
         f32x16 c0, c1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
-#pragma unroll 4
+#pragma unroll 8
         for (int s = 0; s < 32; ++s) {
           const int k = hi * 32 + s;
           const float a = ws.a[li * BLD + k];
@@ -675,6 +747,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
           c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Wt[k * FD + 32 + li], c1, 0, 0, 0);
         }
         // C layout -> LDS (the x tile is dead) -> whole rows as dwordx4
+        PROBE(5)
         wave_sync();
         store_c_tiles(ws.b, c0, c1, li, hi);
         wave_sync();
@@ -682,13 +755,16 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int i = lane + q * 64;
-          if (i < nx4) {
+          if constexpr (FULL) {
+            stv4(dxt + (long)i * 4, ldv4(ws.b + i * 4));
+          } else if (i < nx4) {
             const int r = i / din4, c4 = i - r * din4;
             stv4(dxt + (long)i * 4, ldv4(ws.b + r * FD + c4 * 4));
           }
         }
       }
       wave_sync();
+      PROBE(6)
 
       if (!has_next) break;
       t = tn;
@@ -696,6 +772,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
       base = base_n;
       cnt = cnt_n;
     }
+    PROBE_FLUSH(blockIdx.x * wpb + wave)
   }
 
   // ---- reduce the workgroup's waves through LDS; one partial per workgroup leaves the chip -----
@@ -738,14 +815,20 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
 
 // ------------------------------------------------------------------------------------------------
 // backward, FULL shape: ONE wave per SIMD (4 waves per CU, up to 512 VGPRs and 36 KB LDS each), a
-// two-graph-deep software pipeline so that nothing the wave needs is ever in flight when it needs it:
-//   phase A: 64 MFMAs dW(i) += x(i)^T dFW(i), then the aggregation dFW(i+1) = A^T g(i+1) into the
-//            other dFW buffer (two passes in flight, skewed, for LDS latency);
-//   phase B: 64 MFMAs dX(i) = dFW(i) W^T, then the 32 row stores of dX(i-1) (alternating accumulator
-//            sets), x(i+1), g(i+2), CSR(i+2) registers -> LDS and the global loads of x(i+2),
-//            g(i+3), CSR(i+3) (a full iteration of flight time).
-// MFMAs are kept in clusters: the f32-input MFMA shares the VALU datapath on gfx950 (nothing hides
-// behind it, ~18 cycles per MFMA<->VALU switch; tools/mfma_shadow.hip).
+// two-graph-deep software pipeline so that nothing the wave needs is ever in flight when it needs it.
+// Both contractions run on the bf16 matrix pipe (exact 3-way split, 6 products; 96 MFMAs of 32 cycles per
+// graph instead of 128 f32 MFMAs of 64 cycles on the VALU datapath), and because that pipe runs BESIDE
+// the vector ALU only when the instruction stream alternates, every MFMA carries a slice of the
+// phase's other work behind it:
+//   phase A: per k-step (16 nodes): 32 operand values read + split, then 24 MFMAs of dW(i) += x(i)^T
+//            dFW(i), each followed by one half step of the aggregation dFW(i+1) = A^T g(i+1) (two passes
+//            in flight, skewed, for LDS latency) and, for the first 16, two row stores of dX(i-1);
+//   phase B: 48 MFMAs of dX(i) = dFW(i) W^T -- A fragments split one k-step ahead, B fragments = the W
+//            pieces resident in 96 registers (no W^T in LDS) -- each followed by one slice of:
+//            x(i+1), g(i+2), CSR(i+2) registers -> LDS and the global loads of x(i+2), g(i+3), CSR(i+3)
+//            (a full iteration of flight time).
+// Measured on cfg2 (tools/phase_probe.py): 9,970 cycles per graph and wave (phase A 6,370, B 3,600) vs
+// 13,300 with f32 MFMAs; without the dX stores 7,100 -- the kernel now moves with the HBM write traffic.
 // LDS per wave: dFW[2] (odd stride), x tile, g tile (+ zero row), CSR[2].
 // ------------------------------------------------------------------------------------------------
 constexpr int BWD_FULL_WPB = 4;
@@ -767,8 +850,7 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_full_kernel(
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, hi = lane >> 5;
   const int sub = lane >> 4, cl = lane & 15;
-  float* Wt = reinterpret_cast<float*>(smem);  // [D][D]: Wt[k][j] = W[j][k]
-  unsigned char* sl = smem + D * D * 4 + (size_t)wave * bwd_full_slice_bytes(max_nnz);
+  unsigned char* sl = smem + (size_t)wave * bwd_full_slice_bytes(max_nnz);
   float* dfw0 = reinterpret_cast<float*>(sl);
   float* dfw1 = reinterpret_cast<float*>(sl + DFW_B);
   float* xt = reinterpret_cast<float*>(sl + 2 * DFW_B);
@@ -777,9 +859,20 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_full_kernel(
   const size_t ecv_stride = ecv_bytes(max_nnz) / 8;
   int* tab0 = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(ecv0) + 2 * ecv_bytes(max_nnz));
 
-  for (int i = tid; i < D * D; i += blockDim.x) Wt[i] = w[(i & 63) * D + (i >> 6)];
   for (int i = lane; i < D; i += 64) gt[FN * FD + i] = 0.f;
-  __syncthreads();
+  // B fragments of dX = dFW W^T, resident for the whole kernel: lane (li, hi), tile nt, k-step ks holds
+  // W^T[k][32 nt + li] = W[32 nt + li][k] for k = 16 ks + 8 hi + j -- 8 contiguous floats of a W row --
+  // as three bf16 pieces
+  u32x4 WF[2][4][3];
+  static_for<8>([&](auto c) __attribute__((always_inline)) {
+    constexpr int nt = decltype(c)::value >> 2, ks = decltype(c)::value & 3;
+    const float* src = w + (32 * nt + li) * D + 16 * ks + 8 * hi;
+    const f32x4 lo = ldv4(src), hi4 = ldv4(src + 4);
+    const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    Frag3 f;
+    split8(v, f);
+    WF[nt][ks][0] = f.p1; WF[nt][ks][1] = f.p2; WF[nt][ks][2] = f.p3;
+  });
 
   f32x16 dw00, dw01, dw10, dw11;
 #pragma unroll
@@ -833,14 +926,15 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_full_kernel(
     issue_meta(m_b, slots_t, gptr_t, gidx(3), N, lane);
     wave_sync();
 
-    // dX accumulators: two sets alternate by graph parity, so that dX(i-1) can leave the chip from
-    // one set (32 row stores spread over phase B) while dX(i) accumulates in the other
-    f32x16 ce0, ce1, co0 = {}, co1 = {};
+    // dX accumulators: dX(i) is produced in phase B(i) and leaves the chip behind the first MFMAs of
+    // phase A(i+1) (32 row stores)
+    f32x16 c0 = {}, c1 = {};
     int cur = 0;     // dFW / CSR buffer of the MFMA graph i; the aggregated graph i+1 uses cur^1
 
     // ---- phase A: dW(i) MFMAs  ||  aggregation of graph i+1 (one half step per MFMA) -------------
-    auto phase_a = [&](auto agg_tag) __attribute__((always_inline)) {
-      constexpr bool AGG = decltype(agg_tag)::value;
+    auto phase_a = [&](auto agg_tag, auto st_tag, int iprev) __attribute__((always_inline)) {
+      constexpr bool AGG = decltype(agg_tag)::value, ST = decltype(st_tag)::value;
+      float* dxp = dx + (long)gidx(iprev) * N * D;
       const float* dfc = cur ? dfw1 : dfw0;
       float* dfn = cur ? dfw0 : dfw1;
       const int2* ecv_n = ecv0 + (cur ^ 1) * ecv_stride;
@@ -851,25 +945,58 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_full_kernel(
         d[0] = q.a[0]; d[1] = q.a[1]; d[2] = q.a[2]; d[3] = q.a[3];
         add4(dbacc, q.a);
       };
-      // MFMA cluster first (the f32 MFMA runs on the VALU datapath: nothing hides behind it and
-      // every MFMA<->VALU switch costs ~18 cycles), then the aggregation as one VALU/LDS cluster
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {          // k-step: node n = hi*16 + s, 4 MFMAs
-        const int n = hi * 16 + s;
-        const float a0 = xt[n * FD + li], a1 = xt[n * FD + 32 + li];
-        const float f0 = dfc[n * BLD + li], f1 = dfc[n * BLD + 32 + li];
-        dw00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, f0, dw00, 0, 0, 0);
-        dw01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, f1, dw01, 0, 0, 0);
-        dw10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f0, dw10, 0, 0, 0);
-        dw11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, f1, dw11, 0, 0, 0);
-      }
+      // 2 k-steps x [32 operand values read + split, then 24 bf16 MFMAs (6 split products x 4 accumulator
+      // tiles)].  The matrix pipe runs beside the vector ALU, but an in-order wave only overlaps them when
+      // the instruction stream alternates (tools/mfma_shadow_bf16.hip): ONE aggregation half step of graph
+      // i+1 sits behind every MFMA, so consecutive LDS-dependent halves of a pass are two MFMAs apart.
+      static_for<2>([&](auto ksc) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ksc)::value;
+        u32x4 F[4][3];                           // [operand: x lo, x hi, dFW lo, dFW hi][piece]
+        static_for<16>([&](auto qc) __attribute__((always_inline)) {
+          constexpr int Q = decltype(qc)::value, OP = Q >> 2, J = Q & 3;
+          const int n = hi * 16 + 8 * ks + 2 * J;          // lane (li, hi): columns li / 32+li, 8 nodes
+          const float* src = (OP < 2 ? xt + n * FD : dfc + n * BLD) + (OP & 1) * 32 + li;
+          unsigned q1, q2, q3;
+          split_pair(src[0], src[OP < 2 ? FD : BLD], q1, q2, q3);
+          F[OP][0][J] = q1; F[OP][1][J] = q2; F[OP][2][J] = q3;
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<24>([&](auto mc) __attribute__((always_inline)) {
+          constexpr int m = decltype(mc)::value, pr = m >> 2, tile = m & 3;
+          constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
+          const u32x4 av = F[tile >> 1][PA[pr]], bv = F[2 + (tile & 1)][PB[pr]];
+          if constexpr (tile == 0) dw00 = mfma_bf16(av, bv, dw00);
+          else if constexpr (tile == 1) dw01 = mfma_bf16(av, bv, dw01);
+          else if constexpr (tile == 2) dw10 = mfma_bf16(av, bv, dw10);
+          else dw11 = mfma_bf16(av, bv, dw11);
+#ifndef KGCN_ABL_NO_ST
+          if constexpr (ST && ks == 0 && m < 16) {          // dX(i-1): two row stores per MFMA
+            const int row = (m & 3) + 8 * (m >> 2) + 4 * hi;
+            dxp[row * D + li] = c0[m];
+            dxp[row * D + 32 + li] = c1[m];
+          }
+#endif
+#ifndef KGCN_ABL_NO_AGG
+          if constexpr (AGG) {
+            constexpr int j = 32 * ks + m;
+            agg_dual_half(j, qa, qb, tab_n, ecv_n, srcl, sub, emit);
+            agg_dual_tail(j, qa, qb, ecv_n, srcl);
+          }
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+        });
+#ifndef KGCN_ABL_NO_AGG
+        if constexpr (AGG) {
+          static_for<8>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int j = 32 * ks + 24 + decltype(rc)::value;
+            agg_dual_half(j, qa, qb, tab_n, ecv_n, srcl, sub, emit);
+            agg_dual_tail(j, qa, qb, ecv_n, srcl);
+          });
+        }
+#endif
+      });
 #ifndef KGCN_ABL_NO_AGG
       if constexpr (AGG) {
-#pragma unroll
-        for (int j = 0; j < 64; ++j) {        // two passes in flight, skewed (LDS latency covered)
-          agg_dual_half(j, qa, qb, tab_n, ecv_n, srcl, sub, emit);
-          agg_dual_tail(j, qa, qb, ecv_n, srcl);
-        }
         emit(qa);
         emit(qb);
       }
@@ -879,51 +1006,70 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_full_kernel(
 
     // ---- phase B: dX(i) MFMAs into set `c`  ||  stores of dX(i-1) from set `p`  ||
     //      x(i+1), g(i+2), CSR(i+2) -> LDS  ||  loads of x(i+2), g(i+3), CSR(i+3) --------------------
-    auto phase_b = [&](auto mv_tag, auto st_tag, f32x16& c0, f32x16& c1, const f32x16& p0,
-                       const f32x16& p1, int i) __attribute__((always_inline)) {
-      constexpr bool MV = decltype(mv_tag)::value, ST = decltype(st_tag)::value;
+    auto phase_b = [&](auto mv_tag, int i) __attribute__((always_inline)) {
+      constexpr bool MV = decltype(mv_tag)::value;
       const float* dfc = cur ? dfw1 : dfw0;
       int2* ecv_c = ecv0 + cur * ecv_stride;     // CSR(i) is dead: receives CSR(i+2)
       int* tab_c = tab0 + cur * (FN + 4);
       const float* xsrc = x + (long)gidx(i + 2) * N * D;
       const float* gsrc = g + (long)gidx(i + 3) * N * D;
-      float* dxp = dx + (long)gidx(i - 1) * N * D;
       int base_n = 0, cnt_n = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
-#pragma unroll
-      for (int s = 0; s < 32; ++s) {           // MFMA cluster
-        const int k = hi * 32 + s;
-        const float a = dfc[li * BLD + k];
-        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Wt[k * FD + li], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Wt[k * FD + 32 + li], c1, 0, 0, 0);
-      }
-#ifndef KGCN_ABL_NO_ST
-      if constexpr (ST) {                      // dX(i-1) leaves from the other accumulator set
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          const int row = (rr & 3) + 8 * (rr >> 2) + 4 * hi;
-          dxp[row * D + li] = p0[rr];
-          dxp[row * D + 32 + li] = p1[rr];
-        }
-      }
-#endif
+      // dX(i) = dFW(i) W^T: A fragments = row li of dFW(i), k = 16 ks + 8 hi + j (split here, k-step ks+1
+      // behind the MFMAs of k-step ks); B fragments = the resident W pieces.  48 bf16 MFMAs, and behind
+      // each of them one slice of the phase's memory work:
+      //   MFMA 16..23: x(i+1) -> LDS, x(i+2) load            24..31: g(i+2) -> LDS, g(i+3) load
+      //   MFMA 32..34: CSR(i+2) -> LDS, CSR(i+3) / meta loads
+      u32x4 FA[4][3];
+      auto split_a = [&](auto ksc) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ksc)::value;
+        const float* src = dfc + li * BLD + 16 * ks + 8 * hi;
+        static_for<4>([&](auto jc) __attribute__((always_inline)) {
+          constexpr int J = decltype(jc)::value;
+          unsigned q1, q2, q3;
+          split_pair(src[2 * J], src[2 * J + 1], q1, q2, q3);
+          FA[ks][0][J] = q1; FA[ks][1][J] = q2; FA[ks][2][J] = q3;
+        });
+      };
+      split_a(std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<48>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value, ks = m / 12, pr = (m % 12) >> 1, nt = m & 1;
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+        if constexpr (nt == 0) c0 = mfma_bf16(FA[ks][PA[pr]], WF[0][ks][PB[pr]], c0);
+        else c1 = mfma_bf16(FA[ks][PA[pr]], WF[1][ks][PB[pr]], c1);
+        if constexpr (m % 12 == 0 && ks < 3) split_a(std::integral_constant<int, ks + 1>{});
 #ifndef KGCN_ABL_NO_MV
-      if constexpr (MV) {
-        // x(i+1): registers -> x tile, x(i+2) in flight; g(i+2), CSR(i+2) -> LDS; g(i+3), CSR(i+3)
-        // in flight (a full iteration of flight time)
-        land_tile<true>(xpf, xt, FD, 512, 16, lane);
-        issue_tile<true>(xpf, xsrc, 512, lane);
-        land_tile<true>(gpf, gt, FD, 512, 16, lane);
-        land_csr(cpf, ecv_c, tab_c, cv_t, m_a.slot, base_a, cnt_a, N, lane);
-        base_n = meta_base(m_b);
-        cnt_n = meta_cnt(m_b);
-        issue_cv(cpf, cv_t, base_n, cnt_n, lane);
-        issue_tile<true>(gpf, gsrc, 512, lane);
-        m_a = m_b;
-        issue_meta(m_b, slots_t, gptr_t, gidx(i + 4), N, lane);
-      }
+        if constexpr (MV && m >= 16 && m < 24) {          // x(i+1): registers -> x tile; x(i+2) in flight
+          constexpr int q = m - 16;
+          const int i4 = lane + q * 64;
+          stv4(xt + (i4 >> 4) * FD + (i4 & 15) * 4, xpf.v[q]);
+          xpf.v[q] = ldv4(xsrc + (long)i4 * 4);
+        }
+        if constexpr (MV && m >= 24 && m < 32) {          // g(i+2) -> gather tile; g(i+3) in flight
+          constexpr int q = m - 24;
+          const int i4 = lane + q * 64;
+          stv4(gt + (i4 >> 4) * FD + (i4 & 15) * 4, gpf.v[q]);
+          gpf.v[q] = ldv4(gsrc + (long)i4 * 4);
+        }
+        if constexpr (MV && m == 32) land_csr(cpf, ecv_c, tab_c, cv_t, m_a.slot, base_a, cnt_a, N, lane);
+        if constexpr (MV && m == 33) {
+          base_n = meta_base(m_b);
+          cnt_n = meta_cnt(m_b);
+          issue_cv(cpf, cv_t, base_n, cnt_n, lane);
+        }
+        if constexpr (MV && m == 34) {
+          // a REAL register move, placed here: a plain `m_a = m_b` becomes a loop phi whose copy the
+          // compiler puts on the back edge, behind the new load of m_b -- i.e. s_waitcnt vmcnt(~0) on
+          // every prefetch load of this phase at the top of the next iteration
+          asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+                       : "=&v"(m_a.slot), "=&v"(m_a.gp) : "v"(m_b.slot), "v"(m_b.gp));
+          issue_meta(m_b, slots_t, gptr_t, gidx(i + 4), N, lane);
+        }
 #endif
+        __builtin_amdgcn_sched_barrier(0);
+      });
       if constexpr (MV) {
         base_a = base_n;
         cnt_a = cnt_n;
@@ -931,51 +1077,37 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_full_kernel(
       wave_sync();
     };
 
-    // iterations: MFMA graph i (dX into set i&1), aggregated graph i+1, stores of dX(i-1)
+    // iterations: MFMA graph i, aggregated graph i+1, stores of dX(i-1)
     using Y = std::true_type;
     using Nn = std::false_type;
     PROBE_DECL
     if (cntw > 1) {
-      phase_a(Y{});
-      phase_b(Y{}, Nn{}, ce0, ce1, co0, co1, 0);
+      phase_a(Y{}, Nn{}, 0);
+      phase_b(Y{}, 0);
       cur ^= 1;
       PROBE(0)
-      int i = 1;
-      for (; i + 1 < cntw - 1; i += 2) {       // two graphs per trip: odd set, then even set
-        phase_a(Y{});
+      for (int i = 1; i < cntw - 1; ++i) {
+        phase_a(Y{}, Y{}, i - 1);
         PROBE(1)
-        phase_b(Y{}, Y{}, co0, co1, ce0, ce1, i);
+        phase_b(Y{}, i);
         PROBE(2)
         cur ^= 1;
-        phase_a(Y{});
-        PROBE(1)
-        phase_b(Y{}, Y{}, ce0, ce1, co0, co1, i + 1);
-        PROBE(2)
-        cur ^= 1;
-      }
-      if (i < cntw - 1) {                      // one more full iteration (odd set)
-        phase_a(Y{});
-        phase_b(Y{}, Y{}, co0, co1, ce0, ce1, i);
-        cur ^= 1;
-        ++i;
       }
       // last graph i = cntw-1: its dFW is ready, nothing left to aggregate or prefetch
-      phase_a(Nn{});
-      if (i & 1) phase_b(Nn{}, Y{}, co0, co1, ce0, ce1, i);
-      else phase_b(Nn{}, Y{}, ce0, ce1, co0, co1, i);
+      phase_a(Nn{}, Y{}, cntw - 2);
+      phase_b(Nn{}, cntw - 1);
     } else {
-      phase_a(Nn{});
-      phase_b(Nn{}, Nn{}, ce0, ce1, co0, co1, 0);
+      phase_a(Nn{}, Nn{}, 0);
+      phase_b(Nn{}, 0);
     }
     PROBE_FLUSH(blockIdx.x * BWD_FULL_WPB + wave)
-    {                                           // dX of the last graph (set of parity (cntw-1)&1)
+    {                                           // dX of the last graph
       float* dxp = dx + (long)tl * N * D;
-      const bool odd = (cntw - 1) & 1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        dxp[row * D + li] = odd ? co0[r] : ce0[r];
-        dxp[row * D + 32 + li] = odd ? co1[r] : ce1[r];
+        dxp[row * D + li] = c0[r];
+        dxp[row * D + 32 + li] = c1[r];
       }
     }
   }
@@ -1002,7 +1134,7 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_full_kernel(
   if (lane < 16) stv4(park + FD * FD + lane * 4, dbacc);
   __syncthreads();
   const size_t slice_f = bwd_full_slice_bytes(max_nnz) / 4;
-  const float* slice0 = reinterpret_cast<const float*>(smem + D * D * 4);
+  const float* slice0 = reinterpret_cast<const float*>(smem);
   float* pw = part_dw + (long)blockIdx.x * D * D;
   for (int i = tid; i < D * D; i += blockDim.x) {
     float s = 0.f;
@@ -1139,7 +1271,7 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
   if (!aligned16(x) || !aligned16(dout_grad) || (dx && !aligned16(dx)) || !aligned16(at->cv))
     return fail("kgcn_graphconv_bwd_f32: tensors not 16-byte aligned");
   const bool full = dx != nullptr && is_full(at->rows, din, dout) &&
-                    FD * FD * 4 + BWD_FULL_WPB * bwd_full_slice_bytes(at->max_nnz_per_graph) <= (size_t)kLdsBytes;
+                    BWD_FULL_WPB * bwd_full_slice_bytes(at->max_nnz_per_graph) <= (size_t)kLdsBytes;
   const size_t per = full ? bwd_full_slice_bytes(at->max_nnz_per_graph) : bwd_slice(at->max_nnz_per_graph);
   const int wpb = full ? BWD_FULL_WPB : fused_wpb(per, FD * FD * 4);
   const int blocks = fused_grid(at->num_graphs, wpb);
@@ -1149,7 +1281,7 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
                 (long long)need);
   float* part_dw = static_cast<float*>(workspace);
   float* part_db = part_dw + (long)blocks * din * dout;
-  const size_t lds = FD * FD * 4 + (size_t)wpb * per;
+  const size_t lds = (full ? 0 : FD * FD * 4) + (size_t)wpb * per;
   static thread_local bool attr_set = false;
   if (!attr_set) {
     allow_big_lds(graphconv_bwd_full_kernel);

@@ -13,7 +13,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 out = os.path.join(ROOT, "gpurun_out", "libkgcn_probe.so")
-src = [os.path.join(ROOT, "kgcn_amd", "csrc", f) for f in ("misc.hip", "spmm.hip", "dense.hip", "fused.hip")]
+src = [os.path.join(ROOT, "kgcn_amd", "csrc", f) for f in ("misc.hip", "spmm.hip", "dense.hip", "fused.hip", "pack.hip")]
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                        "-DKGCN_PROBE", "-fno-slp-vectorize", "-o", out] + [a for a in sys.argv[1:] if a.startswith("-D")] + src)
 sys.argv = [a for a in sys.argv if not a.startswith("-D")]
@@ -42,6 +42,8 @@ assert lib.kgcn_probe_set(ctypes.c_void_p(probe.data_ptr())) == 0
 s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 names_f = ["loop-top(wait)", "land", "issue-prefetch", "mfma(t) || aggregate(t-1)+store", "FW->LDS"]
+names_g = ["loop top", "land g + CSR", "aggregate -> dFW", "land x + issue prefetch", "dW (split + bf16 mfma)", "dX mfma",
+           "dX -> LDS -> HBM"]
 names_b = ["prologue+iter0", "phase A: dW mfma || aggregate(i+1) || dX(i-1) stores", "phase B: dX mfma || land/issue next tiles"]
 for which in ("fwd", "bwd"):
     for rep in range(3):
@@ -59,11 +61,14 @@ for which in ("fwd", "bwd"):
         assert rc == 0
     pr = probe.cpu().numpy().reshape(2048, 8).astype(np.float64)
     graphs_per_wave = T / NW[which]
-    pr = pr[:int(NW[which])]
+    nw = int((pr.sum(1) > 0).sum())                     # waves that ran
+    graphs_per_wave = T / nw
+    pr = pr[:nw]
     tot = pr.sum(1).mean() / graphs_per_wave
     print("%s: %.1f us/launch (probe build), per graph per wave: %.0f cycles (s_memtime ticks @100MHz? see ratio)"
           % (which, e0.elapsed_time(e1) * 1e3, tot))
-    names = names_f if which == "fwd" else names_b
+    names = names_f if which == "fwd" else (names_b if os.environ.get("KGCN_BWD_FULL") else names_g)
+    print("   waves: %d" % nw)
     for k, n in enumerate(names):
         v = pr[:, k].mean() / graphs_per_wave
         print("   %-28s %9.1f  (%4.1f%%)" % (n, v, 100 * v / tot))
