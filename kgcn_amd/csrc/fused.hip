@@ -494,10 +494,21 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
   }
 }
 
-// FULL shape (N = 32, din = dout = 64): all sizes compile-time, straight-line aggregation, one
-// graph of lag between the contraction and the aggregation (FW(t) is produced while graph
-// t - nwaves is aggregated out of the gather tile; CSR slices double buffered) so that a wave's
-// LDS/global latencies always have independent work queued behind them.
+// FULL shape (N = 32, din = dout = 64): all sizes compile-time, straight-line aggregation, one graph
+// of lag between the contraction and the aggregation (FW(t) is produced in the step in which graph
+// t - nwaves is aggregated out of the gather tile), two waves per SIMD.
+//
+// FW = X W runs on the bf16 matrix pipe (exact 3-way split of both operands, 6 products per k-step, see
+// split_pair): 48 MFMAs of 32 cycles that execute BESIDE the vector ALU -- while one wave of the SIMD
+// multiplies, the other aggregates -- instead of 64 f32 MFMAs of 64 cycles on the VALU datapath.  The W
+// pieces are resident: p1 and p2 of every B fragment in 64 registers, p3 (used by one product in six) in
+// an 8 KB LDS table shared by the workgroup (register budget: 256 per wave, a spill would put scratch
+// loads -- and their vmcnt waits -- in front of the prefetch loads).
+//
+// LDS: p3 table | per wave: x tile [32][68], gather tile [33][64], ONE CSR slice (landed at the end of the
+// step, after the aggregation of the previous graph released it).
+constexpr size_t FWD_FULL_SHARED = 2 * 4 * 64 * 16;   // W p3 fragments: [tile][k-step][lane] x 16 bytes
+
 __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
     const int* __restrict__ slots, const int* __restrict__ gptr, const int2* __restrict__ cv,
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
@@ -508,17 +519,29 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, hi = lane >> 5;
   const int wpb = blockDim.x >> 6;
-  WaveSlice ws = carve(smem, wave, max_nnz, A_FWD, 2);
-  const size_t ecv_stride = ecv_bytes(max_nnz) / 8;   // int2 elements between the two CSR buffers
+  u32x4* w3 = reinterpret_cast<u32x4*>(smem);
+  WaveSlice ws = carve(smem + FWD_FULL_SHARED, wave, max_nnz, A_FWD, 1);
+
+  // B fragments of FW = X W: lane (li, hi), tile nt, k-step ks holds W[k][32 nt + li] for
+  // k = 16 ks + 8 hi + j as three bf16 pieces
+  u32x4 WF[2][4][2];
+  static_for<8>([&](auto c) __attribute__((always_inline)) {
+    constexpr int nt = decltype(c)::value >> 2, ks = decltype(c)::value & 3;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = w[(16 * ks + 8 * hi + j) * D + 32 * nt + li];
+    Frag3 f;
+    split8(v, f);
+    WF[nt][ks][0] = f.p1; WF[nt][ks][1] = f.p2;
+    if (wave == 0) w3[(nt * 4 + ks) * 64 + lane] = f.p3;
+  });
+  __syncthreads();
 
   const int nwaves = gridDim.x * wpb;
   int t = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
-  if (t >= T) return;
+  if (t >= T) return;   // no workgroup barrier below: idle waves may leave
 
   for (int i = lane; i < D; i += 64) ws.b[FN * FD + i] = 0.f;   // zero row for padding entries
-
-  float wr0[32], wr1[32];
-  load_w_frags<true>(wr0, wr1, w, D, D, li, hi);
   const float b0 = bias ? bias[li] : 0.f;
   const float b1 = bias ? bias[32 + li] : 0.f;
 
@@ -534,76 +557,80 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
   issue_meta(m_nxt, slots, gptr, tn < T ? tn : t, N, lane);
   wave_sync();
 
-  // One pipeline step: land graph t (registers -> LDS), put graph t+nwaves in flight, run FW(t)
-  // on the matrix cores -- with AGG, interleaved with the aggregation of graph t_prev whose FW
-  // sits in the gather tile (CSR buffer pb^1) -- and finally replace the gather tile by FW(t).
-  int pb = 0;          // CSR buffer of the graph being multiplied (t)
   int t_prev = t;      // graph whose FW sits in the gather tile (valid from the second step on)
   bool has_next = true;
   PROBE_DECL
+  auto aggregate_prev = [&]() __attribute__((always_inline)) {
+    float* ot = out + (long)t_prev * N * D;
+    aggregate_rows<true>(ws.ecv, ws.rp, ws.b, N, D, lane, [&](int r, int c4, f32x4 v) {
+      stv4(ot + r * D + c4 * 4, v);
+    });
+  };
   auto step = [&](auto agg_tag) __attribute__((always_inline)) {
     constexpr bool AGG = decltype(agg_tag)::value;
     PROBE(0)
-    int2* ecv_t = ws.ecv + pb * ecv_stride;
-    int* tab_t = ws.rp + pb * (FN + 4);
-    const int2* ecv_p = ws.ecv + (pb ^ 1) * ecv_stride;
-    const int* tab_p = ws.rp + (pb ^ 1) * (FN + 4);
-
-    // ---- 1. graph t: registers -> LDS (x tile, CSR slice into buffer pb) -----------------------
+    // ---- 1. x(t): registers -> LDS; x(t + nwaves) in flight (branch-free: values defined under
+    // `if (has_next)` become phis whose copies make the compiler wait for the prefetch right after
+    // issuing it; on the last step the current graph is re-read (L2 hit), unused) ---------------------
     land_tile<true>(fx, ws.a, ALD, 512, 16, lane);
-    land_csr(fc, ecv_t, tab_t, cv, m_cur.slot, base, cnt, N, lane);
+    has_next = tn < T;
+    const int tp = has_next ? tn : t;
+    issue_tile<true>(fx, x + (long)tp * N * D, 512, lane);
     wave_sync();
     PROBE(1)
 
-    // ---- 2. graph t + nwaves in flight.  Branch-free on purpose: values defined under
-    // `if (has_next)` become phis whose copies make the compiler wait (vmcnt(0)) for the prefetch
-    // right after issuing it; on the last step the current graph is re-read (L2 hit), unused.
-    has_next = tn < T;
-    const int tp = has_next ? tn : t;
+    // ---- 2. aggregation of graph t_prev (its FW sits in the gather tile, its CSR slice in LDS) ------
+    if constexpr (AGG) aggregate_prev();
+    wave_sync();
+    PROBE(2)
+
+    // ---- 3. CSR(t): registers -> LDS (the slice of t_prev is dead); CSR(t + nwaves) in flight ---------
+    land_csr(fc, ws.ecv, ws.rp, cv, m_cur.slot, base, cnt, N, lane);
     const int base_n = meta_base(m_nxt), cnt_n = meta_cnt(m_nxt);
-    issue_tile<true>(fx, x + (long)tp * N * D, 512, lane);
     issue_cv(fc, cv, base_n, cnt_n, lane);
-    m_cur = m_nxt;
+    // a REAL register move before the reload of m_nxt (a plain copy becomes a loop phi whose copy lands
+    // behind the new load: s_waitcnt vmcnt(~0) on the prefetch at the top of the next step)
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+                 : "=&v"(m_cur.slot), "=&v"(m_cur.gp) : "v"(m_nxt.slot), "v"(m_nxt.gp));
     {
       const int tnn = tn + nwaves;
       issue_meta(m_nxt, slots, gptr, tnn < T ? tnn : tp, N, lane);
     }
-    PROBE(2)
 
-    // ---- 3. FW(t) on the matrix cores || aggregation of graph t_prev ---------------------------
+    // ---- 4. FW(t) = X(t) W + b: per k-step 8 values of row li (k = 16 ks + 8 hi + j) are split, then
+    // 6 products x 2 output tiles ------------------------------------------------------------------------
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
-    // The 64 MFMAs stay in ONE cluster: on gfx950 the f32-input MFMA executes on the vector ALU
-    // datapath -- nothing VALU hides behind it (tools/mfma_shadow.hip: 64 cycles alone, 90 with two
-    // v_fma behind it, +4 per further VALU op) and every MFMA<->VALU switch costs ~18 cycles.  The
-    // aggregation of the previous graph follows as one VALU/LDS cluster; the second wave of the SIMD
-    // covers its LDS latency.
-#pragma unroll
-    for (int p8 = 0; p8 < 8; ++p8) {
-      const f32x4 a4 = ldv4(ws.a + li * ALD + hi * 32 + p8 * 4);
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const int sidx = p8 * 4 + s4;
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s4], wr0[sidx], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s4], wr1[sidx], acc1, 0, 0, 0);
-      }
-    }
-    if constexpr (AGG) {
-      float* ot = out + (long)t_prev * N * D;
-      aggregate_rows<true>(ecv_p, tab_p, ws.b, N, D, lane, [&](int r, int c4, f32x4 v) {
-        stv4(ot + r * D + c4 * 4, v);
-      });
-    }
+    static_for<4>([&](auto ksc) __attribute__((always_inline)) {
+      constexpr int ks = decltype(ksc)::value;
+      const float* src = ws.a + li * ALD + 16 * ks + 8 * hi;
+      const f32x4 lo = ldv4(src), hi4 = ldv4(src + 4);
+      const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+      Frag3 fa;
+      split8(v, fa);
+      const u32x4 w30 = w3[ks * 64 + lane], w31 = w3[(4 + ks) * 64 + lane];
+      acc0 = mfma_bf16(fa.p3, WF[0][ks][0], acc0);      // smallest terms first
+      acc1 = mfma_bf16(fa.p3, WF[1][ks][0], acc1);
+      acc0 = mfma_bf16(fa.p2, WF[0][ks][1], acc0);
+      acc1 = mfma_bf16(fa.p2, WF[1][ks][1], acc1);
+      acc0 = mfma_bf16(fa.p1, w30, acc0);
+      acc1 = mfma_bf16(fa.p1, w31, acc1);
+      acc0 = mfma_bf16(fa.p2, WF[0][ks][0], acc0);
+      acc1 = mfma_bf16(fa.p2, WF[1][ks][0], acc1);
+      acc0 = mfma_bf16(fa.p1, WF[0][ks][1], acc0);
+      acc1 = mfma_bf16(fa.p1, WF[1][ks][1], acc1);
+      acc0 = mfma_bf16(fa.p1, WF[0][ks][0], acc0);
+      acc1 = mfma_bf16(fa.p1, WF[1][ks][0], acc1);
+      __builtin_amdgcn_sched_barrier(0);   // one k-step of fragments live at a time (register budget)
+    });
     PROBE(3)
-    // ---- 4. FW(t) replaces the gather tile ------------------------------------------------------
-    wave_sync();
+    // ---- 5. FW(t) replaces the gather tile ------------------------------------------------------
     store_c_tiles(ws.b, acc0, acc1, li, hi);
     wave_sync();
     PROBE(4)
 
     t_prev = t;
-    pb ^= 1;
     t = tn;
     tn += nwaves;
     base = base_n;
@@ -612,15 +639,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
 
   step(std::false_type{});                       // first graph: nothing to aggregate yet
   while (has_next) step(std::true_type{});
-  // ---- epilogue: aggregate the last graph (CSR buffer pb^1, FW in the gather tile) --------------
-  {
-    const int2* ecv_p = ws.ecv + (pb ^ 1) * ecv_stride;
-    const int* tab_p = ws.rp + (pb ^ 1) * (FN + 4);
-    float* ot = out + (long)t_prev * N * D;
-    aggregate_rows<true>(ecv_p, tab_p, ws.b, N, D, lane, [&](int r, int c4, f32x4 v) {
-      stv4(ot + r * D + c4 * 4, v);
-    });
-  }
+  aggregate_prev();                              // epilogue: the last graph
   PROBE_FLUSH(blockIdx.x * wpb + wave)
 }
 
@@ -1164,9 +1183,8 @@ static int fused_grid(int T, int wpb) {
 static bool is_full(int n, int din, int dout) { return n == FN && din == FD && dout == FD; }
 
 // LDS per wave of the forward / backward kernel for a (row-padded) batch
-static size_t fwd_slice(int n, int din, int dout, int max_nnz) {
-  return slice_bytes(max_nnz, A_FWD, is_full(n, din, dout) ? 2 : 1);
-}
+static size_t fwd_slice(int, int, int, int max_nnz) { return slice_bytes(max_nnz, A_FWD, 1); }
+static size_t fwd_shared(int n, int din, int dout) { return is_full(n, din, dout) ? FWD_FULL_SHARED : 0; }
 static size_t bwd_slice(int max_nnz) { return slice_bytes(max_nnz, A_BWD, 1); }
 
 static bool fused_shape_ok(int n, int din, int dout, int max_nnz) {
@@ -1174,7 +1192,7 @@ static bool fused_shape_ok(int n, int din, int dout, int max_nnz) {
   if (din <= 0 || din > FD || (din & 3)) return false;
   if (dout <= 0 || dout > FD || (dout & 3)) return false;
   if (max_nnz < 0 || (max_nnz & 3)) return false;
-  return fused_wpb(fwd_slice(n, din, dout, max_nnz), 0) >= 4 &&
+  return fused_wpb(fwd_slice(n, din, dout, max_nnz), fwd_shared(n, din, dout)) >= 4 &&
          fused_wpb(bwd_slice(max_nnz), FD * FD * 4) >= 4;
 }
 
@@ -1225,8 +1243,9 @@ extern "C" int kgcn_graphconv_fwd_f32(const kgcn_csr_batch* a, const float* x, c
   if (!aligned16(x) || !aligned16(out) || !aligned16(a->cv))
     return fail("kgcn_graphconv_fwd_f32: x/out/cv not 16-byte aligned");
   const size_t per = fwd_slice(a->rows, din, dout, a->max_nnz_per_graph);
-  const int wpb = fused_wpb(per, 0);
-  const size_t lds = (size_t)wpb * per;
+  const size_t shared = fwd_shared(a->rows, din, dout);
+  const int wpb = fused_wpb(per, shared);
+  const size_t lds = shared + (size_t)wpb * per;
   static thread_local bool attr_set = false;
   if (!attr_set) {
     allow_big_lds(graphconv_fwd_full_kernel);

@@ -41,7 +41,7 @@ NW = {'fwd': 2048.0, 'bwd': 1024.0}
 assert lib.kgcn_probe_set(ctypes.c_void_p(probe.data_ptr())) == 0
 s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = lambda t: ctypes.c_void_p(t.data_ptr())
-names_f = ["loop-top(wait)", "land", "issue-prefetch", "mfma(t) || aggregate(t-1)+store", "FW->LDS"]
+names_f = ["loop-top", "land x + issue x(next)", "aggregate(t-1) + store", "land CSR + issue + split + mfma(t)", "FW->LDS"]
 names_g = ["loop top", "land g + CSR", "aggregate -> dFW", "land x + issue prefetch", "dW (split + bf16 mfma)", "dX mfma",
            "dX -> LDS -> HBM"]
 names_b = ["prologue+iter0", "phase A: dW mfma || aggregate(i+1) || dX(i-1) stores", "phase B: dX mfma || land/issue next tiles"]
@@ -67,7 +67,7 @@ for which in ("fwd", "bwd"):
     tot = pr.sum(1).mean() / graphs_per_wave
     print("%s: %.1f us/launch (probe build), per graph per wave: %.0f cycles (s_memtime ticks @100MHz? see ratio)"
           % (which, e0.elapsed_time(e1) * 1e3, tot))
-    names = names_f if which == "fwd" else (names_b if os.environ.get("KGCN_BWD_FULL") else names_g)
+    names = names_f if which == "fwd" else names_b
     print("   waves: %d" % nw)
     for k, n in enumerate(names):
         v = pr[:, k].mean() / graphs_per_wave
