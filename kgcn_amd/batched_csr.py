@@ -221,12 +221,15 @@ class BatchedCSR:
                 self._graph_counts = np.diff(rp)
         return self._graph_counts
 
-    def gather(self, sel):
+    def gather(self, sel, out=None, sel_dev=None):
         """Mini-batch assembly ON THE DEVICE (kgcn_csr_gather_graphs): `self` is the container of the
         whole dataset, sel[t] the dataset index of batch graph t (-1 = empty dummy graph padding a short
         batch, kgcn/feed.py:123-126).  The host only adds up the selected graphs' entry counts (to size
         the output); rowptr / cv / slots never leave HBM.  A^T and the row-padded copy of the batch are
-        gathered lazily from the dataset's own A^T / padded containers."""
+        gathered lazily from the dataset's own A^T / padded containers.
+
+        out: a container made by static_like() -- the batch is written into its (fixed) buffers, so that a
+        captured hipGraph whose kernels hold those pointers can be replayed on the new batch."""
         import torch
         if self.rowptr.device.type != "cuda":
             raise _lib.KgcnHipError("gather(): device-side batch assembly needs a device-resident container")
@@ -242,25 +245,55 @@ class BatchedCSR:
             raise ValueError("batch too large for int32 offsets")
         dev = self.rowptr.device
         i32 = dict(device=dev, dtype=torch.int32)
-        sel_d = torch.from_numpy(sel.astype(np.int32)).to(dev)
-        rowptr = torch.empty(T * M + 1, **i32)
-        cv = torch.empty((total, 2), **i32)
-        gptr = torch.empty(T + 1, **i32)
-        slots = torch.empty(T * M, **i32) if self.row_pad else None
+        sel_d = torch.from_numpy(sel.astype(np.int32)).to(dev) if sel_dev is None else sel_dev
         wsb = _lib.lib.kgcn_csr_gather_workspace_bytes(T)
-        ws = torch.empty(max(wsb, 4) // 4, **i32)
+        if out is None:
+            rowptr = torch.empty(T * M + 1, **i32)
+            cv = torch.empty((total, 2), **i32)
+            gptr = torch.empty(T + 1, **i32)
+            slots = torch.empty(T * M, **i32) if self.row_pad else None
+            ws = torch.empty(max(wsb, 4) // 4, **i32)
+            cap = total
+        else:
+            if (out.num_graphs, out.rows, out.cols, out.row_pad) != (T, M, self.cols, self.row_pad):
+                raise ValueError("static container does not match the batch shape")
+            if total > out.nnz:
+                raise ValueError("batch holds %d entries, static container only %d" % (total, out.nnz))
+            rowptr, cv, gptr, slots, ws, cap = out.rowptr, out.cv, out._gptr_buf, out.slots, out._ws, out.nnz
         _lib.check(_lib.lib.kgcn_csr_gather_graphs(
-            self.desc(), sel_d.data_ptr(), T, rowptr.data_ptr(), cv.data_ptr() if total else 0, total,
+            self.desc(), sel_d.data_ptr(), T, rowptr.data_ptr(), cv.data_ptr() if cap else 0, cap,
             slots.data_ptr() if slots is not None else 0, gptr.data_ptr(), ws.data_ptr(), wsb,
             _lib.current_stream()), "kgcn_csr_gather_graphs")
-        out = BatchedCSR(rowptr, cv, T, M, self.cols, int(per.max()) if T else 0, row_pad=self.row_pad)
-        out._graph_counts = per.astype(np.int64)
+        if out is not None:
+            out._graph_counts = per.astype(np.int64)
+            return out
+        res = BatchedCSR(rowptr, cv, T, M, self.cols, int(per.max()) if T else 0, row_pad=self.row_pad)
+        res._graph_counts = per.astype(np.int64)
         if self.row_pad:
-            out.slots, out.graph_ptr = slots, gptr
+            res.slots, res.graph_ptr = slots, gptr
         else:
             src = self
-            out._make_t = lambda: src.transpose().gather(sel)
-            out._make_p4 = lambda: src.padded4().gather(sel)
+            res._make_t = lambda: src.transpose().gather(sel)
+            res._make_p4 = lambda: src.padded4().gather(sel)
+        return res
+
+    @classmethod
+    def static_like(cls, src, num_graphs):
+        """Fixed-address container for batches of `num_graphs` graphs gathered out of `src`: sized for the
+        worst case (every graph as large as the dataset's largest), max_nnz = that bound (it only sizes the
+        kernels' LDS staging), nnz = capacity.  Filled by src.gather(sel, out=...)."""
+        import torch
+        T, M = int(num_graphs), src.rows
+        worst = max(src.max_nnz, 4 * M if src.row_pad else 0)
+        dev = src.rowptr.device
+        i32 = dict(device=dev, dtype=torch.int32)
+        out = cls(torch.zeros(T * M + 1, **i32), torch.zeros((T * worst, 2), **i32), T, M, src.cols, worst,
+                  row_pad=src.row_pad)
+        out._gptr_buf = torch.zeros(T + 1, **i32)
+        out._ws = torch.empty(max(_lib.lib.kgcn_csr_gather_workspace_bytes(T), 4) // 4, **i32)
+        if src.row_pad:
+            out.slots = torch.zeros(T * M, **i32)
+            out.graph_ptr = out._gptr_buf
         return out
 
     def with_values(self, values):

@@ -242,6 +242,56 @@ class DeviceGraphDataset:
         feat[:batch_idx.shape[0]] = self.features.index_select(0, idx)
         return adj, feat
 
+    def static_batch(self, batch_size, fused=True):
+        """Fixed-address batch buffers for hipGraph replay (kgcn_amd.train.GraphedTrainStep)."""
+        return StaticBatch(self, batch_size, fused)
+
+
+class StaticBatch:
+    """A mini-batch at FIXED device addresses: adjacency containers (A, A^T and -- for graphs of at most
+    32 nodes -- their row-padded copies, pre-linked so that transpose()/padded4() return them) and the
+    feature tensor.  load(batch_idx) refills them on the device; the kernels captured in a hipGraph keep
+    reading the same pointers."""
+
+    def __init__(self, dataset, batch_size, fused=True):
+        import torch
+        self.dataset = dataset
+        self.batch_size = T = int(batch_size)
+        self._sources, chans = [], []
+        for src in dataset.channels:
+            srcs = [src, src.transpose()]
+            padded = fused and src.rows <= BatchedCSR.PAD_COL and src.cols <= BatchedCSR.PAD_COL
+            if padded:
+                srcs += [src.padded4(), src.transpose().padded4()]
+            st = [BatchedCSR.static_like(x, T) for x in srcs]
+            st[0]._t, st[1]._t = st[1], st[0]
+            if padded:
+                st[0]._p4, st[1]._p4 = st[2], st[3]
+            self._sources.append(list(zip(srcs, st)))
+            chans.append(st[0])
+        self.adjacency = BatchedAdjacency(chans)
+        f = dataset.features
+        self.features = None if f is None else f.new_zeros((T,) + tuple(f.shape[1:]))
+        self._sel_dev = torch.zeros(T, dtype=torch.int32, device=dataset.channels[0].rowptr.device)
+        self._idx_dev = torch.zeros(T, dtype=torch.int64, device=self._sel_dev.device)
+
+    def load(self, batch_idx):
+        import torch
+        batch_idx = np.asarray(batch_idx, np.int64).reshape(-1)
+        T, nb = self.batch_size, batch_idx.shape[0]
+        sel = np.full(T, -1, np.int64)
+        sel[:nb] = batch_idx
+        self._sel_dev.copy_(torch.from_numpy(sel.astype(np.int32)), non_blocking=True)
+        for pairs in self._sources:
+            for src, st in pairs:
+                src.gather(sel, out=st, sel_dev=self._sel_dev)
+        if self.features is not None:
+            self._idx_dev.copy_(torch.from_numpy(np.maximum(sel, 0)), non_blocking=True)
+            torch.index_select(self.dataset.features, 0, self._idx_dev, out=self.features)
+            if nb < T:
+                self.features[nb:].zero_()
+        return self
+
 
 # -------------------------------------------------------------------------------------------------
 # block-diagonal batch (kgcn-sparse path, BASELINE config 3)

@@ -9,26 +9,39 @@ class TFAdam:
         lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t);  p -= lr_t * m / (sqrt(v) + eps)
     -- "epsilon hat" OUTSIDE the bias-corrected square root, unlike torch.optim.Adam."""
 
-    def __init__(self, params, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+    def __init__(self, params, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, capturable=False):
         self.params = [p for p in params]
         self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
         self.t = 0
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
+        # capturable: the step counter lives on the device, so that a captured hipGraph advances it
+        self.capturable = capturable
+        self._t_dev = torch.zeros((), dtype=torch.float64, device=self.params[0].device) if capturable else None
 
-    def zero_grad(self):
+    def zero_grad(self, set_to_none=True):
         for p in self.params:
-            p.grad = None
+            if set_to_none or p.grad is None:
+                p.grad = None
+            else:
+                p.grad.zero_()
 
     @torch.no_grad()
     def step(self):
         self.t += 1
-        lr_t = self.lr * (1.0 - self.b2 ** self.t) ** 0.5 / (1.0 - self.b1 ** self.t)
+        if self.capturable:
+            self._t_dev += 1
+            lr_t = (self.lr * torch.sqrt(1.0 - self.b2 ** self._t_dev) / (1.0 - self.b1 ** self._t_dev)).float()
+        else:
+            lr_t = self.lr * (1.0 - self.b2 ** self.t) ** 0.5 / (1.0 - self.b1 ** self.t)
         for p, m, v in zip(self.params, self.m, self.v):
             g = p.grad
             m.mul_(self.b1).add_(g, alpha=1.0 - self.b1)
             v.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
-            p.addcdiv_(m, v.sqrt().add_(self.eps), value=-lr_t)
+            if self.capturable:
+                p.sub_(lr_t * m / (v.sqrt() + self.eps))
+            else:
+                p.addcdiv_(m, v.sqrt().add_(self.eps), value=-lr_t)
 
 
 def train_step(model, optimizer, loss_fn, features, adjs, labels, mask, bucket=None, **fwd_kwargs):
@@ -42,3 +55,56 @@ def train_step(model, optimizer, loss_fn, features, adjs, labels, mask, bucket=N
         bucket.all_reduce_mean()
     optimizer.step()
     return float(cost_sum.detach()), logits.detach()
+
+
+class GraphedTrainStep:
+    """One mini-batch step (forward, loss, backward, TF-Adam update) captured ONCE in a hipGraph and
+    replayed per batch.  At the reference's own batch size (30 graphs of 10 nodes, example_config/synth.json)
+    a step is ~60 tiny kernel launches: launch-bound in eager mode exactly like the reference's B*C tiny TF
+    ops -- the graph replays them back to back without host involvement.  Inputs live in
+    fixed buffers: a kgcn_amd.data_util.StaticBatch (adjacency + features) and labels / mask tensors that
+    the caller overwrites in place before replay().  No tensor of an earlier eager step that still holds
+    its autograd graph (a loss, logits) may be alive at construction: the parameters' AccumulateGrad nodes
+    would stay bound to the eager stream and break the capture.
+
+    model(features, adjacency, **fwd_kwargs) -> logits;  loss_fn(logits, labels, mask) -> (cost_opt, cost_sum)."""
+
+    def __init__(self, model, optimizer, loss_fn, static_batch, labels, mask, warmup=3, **fwd_kwargs):
+        if not optimizer.capturable:
+            raise ValueError("GraphedTrainStep needs TFAdam(capturable=True)")
+        self.model, self.opt, self.loss_fn, self.sb = model, optimizer, loss_fn, static_batch
+        self.labels, self.mask, self.kw = labels, mask, fwd_kwargs
+        self.cost_sum = self.logits = None
+        # warm-up and capture must not train: model and optimiser state are restored afterwards
+        saved = [t.detach().clone() for t in list(optimizer.params) + optimizer.m + optimizer.v]
+        saved_t = optimizer.t
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):              # warm-up on a side stream (allocator, lazy inits)
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._eager()
+        with torch.no_grad():
+            for dst, src in zip(list(optimizer.params) + optimizer.m + optimizer.v, saved):
+                dst.copy_(src)
+            optimizer._t_dev.fill_(saved_t)
+        optimizer.t = saved_t
+
+    def _eager(self):
+        self.opt.zero_grad(set_to_none=False)
+        logits = self.model(self.sb.features, self.sb.adjacency, **self.kw)
+        cost_opt, cost_sum = self.loss_fn(logits, self.labels, self.mask)
+        cost_opt.backward()
+        self.opt.step()
+        self.cost_sum, self.logits = cost_sum.detach(), logits.detach()
+
+    def replay(self):
+        """Runs the captured step on whatever the static buffers hold now; returns (cost_sum, logits)
+        device tensors (no synchronisation)."""
+        self.graph.replay()
+        self.opt.t += 1
+        return self.cost_sum, self.logits

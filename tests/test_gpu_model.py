@@ -188,3 +188,45 @@ def test_model_sparse_block_diagonal(mode):
             _grad_of(conv.bias[ch], g["b%d" % i][ch], "b%d[%d]" % (i, ch), rel=5e-5)
     _grad_of(model.dense.kernel, g["dk"], "dk", rel=5e-5); _grad_of(model.out.kernel, g["ok"], "ok", rel=5e-5)
     _grad_of(model.bn.gamma, g["gamma"], "gamma", rel=5e-5); _grad_of(model.bn.beta, g["beta"], "beta", rel=5e-5)
+
+
+def test_graphed_train_step_matches_eager():
+    """The hipGraph-captured train step (static batch buffers refilled on the device, capturable TF-Adam)
+    follows the eager step: same costs and the same parameters after two epochs with a padded last batch."""
+    from kgcn_amd import data_util as D, models, train
+    raw = load_golden("g1_synthetic_raw.npz")
+    chans, _ = D.build_adjs({"dense_adj": raw["dense_adj"].astype(np.int64), "max_node_num": 10})
+    feats, labels = raw["feature"], raw["label"]
+    ds = D.DeviceGraphDataset(chans, feats, device=dev())
+    torch.manual_seed(0)
+    m_e, m_g = models.GCN(1).to(dev()), models.GCN(1).to(dev())
+    adj0, x0 = ds.batch(np.arange(30), 30)
+    m_e(x0, adj0); m_g(x0, adj0)                                     # lazy parameter creation
+    m_g.load_state_dict(m_e.state_dict())
+    o_e = train.TFAdam(m_e.parameters(), lr=0.01)
+    o_g = train.TFAdam(m_g.parameters(), lr=0.01, capturable=True)
+    sb = ds.static_batch(30)
+    lab = torch.zeros((30, 2), device=dev())
+    mask = torch.zeros(30, device=dev())
+    sb.load(np.arange(30))
+    step = train.GraphedTrainStep(m_g, o_g, models.masked_softmax_ce, sb, lab, mask)
+    for a, b in zip(m_e.parameters(), m_g.parameters()):            # capture did not train
+        assert torch.equal(a, b)
+    rng = np.random.default_rng(2)
+    idx = np.arange(160)
+    for epoch in range(2):
+        rng.shuffle(idx)
+        for it in range(6):
+            bidx = idx[it * 30:(it + 1) * 30]
+            nb = len(bidx)
+            lab.zero_(); lab[:nb] = t32(labels[bidx])
+            mask.zero_(); mask[:nb] = 1
+            adj, x = ds.batch(bidx, 30)
+            cs_e, lg_e = train.train_step(m_e, o_e, models.masked_softmax_ce, x, adj, lab, mask)
+            sb.load(bidx)
+            cs_g, lg_g = step.replay()
+            assert abs(cs_e - float(cs_g)) < 1e-4 * max(1.0, abs(cs_e)), (epoch, it, cs_e, float(cs_g))
+            close(lg_g, lg_e.cpu().numpy(), atol=1e-4, what="logits")
+    assert o_g.t == o_e.t == 12 and float(o_g._t_dev) == 12
+    for a, b in zip(m_e.parameters(), m_g.parameters()):
+        close(b, a.detach().cpu().numpy(), atol=2e-5, what="params after 12 steps")
