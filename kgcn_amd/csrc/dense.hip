@@ -19,6 +19,9 @@
 
 namespace kgcn {
 
+int launch_gemm3_fwd(const float* x, long m, int din, long x_ld, const float* w, long w_ld, int trans_w,
+                     const float* bias, float* y, int dout, long y_ld, hipStream_t s);
+
 constexpr int BM = 128;      // rows per workgroup (32 per wave)
 constexpr int BN = 64;       // output columns per workgroup
 constexpr int BK = 32;       // k chunk
@@ -454,6 +457,10 @@ extern "C" int kgcn_dense_fwd_f32(const float* x, int64_t m, int32_t din, int64_
   if (!x || !w || !y) return fail("kgcn_dense_fwd_f32: NULL operand");
   if (x_ld < din || y_ld < dout) return fail("kgcn_dense_fwd_f32: leading dimension too small");
   if (w_ld < (trans_w ? din : dout)) return fail("kgcn_dense_fwd_f32: w_ld too small");
+  // wide layers: f32-MFMA bound -> the bf16-split GEMM (gemm3.hip)
+  if (dout > 128 && din >= 64)
+    return launch_gemm3_fwd(x, (long)m, din, (long)x_ld, w, (long)w_ld, trans_w, bias, y, dout, (long)y_ld,
+                            as_stream(stream));
   {
     // fast path: weight panel [din_pad x 64] resident in LDS next to 8 per-wave x tiles
     const int kp = ((din + 63) / 64) * 64;

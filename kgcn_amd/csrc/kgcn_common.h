@@ -6,6 +6,9 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "../../include/kgcn_hip.h"
 
 namespace kgcn {
@@ -46,5 +49,54 @@ constexpr int kLdsBytes = 160 * 1024;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- shared device helpers ---------------------------------------------------------------------------
+template <typename Fn, int... I>
+__device__ __forceinline__ void static_for_impl(Fn&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): straight-line code with compile-time
+// indices (register arrays indexed inside `#pragma unroll` loops ended up in scratch memory)
+template <int N, typename Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// ---- fp32 contraction on the bf16 matrix pipe: exact 3-way split ------------------------------------
+// gfx950 runs v_mfma_f32_32x32x2_f32 at the VALU rate AND on the VALU datapath (nothing overlaps it:
+// tools/mfma_shadow.hip), while v_mfma_f32_32x32x16_bf16 is 16x faster per flop and runs beside VALU
+// work (tools/mfma_shadow_bf16.hip).  An fp32 value is the EXACT sum of three bf16 values obtained by
+// truncation -- v = p1 + p2 + p3, 24 significand bits = 8 + 8 + 8 -- and bf16 x bf16 products are exact
+// in the fp32 accumulator, so  a*b = sum_{i+j<=4} a_i b_j + O(2^-23 |ab|): six bf16 MFMAs replace eight
+// f32 MFMAs (K = 16 vs 2) at fp32 accuracy (the dropped terms a2b3 + a3b2 + a3b3 are below one fp32 ulp
+// of the product).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Frag3 { u32x4 p1, p2, p3; };   // 8 k-values of one MFMA operand row/column, three bf16 pieces
+
+__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& q1, unsigned& q2, unsigned& q3) {
+  const unsigned m = 0xffff0000u;
+  const float h0 = __uint_as_float(__float_as_uint(v0) & m), h1 = __uint_as_float(__float_as_uint(v1) & m);
+  const float r0 = v0 - h0, r1 = v1 - h1;                     // exact: the low 16 significand bits
+  const float g0 = __uint_as_float(__float_as_uint(r0) & m), g1 = __uint_as_float(__float_as_uint(r1) & m);
+  const float s0 = r0 - g0, s1 = r1 - g1;                     // exact, <= 8 significant bits: a bf16 value
+  q1 = __builtin_amdgcn_perm(__float_as_uint(v1), __float_as_uint(v0), 0x07060302u);   // high halves
+  q2 = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+  q3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+__device__ __forceinline__ void split8(const float* v, Frag3& f) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned q1, q2, q3;
+    split_pair(v[2 * j], v[2 * j + 1], q1, q2, q3);
+    f.p1[j] = q1; f.p2[j] = q2; f.p3[j] = q3;
+  }
+}
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
+                                                 0, 0, 0);
+}
+// the six products of one (A fragment, B fragment) pair, smallest terms first
+#define KGCN_SPLIT_PRODUCTS(F) F(p3, p1) F(p2, p2) F(p1, p3) F(p2, p1) F(p1, p2) F(p1, p1)
 
 }  // namespace kgcn

@@ -130,4 +130,7 @@ def test_cfg5_gin_ring_graphs_256():
     close(d1.kernel.grad, dk1, rel=1e-5, what="cfg5 dK1")
     dxa, deps = K.gin_bwd(x, adjs, [0.25], dxx1)
     close(tx.grad, dxa, rel=1e-5, what="cfg5 dX")
-    close(gin.epsilon[0].grad, deps[0], rel=1e-5, what="cfg5 deps")
+    # d eps = <dA, x>: a signed sum of B*N*D = 512k products whose terms cancel (weights are random per
+    # run, |sum| can be far below the sum of |terms|): fp32 tolerance relative to sum |dA . x|, like any dot
+    scale = float(np.abs(dxx1.astype(np.float64) * x).sum())
+    assert abs(float(gin.epsilon[0].grad) - float(deps[0])) <= 2e-6 * scale, (float(gin.epsilon[0].grad), deps[0], scale)
