@@ -347,6 +347,19 @@ class BatchedAdjacency:
         self.channels = list(channels)
         self._desc_arr = None
         self._desc_arr_t = None
+        self.values = None      # see with_values()
+
+    def with_values(self, values):
+        """Same containers, with the adjacency VALUES as differentiable inputs: values[c] is a device
+        fp32 tensor [nnz_c] in the CSR order of channel c (channels[c].values gives the stored ones).
+        GraphConv then takes the differentiable route (per-channel Bspmm with d values, kgcn/
+        bspmm_call.py:50-55) -- what the integrated-gradients loop of kgcn/visualization.py:187-260
+        differentiates with respect to."""
+        if len(values) != len(self.channels):
+            raise ValueError("one value tensor per adjacency channel is required")
+        out = BatchedAdjacency(self.channels)
+        out.values = list(values)
+        return out
 
     @classmethod
     def from_adjs(cls, adjs, n_nodes=None, device="cuda"):

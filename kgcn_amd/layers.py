@@ -100,6 +100,14 @@ class GraphConv(nn.Module):
         B, N, din = inputs.shape
         C, dout = self.adj_channel_num, self.output_dim
         x2d = inputs.reshape(B * N, din)
+        if a.values is not None:
+            # adjacency values are differentiable inputs (integrated gradients over `adjs`,
+            # kgcn/visualization.py:207-210): one Bspmm per channel with its d values gradient
+            o = None
+            for c in range(C):
+                oo = ops.bspmm(a.channels[c], ops.dense(x2d, self.w[c], self.bias[c]), values=a.values[c])
+                o = oo if o is None else o + oo
+            return o.reshape(B, N, dout)
         if enabled_bconv:
             # kgcn/layers.py:68-78: FW[b][ch] for every channel, ONE fused op (SpMM + add-n)
             fw = ops.dense(x2d, torch.cat(list(self.w), dim=1), torch.cat(list(self.bias), dim=1))

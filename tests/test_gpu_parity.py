@@ -547,3 +547,35 @@ def test_device_batch_assembly_large_multiblock_scan():
     ref = ops.bspmm(out, ops.dense(x.reshape(T * N, 64), w, None).reshape(T, N, 64))
     close(o, ref.cpu().numpy(), atol=1e-4, what="fused on gathered batch")
     assert float(o[::7].abs().max()) == 0.0                                     # dummy graphs give zeros
+
+
+# ---------------------------------------------------------------------------------------------
+# d values through the layer + the integrated-gradients loop
+# ---------------------------------------------------------------------------------------------
+def test_integrated_gradients_features_and_adjacency():
+    from kgcn_amd import BatchedAdjacency, layers, visualization
+    rng = np.random.default_rng(19)
+    B, N, F, Dh, D = 3, 10, 3, 8, 50
+    adjs = K.normalize_adj(K.synth_mol_graphs(rng, B, N, 2))
+    x = rng.standard_normal((B, N, F)).astype(np.float32)
+    conv = layers.GraphConv(Dh, 1).to(dev())
+    adj = BatchedAdjacency.from_adjs(adjs, n_nodes=N, device=dev())
+    conv(t32(x), adj=adj)
+    w, b = [conv.w[0].detach().cpu().numpy()], [conv.bias[0].detach().cpu().numpy()]
+    ro = rng.standard_normal(Dh).astype(np.float32)
+    tro = t32(ro)
+
+    def score_fn(feat, a):
+        return (layers.GraphGather()(torch.sigmoid(conv(feat, adj=a))) @ tro).sum()
+
+    res = visualization.integrated_gradients(score_fn, t32(x), adj, divide_number=D)
+    ig_x, ig_a = K.integrated_gradients(x, adjs, w, b, ro, D)
+    close(res["features"], ig_x, atol=2e-6, what="IG features")
+    # the reference's COO order is row-major here, = the CSR order of the container
+    close(res["adjs"], np.concatenate(ig_a), atol=2e-6, what="IG adjacency values")
+    assert abs(res["sum_of_ig"] - (res["end_score"] - res["start_score"])) < 0.05 * max(1.0, abs(res["end_score"]))
+    dense = visualization.values_to_dense(adj.channels[0], res["adjs"])
+    assert tuple(dense.shape) == (B, N, N) and abs(float(dense.sum()) - float(res["adjs"].sum())) < 1e-5
+    one = visualization.integrated_gradients(score_fn, t32(x), adj, method="grad", modal=("adjs",))
+    dx, dvals = K.probe_score_grads(x, adjs, w, b, ro)
+    close(one["adjs"], np.concatenate([d[0] for d in dvals]), atol=2e-6, what="d score / d values")

@@ -233,3 +233,20 @@ def test_graph_maxpool_tie_split():
     x0 = np.array([[[-1.0], [0.0], [-3.0], [7.0]]])         # row 0: entry value 0 ties with 2 implicit zeros
     dx0 = K.graph_maxpool_bwd(x0, adj, g)
     np.testing.assert_allclose(dx0[0, :, 0], [0.0, 1.0 / 3.0, 0.0, 0.0])
+
+
+def test_integrated_gradients_completeness():
+    """Oracle of the attribution loop (kgcn/visualization.py:187-275): with features and adjacency values
+    both scaled, the sum of the integrated gradients approaches score(1) - score(0)."""
+    rng = np.random.default_rng(9)
+    B, N, F, Dh = 2, 6, 3, 4
+    adjs = K.normalize_adj(K.synth_mol_graphs(rng, B, N, 1))
+    x = rng.standard_normal((B, N, F))
+    w, b = [rng.standard_normal((F, Dh)) * 0.5], [rng.standard_normal((1, Dh)) * 0.1]
+    ro = rng.standard_normal(Dh)
+    ig_x, ig_a = K.integrated_gradients(x, adjs, w, b, ro, 400)
+    zero_adjs = [[(m[0], np.zeros_like(m[1]), m[2]) for m in chs] for chs in adjs]
+    s1 = K.probe_score(x, adjs, w, b, ro)[0]
+    s0 = K.probe_score(x * 0, zero_adjs, w, b, ro)[0]
+    total = ig_x.sum() + sum(a.sum() for a in ig_a)
+    assert abs(total - (s1 - s0)) < 5e-3 * max(1.0, abs(s1 - s0)), (total, s1 - s0)
