@@ -185,6 +185,21 @@ int kgcn_graph_maxpool_bwd_f32(const kgcn_csr_batch* a, const kgcn_csr_batch* at
                                const float* dout_grad, int32_t d, float* dx, float beta,
                                void* workspace, int64_t workspace_bytes, void* stream);
 
+/* -- GAT ------------------------------------------------------------------------------------ */
+/* kgcn/layers.py:477-542, one adjacency channel per call (beta = 1 accumulates the channel add-n).  Only
+ * the PATTERN of `a` is used (the reference ignores the values, :517-520).  weight_a: device [2*d]
+ * (the layer's `weight_a{i}` [2d,1]).  With t_e = x[col_e].wa[0:d] + x[row_e].wa[d:2d], E_e = exp(leaky_relu(
+ * t_e, 0.2)), denom[i] = sum over row i of E, alpha_e = E_e / (denom[col_e] + 1e-10) (column-indexed, as the
+ * reference gathers it):   out[t,i,:] = beta*out + sigmoid(sum_{e in row i} alpha_e x[t, col_e, :]). */
+int64_t kgcn_gat_workspace_bytes(int32_t num_graphs, int32_t n_nodes, int32_t d);
+int kgcn_gat_fwd_f32(const kgcn_csr_batch* a, const float* x, int32_t d, const float* weight_a, float* out,
+                     float beta, void* workspace, int64_t workspace_bytes, void* stream);
+/* dx = beta*dx + d loss / d x,  dweight_a [2*d] overwritten (deterministic two-stage reduction).
+ * at = batched CSR of the transposed pattern. */
+int kgcn_gat_bwd_f32(const kgcn_csr_batch* a, const kgcn_csr_batch* at, const float* x, int32_t d,
+                     const float* weight_a, const float* dout_grad, float* dx, float beta, float* dweight_a,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+
 /* -- GraphGather ---------------------------------------------------------------------------- */
 /* kgcn/layers.py:163-164: out[b, :] = sum_n x[b, n, :] (padding rows included). */
 int kgcn_graph_gather_fwd_f32(const float* x, int64_t batch, int32_t n_nodes, int32_t d,

@@ -224,6 +224,39 @@ class GraphMaxPooling(nn.Module):
         return ops.graph_maxpool(inputs, a)
 
 
+class GAT(nn.Module):
+    """kgcn/layers.py:477-542: graph attention WITHOUT its own weight matrix (the reference's note: put a
+    GraphDense in front).  Per channel a vector weight_a{i} [2*Din, 1] (initializer, default glorot
+    uniform); out = sum_c sigmoid(sum_e alpha_e x[col_e]) with the softmax-like alpha of the reference
+    (denominator gathered at the column index, padded / empty rows give sigmoid(0) = 0.5)."""
+
+    def __init__(self, adj_channel_num, initializer="glorot_uniform", input_dim=None, **kwargs):
+        super().__init__()
+        self.adj_channel_num = int(adj_channel_num)
+        self.initializer = initializer
+        self.input_dim = input_dim
+        self.weight_a = nn.ParameterList()
+        self.built = False
+
+    def build(self, input_shape, device=None):
+        d = int(input_shape[2] if self.input_dim is None else self.input_dim)
+        for _ in range(self.adj_channel_num):
+            self.weight_a.append(nn.Parameter(_init_tensor((2 * d, 1), self.initializer, device)))
+        self.built = True
+
+    def compute_output_shape(self, input_shape):
+        return input_shape
+
+    def forward(self, inputs, adj=None):
+        if not self.built:
+            self.build(inputs.shape, inputs.device)
+        a = _pack(adj, inputs)
+        if a.num_channels != self.adj_channel_num:
+            raise ValueError("layer has %d adjacency channels, adj has %d"
+                             % (self.adj_channel_num, a.num_channels))
+        return ops.gat(inputs, a, list(self.weight_a))
+
+
 class GraphBatchNormalization(nn.Module):
     """kgcn/layers.py:170-220 with Keras' learning phase at its TF1 default (quirk Q6): the wrapped
     BatchNormalization normalises with its moving statistics (mean 0, variance 1, epsilon 1e-3):
@@ -264,5 +297,5 @@ class GraphGather(nn.Module):
 
 
 __all__ = ["GraphConv", "GraphDense", "GINAggregate", "GraphGather", "GraphMaxPooling",
-           "GraphBatchNormalization", "load_bspmm",
+           "GraphBatchNormalization", "GAT", "load_bspmm",
            "BatchedAdjacency"]

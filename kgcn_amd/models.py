@@ -4,6 +4,7 @@ activations, the loss and the BatchNorm affine are elementwise torch ops around 
 
   GCN  -- example_model/model.py:41-61      GraphConv(50) x3, BN, GraphDense(50), GraphGather, Dense(2)
   GIN  -- example_model/model_gin.py:40-67  2 x [GINAggregate, GraphDense(50) x2], Gather x2, Dense(2)
+  GATNet -- example_model/model_gat.py:40-62  3 x [GraphDense(50), GAT], Gather of blocks 2 and 3, Dense(2)
   MultitaskGCN -- example_model/model_multitask.py:45-101  GraphConv 256/256, GraphDense 256, GraphConv 50, BN,
                   GraphDense 50, Gather, Dense(label_dim); masked (weighted) sigmoid cross entropy
   SparseGCN    -- example_model/sparse.py:45-134  block-diagonal batch of one: 3 x [GraphConv(256) relu],
@@ -173,3 +174,23 @@ class SparseGCN(nn.Module):
         net = ops.bspmm(batch.segments, net.unsqueeze(0))       # per-molecule node sum (:83-94)
         net = torch.tanh(net.reshape(len(batch.sizes), -1))
         return self.out(net)                                    # probabilities = softmax(logits)
+
+
+class GATNet(nn.Module):
+    """example_model/model_gat.py:30-80."""
+
+    def __init__(self, adj_channel_num=1, num_classes=2):
+        super().__init__()
+        self.dense = nn.ModuleList([layers.GraphDense(50) for _ in range(3)])
+        self.gat = nn.ModuleList([layers.GAT(adj_channel_num) for _ in range(3)])
+        self.gather = layers.GraphGather()
+        self.out = KerasDense(num_classes)
+
+    def forward(self, features, adjs, enabled_node_nums=None):
+        layer = features
+        block_out = []
+        for i in range(3):
+            layer = self.gat[i](self.dense[i](layer), adj=adjs)
+            if i > 0:
+                block_out.append(layer)
+        return self.out(torch.cat([self.gather(o) for o in block_out], dim=1))

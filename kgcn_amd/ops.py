@@ -308,6 +308,52 @@ def graph_maxpool(x, adj):
 
 
 # -------------------------------------------------------------------------------------------------
+# GAT
+# -------------------------------------------------------------------------------------------------
+class _Gat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, adj, *weight_a):
+        x = _f32c(x, "inputs")
+        T, N, d = x.shape
+        if (T, N) != (adj.num_graphs, adj.n_nodes) or adj.channels[0].cols != N:
+            raise _lib.KgcnHipError("inputs %s do not match the adjacency batch" % (tuple(x.shape),))
+        was = [_f32c(w.reshape(-1), "weight_a") for w in weight_a]
+        if len(was) != adj.num_channels or any(w.numel() != 2 * d for w in was):
+            raise _lib.KgcnHipError("one weight_a [2*%d, 1] per adjacency channel is required" % d)
+        out = torch.empty_like(x)
+        wsb = lib.kgcn_gat_workspace_bytes(T, N, d)
+        ws = torch.empty((max(wsb, 4) // 4,), device=x.device, dtype=torch.float32)
+        for c, ch in enumerate(adj.channels):
+            check(lib.kgcn_gat_fwd_f32(ch.desc(), ptr(x), d, ptr(was[c]), ptr(out), 0.0 if c == 0 else 1.0, ptr(ws), wsb,
+                                       current_stream()), "kgcn_gat_fwd_f32")
+        ctx.adj = adj
+        ctx.save_for_backward(x, *was)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, *was = ctx.saved_tensors
+        adj = ctx.adj
+        g = _f32c(g, "grad")
+        T, N, d = x.shape
+        dx = torch.empty_like(x)
+        wsb = lib.kgcn_gat_workspace_bytes(T, N, d)
+        ws = torch.empty((max(wsb, 4) // 4,), device=x.device, dtype=torch.float32)
+        dws = []
+        for c, ch in enumerate(adj.channels):
+            dw = torch.empty(2 * d, device=x.device, dtype=torch.float32)
+            check(lib.kgcn_gat_bwd_f32(ch.desc(), ch.transpose().desc(), ptr(x), d, ptr(was[c]), ptr(g), ptr(dx),
+                                       0.0 if c == 0 else 1.0, ptr(dw), ptr(ws), wsb, current_stream()),
+                  "kgcn_gat_bwd_f32")
+            dws.append(dw.reshape(2 * d, 1))
+        return (dx, None) + tuple(dws)
+
+
+def gat(x, adj, weight_a):
+    return _Gat.apply(x, adj, *weight_a)
+
+
+# -------------------------------------------------------------------------------------------------
 # GraphGather
 # -------------------------------------------------------------------------------------------------
 class _Gather(torch.autograd.Function):
@@ -337,4 +383,4 @@ def graph_gather(x):
 
 __all__ = ["BatchedCSR", "BatchedAdjacency", "bspmm", "bspmm_raw", "bconv", "dense",
            "graphconv_fused", "graphconv_fused_supported", "gin_aggregate", "graph_gather",
-           "graph_maxpool"]
+           "graph_maxpool", "gat"]

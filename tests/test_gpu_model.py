@@ -63,7 +63,7 @@ def test_model_py_gradients_and_adam_trajectory(batch):
         close(t, np.asarray(ref).reshape(tuple(t.shape)), atol=2e-4, what="param " + k)
 
 
-@pytest.mark.parametrize("kind", ["GCN", "GIN"])
+@pytest.mark.parametrize("kind", ["GCN", "GIN", "GAT"])
 def test_short_training_run_on_synthetic_jbl(kind):
     """kgcn train --config example_config/synth.json in miniature: batch 30, padded last batch,
     shuffled epochs, TF Adam; through the product's loaders.  The loss must fall."""
@@ -71,7 +71,7 @@ def test_short_training_run_on_synthetic_jbl(kind):
     raw = load_golden("g1_synthetic_raw.npz")
     chans, enabled = D.build_adjs({"dense_adj": raw["dense_adj"].astype(np.int64), "max_node_num": 10})
     feats, labels = raw["feature"], raw["label"]
-    model = (models.GCN(1) if kind == "GCN" else models.GIN(1)).to(dev())
+    model = {"GCN": models.GCN, "GIN": models.GIN, "GAT": models.GATNet}[kind](1).to(dev())
     rng = np.random.default_rng(1234)
     idx = np.arange(160)
     opt = None

@@ -579,3 +579,29 @@ def test_integrated_gradients_features_and_adjacency():
     one = visualization.integrated_gradients(score_fn, t32(x), adj, method="grad", modal=("adjs",))
     dx, dvals = K.probe_score_grads(x, adjs, w, b, ro)
     close(one["adjs"], np.concatenate([d[0] for d in dvals]), atol=2e-6, what="d score / d values")
+
+
+# ---------------------------------------------------------------------------------------------
+# GAT (kgcn/layers.py:477-542)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("channels,D", [("plain", 3), ("split", 16), ("norm", 50), ("plain", 130)])
+def test_gat_layer(channels, D):
+    from kgcn_amd import layers
+    _, adjs = synthetic_batch("b30", channels)              # 10 real + 20 dummy graphs: rows of sigmoid(0)
+    C = len(adjs[0])
+    rng = np.random.default_rng(D + C)
+    x = (rng.standard_normal((30, 10, D)) * 0.7).astype(np.float32)
+    layer = layers.GAT(C).to(dev())
+    tx = t32(x).requires_grad_(True)
+    out = layer(tx, adj=adjs)
+    assert len(layer.weight_a) == C and tuple(layer.weight_a[0].shape) == (2 * D, 1)
+    wa = [w.detach().cpu().numpy() for w in layer.weight_a]
+    ref = K.gat_fwd(x, adjs, wa)
+    close(out, ref, atol=2e-5, what="gat fwd")
+    assert float(out[-1].min()) == 0.5 * C == float(out[-1].max())         # dummy graph
+    g = rng.standard_normal(x.shape).astype(np.float32)
+    out.backward(t32(g))
+    dx, dwa = K.gat_bwd(x, adjs, wa, g)
+    close(tx.grad, dx, atol=2e-5, rel=1e-5, what="gat dx")
+    for c in range(C):
+        close(layer.weight_a[c].grad, dwa[c], atol=2e-5, rel=2e-5, what="gat dweight_a[%d]" % c)

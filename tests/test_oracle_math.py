@@ -250,3 +250,54 @@ def test_integrated_gradients_completeness():
     s0 = K.probe_score(x * 0, zero_adjs, w, b, ro)[0]
     total = ig_x.sum() + sum(a.sum() for a in ig_a)
     assert abs(total - (s1 - s0)) < 5e-3 * max(1.0, abs(s1 - s0)), (total, s1 - s0)
+
+
+def test_gat_literal_and_finite_differences():
+    """GAT oracle vs the reference's literal formulation (one-hot matmuls, kgcn/layers.py:517-533) and
+    its gradients vs central differences."""
+    rng = np.random.default_rng(4)
+    B, N, D, C = 2, 7, 3, 2
+    adjs = []
+    for b in range(B):
+        chans = []
+        for c in range(C):
+            dense = (rng.random((N, N)) < 0.35).astype(np.float32)
+            dense[5] = 0                                            # an empty row: sigmoid(0) = 0.5
+            idx = np.argwhere(dense != 0).astype(np.int32)
+            chans.append((idx, np.ones(len(idx), np.float32), [N, N]))
+        adjs.append(chans)
+    x = rng.standard_normal((B, N, D))
+    wa = [rng.standard_normal((2 * D, 1)) * 0.7 for _ in range(C)]
+    out = K.gat_fwd(x, adjs, wa)
+    ref = np.zeros_like(out)
+    for b in range(B):
+        for c in range(C):
+            idx = adjs[b][c][0]
+            a1, a2 = x[b][idx[:, 1]], x[b][idx[:, 0]]
+            ii = np.eye(N)[idx[:, 0]].T                             # tf.transpose(tf.one_hot(idx[:,0], N))
+            layer = np.concatenate([a1, a2], axis=1) @ wa[c]
+            layer = np.where(layer > 0, layer, 0.2 * layer)
+            e = np.exp(layer)
+            denom = ii @ e
+            alpha = e / (denom[idx[:, 1]] + 1.0e-10)
+            ref[b] += 1.0 / (1.0 + np.exp(-(ii @ (alpha * a1))))
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-12)
+    assert np.all(out[:, 5] == 0.5 * C)
+    g = rng.standard_normal(out.shape)
+    dx, dwa = K.gat_bwd(x, adjs, wa, g)
+    h = 1e-6
+    for _ in range(8):
+        i = tuple(rng.integers(0, s) for s in x.shape)
+        xp, xm = x.copy(), x.copy()
+        xp[i] += h
+        xm[i] -= h
+        fd = ((K.gat_fwd(xp, adjs, wa) - K.gat_fwd(xm, adjs, wa)) * g).sum() / (2 * h)
+        assert abs(fd - dx[i]) < 1e-6 * max(1.0, abs(fd)), (i, fd, dx[i])
+    for c in range(C):
+        for k in (0, D - 1, D, 2 * D - 1):
+            wp = [w.copy() for w in wa]
+            wm = [w.copy() for w in wa]
+            wp[c][k, 0] += h
+            wm[c][k, 0] -= h
+            fd = ((K.gat_fwd(x, adjs, wp) - K.gat_fwd(x, adjs, wm)) * g).sum() / (2 * h)
+            assert abs(fd - dwa[c][k, 0]) < 1e-6 * max(1.0, abs(fd)), (c, k, fd, dwa[c][k, 0])
