@@ -21,6 +21,8 @@ namespace kgcn {
 
 int launch_gemm3_fwd(const float* x, long m, int din, long x_ld, const float* w, long w_ld, int trans_w,
                      const float* bias, float* y, int dout, long y_ld, hipStream_t s);
+int launch_gemm3_wgrad(const float* x, long x_ld, const float* dy, long dy_ld, long m, int din, int dout,
+                       float* part_dw, float* part_db, int nblocks, hipStream_t s);
 
 constexpr int BM = 128;      // rows per workgroup (32 per wave)
 constexpr int BN = 64;       // output columns per workgroup
@@ -524,6 +526,23 @@ extern "C" int kgcn_dense_wgrad_f32(const float* x, int64_t x_ld, const float* d
                 (long long)need);
   long rpc;
   int nchunks;
+  if (din > 64 && dout > 128) {
+    // wide layers: bf16-split GEMM (gemm3.hip); one partial per row-range workgroup, <= kNumCU of them
+    const int tiles = ((din + 127) / 128) * ((dout + 255) / 256);
+    long nb = kNumCU / tiles;
+    if (nb < 1) nb = 1;
+    const long chunks = (m + 31) / 32;
+    if (nb > chunks) nb = chunks;
+    float* part_dw = static_cast<float*>(workspace);
+    float* part_db = part_dw + nb * din * dout;
+    if (int rc = launch_gemm3_wgrad(x, (long)x_ld, dy, (long)dy_ld, (long)m, din, dout, part_dw, part_db, (int)nb, s))
+      return rc;
+    if (dw)
+      if (int rc = launch_reduce_partials(part_dw, (int)nb, (long)din * dout, dw, s)) return rc;
+    if (dbias)
+      if (int rc = launch_reduce_partials(part_db, (int)nb, dout, dbias, s)) return rc;
+    return 0;
+  }
   {
     // persistent kernel: one workgroup (8 waves) per CU and per 64x64 output block
     nchunks = persist_blocks(m);

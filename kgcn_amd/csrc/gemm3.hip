@@ -312,4 +312,174 @@ int launch_gemm3_fwd(const float* x, long m, int din, long x_ld, const float* w,
   return check_launch("gemm3_fwd_kernel");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient:  dW[din, dout] = x^T dy,  dbias = colsum(dy).  The batch rows are the K dimension.
+// One workgroup owns a [128 x 256] block of dW and a contiguous range of 32-row chunks; both operands are
+// staged like the forward's W chunk -- task (column, 8-row group): 8 strided loads, coalesced across the
+// columns of consecutive threads -> split -> fragment tables (A: 4 m-tiles of x columns, B: 8 n-tiles of dy
+// columns).  The block's partial dW (and the column sums of dy accumulated by the staging threads) go to the
+// workspace; reduce_partials_kernel adds the partials in a fixed order.
+// ------------------------------------------------------------------------------------------------
+constexpr int G3W_BM = 128;   // din columns per workgroup
+struct G3RawT { float a[8], b0[8], b1[8]; };
+
+__global__ __launch_bounds__(512, 2) void gemm3_wgrad_kernel(
+    const float* __restrict__ x, long x_ld, const float* __restrict__ dy, long dy_ld, long m, int din, int dout,
+    float* __restrict__ part_dw, float* __restrict__ part_db, long chunks_per_block) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  u32x4* lds = reinterpret_cast<u32x4*>(dsm);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, hi = lane >> 5;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int i0 = blockIdx.y * G3W_BM, j0 = blockIdx.z * G3_BN;
+  const long nchunks = (m + G3_BK - 1) / G3_BK;
+  const long c_begin = (long)blockIdx.x * chunks_per_block;
+  long c_end = c_begin + chunks_per_block;
+  if (c_end > nchunks) c_end = nchunks;
+
+  // staging tasks.  x: (column tid % 128, q = tid / 128) -- one 8-row group of one column;
+  // dy: columns tid % 256 with q = tid / 256 (rows 0-15) and q + 2 (rows 16-31)
+  const int ac = tid & 127, aq = tid >> 7;
+  const int bc = tid & 255, bq = tid >> 8;
+  const bool aok = i0 + ac < din, bok = j0 + bc < dout;
+  const int ca = aok ? i0 + ac : din - 1, cb = bok ? j0 + bc : dout - 1;
+  auto issue = [&](G3RawT& r, long chunk) __attribute__((always_inline)) {
+    const long row0 = chunk * G3_BK;      // clamped rows / columns, masked at split time
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long ra = row0 + 8 * aq + j, rb0 = row0 + 8 * bq + j, rb1 = row0 + 8 * (bq + 2) + j;
+      r.a[j] = x[(ra < m ? ra : m - 1) * x_ld + ca];
+      r.b0[j] = dy[(rb0 < m ? rb0 : m - 1) * dy_ld + cb];
+      r.b1[j] = dy[(rb1 < m ? rb1 : m - 1) * dy_ld + cb];
+    }
+  };
+  float colsum = 0.f;               // of dy column bc over this thread's row groups
+  Frag3 fa, f0, f1;
+  auto split_step = [&](auto sc, const G3RawT& r, long chunk) __attribute__((always_inline)) {
+    constexpr int STEP = decltype(sc)::value, J = STEP & 3;
+    const long row0 = chunk * G3_BK;
+    unsigned q1, q2, q3;
+    if constexpr (STEP < 4) {
+      const long row = row0 + 8 * aq + 2 * J;
+      split_pair((aok && row < m) ? r.a[2 * J] : 0.f, (aok && row + 1 < m) ? r.a[2 * J + 1] : 0.f, q1, q2, q3);
+      fa.p1[J] = q1; fa.p2[J] = q2; fa.p3[J] = q3;
+    } else if constexpr (STEP < 8) {
+      const long row = row0 + 8 * bq + 2 * J;
+      const float v0 = (bok && row < m) ? r.b0[2 * J] : 0.f, v1 = (bok && row + 1 < m) ? r.b0[2 * J + 1] : 0.f;
+      colsum += v0 + v1;
+      split_pair(v0, v1, q1, q2, q3);
+      f0.p1[J] = q1; f0.p2[J] = q2; f0.p3[J] = q3;
+    } else {
+      const long row = row0 + 8 * (bq + 2) + 2 * J;
+      const float v0 = (bok && row < m) ? r.b1[2 * J] : 0.f, v1 = (bok && row + 1 < m) ? r.b1[2 * J + 1] : 0.f;
+      colsum += v0 + v1;
+      split_pair(v0, v1, q1, q2, q3);
+      f1.p1[J] = q1; f1.p2[J] = q2; f1.p3[J] = q3;
+    }
+  };
+  auto write_tables = [&](u32x4* xp, u32x4* wp, int which) __attribute__((always_inline)) {
+    if (which == 0) g3_write(xp, ac >> 5, aq, ac & 31, fa);
+    else if (which == 1) g3_write(wp, bc >> 5, bq, bc & 31, f0);
+    else g3_write(wp, bc >> 5, bq + 2, bc & 31, f1);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  if (c_begin < c_end) {
+    G3RawT ra, rb;
+    issue(ra, c_begin);
+    static_for<12>([&](auto sc) __attribute__((always_inline)) { split_step(sc, ra, c_begin); });
+    write_tables(lds, lds + G3_XP, 0); write_tables(lds, lds + G3_XP, 1); write_tables(lds, lds + G3_XP, 2);
+    issue(rb, c_begin + 1 < c_end ? c_begin + 1 : c_begin);
+    __syncthreads();
+    int buf = 0;
+    long c = c_begin;
+    auto step = [&](G3RawT& RS, G3RawT& RL) __attribute__((always_inline)) {
+      const bool have1 = c + 1 < c_end;
+      const long c1 = have1 ? c + 1 : c;                  // chunk being split (garbage copy of c at the very end)
+      const long c2 = c + 2 < c_end ? c + 2 : c1;         // chunk being requested
+      const u32x4* xp = lds + buf * (G3_XP + G3_WP);
+      const u32x4* wp = xp + G3_XP;
+      u32x4* xq = lds + (buf ^ 1) * (G3_XP + G3_WP);
+      u32x4* wq = xq + G3_XP;
+      const float keep = colsum;
+      static_for<2>([&](auto ksc) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ksc)::value;
+        u32x4 A[2][3], B[2][3];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            A[t2][p] = xp[g3_slot(2 * wr + t2, ks, p, li, hi)];
+            B[t2][p] = wp[g3_slot(2 * wc + t2, ks, p, li, hi)];
+          }
+        static_for<24>([&](auto mc) __attribute__((always_inline)) {
+          constexpr int mm = decltype(mc)::value, pr = mm >> 2, tl4 = mm & 3, slot = 24 * ks + mm;
+          constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
+          acc[tl4 >> 1][tl4 & 1] = mfma_bf16(A[tl4 >> 1][PA[pr]], B[tl4 & 1][PB[pr]], acc[tl4 >> 1][tl4 & 1]);
+          if constexpr (slot < 12) split_step(std::integral_constant<int, slot>{}, RS, c1);
+          else if constexpr (slot == 12) write_tables(xq, wq, 0);
+          else if constexpr (slot == 13) write_tables(xq, wq, 1);
+          else if constexpr (slot == 14) write_tables(xq, wq, 2);
+          else if constexpr (slot == 16) issue(RL, c2);
+        });
+      });
+      if (!have1) colsum = keep;                           // the re-split of the last chunk must not count twice
+      __syncthreads();
+      buf ^= 1;
+      ++c;
+    };
+    for (;;) {
+      step(rb, ra);
+      if (c >= c_end) break;
+      step(ra, rb);
+      if (c >= c_end) break;
+    }
+  }
+
+  // ---- partial dW block of this workgroup ------------------------------------------------------------
+  float* pw = part_dw + (long)blockIdx.x * din * dout;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = j0 + 64 * wc + 32 * nt + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + 64 * wr + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (row < din && col < dout) pw[(long)row * dout + col] = acc[mt][nt][r];
+      }
+    }
+  // ---- column sums of dy: the two row-group threads of a column meet in LDS ----------------------------
+  if (part_db && blockIdx.y == 0) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(dsm);
+    red[tid] = colsum;
+    __syncthreads();
+    if (tid < 256 && j0 + tid < dout) part_db[(long)blockIdx.x * dout + j0 + tid] = red[tid] + red[tid + 256];
+  }
+}
+
+int launch_gemm3_wgrad(const float* x, long x_ld, const float* dy, long dy_ld, long m, int din, int dout,
+                       float* part_dw, float* part_db, int nblocks, hipStream_t s) {
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_wgrad_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    attr_set = true;
+  }
+  const long nchunks = (m + G3_BK - 1) / G3_BK;
+  const long cpb = (nchunks + nblocks - 1) / nblocks;
+  const dim3 grid((unsigned)nblocks, (unsigned)((din + G3W_BM - 1) / G3W_BM), (unsigned)((dout + G3_BN - 1) / G3_BN));
+  hipLaunchKernelGGL(gemm3_wgrad_kernel, grid, dim3(512), G3_LDS, s, x, x_ld, dy, dy_ld, m, din, dout, part_dw, part_db,
+                     cpb);
+  return check_launch("gemm3_wgrad_kernel");
+}
+
 }  // namespace kgcn
