@@ -133,6 +133,39 @@ __device__ __forceinline__ void issue_tile(TileRegs& f, const float* __restrict_
   }
 }
 
+template <bool FULL>
+__device__ __forceinline__ void land_tile(const TileRegs& f, float* tile, int ld, int n4, int d4, int lane);
+
+// Feature widths that are not multiples of 4 (the 50 and 3 of example_model/model.py:42-46): the tile is
+// moved element by element, e = lane + 64 q over the N*d contiguous floats of the graph.
+__device__ __forceinline__ void issue_tile_s(TileRegs& f, const float* __restrict__ src, int n, int lane) {
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int e = lane + q * 64;
+    f.v[q >> 2][q & 3] = (e < n) ? src[e] : 0.f;
+  }
+}
+__device__ __forceinline__ void land_tile_s(const TileRegs& f, float* tile, int ld, int n, int d, int lane) {
+  int r = lane / d, c = lane - r * d;
+  const int dr = 64 / d, dc = 64 - dr * d;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    if (lane + q * 64 < n) tile[r * ld + c] = f.v[q >> 2][q & 3];
+    c += dc; r += dr;
+    if (c >= d) { c -= d; ++r; }
+  }
+}
+template <bool VEC>
+__device__ __forceinline__ void issue_tile_g(TileRegs& f, const float* __restrict__ src, int n, int lane) {
+  if constexpr (VEC) issue_tile<false>(f, src, n >> 2, lane);
+  else issue_tile_s(f, src, n, lane);
+}
+template <bool VEC>
+__device__ __forceinline__ void land_tile_g(const TileRegs& f, float* tile, int ld, int n, int d, int lane) {
+  if constexpr (VEC) land_tile<false>(f, tile, ld, n >> 2, d >> 2, lane);
+  else land_tile_s(f, tile, ld, n, d, lane);
+}
+
 // Row-padded layout: the graph's entry count is a multiple of 4 and its first entry index too, so
 // entries can be moved two at a time as aligned 16-byte words.
 __device__ __forceinline__ void issue_cv(CsrRegs& f, const int2* __restrict__ cv, int base, int cnt,
@@ -355,7 +388,8 @@ __device__ __forceinline__ void store_c_tiles(float* tile, const f32x16& c0, con
   }
 }
 
-// Generic shapes (N <= 32, din/dout <= 64 multiples of 4): prefetch + phase-sequential per graph.
+// Generic shapes (N <= 32, din/dout <= 64; VEC: both multiples of 4): prefetch + phase-sequential per graph.
+template <bool VEC>
 __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
     const int* __restrict__ slots, const int* __restrict__ gptr, const int2* __restrict__ cv,
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
@@ -380,15 +414,14 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
   const float b0 = (bias && li < dout) ? bias[li] : 0.f;
   const float b1 = (bias && 32 + li < dout) ? bias[32 + li] : 0.f;
 
-  const int din4 = din >> 2;
-  const int n4 = N * din4;
+  const int nx = N * din;
 
   TileRegs fx;
   CsrRegs fc;
   MetaRegs m_cur, m_nxt;
   issue_meta(m_cur, slots, gptr, t, N, lane);
   int base = meta_base(m_cur), cnt = meta_cnt(m_cur);
-  issue_tile<false>(fx, x + (long)t * N * din, n4, lane);
+  issue_tile_g<VEC>(fx, x + (long)t * N * din, nx, lane);
   issue_cv(fc, cv, base, cnt, lane);
   int tn = t + nwaves;
   // unconditional (index clamped): a conditional load becomes a phi whose copy forces
@@ -397,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
   wave_sync();
 
   for (;;) {
-    land_tile<false>(fx, ws.a, ALD, n4, din4, lane);
+    land_tile_g<VEC>(fx, ws.a, ALD, nx, din, lane);
     land_csr(fc, ws.ecv, ws.rp, cv, m_cur.slot, base, cnt, N, lane);
     wave_sync();
 
@@ -407,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
     const bool has_next = tn < T;
     const int tp = has_next ? tn : t;
     const int base_n = meta_base(m_nxt), cnt_n = meta_cnt(m_nxt);
-    issue_tile<false>(fx, x + (long)tp * N * din, n4, lane);
+    issue_tile_g<VEC>(fx, x + (long)tp * N * din, nx, lane);
     issue_cv(fc, cv, base_n, cnt_n, lane);
     m_cur = m_nxt;
     {
@@ -434,7 +467,13 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
 
     float* ot = out + (long)t * N * dout;
     aggregate_rows<false>(ws.ecv, ws.rp, ws.b, N, dout, lane, [&](int r, int cl, f32x4 acc) {
-      stv4(ot + (long)r * dout + cl * 4, acc);
+      if constexpr (VEC) {
+        stv4(ot + (long)r * dout + cl * 4, acc);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (cl * 4 + j < dout) ot[(long)r * dout + cl * 4 + j] = acc[j];
+      }
     });
     wave_sync();
 
@@ -598,6 +637,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
 // ------------------------------------------------------------------------------------------------
 // backward, generic shapes: prefetch + phase-sequential per graph, 2 waves per SIMD
 // ------------------------------------------------------------------------------------------------
+template <bool VEC>
 __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
     const int* __restrict__ slots_t, const int* __restrict__ gptr_t, const int2* __restrict__ cv_t,
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ g,
@@ -625,8 +665,9 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
   for (int r = 0; r < 16; ++r) { dw00[r] = 0.f; dw01[r] = 0.f; dw10[r] = 0.f; dw11[r] = 0.f; }
   f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
 
-  const int din4 = din >> 2, dout4 = dout >> 2;
-  const int nx4 = N * din4, ng4 = N * dout4;
+  const int din4 = din >> 2;
+  const int nx4 = N * din4;
+  const int nxe = N * din, nge = N * dout;
   const int nwaves = gridDim.x * wpb;
   int t = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
 
@@ -636,9 +677,9 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
     MetaRegs m_cur, m_nxt;
     issue_meta(m_cur, slots_t, gptr_t, t, N, lane);
     int base = meta_base(m_cur), cnt = meta_cnt(m_cur);
-    issue_tile<FULL>(fg, g + (long)t * N * dout, ng4, lane);
+    issue_tile_g<VEC>(fg, g + (long)t * N * dout, nge, lane);
     issue_cv(fc, cv_t, base, cnt, lane);
-    issue_tile<FULL>(fx, x + (long)t * N * din, nx4, lane);
+    issue_tile_g<VEC>(fx, x + (long)t * N * din, nxe, lane);
     int tn = t + nwaves;
     issue_meta(m_nxt, slots_t, gptr_t, tn < T ? tn : t, N, lane);
 
@@ -646,7 +687,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
     for (;;) {
       PROBE(0)
       // ---- 1. g[t], CSR(A^T) slice: registers -> LDS ------------------------------------------
-      land_tile<FULL>(fg, ws.b, FD, ng4, dout4, lane);
+      land_tile_g<VEC>(fg, ws.b, FD, nge, dout, lane);
       land_csr(fc, ws.ecv, ws.rp, cv_t, m_cur.slot, base, cnt, N, lane);
       wave_sync();
 
@@ -661,7 +702,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
       PROBE(2)
 
       // ---- 3. x[t] -> gather tile (g is dead) --------------------------------------------------
-      land_tile<FULL>(fx, ws.b, FD, nx4, din4, lane);
+      land_tile_g<VEC>(fx, ws.b, FD, nxe, din, lane);
 
       wave_sync();
       PROBE(3)
@@ -695,9 +736,9 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
       const bool has_next = tn < T;
       const int tp = has_next ? tn : t;
       const int base_n = meta_base(m_nxt), cnt_n = meta_cnt(m_nxt);
-      issue_tile<FULL>(fg, g + (long)tp * N * dout, ng4, lane);
+      issue_tile_g<VEC>(fg, g + (long)tp * N * dout, nge, lane);
       issue_cv(fc, cv_t, base_n, cnt_n, lane);
-      issue_tile<FULL>(fx, x + (long)tp * N * din, nx4, lane);
+      issue_tile_g<VEC>(fx, x + (long)tp * N * din, nxe, lane);
       m_cur = m_nxt;
       {
         const int tnn = tn + nwaves;
@@ -723,14 +764,24 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
         store_c_tiles(ws.b, c0, c1, li, hi);
         wave_sync();
         float* dxt = dx + (long)t * N * din;
+        if constexpr (VEC) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int i = lane + q * 64;
-          if constexpr (FULL) {
-            stv4(dxt + (long)i * 4, ldv4(ws.b + i * 4));
-          } else if (i < nx4) {
-            const int r = i / din4, c4 = i - r * din4;
-            stv4(dxt + (long)i * 4, ldv4(ws.b + r * FD + c4 * 4));
+          for (int q = 0; q < 8; ++q) {
+            const int i = lane + q * 64;
+            if (i < nx4) {
+              const int r = i / din4, c4 = i - r * din4;
+              stv4(dxt + (long)i * 4, ldv4(ws.b + r * FD + c4 * 4));
+            }
+          }
+        } else {
+          int r = lane / din, c = lane - r * din;
+          const int dr = 64 / din, dc = 64 - dr * din;
+#pragma unroll
+          for (int q = 0; q < 32; ++q) {
+            const int e = lane + q * 64;
+            if (e < nxe) dxt[e] = ws.b[r * FD + c];
+            c += dc; r += dr;
+            if (c >= din) { c -= din; ++r; }
           }
         }
       }
@@ -1141,8 +1192,8 @@ static size_t bwd_slice(int max_nnz) { return slice_bytes(max_nnz, A_BWD, 1); }
 
 static bool fused_shape_ok(int n, int din, int dout, int max_nnz) {
   if (n <= 0 || n > FN) return false;
-  if (din <= 0 || din > FD || (din & 3)) return false;
-  if (dout <= 0 || dout > FD || (dout & 3)) return false;
+  if (din <= 0 || din > FD) return false;
+  if (dout <= 0 || dout > FD) return false;
   if (max_nnz < 0 || (max_nnz & 3)) return false;
   return fused_wpb(fwd_slice(n, din, dout, max_nnz), fwd_shared(n, din, dout)) >= 4 &&
          fused_wpb(bwd_slice(max_nnz), FD * FD * 4) >= 4;
@@ -1192,7 +1243,8 @@ extern "C" int kgcn_graphconv_fwd_f32(const kgcn_csr_batch* a, const float* x, c
                 a->rows, din, dout, a->max_nnz_per_graph);
   if (a->num_graphs == 0) return 0;
   if (!x || !w || !out) return fail("kgcn_graphconv_fwd_f32: NULL operand");
-  if (!aligned16(x) || !aligned16(out) || !aligned16(a->cv))
+  const bool vec = !(din & 3) && !(dout & 3);
+  if ((vec && (!aligned16(x) || !aligned16(out))) || !aligned16(a->cv))
     return fail("kgcn_graphconv_fwd_f32: x/out/cv not 16-byte aligned");
   const size_t per = fwd_slice(a->rows, din, dout, a->max_nnz_per_graph);
   const size_t shared = fwd_shared(a->rows, din, dout);
@@ -1201,7 +1253,8 @@ extern "C" int kgcn_graphconv_fwd_f32(const kgcn_csr_batch* a, const float* x, c
   static thread_local bool attr_set = false;
   if (!attr_set) {
     allow_big_lds(graphconv_fwd_full_kernel);
-    allow_big_lds(graphconv_fwd_kernel);
+    allow_big_lds(graphconv_fwd_kernel<true>);
+    allow_big_lds(graphconv_fwd_kernel<false>);
     attr_set = true;
   }
   const dim3 grid(fused_grid(a->num_graphs, wpb)), block(64 * wpb);
@@ -1209,8 +1262,12 @@ extern "C" int kgcn_graphconv_fwd_f32(const kgcn_csr_batch* a, const float* x, c
   if (is_full(a->rows, din, dout))
     hipLaunchKernelGGL(graphconv_fwd_full_kernel, grid, block, lds, as_stream(stream), a->slots,
                        a->graph_ptr, cv, x, w, bias, out, a->num_graphs, a->max_nnz_per_graph);
+  else if (vec)
+    hipLaunchKernelGGL(graphconv_fwd_kernel<true>, grid, block, lds, as_stream(stream), a->slots,
+                       a->graph_ptr, cv, x, w, bias, out, a->num_graphs, a->rows, din, dout,
+                       a->max_nnz_per_graph);
   else
-    hipLaunchKernelGGL(graphconv_fwd_kernel, grid, block, lds, as_stream(stream), a->slots,
+    hipLaunchKernelGGL(graphconv_fwd_kernel<false>, grid, block, lds, as_stream(stream), a->slots,
                        a->graph_ptr, cv, x, w, bias, out, a->num_graphs, a->rows, din, dout,
                        a->max_nnz_per_graph);
   return check_launch("graphconv_fwd_kernel");
@@ -1239,7 +1296,8 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
     return 0;
   }
   if (!x || !w || !dout_grad) return fail("kgcn_graphconv_bwd_f32: NULL operand");
-  if (!aligned16(x) || !aligned16(dout_grad) || (dx && !aligned16(dx)) || !aligned16(at->cv))
+  const bool vec = !(din & 3) && !(dout & 3);
+  if ((vec && (!aligned16(x) || !aligned16(dout_grad) || (dx && !aligned16(dx)))) || !aligned16(at->cv))
     return fail("kgcn_graphconv_bwd_f32: tensors not 16-byte aligned");
   const bool full = dx != nullptr && is_full(at->rows, din, dout) &&
                     BWD_FULL_WPB * bwd_full_slice_bytes(at->max_nnz_per_graph) <= (size_t)kLdsBytes;
@@ -1256,7 +1314,8 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
   static thread_local bool attr_set = false;
   if (!attr_set) {
     allow_big_lds(graphconv_bwd_full_kernel);
-    allow_big_lds(graphconv_bwd_kernel);
+    allow_big_lds(graphconv_bwd_kernel<true>);
+    allow_big_lds(graphconv_bwd_kernel<false>);
     attr_set = true;
   }
   const int2* cv = reinterpret_cast<const int2*>(at->cv);
@@ -1264,8 +1323,12 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
     hipLaunchKernelGGL(graphconv_bwd_full_kernel, dim3(blocks), dim3(64 * wpb), lds, s, at->slots,
                        at->graph_ptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
                        at->max_nnz_per_graph);
+  else if (vec)
+    hipLaunchKernelGGL(graphconv_bwd_kernel<true>, dim3(blocks), dim3(64 * wpb), lds, s, at->slots,
+                       at->graph_ptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
+                       at->rows, din, dout, at->max_nnz_per_graph);
   else
-    hipLaunchKernelGGL(graphconv_bwd_kernel, dim3(blocks), dim3(64 * wpb), lds, s, at->slots,
+    hipLaunchKernelGGL(graphconv_bwd_kernel<false>, dim3(blocks), dim3(64 * wpb), lds, s, at->slots,
                        at->graph_ptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
                        at->rows, din, dout, at->max_nnz_per_graph);
   if (int rc = check_launch("graphconv_bwd_kernel")) return rc;

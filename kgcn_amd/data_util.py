@@ -272,8 +272,15 @@ class StaticBatch:
         self.adjacency = BatchedAdjacency(chans)
         f = dataset.features
         self.features = None if f is None else f.new_zeros((T,) + tuple(f.shape[1:]))
+        self._pruned = False
         self._sel_dev = torch.zeros(T, dtype=torch.int32, device=dataset.channels[0].rowptr.device)
         self._idx_dev = torch.zeros(T, dtype=torch.int64, device=self._sel_dev.device)
+
+    def prune_unused(self):
+        """After the consumer (e.g. a captured hipGraph) has run once: refill only the containers whose
+        descriptor a kernel actually received -- a fused-kernel model reads the two row-padded containers,
+        an unfused one A and A^T, never all four."""
+        self._pruned = True
 
     def load(self, batch_idx):
         import torch
@@ -284,7 +291,8 @@ class StaticBatch:
         self._sel_dev.copy_(torch.from_numpy(sel.astype(np.int32)), non_blocking=True)
         for pairs in self._sources:
             for src, st in pairs:
-                src.gather(sel, out=st, sel_dev=self._sel_dev)
+                if not self._pruned or st._desc is not None:
+                    src.gather(sel, out=st, sel_dev=self._sel_dev)
         if self.features is not None:
             self._idx_dev.copy_(torch.from_numpy(np.maximum(sel, 0)), non_blocking=True)
             torch.index_select(self.dataset.features, 0, self._idx_dev, out=self.features)

@@ -20,28 +20,33 @@ class TFAdam:
         self._t_dev = torch.zeros((), dtype=torch.float64, device=self.params[0].device) if capturable else None
 
     def zero_grad(self, set_to_none=True):
-        for p in self.params:
-            if set_to_none or p.grad is None:
+        if set_to_none or any(p.grad is None for p in self.params):
+            for p in self.params:
                 p.grad = None
-            else:
-                p.grad.zero_()
+        else:
+            torch._foreach_zero_([p.grad for p in self.params])
 
     @torch.no_grad()
     def step(self):
+        """One update of every parameter with multi-tensor (_foreach) ops: 8 launches for the whole model
+        instead of 9 per parameter -- at the reference's batch size the step is launch-bound."""
         self.t += 1
+        grads = [p.grad for p in self.params]
+        torch._foreach_mul_(self.m, self.b1)
+        torch._foreach_add_(self.m, grads, alpha=1.0 - self.b1)
+        torch._foreach_mul_(self.v, self.b2)
+        torch._foreach_addcmul_(self.v, grads, grads, value=1.0 - self.b2)
+        denom = torch._foreach_sqrt(self.v)
+        torch._foreach_add_(denom, self.eps)
+        upd = torch._foreach_div(self.m, denom)
         if self.capturable:
             self._t_dev += 1
             lr_t = (self.lr * torch.sqrt(1.0 - self.b2 ** self._t_dev) / (1.0 - self.b1 ** self._t_dev)).float()
+            torch._foreach_mul_(upd, lr_t)
+            torch._foreach_sub_(self.params, upd)
         else:
             lr_t = self.lr * (1.0 - self.b2 ** self.t) ** 0.5 / (1.0 - self.b1 ** self.t)
-        for p, m, v in zip(self.params, self.m, self.v):
-            g = p.grad
-            m.mul_(self.b1).add_(g, alpha=1.0 - self.b1)
-            v.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
-            if self.capturable:
-                p.sub_(lr_t * m / (v.sqrt() + self.eps))
-            else:
-                p.addcdiv_(m, v.sqrt().add_(self.eps), value=-lr_t)
+            torch._foreach_add_(self.params, upd, alpha=-lr_t)
 
 
 def train_step(model, optimizer, loss_fn, features, adjs, labels, mask, bucket=None, **fwd_kwargs):
@@ -93,6 +98,8 @@ class GraphedTrainStep:
                 dst.copy_(src)
             optimizer._t_dev.fill_(saved_t)
         optimizer.t = saved_t
+        if hasattr(static_batch, "prune_unused"):
+            static_batch.prune_unused()
 
     def _eager(self):
         self.opt.zero_grad(set_to_none=False)

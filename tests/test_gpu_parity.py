@@ -282,7 +282,8 @@ def test_model_py_layer_stack():
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,din,dout,T", [(32, 64, 64, 300), (32, 64, 64, 5), (10, 4, 52, 30),
                                           (20, 12, 36, 77), (32, 32, 64, 129), (17, 64, 8, 64),
-                                          (32, 64, 64, 3001)])
+                                          (32, 64, 64, 3001), (10, 3, 50, 30), (10, 50, 50, 200),
+                                          (7, 5, 6, 65), (32, 63, 1, 40), (31, 2, 61, 33)])
 def test_graphconv_fused(N, din, dout, T):
     from kgcn_amd import BatchedCSR, ops
     rng = np.random.default_rng(N + din + dout + T)
