@@ -22,7 +22,8 @@
 //
 // Two instantiations of every kernel: FULL (N = 32, din = dout = 64: the benchmark shape; all
 // sizes are compile-time constants, the 8 aggregation passes are straight-line code) and generic
-// (N <= 32, din,dout <= 64 multiples of 4).  Other shapes use kgcn_dense_* + kgcn_bconv_f32.
+// (N <= 32, din,dout <= 64; widths that are not multiples of 4 take an element-wise tile path).  Other shapes use
+// kgcn_dense_* + kgcn_bconv_f32.
 #include <type_traits>
 
 #include "kgcn_common.h"

@@ -49,7 +49,8 @@ def test_shape_queries_and_validation():
     lib = _lib.lib
     assert lib.kgcn_graphconv_fused_supported(32, 64, 64, 100) == 1
     assert lib.kgcn_graphconv_fused_supported(10, 4, 52, 24) == 1
-    assert lib.kgcn_graphconv_fused_supported(10, 3, 50, 24) == 0       # din not a multiple of 4
+    assert lib.kgcn_graphconv_fused_supported(10, 3, 50, 24) == 1       # any width <= 64 (scalar tile path)
+    assert lib.kgcn_graphconv_fused_supported(10, 65, 50, 24) == 0
     assert lib.kgcn_graphconv_fused_supported(50, 64, 64, 160) == 0      # N > 32
     assert lib.kgcn_graphconv_fused_supported(32, 128, 64, 100) == 0
     assert lib.kgcn_dense_wgrad_workspace_bytes(3_200_000, 64, 64) > 0
