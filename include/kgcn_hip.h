@@ -21,8 +21,9 @@
  *  - return value: 0 = ok, non-zero = error; text via kgcn_last_error().  No exception crosses
  *    the ABI.
  *  - all tensors are IEEE fp32, indices int32.  Contractions accumulate in fp32 and are evaluated either
- *    with v_mfma_f32_32x32x2_f32 (kgcn_dense_*) or, in the fused GraphConv kernels, on the bf16 matrix
- *    pipe with an EXACT 3-way bf16 split of every fp32 operand (v = p1 + p2 + p3, 8+8+8 significand bits)
+ *    with v_mfma_f32_32x32x2_f32 (kgcn_dense_* up to 128 output columns) or -- in the fused GraphConv
+ *    kernels and in the wide-layer GEMMs of kgcn_dense_* -- on the bf16 matrix pipe with an EXACT 3-way
+ *    bf16 split of every fp32 operand (v = p1 + p2 + p3, 8+8+8 significand bits)
  *    and the six products a_i b_j with i + j <= 4: the neglected terms are below 2^-23 |a b|, i.e. one
  *    fp32 rounding of the product -- no reduced-precision inputs, measured error vs fp64 identical to
  *    the f32-MFMA path (profiles/r01_g_accuracy.json).
