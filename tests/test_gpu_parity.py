@@ -421,8 +421,8 @@ def test_errors_are_loud():
     with pytest.raises(_lib.KgcnHipError):
         ops.bspmm(csr, torch.zeros((10, 4), device=dev(), dtype=torch.float64))
     with pytest.raises(_lib.KgcnHipError):
-        _lib.check(_lib.lib.kgcn_graphconv_fwd_f32(csr.padded4().desc(), None, None, None, 3, 50, None, None), "fused")
-    assert b"not supported" in _lib.lib.kgcn_last_error()
+        _lib.check(_lib.lib.kgcn_graphconv_fwd_f32(csr.padded4().desc(), None, None, None, 3, 80, None, None), "fused")
+    assert b"not supported" in _lib.lib.kgcn_last_error()   # dout > 64
     with pytest.raises(_lib.KgcnHipError):                    # fused kernels want the row-padded layout
         _lib.check(_lib.lib.kgcn_graphconv_fwd_f32(csr.desc(), None, None, None, 4, 4, None, None), "fused")
     assert b"row_pad" in _lib.lib.kgcn_last_error()
