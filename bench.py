@@ -259,7 +259,7 @@ def main():
                        "adjacency_values": "kipf" if args.normalize else "ones"},
             "roofline": {"bound": "hbm",
                          "kernel": "dense_wgrad+bspmm (unfused)" if args.unfused else
-                                   "graphconv_bwd_full_kernel (+2 reduce_partials launches, ~10 us, in the event bracket)",
+                                   "graphconv_bwd_full_kernel (+1 reduce_partials launch, ~5 us, in the event bracket)",
                          "achieved": bwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": bwd_gbs / HBM_PEAK_GBS, "traffic": traffic_bwd,
                          "traffic_note": "HBM bytes per launch, rocprofv3 PMC (profiles/traffic_cfg2.json); "

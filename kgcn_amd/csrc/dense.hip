@@ -181,30 +181,39 @@ __global__ __launch_bounds__(256) void dense_wgrad_kernel(
 // out[i] = sum_p part[p*n + i]   (deterministic second stage).  A workgroup owns 32 consecutive
 // outputs (128 contiguous bytes per partial); its 8 lane-groups stride over the partials with 8
 // independent loads in flight each, then combine through LDS in a fixed order.
+// Two partial arrays (e.g. dW and dbias of one layer) are reduced by ONE launch: outputs [0, n) come from
+// `part`, outputs [n, n + n2) from `part2`.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part,
                                                               int nparts, long n,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out,
+                                                              const float* __restrict__ part2, long n2,
+                                                              float* __restrict__ out2) {
   __shared__ float red[8][33];
   const int oi = threadIdx.x & 31, pg = threadIdx.x >> 5;
-  const long o = (long)blockIdx.x * 32 + oi;
+  long o = (long)blockIdx.x * 32 + oi;
+  const bool second = o >= n;
+  const float* src = second ? part2 : part;
+  float* dst = second ? out2 : out;
+  const long nn = second ? n2 : n;
+  if (second) o -= n;
   float s[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) s[u] = 0.f;
-  if (o < n) {
+  if (o < nn) {
     int p = pg;
     for (; p + 56 < nparts; p += 64) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s[u] += part[(long)(p + 8 * u) * n + o];
+      for (int u = 0; u < 8; ++u) s[u] += src[(long)(p + 8 * u) * nn + o];
     }
-    for (; p < nparts; p += 8) s[0] += part[(long)p * n + o];
+    for (; p < nparts; p += 8) s[0] += src[(long)p * nn + o];
   }
   red[pg][oi] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
-  if (pg == 0 && o < n) {
+  if (pg == 0 && o < nn) {
     float t = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) t += red[q][oi];
-    out[o] = t;
+    dst[o] = t;
   }
 }
 
@@ -442,7 +451,20 @@ static void wgrad_plan(long m, long* rows_per_chunk, int* nchunks) {
 
 int launch_reduce_partials(const float* part, int nparts, long n, float* out, hipStream_t s) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s,
-                     part, nparts, n, out);
+                     part, nparts, n, out, nullptr, 0L, nullptr);
+  return check_launch("reduce_partials_kernel");
+}
+
+// both reductions of a layer (dW [n], dbias [n2]) in one launch; n is rounded up to whole 32-output groups
+// of the first array, so no workgroup straddles the two
+int launch_reduce_partials2(const float* part, int nparts, long n, float* out, const float* part2, long n2,
+                            float* out2, hipStream_t s) {
+  if (n % 32) {                         // keep the simple kernel: two launches when dW is not a multiple of 32
+    if (int rc = launch_reduce_partials(part, nparts, n, out, s)) return rc;
+    return launch_reduce_partials(part2, nparts, n2, out2, s);
+  }
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + n2 + 31) / 32)), dim3(256), 0, s,
+                     part, nparts, n, out, part2, n2, out2);
   return check_launch("reduce_partials_kernel");
 }
 

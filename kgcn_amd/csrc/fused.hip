@@ -31,6 +31,8 @@
 namespace kgcn {
 
 int launch_reduce_partials(const float* part, int nparts, long n, float* out, hipStream_t s);
+int launch_reduce_partials2(const float* part, int nparts, long n, float* out, const float* part2, long n2,
+                            float* out2, hipStream_t s);
 
 constexpr int FN = 32;    // node tile (MFMA M)
 constexpr int FD = 64;    // feature tile (K of the forward GEMM, two 32-wide output tiles)
@@ -1333,6 +1335,5 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
                        at->graph_ptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
                        at->rows, din, dout, at->max_nnz_per_graph);
   if (int rc = check_launch("graphconv_bwd_kernel")) return rc;
-  if (int rc = launch_reduce_partials(part_dw, blocks, (long)din * dout, dw, s)) return rc;
-  return launch_reduce_partials(part_db, blocks, dout, dbias, s);
+  return launch_reduce_partials2(part_dw, blocks, (long)din * dout, dw, part_db, dout, dbias, s);
 }
