@@ -201,6 +201,18 @@ int kgcn_gat_bwd_f32(const kgcn_csr_batch* a, const kgcn_csr_batch* at, const fl
                      const float* weight_a, const float* dout_grad, float* dx, float beta, float* dweight_a,
                      void* workspace, int64_t workspace_bytes, void* stream);
 
+/* -- decoders: per-graph weighted Gram matrix ------------------------------------------------ */
+/* GraphDecoderInnerProd (kgcn/layers.py:268-282, w = NULL), GraphDecoderDistMult (:285-305), DistMult.call
+ * (:347-354, one relation channel per call):  out[t,i,j] = sum_k w[k] x[t,i,k] x[t,j,k].
+ * x [T, N, d], w [d] or NULL, out [T, N, N].  Backward: dx = beta*dx + w * ((g + g^T) x); dw [d] overwritten
+ * (NULL to skip; workspace >= kgcn_gram_workspace_bytes(d), deterministic two-stage sum). */
+int64_t kgcn_gram_workspace_bytes(int32_t d);
+int kgcn_gram_fwd_f32(const float* x, int32_t num_graphs, int32_t n_nodes, int32_t d, const float* w, float* out,
+                      void* stream);
+int kgcn_gram_bwd_f32(const float* x, int32_t num_graphs, int32_t n_nodes, int32_t d, const float* w,
+                      const float* dout_grad, float* dx, float beta, float* dw, void* workspace,
+                      int64_t workspace_bytes, void* stream);
+
 /* -- GraphGather ---------------------------------------------------------------------------- */
 /* kgcn/layers.py:163-164: out[b, :] = sum_n x[b, n, :] (padding rows included). */
 int kgcn_graph_gather_fwd_f32(const float* x, int64_t batch, int32_t n_nodes, int32_t d,

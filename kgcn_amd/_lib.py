@@ -75,6 +75,10 @@ SIGNATURES = {
                                         ctypes.c_void_p]),
     "kgcn_gat_bwd_f32": (ctypes.c_int, [_CSRP, _CSRP, c_f32p, c_i32, c_f32p, c_f32p, c_f32p, ctypes.c_float, c_f32p,
                                         ctypes.c_void_p, c_i64, ctypes.c_void_p]),
+    "kgcn_gram_workspace_bytes": (c_i64, [c_i32]),
+    "kgcn_gram_fwd_f32": (ctypes.c_int, [c_f32p, c_i32, c_i32, c_i32, c_f32p, c_f32p, ctypes.c_void_p]),
+    "kgcn_gram_bwd_f32": (ctypes.c_int, [c_f32p, c_i32, c_i32, c_i32, c_f32p, c_f32p, c_f32p, ctypes.c_float, c_f32p,
+                                         ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_graph_gather_fwd_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i32, c_f32p,
                                                  ctypes.c_void_p]),
     "kgcn_graph_gather_bwd_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i32, c_f32p,

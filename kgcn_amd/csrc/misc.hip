@@ -163,3 +163,136 @@ extern "C" int kgcn_dot_f32(const float* a, const float* b, int64_t n, float* ou
   hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, s, part, (int)blocks, out);
   return check_launch("dot_final_kernel");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Decoders (kgcn/layers.py:268-361): per graph the weighted Gram matrix
+//   out[t, i, j] = sum_k w[k] x[t, i, k] x[t, j, k]           (w = NULL: plain inner products)
+// GraphDecoderInnerProd (:268-282), GraphDecoderDistMult (:285-305), DistMult.call (:347-354, one channel
+// per call).  Tiny per-graph contractions (N <= ~50 nodes): one workgroup stages the graph's x tile in LDS
+// and loops over graphs; backward  dx = w * ((g + g^T) x),  dw[k] = 1/2 sum_i x[i,k] ((g + g^T) x)[i,k]
+// with one partial per workgroup (deterministic second stage).
+// ------------------------------------------------------------------------------------------------
+namespace kgcn {
+int launch_reduce_partials(const float* part, int nparts, long n, float* out, hipStream_t s);
+
+__global__ __launch_bounds__(256) void gram_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ out, int T, int N, int D) {
+  extern __shared__ float gsm[];
+  float* xs = gsm;                 // [N][D + 1]
+  float* ws = gsm + (size_t)N * (D + 1);
+  const int ld = D + 1;
+  for (int k = threadIdx.x; k < D; k += 256) ws[k] = w ? w[k] : 1.f;
+  for (int t = blockIdx.x; t < T; t += gridDim.x) {
+    __syncthreads();
+    const float* xt = x + (long)t * N * D;
+    for (int e = threadIdx.x; e < N * D; e += 256) xs[(e / D) * ld + e % D] = xt[e];
+    __syncthreads();
+    float* ot = out + (long)t * N * N;
+    for (int p = threadIdx.x; p < N * N; p += 256) {
+      const int i = p / N, j = p - i * N;
+      const float* a = xs + i * ld;
+      const float* b = xs + j * ld;
+      float s = 0.f;
+      for (int k = 0; k < D; ++k) s = __builtin_fmaf(ws[k] * a[k], b[k], s);
+      ot[p] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gram_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ g, float* __restrict__ dx,
+                                                        float* __restrict__ part_dw, int T, int N, int D, float beta) {
+  extern __shared__ float gsm[];
+  float* xs = gsm;                               // [N][D + 1]
+  float* gs = gsm + (size_t)N * (D + 1);         // [N][N + 1]: g + g^T
+  float* dws = gs + (size_t)N * (N + 1);         // [D] partial of this workgroup
+  const int ld = D + 1, lg = N + 1;
+  for (int k = threadIdx.x; k < D; k += 256) dws[k] = 0.f;
+  for (int t = blockIdx.x; t < T; t += gridDim.x) {
+    __syncthreads();
+    const float* xt = x + (long)t * N * D;
+    const float* gt = g + (long)t * N * N;
+    for (int e = threadIdx.x; e < N * D; e += 256) xs[(e / D) * ld + e % D] = xt[e];
+    for (int p = threadIdx.x; p < N * N; p += 256) {
+      const int i = p / N, j = p - i * N;
+      gs[i * lg + j] = gt[p] + gt[j * N + i];
+    }
+    __syncthreads();
+    float* dxt = dx + (long)t * N * D;
+    // thread <-> column k, all rows in order: the dw partial of a column is a fixed-order sum in ONE thread
+    // (deterministic, no atomics); g + g^T is read as a broadcast, x along rows without bank conflicts
+    for (int k = threadIdx.x; k < D; k += 256) {
+      const float wk = w ? w[k] : 1.f;
+      float dwk = 0.f;
+      for (int i = 0; i < N; ++i) {
+        float h = 0.f;
+        for (int j = 0; j < N; ++j) h = __builtin_fmaf(gs[i * lg + j], xs[j * ld + k], h);
+        float* o = dxt + i * D + k;
+        *o = (beta != 0.f ? *o : 0.f) + wk * h;
+        dwk = __builtin_fmaf(0.5f * xs[i * ld + k], h, dwk);
+      }
+      dws[k] += dwk;
+    }
+  }
+  __syncthreads();
+  if (part_dw)
+    for (int k = threadIdx.x; k < D; k += 256) part_dw[(long)blockIdx.x * D + k] = dws[k];
+}
+}  // namespace kgcn
+
+extern "C" int64_t kgcn_gram_workspace_bytes(int32_t d) { return d > 0 ? (int64_t)512 * d * 4 : 0; }
+
+static size_t gram_lds(int N, int D, bool bwd) {
+  return ((size_t)N * (D + 1) + (bwd ? (size_t)N * (N + 1) + D : (size_t)D)) * 4;
+}
+
+extern "C" int kgcn_gram_fwd_f32(const float* x, int32_t num_graphs, int32_t n_nodes, int32_t d, const float* w,
+                                 float* out, void* stream) {
+  if (num_graphs < 0 || n_nodes <= 0 || d <= 0) return kgcn::fail("kgcn_gram_fwd_f32: bad shape");
+  if (num_graphs == 0) return 0;
+  if (!x || !out) return kgcn::fail("kgcn_gram_fwd_f32: NULL operand");
+  const size_t lds = gram_lds(n_nodes, d, false);
+  if (lds > (size_t)kgcn::kLdsBytes) return kgcn::fail("kgcn_gram_fwd_f32: graph tile %d x %d does not fit LDS", n_nodes, d);
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kgcn::gram_fwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kgcn::kLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kgcn::gram_bwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kgcn::kLdsBytes);
+    attr_set = true;
+  }
+  const int blocks = num_graphs < 2048 ? num_graphs : 2048;
+  hipLaunchKernelGGL(kgcn::gram_fwd_kernel, dim3(blocks), dim3(256), lds, kgcn::as_stream(stream), x, w, out, num_graphs,
+                     n_nodes, d);
+  return kgcn::check_launch("gram_fwd_kernel");
+}
+
+extern "C" int kgcn_gram_bwd_f32(const float* x, int32_t num_graphs, int32_t n_nodes, int32_t d, const float* w,
+                                 const float* dout_grad, float* dx, float beta, float* dw, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+  if (num_graphs < 0 || n_nodes <= 0 || d <= 0) return kgcn::fail("kgcn_gram_bwd_f32: bad shape");
+  hipStream_t s = kgcn::as_stream(stream);
+  if (num_graphs == 0) {
+    if (dw) (void)hipMemsetAsync(dw, 0, (size_t)d * 4, s);
+    return 0;
+  }
+  if (!x || !dout_grad || !dx) return kgcn::fail("kgcn_gram_bwd_f32: NULL operand");
+  if (beta != 0.f && beta != 1.f) return kgcn::fail("kgcn_gram_bwd_f32: beta must be 0 or 1");
+  const size_t lds = gram_lds(n_nodes, d, true);
+  if (lds > (size_t)kgcn::kLdsBytes) return kgcn::fail("kgcn_gram_bwd_f32: graph tile %d x %d does not fit LDS", n_nodes, d);
+  const int blocks = num_graphs < 512 ? num_graphs : 512;
+  if (dw && (!workspace || workspace_bytes < (int64_t)blocks * d * 4))
+    return kgcn::fail("kgcn_gram_bwd_f32: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                      (long long)blocks * d * 4);
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kgcn::gram_bwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kgcn::kLdsBytes);
+    attr_set = true;
+  }
+  float* part = dw ? static_cast<float*>(workspace) : nullptr;
+  hipLaunchKernelGGL(kgcn::gram_bwd_kernel, dim3(blocks), dim3(256), lds, s, x, w, dout_grad, dx, part, num_graphs,
+                     n_nodes, d, beta);
+  if (int rc = kgcn::check_launch("gram_bwd_kernel")) return rc;
+  return dw ? kgcn::launch_reduce_partials(part, blocks, d, dw, s) : 0;
+}

@@ -16,7 +16,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .batched_csr import BatchedAdjacency, as_batched_adjacency
+from .batched_csr import BatchedAdjacency, BatchedCSR, as_batched_adjacency
 
 enabled_batched = False
 enabled_bspmm = False
@@ -52,6 +52,26 @@ def _init_tensor(shape, initializer, device):
         nn.init.zeros_(t)
     elif initializer == "ones":
         nn.init.ones_(t)
+    else:
+        raise ValueError("unsupported initializer %r" % (initializer,))
+    return t
+
+
+def _init_vector(d, initializer, device, fan=None):
+    """1-D Keras kernels (GraphDecoderDistMult's [Din]; rows of DistMult's [C, Din]): glorot limits from the
+    variable's own shape, as Keras computes them (fan_in = fan_out = d for a vector)."""
+    t = torch.empty((d,), dtype=torch.float32, device=device)
+    if initializer == "glorot_uniform":
+        fi, fo = (d, d) if fan is None else fan
+        lim = math.sqrt(6.0 / (fi + fo))
+        nn.init.uniform_(t, -lim, lim)
+    elif initializer == "zeros":
+        nn.init.zeros_(t)
+    elif initializer == "ones":
+        nn.init.ones_(t)
+    elif callable(initializer):
+        with torch.no_grad():
+            t.copy_(torch.as_tensor(initializer((d,)), dtype=torch.float32))
     else:
         raise ValueError("unsupported initializer %r" % (initializer,))
     return t
@@ -257,6 +277,114 @@ class GAT(nn.Module):
         return ops.gat(inputs, a, list(self.weight_a))
 
 
+class GraphDecoderInnerProd(nn.Module):
+    """kgcn/layers.py:268-282: adj_hat[b] = X[b] X[b]^T."""
+
+    def compute_output_shape(self, input_shape):
+        return input_shape[0], input_shape[1], input_shape[1]
+
+    def forward(self, inputs, **kwargs):
+        return ops.gram(inputs)
+
+
+class GraphDecoderDistMult(nn.Module):
+    """kgcn/layers.py:285-305: adj_hat[b] = (kernel * X[b]) X[b]^T, kernel [Din] (initializer)."""
+
+    def __init__(self, initializer="glorot_uniform", **kwargs):
+        super().__init__()
+        self.initializer = initializer
+        self.w = nn.ParameterList()
+        self.built = False
+
+    def build(self, input_shape, device=None):
+        self.w.append(nn.Parameter(_init_vector(int(input_shape[2]), self.initializer, device)))
+        self.built = True
+
+    def compute_output_shape(self, input_shape):
+        return input_shape[0], input_shape[1], input_shape[1]
+
+    def forward(self, inputs, **kwargs):
+        if not self.built:
+            self.build(inputs.shape, inputs.device)
+        return ops.gram(inputs, self.w[0])
+
+
+class DistMult(nn.Module):
+    """kgcn/layers.py:307-361: one relation vector per adjacency channel, kernel [C, Din];
+    call -> [B, C, N, N]; compute_score / compute_left_prediction / compute_right_prediction as the reference."""
+
+    def __init__(self, initializer="glorot_uniform", adj_channel_num=1, **kwargs):
+        super().__init__()
+        self.initializer = initializer
+        self.adj_channel_num = int(adj_channel_num)
+        self.w = nn.ParameterList()
+        self.built = False
+
+    def build(self, input_shape, device=None):
+        d = int(input_shape[-1])
+        t = torch.stack([_init_vector(d, self.initializer, device, fan=(self.adj_channel_num, d))
+                         for _ in range(self.adj_channel_num)])
+        self.w.append(nn.Parameter(t))
+        self.built = True
+
+    def _ensure(self, like):
+        if not self.built:
+            self.build(like.shape, like.device)
+
+    def compute_score(self, layer1, layer2, channel, **kwargs):          # :321-325
+        self._ensure(layer1)
+        return (layer1 * layer2 * self.w[0][channel]).sum(dim=1)
+
+    def compute_left_prediction(self, layer, right_layer, channel, **kwargs):   # :327-336
+        self._ensure(layer)
+        return ops.dense(right_layer * self.w[0][channel], layer.t().contiguous())
+
+    def compute_right_prediction(self, left_layer, layer, channel, **kwargs):   # :338-347
+        self._ensure(left_layer)
+        return torch.matmul(layer, (left_layer * self.w[0][channel]).unsqueeze(2)).squeeze(2)
+
+    def compute_output_shape(self, input_shape):
+        return input_shape[0], self.adj_channel_num, input_shape[1], input_shape[1]
+
+    def forward(self, inputs, **kwargs):
+        self._ensure(inputs)
+        return torch.stack([ops.gram(inputs, self.w[0][i]) for i in range(self.adj_channel_num)], dim=1)
+
+
+class BatchGraphConv(nn.Module):
+    """kgcn/layers.py:363-397: relu(A @ (X W + b)) on ONE block-diagonal sparse matrix, inputs = [net [sumN, Din],
+    adj].  The reference's build loop overwrites self.w / self.bias per channel, so exactly one kernel / bias
+    pair exists whatever adj_channel_num is; bias [Dout]."""
+
+    def __init__(self, output_dim, adj_channel_num=1, initializer="glorot_uniform", input_dim=None, **kwargs):
+        super().__init__()
+        self.output_dim = int(output_dim)
+        self.adj_channel_num = int(adj_channel_num)
+        self.initializer = initializer
+        self.input_dim = input_dim
+        self.w = None
+        self.bias = None
+
+    def compute_output_shape(self, input_shape):
+        return input_shape[0][0], self.output_dim
+
+    def forward(self, inputs, **kwargs):
+        net, adj = inputs[0], inputs[1]
+        if self.w is None:
+            din = int(net.shape[1] if self.input_dim is None else self.input_dim)
+            self.w = nn.Parameter(_init_tensor((din, self.output_dim), self.initializer, net.device))
+            self.bias = nn.Parameter(_init_tensor((self.output_dim,), "zeros", net.device))
+        n = int(net.shape[0])
+        if isinstance(adj, BatchedAdjacency):
+            csr = adj.channels[0]
+        elif isinstance(adj, BatchedCSR):
+            csr = adj
+        else:                                   # one COO matrix (tuple or SparseTensor-like), [sumN, sumN]
+            csr = BatchedCSR.from_coo_list([adj], rows=n, cols=n, device=net.device)
+        fw = ops.dense(net, self.w, self.bias)
+        return torch.relu(ops.bspmm(csr, fw))
+
+
 class GraphBatchNormalization(nn.Module):
     """kgcn/layers.py:170-220 with Keras' learning phase at its TF1 default (quirk Q6): the wrapped
     BatchNormalization normalises with its moving statistics (mean 0, variance 1, epsilon 1e-3):
@@ -297,5 +425,6 @@ class GraphGather(nn.Module):
 
 
 __all__ = ["GraphConv", "GraphDense", "GINAggregate", "GraphGather", "GraphMaxPooling",
-           "GraphBatchNormalization", "GAT", "load_bspmm",
+           "GraphBatchNormalization", "GAT", "GraphDecoderInnerProd",
+           "GraphDecoderDistMult", "DistMult", "BatchGraphConv", "load_bspmm",
            "BatchedAdjacency"]

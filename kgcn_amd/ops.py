@@ -354,6 +354,42 @@ def gat(x, adj, weight_a):
 
 
 # -------------------------------------------------------------------------------------------------
+# decoders: weighted Gram matrix per graph
+# -------------------------------------------------------------------------------------------------
+class _Gram(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        x = _f32c(x, "inputs")
+        T, N, d = x.shape
+        wv = None if w is None else _f32c(w.reshape(-1), "kernel")
+        out = torch.empty((T, N, N), device=x.device, dtype=torch.float32)
+        check(lib.kgcn_gram_fwd_f32(ptr(x), T, N, d, 0 if wv is None else ptr(wv), ptr(out), current_stream()),
+              "kgcn_gram_fwd_f32")
+        ctx.has_w = wv is not None
+        ctx.w_shape = None if w is None else tuple(w.shape)
+        ctx.save_for_backward(x, wv if wv is not None else x.new_empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wv = ctx.saved_tensors
+        g = _f32c(g, "grad")
+        T, N, d = x.shape
+        dx = torch.empty_like(x)
+        dw = torch.empty(d, device=x.device, dtype=torch.float32) if ctx.has_w else None
+        wsb = lib.kgcn_gram_workspace_bytes(d)
+        ws = torch.empty((max(wsb, 4) // 4,), device=x.device, dtype=torch.float32)
+        check(lib.kgcn_gram_bwd_f32(ptr(x), T, N, d, ptr(wv) if ctx.has_w else 0, ptr(g), ptr(dx), 0.0,
+                                    ptr(dw) if ctx.has_w else 0, ptr(ws), wsb, current_stream()), "kgcn_gram_bwd_f32")
+        return dx, (dw.reshape(ctx.w_shape) if ctx.has_w else None)
+
+
+def gram(x, w=None):
+    """out[t] = (x[t] * w) @ x[t]^T  (w: [d] or None)."""
+    return _Gram.apply(x, w)
+
+
+# -------------------------------------------------------------------------------------------------
 # GraphGather
 # -------------------------------------------------------------------------------------------------
 class _Gather(torch.autograd.Function):
@@ -383,4 +419,4 @@ def graph_gather(x):
 
 __all__ = ["BatchedCSR", "BatchedAdjacency", "bspmm", "bspmm_raw", "bconv", "dense",
            "graphconv_fused", "graphconv_fused_supported", "gin_aggregate", "graph_gather",
-           "graph_maxpool", "gat"]
+           "graph_maxpool", "gat", "gram"]

@@ -606,3 +606,70 @@ def test_gat_layer(channels, D):
     close(tx.grad, dx, atol=2e-5, rel=1e-5, what="gat dx")
     for c in range(C):
         close(layer.weight_a[c].grad, dwa[c], atol=2e-5, rel=2e-5, what="gat dweight_a[%d]" % c)
+
+
+# ---------------------------------------------------------------------------------------------
+# decoders and BatchGraphConv (kgcn/layers.py:268-397)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,N,D", [(30, 10, 50), (7, 50, 256), (300, 32, 64), (1, 3, 5)])
+def test_decoders(B, N, D):
+    from kgcn_amd import layers
+    rng = np.random.default_rng(B + N + D)
+    x = (rng.standard_normal((B, N, D)) * 0.5).astype(np.float32)
+    g = rng.standard_normal((B, N, N)).astype(np.float32)
+    tx = t32(x).requires_grad_(True)
+    inner = layers.GraphDecoderInnerProd()
+    out = inner(tx)
+    assert tuple(out.shape) == (B, N, N) == tuple(inner.compute_output_shape((B, N, D)))
+    close(out, K.gram_fwd(x), rel=2e-6, what="inner-product decoder")
+    out.backward(t32(g))
+    close(tx.grad, K.gram_bwd(x, None, g)[0], rel=5e-6, what="inner-product decoder dx")
+    dm = layers.GraphDecoderDistMult().to(dev())
+    tx2 = t32(x).requires_grad_(True)
+    out2 = dm(tx2)
+    w = dm.w[0].detach().cpu().numpy()
+    assert w.shape == (D,)
+    close(out2, K.gram_fwd(x, w), rel=2e-6, what="distmult decoder")
+    out2.backward(t32(g))
+    dx, dw = K.gram_bwd(x, w, g)
+    close(tx2.grad, dx, rel=5e-6, what="distmult decoder dx")
+    close(dm.w[0].grad, dw, rel=1e-5, what="distmult decoder dw")
+    C = 3
+    dist = layers.DistMult(adj_channel_num=C).to(dev())
+    tx3 = t32(x).requires_grad_(True)
+    out3 = dist(tx3)
+    assert tuple(out3.shape) == (B, C, N, N) and tuple(dist.w[0].shape) == (C, D)
+    ww = dist.w[0].detach().cpu().numpy()
+    for c in range(C):
+        close(out3[:, c], K.gram_fwd(x, ww[c]), rel=2e-6, what="DistMult channel %d" % c)
+    g4 = rng.standard_normal((B, C, N, N)).astype(np.float32)
+    out3.backward(t32(g4))
+    dxs = sum(K.gram_bwd(x, ww[c], g4[:, c])[0] for c in range(C))
+    close(tx3.grad, dxs, rel=5e-6, what="DistMult dx")
+    close(dist.w[0].grad, np.stack([K.gram_bwd(x, ww[c], g4[:, c])[1] for c in range(C)]), rel=1e-5, what="DistMult dw")
+    l1, l2 = t32(x[:, 0]), t32(x[:, 1])
+    close(dist.compute_score(l1, l2, 1), (x[:, 0] * x[:, 1] * ww[1]).sum(1), rel=2e-6, what="DistMult score")
+    close(dist.compute_left_prediction(t32(x[0]), l2, 2), (x[:, 1] * ww[2]) @ x[0].T, rel=2e-6, what="left prediction")
+    close(dist.compute_right_prediction(l1, t32(x), 0), np.einsum("bnd,bd->bn", x, x[:, 0] * ww[0]), rel=2e-6,
+          what="right prediction")
+
+
+def test_batch_graphconv_block_diagonal():
+    from kgcn_amd import layers
+    rng = np.random.default_rng(12)
+    G, N, F, Dout = 16, 20, 24, 40
+    adjs = K.synth_mol_graphs(rng, G, N, 2, normalize=True)
+    big = K.block_diag_csr(adjs, 0, N).tocoo()
+    coo = (np.stack([big.row, big.col], 1).astype(np.int64), big.data.astype(np.float32), [G * N, G * N])
+    net = rng.standard_normal((G * N, F)).astype(np.float32)
+    layer = layers.BatchGraphConv(Dout)
+    tn = t32(net).requires_grad_(True)
+    out = layer([tn, coo])
+    with torch.no_grad():
+        layer.bias.copy_(t32(rng.standard_normal(Dout) * 0.1))
+    out = layer([tn, coo])
+    assert tuple(out.shape) == (G * N, Dout) and tuple(layer.bias.shape) == (Dout,)
+    ref = K.batch_graphconv_fwd(net, coo, layer.w.detach().cpu().numpy(), layer.bias.detach().cpu().numpy())
+    close(out, ref, rel=2e-6, what="BatchGraphConv")
+    out.sum().backward()
+    assert torch.isfinite(tn.grad).all() and torch.isfinite(layer.w.grad).all()

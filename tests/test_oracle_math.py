@@ -301,3 +301,26 @@ def test_gat_literal_and_finite_differences():
             wm[c][k, 0] -= h
             fd = ((K.gat_fwd(x, adjs, wp) - K.gat_fwd(x, adjs, wm)) * g).sum() / (2 * h)
             assert abs(fd - dwa[c][k, 0]) < 1e-6 * max(1.0, abs(fd)), (c, k, fd, dwa[c][k, 0])
+
+
+def test_gram_decoder_gradients():
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((3, 5, 4))
+    w = rng.standard_normal(4)
+    g = rng.standard_normal((3, 5, 5))
+    out = K.gram_fwd(x, w)
+    np.testing.assert_allclose(out[1], (x[1] * w) @ x[1].T, atol=1e-12)
+    dx, dw = K.gram_bwd(x, w, g)
+    h = 1e-6
+    for i in [(0, 1, 2), (2, 4, 0)]:
+        xp, xm = x.copy(), x.copy()
+        xp[i] += h; xm[i] -= h
+        fd = ((K.gram_fwd(xp, w) - K.gram_fwd(xm, w)) * g).sum() / (2 * h)
+        assert abs(fd - dx[i]) < 1e-6 * max(1, abs(fd))
+    for k in range(4):
+        wp, wm = w.copy(), w.copy()
+        wp[k] += h; wm[k] -= h
+        fd = ((K.gram_fwd(x, wp) - K.gram_fwd(x, wm)) * g).sum() / (2 * h)
+        assert abs(fd - dw[k]) < 1e-6 * max(1, abs(fd))
+    dx0, none = K.gram_bwd(x, None, g)
+    assert none is None and np.allclose(dx0, K.gram_bwd(x, np.ones(4), g)[0])
