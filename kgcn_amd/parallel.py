@@ -33,22 +33,26 @@ class GradBucket:
             self._flat = torch.empty((self.total,), dtype=torch.float32, device=like.device)
         return self._flat
 
+    def _views(self, flat):
+        out, off = [], 0
+        for p, n in zip(self.params, self.sizes):
+            out.append(flat[off:off + n].view(p.shape))
+            off += n
+        return out
+
     def all_reduce_mean(self, group=None):
-        """flat <- concat(grads); all_reduce(sum); /world; scatter back into .grad (in place)."""
+        """flat <- concat(grads); all_reduce (mean over ranks); scatter back into .grad (in place).
+        Four launches per step whatever the number of parameters: one multi-tensor pack, the collective,
+        one scale, one multi-tensor unpack -- the payload is latency-bound, so launches are what it costs."""
         grads = [p.grad for p in self.params]
         if any(g is None for g in grads):
             raise RuntimeError("GradBucket: a parameter has no gradient")
         flat = self._buffer(grads[0])
-        off = 0
-        for g, n in zip(grads, self.sizes):
-            flat[off:off + n].copy_(g.reshape(-1))
-            off += n
+        views = self._views(flat)
+        torch._foreach_copy_(views, grads)
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         if world > 1:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
             flat.div_(world)
-        off = 0
-        for g, n in zip(grads, self.sizes):
-            g.copy_(flat[off:off + n].reshape(g.shape))
-            off += n
+        torch._foreach_copy_(grads, views)
         return flat
