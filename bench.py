@@ -200,10 +200,11 @@ def main():
         if bucket is not None:
             bucket.all_reduce_mean()
 
-    # setup: prime the caching allocator, the lazily built A^T / row-padded containers and the LDS
-    # attributes with a few untimed passes (part of initialisation, like data generation), then the
-    # W warm-up steps of the contract
-    for _ in range(3):
+    # setup: prime the caching allocator, the lazily built A^T / row-padded containers, the LDS attributes
+    # and the clocks (the GPU idles at 107 MHz and needs some tens of milliseconds of load to reach its
+    # sustained state, profiles/r01_h_power_clocks.txt) with untimed passes -- part of initialisation, like
+    # data generation -- then the W warm-up steps of the contract
+    for _ in range(25):
         step()
     torch.cuda.synchronize()
     for _ in range(args.warmup):
