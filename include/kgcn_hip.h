@@ -175,7 +175,8 @@ int kgcn_csr_gather_graphs(const kgcn_csr_batch* src, const int32_t* sel, int32_
 /* kgcn/layers.py:122-150 (one adjacency channel per call; beta = 1 accumulates the channel add-n):
  *   out[t,i,k] = beta*out[t,i,k] + max_j dense(A[t] .* x[t][:,k])[i,j]
  * = the maximum of a_ij * x[t][j,k] over the stored entries of row i, with 0 as a candidate unless
- * the row stores all `cols` entries (absent entries of the densified row are zeros). */
+ * the row stores all `cols` entries (absent entries of the densified row are zeros).  Entries of a row must
+ * be unique (the reference densifies with tf.sparse_tensor_to_dense, which rejects repeated indices). */
 int kgcn_graph_maxpool_fwd_f32(const kgcn_csr_batch* a, const float* x, int32_t d, float* out,
                                float beta, void* stream);
 /* Gradient as TF builds it (reduce_max splits the gradient equally among ALL maximal elements of
