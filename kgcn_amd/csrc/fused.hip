@@ -22,7 +22,8 @@
 //
 // Two instantiations of every kernel: FULL (N = 32, din = dout = 64: the benchmark shape; all
 // sizes are compile-time constants, the 8 aggregation passes are straight-line code) and generic
-// (N <= 32, din,dout <= 64; widths that are not multiples of 4 take an element-wise tile path).  Other shapes use
+// (N <= 32, din,dout <= 64; small graphs share a tile, widths that are not multiples of 4 take the flat-float4 or the
+// element-wise tile path).  Other shapes use
 // kgcn_dense_* + kgcn_bconv_f32.
 #include <type_traits>
 
@@ -158,14 +159,36 @@ __device__ __forceinline__ void land_tile_s(const TileRegs& f, float* tile, int 
     if (c >= d) { c -= d; ++r; }
   }
 }
-template <bool VEC>
+// Tile movement mode of the generic kernels:  2 = every width a multiple of 4 (float4 rows);  1 = widths are
+// not, but every tile (rows * d floats, contiguous) is a whole number of aligned float4: the tile is LOADED
+// as float4 (a quarter of the instructions) and scattered to its rows element by element;  0 = scalar.
+__device__ __forceinline__ void land_tile_f4(const TileRegs& f, float* tile, int ld, int n4, int d, int lane) {
+  int e = lane * 4;
+  int r = e / d, c = e - r * d;
+  const int dr = 256 / d, dc = 256 - dr * d;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    if (lane + q * 64 < n4) {
+      int rr = r, cc = c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        tile[rr * ld + cc] = f.v[q][j];
+        if (++cc == d) { cc = 0; ++rr; }
+      }
+    }
+    c += dc; r += dr;
+    if (c >= d) { c -= d; ++r; }
+  }
+}
+template <int MODE>
 __device__ __forceinline__ void issue_tile_g(TileRegs& f, const float* __restrict__ src, int n, int lane) {
-  if constexpr (VEC) issue_tile<false>(f, src, n >> 2, lane);
+  if constexpr (MODE >= 1) issue_tile<false>(f, src, n >> 2, lane);
   else issue_tile_s(f, src, n, lane);
 }
-template <bool VEC>
+template <int MODE>
 __device__ __forceinline__ void land_tile_g(const TileRegs& f, float* tile, int ld, int n, int d, int lane) {
-  if constexpr (VEC) land_tile<false>(f, tile, ld, n >> 2, d >> 2, lane);
+  if constexpr (MODE == 2) land_tile<false>(f, tile, ld, n >> 2, d >> 2, lane);
+  else if constexpr (MODE == 1) land_tile_f4(f, tile, ld, n >> 2, d, lane);
   else land_tile_s(f, tile, ld, n, d, lane);
 }
 
@@ -218,6 +241,49 @@ __device__ __forceinline__ void issue_meta(MetaRegs& m, const int* __restrict__ 
 __device__ __forceinline__ int meta_base(const MetaRegs& m) { return __builtin_amdgcn_readlane(m.gp, 0); }
 __device__ __forceinline__ int meta_cnt(const MetaRegs& m) {
   return __builtin_amdgcn_readlane(m.gp, 1) - __builtin_amdgcn_readlane(m.gp, 0);
+}
+
+// ---- graph packing (generic kernels) --------------------------------------------------------------------
+// A graph of N <= 16 nodes leaves most of the 32-row tile (and of its MFMAs) empty, so P = min(4, 32 / N)
+// CONSECUTIVE graphs share one tile: their features, CSR slices and slot tables are contiguous in the batch
+// containers, i.e. the pack is read like one graph of P*N rows; only the graph-local column indices, row
+// numbers and entry offsets are shifted when the slices are landed in LDS (padding entries keep col = FN).
+constexpr int MAX_PACK = 4;
+__device__ __forceinline__ void issue_meta_p(MetaRegs& m, const int* __restrict__ slots,
+                                             const int* __restrict__ gptr, int t, int P, int N, int lane) {
+  const int rows = P * N;
+  m.slot = slots[(long)t * N + (lane < rows ? lane : rows - 1)];
+  m.gp = gptr[t + (lane < P ? lane : P)];       // lane p <= P: first entry of graph t + p
+}
+__device__ __forceinline__ int meta_cnt_p(const MetaRegs& m, int P) {
+  return __builtin_amdgcn_readlane(m.gp, P) - __builtin_amdgcn_readlane(m.gp, 0);
+}
+__device__ __forceinline__ void land_csr_p(const CsrRegs& f, int2* ecv, int* tab, const int2* __restrict__ cv,
+                                           const MetaRegs& m, int base, int cnt, int N, int P, int lane) {
+  // entry index (inside the pack) at which graphs 1..3 start; INT_MAX for graphs the pack does not hold
+  const int big = 0x7fffffff;
+  const int s1 = P > 1 ? __builtin_amdgcn_readlane(m.gp, 1) - base : big;
+  const int s2 = P > 2 ? __builtin_amdgcn_readlane(m.gp, 2) - base : big;
+  const int s3 = P > 3 ? __builtin_amdgcn_readlane(m.gp, 3) - base : big;
+  auto shift = [&](i32x4 e, int idx) {             // both entries of a 16-byte pair belong to the same graph
+    const int off = ((idx >= s1) + (idx >= s2) + (idx >= s3)) * N;
+    e.x = (e.x == FN) ? FN : e.x + off;
+    e.z = (e.z == FN) ? FN : e.z + off;
+    return e;
+  };
+  i32x4* dst = reinterpret_cast<i32x4*>(ecv);
+  if (2 * lane < cnt) dst[lane] = shift(f.e0, 2 * lane);
+  if (128 + 2 * lane < cnt) dst[64 + lane] = shift(f.e1, 128 + 2 * lane);
+  for (int i = 256 + lane; i < cnt; i += 64) {     // rare: > 256 entries
+    int2 e = cv[base + i];
+    if (e.x != FN) e.x += ((i >= s1) + (i >= s2) + (i >= s3)) * N;
+    ecv[i] = e;
+  }
+  if (lane < P * N) {
+    const int pg = (lane >= N) + (lane >= 2 * N) + (lane >= 3 * N);
+    const int st = pg == 0 ? 0 : pg == 1 ? s1 : pg == 2 ? s2 : s3;
+    tab[lane] = m.slot + st + ((pg * N) << 24);    // offset field += start of the graph, row field += pg * N
+  }
 }
 
 // slot = (offset of the row's first entry inside the graph) | (entry count << 16) | (row << 24)
@@ -392,23 +458,25 @@ __device__ __forceinline__ void store_c_tiles(float* tile, const f32x16& c0, con
 }
 
 // Generic shapes (N <= 32, din/dout <= 64; VEC: both multiples of 4): prefetch + phase-sequential per graph.
-template <bool VEC>
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
     const int* __restrict__ slots, const int* __restrict__ gptr, const int2* __restrict__ cv,
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-    float* __restrict__ out, int T, int N, int din, int dout, int max_nnz) {
+    float* __restrict__ out, int T, int N, int din, int dout, int max_nnz, int pack) {
+  constexpr bool VEC = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, hi = lane >> 5;
   const int wpb = blockDim.x >> 6;
-  WaveSlice ws = carve(smem, wave, max_nnz, A_FWD, 1);
+  WaveSlice ws = carve(smem, wave, max_nnz * pack, A_FWD, 1);
 
-  const int nwaves = gridDim.x * wpb;
-  int t = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
+  const int stride = gridDim.x * wpb * pack;          // graphs between two tiles of this wave
+  int t = __builtin_amdgcn_readfirstlane((blockIdx.x * wpb + wave) * pack);   // first graph of the tile
   if (t >= T) return;  // no workgroup barrier below: idle waves may leave
 
-  // zero the A tile once: padding rows (>= N) and columns (>= din) stay zero for every graph
+  // zero the A tile once: rows and columns no tile ever writes stay zero; rows a SHORTER last pack leaves
+  // behind only produce FW rows that nothing gathers and nobody stores
   for (int i = lane; i < A_FWD; i += 64) ws.a[i] = 0.f;
   for (int i = lane; i < FD; i += 64) ws.b[FN * FD + i] = 0.f;
 
@@ -417,38 +485,44 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
   const float b0 = (bias && li < dout) ? bias[li] : 0.f;
   const float b1 = (bias && 32 + li < dout) ? bias[32 + li] : 0.f;
 
-  const int nx = N * din;
+  auto graphs_at = [&](int tt) { return T - tt < pack ? T - tt : pack; };
+  int P = graphs_at(t);
 
   TileRegs fx;
   CsrRegs fc;
   MetaRegs m_cur, m_nxt;
-  issue_meta(m_cur, slots, gptr, t, N, lane);
-  int base = meta_base(m_cur), cnt = meta_cnt(m_cur);
-  issue_tile_g<VEC>(fx, x + (long)t * N * din, nx, lane);
+  issue_meta_p(m_cur, slots, gptr, t, P, N, lane);
+  int base = meta_base(m_cur), cnt = meta_cnt_p(m_cur, P);
+  issue_tile_g<MODE>(fx, x + (long)t * N * din, P * N * din, lane);
   issue_cv(fc, cv, base, cnt, lane);
-  int tn = t + nwaves;
+  int tn = t + stride;
   // unconditional (index clamped): a conditional load becomes a phi whose copy forces
   // s_waitcnt vmcnt(0) right behind the prefetch
-  issue_meta(m_nxt, slots, gptr, tn < T ? tn : t, N, lane);
+  int Pn = graphs_at(tn < T ? tn : t);
+  issue_meta_p(m_nxt, slots, gptr, tn < T ? tn : t, Pn, N, lane);
   wave_sync();
 
   for (;;) {
-    land_tile_g<VEC>(fx, ws.a, ALD, nx, din, lane);
-    land_csr(fc, ws.ecv, ws.rp, cv, m_cur.slot, base, cnt, N, lane);
+    const int rows = P * N;
+    land_tile_g<MODE>(fx, ws.a, ALD, rows * din, din, lane);
+    land_csr_p(fc, ws.ecv, ws.rp, cv, m_cur, base, cnt, N, P, lane);
     wave_sync();
 
-    // next graph in flight while this one is computed.  Branch-free on purpose: values defined
+    // next tile in flight while this one is computed.  Branch-free on purpose: values defined
     // under `if (has_next)` become phis whose copies make the compiler wait (vmcnt(0)) for the
-    // prefetch right after issuing it; on the last iteration the current graph is re-read (L2 hit).
+    // prefetch right after issuing it; on the last iteration the current tile is re-read (L2 hit).
     const bool has_next = tn < T;
     const int tp = has_next ? tn : t;
-    const int base_n = meta_base(m_nxt), cnt_n = meta_cnt(m_nxt);
-    issue_tile_g<VEC>(fx, x + (long)tp * N * din, nx, lane);
+    const int base_n = meta_base(m_nxt), cnt_n = meta_cnt_p(m_nxt, Pn);
+    issue_tile_g<MODE>(fx, x + (long)tp * N * din, Pn * N * din, lane);
     issue_cv(fc, cv, base_n, cnt_n, lane);
     m_cur = m_nxt;
+    const int P_next = Pn;
     {
-      const int tnn = tn + nwaves;
-      issue_meta(m_nxt, slots, gptr, tnn < T ? tnn : tp, N, lane);
+      const int tnn = tn + stride;
+      const int tq = tnn < T ? tnn : tp;
+      Pn = graphs_at(tq);
+      issue_meta_p(m_nxt, slots, gptr, tq, Pn, N, lane);
     }
 
     f32x16 acc0, acc1;
@@ -469,7 +543,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
     wave_sync();
 
     float* ot = out + (long)t * N * dout;
-    aggregate_rows<false>(ws.ecv, ws.rp, ws.b, N, dout, lane, [&](int r, int cl, f32x4 acc) {
+    aggregate_rows<false>(ws.ecv, ws.rp, ws.b, rows, dout, lane, [&](int r, int cl, f32x4 acc) {
       if constexpr (VEC) {
         stv4(ot + (long)r * dout + cl * 4, acc);
       } else {
@@ -482,7 +556,8 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_kernel(
 
     if (!has_next) break;
     t = tn;
-    tn += nwaves;
+    tn += stride;
+    P = P_next;
     base = base_n;
     cnt = cnt_n;
   }
@@ -640,20 +715,21 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
 // ------------------------------------------------------------------------------------------------
 // backward, generic shapes: prefetch + phase-sequential per graph, 2 waves per SIMD
 // ------------------------------------------------------------------------------------------------
-template <bool VEC>
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
     const int* __restrict__ slots_t, const int* __restrict__ gptr_t, const int2* __restrict__ cv_t,
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ g,
     float* __restrict__ dx, float* __restrict__ part_dw, float* __restrict__ part_db, int T, int N,
-    int din, int dout, int max_nnz) {
+    int din, int dout, int max_nnz, int pack) {
   constexpr bool FULL = false;
+  constexpr bool VEC = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, hi = lane >> 5;
   const int wpb = blockDim.x >> 6;
   float* Wt = reinterpret_cast<float*>(smem);  // [FD][FD]: Wt[k][j] = W[j][k] (zero padded)
-  WaveSlice ws = carve(smem + FD * FD * 4, wave, max_nnz, A_BWD, 1);
+  WaveSlice ws = carve(smem + FD * FD * 4, wave, max_nnz * pack, A_BWD, 1);
 
   for (int i = tid; i < FD * FD; i += blockDim.x) {
     const int k = i >> 6, j = i & 63;
@@ -669,34 +745,41 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
   f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
 
   const int din4 = din >> 2;
-  const int nx4 = N * din4;
-  const int nxe = N * din, nge = N * dout;
-  const int nwaves = gridDim.x * wpb;
-  int t = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
+  const int stride = gridDim.x * wpb * pack;           // graphs between two tiles of this wave (see the forward)
+  int t = __builtin_amdgcn_readfirstlane((blockIdx.x * wpb + wave) * pack);
 
   if (t < T) {
+    auto graphs_at = [&](int tt) { return T - tt < pack ? T - tt : pack; };
+    int P = graphs_at(t);
     TileRegs fg, fx;
     CsrRegs fc;
     MetaRegs m_cur, m_nxt;
-    issue_meta(m_cur, slots_t, gptr_t, t, N, lane);
-    int base = meta_base(m_cur), cnt = meta_cnt(m_cur);
-    issue_tile_g<VEC>(fg, g + (long)t * N * dout, nge, lane);
+    issue_meta_p(m_cur, slots_t, gptr_t, t, P, N, lane);
+    int base = meta_base(m_cur), cnt = meta_cnt_p(m_cur, P);
+    issue_tile_g<MODE>(fg, g + (long)t * N * dout, P * N * dout, lane);
     issue_cv(fc, cv_t, base, cnt, lane);
-    issue_tile_g<VEC>(fx, x + (long)t * N * din, nxe, lane);
-    int tn = t + nwaves;
-    issue_meta(m_nxt, slots_t, gptr_t, tn < T ? tn : t, N, lane);
+    issue_tile_g<MODE>(fx, x + (long)t * N * din, P * N * din, lane);
+    int tn = t + stride;
+    int Pn = graphs_at(tn < T ? tn : t);
+    issue_meta_p(m_nxt, slots_t, gptr_t, tn < T ? tn : t, Pn, N, lane);
 
     PROBE_DECL
     for (;;) {
       PROBE(0)
       // ---- 1. g[t], CSR(A^T) slice: registers -> LDS ------------------------------------------
-      land_tile_g<VEC>(fg, ws.b, FD, nge, dout, lane);
-      land_csr(fc, ws.ecv, ws.rp, cv_t, m_cur.slot, base, cnt, N, lane);
+      const int rows = P * N;
+      const int nxe = rows * din, nge = rows * dout, nx4 = rows * din4;
+      land_tile_g<MODE>(fg, ws.b, FD, nge, dout, lane);
+      land_csr_p(fc, ws.ecv, ws.rp, cv_t, m_cur, base, cnt, N, P, lane);
+      if (P < pack) {
+        // a shorter last pack: the dFW rows a full pack of this wave left behind must not reach dW
+        for (int i = rows * BLD + lane; i < pack * N * BLD; i += 64) ws.a[i] = 0.f;
+      }
       wave_sync();
 
       PROBE(1)
       // ---- 2. dFW = A^T @ g -> dFW tile (odd stride), dbias partial ----------------------------
-      aggregate_rows<FULL>(ws.ecv, ws.rp, ws.b, N, dout, lane, [&](int r, int cl, f32x4 acc) {
+      aggregate_rows<FULL>(ws.ecv, ws.rp, ws.b, rows, dout, lane, [&](int r, int cl, f32x4 acc) {
         float* d = ws.a + r * BLD + cl * 4;
         d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2]; d[3] = acc[3];
         dbacc += acc;
@@ -705,7 +788,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
       PROBE(2)
 
       // ---- 3. x[t] -> gather tile (g is dead) --------------------------------------------------
-      land_tile_g<VEC>(fx, ws.b, FD, nxe, din, lane);
+      land_tile_g<MODE>(fx, ws.b, FD, nxe, din, lane);
 
       wave_sync();
       PROBE(3)
@@ -738,14 +821,17 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
       // AFTER the dW phase: its 72 registers would not fit beside the split fragments) ---------------
       const bool has_next = tn < T;
       const int tp = has_next ? tn : t;
-      const int base_n = meta_base(m_nxt), cnt_n = meta_cnt(m_nxt);
-      issue_tile_g<VEC>(fg, g + (long)tp * N * dout, nge, lane);
+      const int base_n = meta_base(m_nxt), cnt_n = meta_cnt_p(m_nxt, Pn);
+      issue_tile_g<MODE>(fg, g + (long)tp * N * dout, Pn * N * dout, lane);
       issue_cv(fc, cv_t, base_n, cnt_n, lane);
-      issue_tile_g<VEC>(fx, x + (long)tp * N * din, nxe, lane);
+      issue_tile_g<MODE>(fx, x + (long)tp * N * din, Pn * N * din, lane);
       m_cur = m_nxt;
+      const int P_next = Pn;
       {
-        const int tnn = tn + nwaves;
-        issue_meta(m_nxt, slots_t, gptr_t, tnn < T ? tnn : tp, N, lane);
+        const int tnn = tn + stride;
+        const int tq = tnn < T ? tnn : tp;
+        Pn = graphs_at(tq);
+        issue_meta_p(m_nxt, slots_t, gptr_t, tq, Pn, N, lane);
       }
 
       PROBE(4)
@@ -776,6 +862,26 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
               stv4(dxt + (long)i * 4, ldv4(ws.b + r * FD + c4 * 4));
             }
           }
+        } else if constexpr (MODE == 1) {
+          int e0 = lane * 4;
+          int r = e0 / din, c = e0 - r * din;
+          const int dr = 256 / din, dc = 256 - dr * din;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int i = lane + q * 64;
+            if (i < (nxe >> 2)) {
+              f32x4 v4;
+              int rr = r, cc = c;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                v4[j] = ws.b[rr * FD + cc];
+                if (++cc == din) { cc = 0; ++rr; }
+              }
+              stv4(dxt + (long)i * 4, v4);
+            }
+            c += dc; r += dr;
+            if (c >= din) { c -= din; ++r; }
+          }
         } else {
           int r = lane / din, c = lane - r * din;
           const int dr = 64 / din, dc = 64 - dr * din;
@@ -793,7 +899,8 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
 
       if (!has_next) break;
       t = tn;
-      tn += nwaves;
+      tn += stride;
+      P = P_next;
       base = base_n;
       cnt = cnt_n;
     }
@@ -822,7 +929,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
   }
   if (lane < 16) stv4(park + FD * FD + lane * 4, dbacc);
   __syncthreads();
-  const size_t slice_f = slice_bytes(max_nnz, A_BWD, 1) / 4;
+  const size_t slice_f = slice_bytes(max_nnz * pack, A_BWD, 1) / 4;
   const float* slice0 = reinterpret_cast<const float*>(smem + FD * FD * 4);
   float* pw = part_dw + (long)blockIdx.x * din * dout;
   for (int i = tid; i < FD * FD; i += blockDim.x) {
@@ -1188,6 +1295,20 @@ static int fused_grid(int T, int wpb) {
 
 static bool is_full(int n, int din, int dout) { return n == FN && din == FD && dout == FD; }
 
+// graphs per 32-row tile in the generic kernels (see "graph packing"): as many as fit, at most MAX_PACK, and only
+// while the packed CSR slices still leave room for >= 4 waves per workgroup
+static int pack_factor(int n, int max_nnz, size_t a_floats_shared) {
+  int p = FN / n;
+  if (p > MAX_PACK) p = MAX_PACK;
+  while (p > 1) {
+    const size_t per = slice_bytes(max_nnz * p, a_floats_shared == 0 ? A_FWD : A_BWD, 1);
+    long fit = ((long)kLdsBytes - (long)a_floats_shared) / (long)per;
+    if (fit >= 4 && (long)max_nnz * p < 65536) break;
+    --p;
+  }
+  return p < 1 ? 1 : p;
+}
+
 // LDS per wave of the forward / backward kernel for a (row-padded) batch
 static size_t fwd_slice(int, int, int, int max_nnz) { return slice_bytes(max_nnz, A_FWD, 1); }
 static size_t fwd_shared(int n, int din, int dout) { return is_full(n, din, dout) ? FWD_FULL_SHARED : 0; }
@@ -1249,30 +1370,40 @@ extern "C" int kgcn_graphconv_fwd_f32(const kgcn_csr_batch* a, const float* x, c
   const bool vec = !(din & 3) && !(dout & 3);
   if ((vec && (!aligned16(x) || !aligned16(out))) || !aligned16(a->cv))
     return fail("kgcn_graphconv_fwd_f32: x/out/cv not 16-byte aligned");
-  const size_t per = fwd_slice(a->rows, din, dout, a->max_nnz_per_graph);
+  // tile movement mode (see land_tile_f4): 1 when every graph's [N x d] block is a whole number of aligned float4
+  const int mode = vec ? 2 : (((a->rows * din) & 3) == 0 && ((a->rows * dout) & 3) == 0 && aligned16(x)) ? 1 : 0;
+  const bool full_shape = is_full(a->rows, din, dout);
+  const int pack = full_shape ? 1 : pack_factor(a->rows, a->max_nnz_per_graph, 0);
+  const size_t per = fwd_slice(a->rows, din, dout, a->max_nnz_per_graph * pack);
   const size_t shared = fwd_shared(a->rows, din, dout);
   const int wpb = fused_wpb(per, shared);
   const size_t lds = shared + (size_t)wpb * per;
+  const int tiles = (a->num_graphs + pack - 1) / pack;
   static thread_local bool attr_set = false;
   if (!attr_set) {
     allow_big_lds(graphconv_fwd_full_kernel);
-    allow_big_lds(graphconv_fwd_kernel<true>);
-    allow_big_lds(graphconv_fwd_kernel<false>);
+    allow_big_lds(graphconv_fwd_kernel<2>);
+    allow_big_lds(graphconv_fwd_kernel<1>);
+    allow_big_lds(graphconv_fwd_kernel<0>);
     attr_set = true;
   }
-  const dim3 grid(fused_grid(a->num_graphs, wpb)), block(64 * wpb);
+  const dim3 grid(fused_grid(tiles, wpb)), block(64 * wpb);
   const int2* cv = reinterpret_cast<const int2*>(a->cv);
-  if (is_full(a->rows, din, dout))
+  if (full_shape)
     hipLaunchKernelGGL(graphconv_fwd_full_kernel, grid, block, lds, as_stream(stream), a->slots,
                        a->graph_ptr, cv, x, w, bias, out, a->num_graphs, a->max_nnz_per_graph);
-  else if (vec)
-    hipLaunchKernelGGL(graphconv_fwd_kernel<true>, grid, block, lds, as_stream(stream), a->slots,
+  else if (mode == 2)
+    hipLaunchKernelGGL(graphconv_fwd_kernel<2>, grid, block, lds, as_stream(stream), a->slots,
                        a->graph_ptr, cv, x, w, bias, out, a->num_graphs, a->rows, din, dout,
-                       a->max_nnz_per_graph);
+                       a->max_nnz_per_graph, pack);
+  else if (mode == 1)
+    hipLaunchKernelGGL(graphconv_fwd_kernel<1>, grid, block, lds, as_stream(stream), a->slots,
+                       a->graph_ptr, cv, x, w, bias, out, a->num_graphs, a->rows, din, dout,
+                       a->max_nnz_per_graph, pack);
   else
-    hipLaunchKernelGGL(graphconv_fwd_kernel<false>, grid, block, lds, as_stream(stream), a->slots,
+    hipLaunchKernelGGL(graphconv_fwd_kernel<0>, grid, block, lds, as_stream(stream), a->slots,
                        a->graph_ptr, cv, x, w, bias, out, a->num_graphs, a->rows, din, dout,
-                       a->max_nnz_per_graph);
+                       a->max_nnz_per_graph, pack);
   return check_launch("graphconv_fwd_kernel");
 }
 
@@ -1302,11 +1433,14 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
   const bool vec = !(din & 3) && !(dout & 3);
   if ((vec && (!aligned16(x) || !aligned16(dout_grad) || (dx && !aligned16(dx)))) || !aligned16(at->cv))
     return fail("kgcn_graphconv_bwd_f32: tensors not 16-byte aligned");
+  const int mode = vec ? 2 : (((at->rows * din) & 3) == 0 && ((at->rows * dout) & 3) == 0 && aligned16(x) &&
+                              aligned16(dout_grad) && (!dx || aligned16(dx))) ? 1 : 0;
   const bool full = dx != nullptr && is_full(at->rows, din, dout) &&
                     BWD_FULL_WPB * bwd_full_slice_bytes(at->max_nnz_per_graph) <= (size_t)kLdsBytes;
-  const size_t per = full ? bwd_full_slice_bytes(at->max_nnz_per_graph) : bwd_slice(at->max_nnz_per_graph);
+  const int pack = (full || is_full(at->rows, din, dout)) ? 1 : pack_factor(at->rows, at->max_nnz_per_graph, FD * FD * 4);
+  const size_t per = full ? bwd_full_slice_bytes(at->max_nnz_per_graph) : bwd_slice(at->max_nnz_per_graph * pack);
   const int wpb = full ? BWD_FULL_WPB : fused_wpb(per, FD * FD * 4);
-  const int blocks = fused_grid(at->num_graphs, wpb);
+  const int blocks = fused_grid((at->num_graphs + pack - 1) / pack, wpb);
   const int64_t need = (int64_t)blocks * ((int64_t)din * dout + dout) * 4;
   if (!workspace || workspace_bytes < need)
     return fail("kgcn_graphconv_bwd_f32: workspace %lld < %lld bytes", (long long)workspace_bytes,
@@ -1317,8 +1451,9 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
   static thread_local bool attr_set = false;
   if (!attr_set) {
     allow_big_lds(graphconv_bwd_full_kernel);
-    allow_big_lds(graphconv_bwd_kernel<true>);
-    allow_big_lds(graphconv_bwd_kernel<false>);
+    allow_big_lds(graphconv_bwd_kernel<2>);
+    allow_big_lds(graphconv_bwd_kernel<1>);
+    allow_big_lds(graphconv_bwd_kernel<0>);
     attr_set = true;
   }
   const int2* cv = reinterpret_cast<const int2*>(at->cv);
@@ -1326,14 +1461,18 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
     hipLaunchKernelGGL(graphconv_bwd_full_kernel, dim3(blocks), dim3(64 * wpb), lds, s, at->slots,
                        at->graph_ptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
                        at->max_nnz_per_graph);
-  else if (vec)
-    hipLaunchKernelGGL(graphconv_bwd_kernel<true>, dim3(blocks), dim3(64 * wpb), lds, s, at->slots,
+  else if (mode == 2)
+    hipLaunchKernelGGL(graphconv_bwd_kernel<2>, dim3(blocks), dim3(64 * wpb), lds, s, at->slots,
                        at->graph_ptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
-                       at->rows, din, dout, at->max_nnz_per_graph);
+                       at->rows, din, dout, at->max_nnz_per_graph, pack);
+  else if (mode == 1)
+    hipLaunchKernelGGL(graphconv_bwd_kernel<1>, dim3(blocks), dim3(64 * wpb), lds, s, at->slots,
+                       at->graph_ptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
+                       at->rows, din, dout, at->max_nnz_per_graph, pack);
   else
-    hipLaunchKernelGGL(graphconv_bwd_kernel<false>, dim3(blocks), dim3(64 * wpb), lds, s, at->slots,
+    hipLaunchKernelGGL(graphconv_bwd_kernel<0>, dim3(blocks), dim3(64 * wpb), lds, s, at->slots,
                        at->graph_ptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
-                       at->rows, din, dout, at->max_nnz_per_graph);
+                       at->rows, din, dout, at->max_nnz_per_graph, pack);
   if (int rc = check_launch("graphconv_bwd_kernel")) return rc;
   return launch_reduce_partials2(part_dw, blocks, (long)din * dout, dw, part_db, dout, dbias, s);
 }
