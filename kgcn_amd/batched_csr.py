@@ -233,6 +233,19 @@ class BatchedCSR:
         import torch
         if self.rowptr.device.type != "cuda":
             raise _lib.KgcnHipError("gather(): device-side batch assembly needs a device-resident container")
+        if out is not None and sel_dev is not None:
+            # refill of a static container (sized for the worst case, indices validated by the caller once per
+            # batch): no host arithmetic at all, one kernel sequence
+            T = int(sel_dev.shape[0])
+            if (out.num_graphs, out.rows, out.cols, out.row_pad) != (T, self.rows, self.cols, self.row_pad):
+                raise ValueError("static container does not match the batch shape")
+            wsb = _lib.lib.kgcn_csr_gather_workspace_bytes(T)
+            _lib.check(_lib.lib.kgcn_csr_gather_graphs(
+                self.desc(), sel_dev.data_ptr(), T, out.rowptr.data_ptr(), out.cv.data_ptr() if out.nnz else 0, out.nnz,
+                out.slots.data_ptr() if out.slots is not None else 0, out._gptr_buf.data_ptr(), out._ws.data_ptr(), wsb,
+                _lib.current_stream()), "kgcn_csr_gather_graphs")
+            out._graph_counts = None
+            return out
         sel = np.asarray(sel, np.int64).reshape(-1)
         T, M = sel.shape[0], self.rows
         if T and (sel.max() >= self.num_graphs or sel.min() < -1):

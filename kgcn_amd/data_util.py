@@ -286,6 +286,8 @@ class StaticBatch:
         import torch
         batch_idx = np.asarray(batch_idx, np.int64).reshape(-1)
         T, nb = self.batch_size, batch_idx.shape[0]
+        if nb > T or (nb and (batch_idx.max() >= self.dataset.num_graphs or batch_idx.min() < 0)):
+            raise ValueError("batch indices out of range")
         sel = np.full(T, -1, np.int64)
         sel[:nb] = batch_idx
         self._sel_dev.copy_(torch.from_numpy(sel.astype(np.int32)), non_blocking=True)
