@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libkgcn_hip.so")
+# KGCN_HIP_LIB: development override (tools/variant_bench.py times alternative builds of the same library)
+LIB_PATH = os.environ.get("KGCN_HIP_LIB") or os.path.join(_HERE, "csrc", "libkgcn_hip.so")
 
 c_f32p = ctypes.c_void_p
 c_i32p = ctypes.c_void_p

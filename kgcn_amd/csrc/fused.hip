@@ -964,6 +964,11 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
 // LDS per wave: dFW[2] (odd stride), x tile, g tile (+ zero row), CSR[2].
 // ------------------------------------------------------------------------------------------------
 constexpr int BWD_FULL_WPB = 4;
+// how dX leaves the chip (see phase A): 0 = dword stores out of the C layout of dX = dFW W^T, 1 = 16-byte stores out
+// of the C layout of dX^T = W dFW^T (32-byte segments), 2 = that layout staged through LDS, whole rows as 1 KiB stores
+#ifndef KGCN_DX_STORE
+#define KGCN_DX_STORE 2
+#endif
 
 __host__ __device__ inline size_t bwd_full_slice_bytes(int max_nnz) {
   return 2 * (((size_t)A_BWD * 4 + 15) & ~(size_t)15) + (size_t)FN * FD * 4 + (size_t)(FN + 1) * FD * 4 +
@@ -1016,7 +1021,11 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_full_kernel(
   if (t0 < T) {
     const int cntw = (T - 1 - t0) / nwaves + 1;              // graphs of this wave
     const int tl = t0 + (cntw - 1) * nwaves;                  // its last graph
+#ifdef KGCN_ABL_HOT   // ablation: every wave keeps re-reading / re-writing its first two graphs (cache resident)
+    auto gidx = [&](int k) { const int t = t0 + (k & 1) * nwaves; return t < tl ? t : tl; };
+#else
     auto gidx = [&](int k) { const int t = t0 + k * nwaves; return t < tl ? t : tl; };  // clamped
+#endif
     const float* srcl = gt + cl * 4;
 
     TileRegs gpf, xpf;
@@ -1102,11 +1111,40 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_full_kernel(
           else if constexpr (tile == 2) dw10 = mfma_bf16(av, bv, dw10);
           else dw11 = mfma_bf16(av, bv, dw11);
 #ifndef KGCN_ABL_NO_ST
+#if KGCN_DX_STORE == 0
           if constexpr (ST && ks == 0 && m < 16) {          // dX(i-1): two row stores per MFMA
             const int row = (m & 3) + 8 * (m >> 2) + 4 * hi;
             dxp[row * D + li] = c0[m];
             dxp[row * D + 32 + li] = c1[m];
           }
+#elif KGCN_DX_STORE == 1
+          // dX(i-1) in the C layout of dX^T = W dFW^T: lane (li, hi) holds row li, floats 8q + 4hi .. +3 of each
+          // 32-wide half: one 16-byte store behind every second MFMA (32-byte segments per row)
+          if constexpr (ST && ks == 0 && m < 16 && (m & 1) == 0) {
+            constexpr int q = (m >> 1) & 3, nt = m >> 3;
+            const f32x16& c = nt ? c1 : c0;
+            const f32x4 v = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+            stv4(dxp + li * D + 32 * nt + 8 * q + 4 * hi, v);
+          }
+#else
+          // dX(i-1): C layout of dX^T = W dFW^T (lane = row li, 16-byte chunk ch = 8 nt + 2 q + hi) -> the dead
+          // dFW buffer `dfn` (the aggregation of graph i+1 starts writing it at MFMA 16), chunk position XORed
+          // with the row so that both the 8-lane write groups and the 16-lane read groups are conflict free
+          // -> whole rows as 1 KiB stores
+          if constexpr (ST && ks == 0 && m < 4) {
+            static_for<2>([&](auto hc) __attribute__((always_inline)) {
+              constexpr int cc = 2 * m + decltype(hc)::value, q = cc & 3, nt = cc >> 2;
+              const f32x16& c = nt ? c1 : c0;
+              const f32x4 v = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+              stv4(dfn + li * FD + (((8 * nt + 2 * q + hi) ^ (li & 15)) << 2), v);
+            });
+          }
+          if constexpr (ST && ks == 0 && m >= 5 && m < 13) {
+            constexpr int q = m - 5;
+            const int i4 = lane + q * 64, r = i4 >> 4, ch = i4 & 15;
+            stv4(dxp + (long)i4 * 4, ldv4(dfn + r * FD + ((ch ^ (r & 15)) << 2)));
+          }
+#endif
 #endif
 #ifndef KGCN_ABL_NO_AGG
           if constexpr (AGG) {
@@ -1169,9 +1207,20 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_full_kernel(
       static_for<48>([&](auto mc) __attribute__((always_inline)) {
         constexpr int m = decltype(mc)::value, ks = m / 12, pr = (m % 12) >> 1, nt = m & 1;
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#if KGCN_DX_STORE == 0
         if constexpr (nt == 0) c0 = mfma_bf16(FA[ks][PA[pr]], WF[0][ks][PB[pr]], c0);
         else c1 = mfma_bf16(FA[ks][PA[pr]], WF[1][ks][PB[pr]], c1);
+#else
+        // operands swapped: the accumulators hold dX^T = W dFW^T, i.e. lane (li, hi) owns 4 CONSECUTIVE floats of
+        // row li per register quad -- 16-byte pieces instead of single dwords
+        if constexpr (nt == 0) c0 = mfma_bf16(WF[0][ks][PB[pr]], FA[ks][PA[pr]], c0);
+        else c1 = mfma_bf16(WF[1][ks][PB[pr]], FA[ks][PA[pr]], c1);
+#endif
+#ifdef KGCN_ABL_NOSPLITB   // timing ablation (wrong results): phase B reuses the fragments of k-step 0
+        if constexpr (m % 12 == 0 && ks < 3) { FA[ks + 1][0] = FA[0][0]; FA[ks + 1][1] = FA[0][1]; FA[ks + 1][2] = FA[0][2]; }
+#else
         if constexpr (m % 12 == 0 && ks < 3) split_a(std::integral_constant<int, ks + 1>{});
+#endif
 #ifndef KGCN_ABL_NO_MV
         if constexpr (MV && m >= 16 && m < 24) {          // x(i+1): registers -> x tile; x(i+2) in flight
           constexpr int q = m - 16;
@@ -1235,12 +1284,22 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_full_kernel(
     PROBE_FLUSH(blockIdx.x * BWD_FULL_WPB + wave)
     {                                           // dX of the last graph
       float* dxp = dx + (long)tl * N * D;
+#if KGCN_DX_STORE == 0
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
         dxp[row * D + li] = c0[r];
         dxp[row * D + 32 + li] = c1[r];
       }
+#else
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v0 = {c0[4 * q], c0[4 * q + 1], c0[4 * q + 2], c0[4 * q + 3]};
+        const f32x4 v1 = {c1[4 * q], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]};
+        stv4(dxp + li * D + 8 * q + 4 * hi, v0);
+        stv4(dxp + li * D + 32 + 8 * q + 4 * hi, v1);
+      }
+#endif
     }
   }
 
@@ -1266,6 +1325,486 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_full_kernel(
   if (lane < 16) stv4(park + FD * FD + lane * 4, dbacc);
   __syncthreads();
   const size_t slice_f = bwd_full_slice_bytes(max_nnz) / 4;
+  const float* slice0 = reinterpret_cast<const float*>(smem);
+  float* pw = part_dw + (long)blockIdx.x * D * D;
+  for (int i = tid; i < D * D; i += blockDim.x) {
+    float s = 0.f;
+    for (int wv = 0; wv < BWD_FULL_WPB; ++wv) s += slice0[wv * slice_f + i];
+    pw[i] = s;
+  }
+  if (tid < D) {
+    float s = 0.f;
+    for (int wv = 0; wv < BWD_FULL_WPB; ++wv) s += slice0[wv * slice_f + D * D + tid];
+    part_db[(long)blockIdx.x * D + tid] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, FULL shape, "planes" version: every fp32 -> 3 x bf16 split happens ONCE, at the producer.
+//   * dFW(i+1) = A^T g(i+1) leaves the aggregation as three bf16 planes [32 nodes x 64 features] in LDS (two
+//     split_pair + three 8-byte stores per row and lane).  Both contractions read their operand fragments straight
+//     out of the planes: dX = dFW W^T wants 8 consecutive features of a node  -> one ds_read_b128 per piece and
+//     k-step; dW = x^T dFW wants 8 consecutive NODES of a feature column -> two ds_read_b64_tr_b16 (the LDS
+//     transpose read of gfx950: within 16 lanes, lane l element j receives element l&3 of what lane 4j + (l>>2)&3
+//     addressed) per piece, tile and k-step.  No operand is split twice and no split sits in front of an MFMA group.
+//   * x never touches LDS: its tile is loaded from HBM directly in the A-fragment layout of dW (lane (li, hi): feature
+//     32 mt + li of nodes 16 ks + 8 hi + j -- 32 dword loads, every one of them two full 128-byte lines), a whole
+//     iteration ahead, and is split into resident fragments behind the MFMAs of phase B.
+//   * dX is accumulated TRANSPOSED (dX^T = W dFW^T: operands swapped), so a lane owns 4 consecutive floats of a row per
+//     register quad and dX leaves as 16-byte stores (tools/bwd_skeleton.hip: the memory system is indifferent to the
+//     store shape of this kernel; the instruction stream is not).
+// Plane layout (bytes inside one 4 KiB plane; R = r >> 2, a = r & 3, h = f >> 5, c = (f & 31) >> 3):
+//     ((2R + h) << 8) | ((a ^ h) << 6) | ((c ^ (R & 3)) << 4) | ((f & 7) << 1)
+// i.e. four consecutive rows share a 256-byte bank row (one 64-byte quarter each), the two 32-feature halves sit in
+// different quarters, 16-byte chunks are rotated by the row quad: the 8-byte row stores of the aggregation, the
+// transpose reads (4 rows x 64 bytes per 32 lanes) and the 16-byte row reads (16-lane groups of ds_read_b128) are all
+// bank-conflict free, and the address splits into (row word from the slot table) XOR (lane constant).
+// Instruction count per graph 1,580 -> ~1,150 (VALU 990 -> ~700).
+// ------------------------------------------------------------------------------------------------
+constexpr int PL_BYTES = FN * FD * 2;          // one bf16 plane
+constexpr int DFWP_BYTES = 3 * PL_BYTES;       // p1 | p2 | p3
+
+// LDS of the workgroup: [4 waves x 2 plane buffers (4 KiB aligned: XOR addressing)] [W p2 / p3 fragment table]
+// [4 waves x (gather tile, 2 CSR slices)]
+constexpr int BWD_WPB_ = 4;
+constexpr size_t PLANES_ALL = (size_t)BWD_WPB_ * 2 * DFWP_BYTES;            // 98,304
+constexpr size_t WTAB_BYTES = 2 * 8 * 64 * 16;                             // [piece p2,p3][nt][ks][lane] x 16 bytes
+__host__ __device__ inline size_t bwd_planes_wave_bytes(int max_nnz) {
+  return (size_t)(FN + 1) * FD * 4 + 2 * (ecv_bytes(max_nnz) + RP_BYTES);
+}
+__host__ __device__ inline size_t bwd_planes_lds_bytes(int max_nnz) {
+  return PLANES_ALL + WTAB_BYTES + BWD_WPB_ * bwd_planes_wave_bytes(max_nnz);
+}
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+#define KGCN_LDS __attribute__((address_space(3)))
+__device__ __forceinline__ unsigned lds_off(const void* p) {
+  return (unsigned)(uintptr_t)(const KGCN_LDS unsigned char*)p;
+}
+__device__ __forceinline__ u32x4 lds_ld128(unsigned a) { return *(const KGCN_LDS u32x4*)(uintptr_t)a; }
+__device__ __forceinline__ void lds_st64(unsigned a, unsigned lo, unsigned hi) {
+  u32x2 v = {lo, hi};
+  *(KGCN_LDS u32x2*)(uintptr_t)a = v;
+}
+__device__ __forceinline__ u32x2 lds_ld_tr16(unsigned a) {
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((KGCN_LDS i16x4*)(uintptr_t)a));
+}
+
+// slot word of the packer (offset | count << 16 | row << 24) -> offset (12 bits) | count << 12 | row word << 20, where
+// the row word is the row's share of the plane address (>> 4):  R << 5 | a << 2 | (R & 3)
+__device__ __forceinline__ int slot_plane_word(int v) {
+  const unsigned u = (unsigned)v, row = u >> 24, R = row >> 2;
+  const unsigned rw = (R << 5) | ((row & 3) << 2) | (R & 3);
+  return (int)((u & 0xfffu) | (((u >> 16) & 0xffu) << 12) | (rw << 24));
+}
+
+struct PlaneSteps {       // PassSteps on the plane slot word
+  int s, len;
+  unsigned rw;            // row word << 4 (byte address share of the row)
+  i32x4 q0, q1;
+  f32x4 x0, x1, x2, x3;
+  f32x4 a;
+  __device__ __forceinline__ void slot(const int* tab, int j) {
+    const unsigned u = (unsigned)tab[j];
+    s = (int)(u & 0xfffu);
+    len = (int)((u >> 12) & 0xffu);
+    rw = (u >> 24) << 4;
+  }
+  __device__ __forceinline__ void tail(const int2* ecv_, const float* srcl) {
+    if (__builtin_amdgcn_ballot_w64(len > 4)) {
+      for (int k = 4; __builtin_amdgcn_ballot_w64(k < len); k += 4)
+        if (k < len) add4(a, gather4(ecv_, srcl, s + k));
+    }
+  }
+};
+template <typename Emit>
+__device__ __forceinline__ void plane_half(PlaneSteps& P, int h, bool do_emit, const int* tab, int j,
+                                           const int2* ecv, const float* srcl, Emit&& emit) {
+  if (h == 0) { if (do_emit) emit(P); }
+  else if (h == 1) P.slot(tab, j);
+  else if (h == 2) P.q0 = *reinterpret_cast<const i32x4*>(ecv + P.s);
+  else if (h == 3) P.q1 = *reinterpret_cast<const i32x4*>(ecv + P.s + 2);
+  else if (h == 4) { P.x0 = ldv4(srcl + P.q0.x * FD); P.x1 = ldv4(srcl + P.q0.z * FD); }
+  else if (h == 5) { P.x2 = ldv4(srcl + P.q1.x * FD); P.x3 = ldv4(srcl + P.q1.z * FD); }
+  else if (h == 6) {
+    const float v = __int_as_float(P.q0.y);
+    P.a[0] = v * P.x0[0]; P.a[1] = v * P.x0[1]; P.a[2] = v * P.x0[2]; P.a[3] = v * P.x0[3];
+    fma4(P.a, __int_as_float(P.q0.w), P.x1);
+  } else {
+    fma4(P.a, __int_as_float(P.q1.y), P.x2);
+    fma4(P.a, __int_as_float(P.q1.w), P.x3);
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void graphconv_bwd_planes_kernel(
+    const int* __restrict__ slots_t, const int* __restrict__ gptr_t, const int2* __restrict__ cv_t,
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ g,
+    float* __restrict__ dx, float* __restrict__ part_dw, float* __restrict__ part_db, int T,
+    int max_nnz) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int N = FN, D = FD;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, hi = lane >> 5;
+  const int sub = lane >> 4, cl = lane & 15;
+  static_assert(BWD_WPB_ == BWD_FULL_WPB, "waves per workgroup");
+  unsigned char* sl = smem + (size_t)wave * 2 * DFWP_BYTES;
+  const unsigned pl0 = lds_off(sl);                               // dFW planes, buffer 0 (buffer 1: + DFWP_BYTES)
+  if (pl0 & 4095u) __builtin_trap();                              // XOR addressing needs 4 KiB aligned plane buffers
+  const unsigned wtab = lds_off(smem + PLANES_ALL) + (unsigned)lane * 16;
+  float* gt = reinterpret_cast<float*>(smem + PLANES_ALL + WTAB_BYTES +
+                                       (size_t)wave * bwd_planes_wave_bytes(max_nnz));   // [FN+1][FD], row FN stays zero
+  int2* ecv0 = reinterpret_cast<int2*>(gt + (FN + 1) * FD);
+  const size_t ecv_stride = ecv_bytes(max_nnz) / 8;
+  int* tab0 = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(ecv0) + 2 * ecv_bytes(max_nnz));
+
+  for (int i = lane; i < D; i += 64) gt[FN * FD + i] = 0.f;
+
+  // ---- lane constants of the plane addressing ---------------------------------------------------------------
+  // aggregation rows (lane (sub, cl): features 4cl .. 4cl+3 of the row): address = row word ^ this, per buffer
+  const unsigned h_e = (unsigned)cl >> 3;
+  const unsigned lanexor = (h_e << 8) | (h_e << 6) | ((((unsigned)cl & 7) >> 1) << 4) | (((unsigned)cl & 1) << 3);
+  // transpose reads: lane l addresses 4 features (16 nb + 4 a4 ..) of node 16 ks + 8 hi + 4 rd + jj
+  const unsigned nb = ((unsigned)lane >> 4) & 1, jj = ((unsigned)lane >> 2) & 3, a4 = (unsigned)lane & 3;
+  unsigned TRB[2][2];                                            // [feature half nt][read rd]
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd)
+      TRB[nt][rd] = pl0 + (((unsigned)hi << 10) | ((jj ^ (unsigned)nt) << 6) |
+                           (((2 * nb + (a4 >> 1)) ^ (2 * (unsigned)hi + (unsigned)rd)) << 4) | ((a4 & 1) << 3));
+  // row reads: lane (li, hi) addresses features 16 ks + 8 hi .. + 7 of node li
+  unsigned LB[4];
+  {
+    const unsigned R = (unsigned)li >> 2, a = (unsigned)li & 3;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      LB[ks] = pl0 + ((R << 9) | ((a ^ (unsigned)(ks >> 1)) << 6) |
+                      (((2 * (unsigned)(ks & 1) + (unsigned)hi) ^ (R & 3)) << 4));
+  }
+
+  // A fragments of dX^T = W dFW^T: lane (li, hi), tile nt, k-step ks holds W[32 nt + li][16 ks + 8 hi + j].  The p1 pieces
+  // (three products in six) are resident in 32 registers, p2 / p3 sit in a 16 KiB table shared by the workgroup and are
+  // read one k-step ahead in phase B (the only phase that uses W: 64 registers less in phase A, the register peak).
+  u32x4 WF1[2][4];
+  static_for<8>([&](auto c) __attribute__((always_inline)) {
+    constexpr int nt = decltype(c)::value >> 2, ks = decltype(c)::value & 3;
+    const float* src = w + (32 * nt + li) * D + 16 * ks + 8 * hi;
+    const f32x4 lo = ldv4(src), hi4 = ldv4(src + 4);
+    const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    Frag3 f;
+    split8(v, f);
+    WF1[nt][ks] = f.p1;
+    if (wave == (decltype(c)::value >> 1)) {
+      *(KGCN_LDS u32x4*)(uintptr_t)(wtab + (0 * 8 + nt * 4 + ks) * 1024) = f.p2;
+      *(KGCN_LDS u32x4*)(uintptr_t)(wtab + (1 * 8 + nt * 4 + ks) * 1024) = f.p3;
+    }
+  });
+  __syncthreads();
+
+  f32x16 dw00, dw01, dw10, dw11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dw00[r] = 0.f; dw01[r] = 0.f; dw10[r] = 0.f; dw11[r] = 0.f; }
+  f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
+
+  const int nwaves = gridDim.x * BWD_FULL_WPB;
+  const int t0 = __builtin_amdgcn_readfirstlane(blockIdx.x * BWD_FULL_WPB + wave);
+  if (t0 < T) {
+    const int cntw = (T - 1 - t0) / nwaves + 1;              // graphs of this wave
+    const int tl = t0 + (cntw - 1) * nwaves;                  // its last graph
+#ifdef KGCN_ABL_HOT
+    auto gidx = [&](int k) { const int t = t0 + (k & 1) * nwaves; return t < tl ? t : tl; };
+#else
+    auto gidx = [&](int k) { const int t = t0 + k * nwaves; return t < tl ? t : tl; };  // clamped
+#endif
+    const float* srcl = gt + cl * 4;
+    const int xlane = (8 * hi) * D + li;                      // lane share of the x fragment addresses
+
+    TileRegs gpf;
+    CsrRegs cpf;
+    MetaRegs m_a, m_b;   // m_a: graph whose g/CSR are in flight; m_b: the one after it
+    float xr[32];        // x tile in flight, A-fragment layout of dW: xr[(2 ks + mt) * 8 + j]
+    u32x4 XF[2][2][3];   // x(i) fragments [k-step][feature half mt][piece]
+    u32x4 BF0[2][3];     // dFW(i) fragments of k-step 0 [feature half nt][piece] (read one phase ahead)
+
+    auto issue_x = [&](int k) __attribute__((always_inline)) {
+      const float* xs = x + (long)gidx(k) * N * D + xlane;
+      static_for<32>([&](auto qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value, ks = q >> 4, mt = (q >> 3) & 1, j = q & 7;
+        xr[q] = xs[(16 * ks + j) * D + 32 * mt];
+      });
+    };
+    auto split_x = [&](auto qc) __attribute__((always_inline)) {   // pair q of 16: values 2q, 2q+1 of xr
+      constexpr int q = decltype(qc)::value, ks = q >> 3, mt = (q >> 2) & 1, J = q & 3;
+      unsigned q1, q2, q3;
+      split_pair(xr[2 * q], xr[2 * q + 1], q1, q2, q3);
+      XF[ks][mt][0][J] = q1; XF[ks][mt][1][J] = q2; XF[ks][mt][2][J] = q3;
+    };
+    auto read_bf = [&](u32x4 (&BF)[2][3], auto ksc, auto ntc, auto pcc, unsigned buf_off) __attribute__((always_inline)) {
+      constexpr int ks = decltype(ksc)::value, nt = decltype(ntc)::value, pc = decltype(pcc)::value;
+      const u32x2 r0 = lds_ld_tr16(TRB[nt][0] + buf_off + (ks << 11) + (nt << 8) + pc * PL_BYTES);
+      const u32x2 r1 = lds_ld_tr16(TRB[nt][1] + buf_off + (ks << 11) + (1 << 9) + (nt << 8) + pc * PL_BYTES);
+      BF[nt][pc][0] = r0[0]; BF[nt][pc][1] = r0[1]; BF[nt][pc][2] = r1[0]; BF[nt][pc][3] = r1[1];
+    };
+    // finished aggregation pass -> planes of buffer `eb` (lane constant ^ row word), dbias
+    auto emit_to = [&](unsigned lx, const PlaneSteps& q) __attribute__((always_inline)) {
+      unsigned q1, q2, q3, r1, r2, r3;
+      split_pair(q.a[0], q.a[1], q1, q2, q3);
+      split_pair(q.a[2], q.a[3], r1, r2, r3);
+      const unsigned ad = q.rw ^ lx;
+      lds_st64(ad, q1, r1);
+      lds_st64(ad + PL_BYTES, q2, r2);
+      lds_st64(ad + 2 * PL_BYTES, q3, r3);
+      add4(dbacc, q.a);
+    };
+
+    // ---- prologue: graph 0 aggregated without overlap; the pipeline state of iteration 0 -------
+    issue_meta(m_a, slots_t, gptr_t, gidx(0), N, lane);
+    int base_a = meta_base(m_a), cnt_a = meta_cnt(m_a);
+    issue_tile<true>(gpf, g + (long)gidx(0) * N * D, 512, lane);
+    issue_cv(cpf, cv_t, base_a, cnt_a, lane);
+    issue_x(0);
+    issue_meta(m_b, slots_t, gptr_t, gidx(1), N, lane);
+    land_tile<true>(gpf, gt, FD, 512, 16, lane);
+    land_csr(cpf, ecv0, tab0, cv_t, slot_plane_word(m_a.slot), base_a, cnt_a, N, lane);
+    wave_sync();
+    // g(1), CSR(1) in flight
+    m_a = m_b;
+    base_a = meta_base(m_a);
+    cnt_a = meta_cnt(m_a);
+    issue_tile<true>(gpf, g + (long)gidx(1) * N * D, 512, lane);
+    issue_cv(cpf, cv_t, base_a, cnt_a, lane);
+    issue_meta(m_b, slots_t, gptr_t, gidx(2), N, lane);
+    {
+      const unsigned lx0 = lanexor | pl0;
+#pragma unroll
+      for (int p8 = 0; p8 < 8; ++p8) {
+        PlaneSteps ps;
+        ps.slot(tab0, 4 * p8 + sub);
+        ps.q0 = *reinterpret_cast<const i32x4*>(ecv0 + ps.s);
+        ps.q1 = *reinterpret_cast<const i32x4*>(ecv0 + ps.s + 2);
+        ps.x0 = ldv4(srcl + ps.q0.x * FD); ps.x1 = ldv4(srcl + ps.q0.z * FD);
+        ps.x2 = ldv4(srcl + ps.q1.x * FD); ps.x3 = ldv4(srcl + ps.q1.z * FD);
+        const float v = __int_as_float(ps.q0.y);
+        ps.a[0] = v * ps.x0[0]; ps.a[1] = v * ps.x0[1]; ps.a[2] = v * ps.x0[2]; ps.a[3] = v * ps.x0[3];
+        fma4(ps.a, __int_as_float(ps.q0.w), ps.x1);
+        fma4(ps.a, __int_as_float(ps.q1.y), ps.x2);
+        fma4(ps.a, __int_as_float(ps.q1.w), ps.x3);
+        ps.tail(ecv0, srcl);
+        emit_to(lx0, ps);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    wave_sync();
+    // x(0) -> fragments, x(1) in flight; g(1), CSR(1) -> LDS (buffer 1); g(2), CSR(2) in flight
+    static_for<16>([&](auto qc) __attribute__((always_inline)) { split_x(qc); });
+    __builtin_amdgcn_sched_barrier(0);
+    issue_x(1);
+    land_tile<true>(gpf, gt, FD, 512, 16, lane);
+    land_csr(cpf, ecv0 + ecv_stride, tab0 + (FN + 4), cv_t, slot_plane_word(m_a.slot), base_a, cnt_a, N, lane);
+    m_a = m_b;
+    base_a = meta_base(m_a);
+    cnt_a = meta_cnt(m_a);
+    issue_tile<true>(gpf, g + (long)gidx(2) * N * D, 512, lane);
+    issue_cv(cpf, cv_t, base_a, cnt_a, lane);
+    issue_meta(m_b, slots_t, gptr_t, gidx(3), N, lane);
+    static_for<6>([&](auto c) __attribute__((always_inline)) {
+      constexpr int v = decltype(c)::value;
+      read_bf(BF0, std::integral_constant<int, 0>{}, std::integral_constant<int, v / 3>{},
+              std::integral_constant<int, v % 3>{}, 0u);
+    });
+    wave_sync();
+
+    f32x16 c0 = {}, c1 = {};   // dX(i)^T, produced in phase B(i), stored behind the first MFMAs of phase A(i+1)
+    int cur = 0;               // plane / CSR buffer of the MFMA graph i; the aggregated graph i+1 uses cur^1
+
+    // ---- phase A: dW(i) MFMAs  ||  aggregation of graph i+1 -> planes(cur^1)  ||  stores of dX(i-1) ----------
+    auto phase_a = [&](auto agg_tag, auto st_tag, int iprev) __attribute__((always_inline)) {
+      constexpr bool AGG = decltype(agg_tag)::value, ST = decltype(st_tag)::value;
+      float* dxp = dx + (long)gidx(iprev) * N * D + li * D + 4 * hi;
+      const unsigned cur_off = cur ? (unsigned)DFWP_BYTES : 0u;
+      const unsigned lx = lanexor | (pl0 + (cur ? 0u : (unsigned)DFWP_BYTES));
+      const int2* ecv_n = ecv0 + (cur ^ 1) * ecv_stride;
+      const int* tab_n = tab0 + (cur ^ 1) * (FN + 4);
+      PlaneSteps qa, qb;
+      auto emit = [&](const PlaneSteps& q) __attribute__((always_inline)) { emit_to(lx, q); };
+      auto agg_half = [&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value, gq = j >> 4, wq = j & 15;
+        if constexpr ((wq & 1) == 0) plane_half(qa, wq >> 1, gq > 0, tab_n, 8 * gq + sub, ecv_n, srcl, emit);
+        else plane_half(qb, wq >> 1, gq > 0, tab_n, 8 * gq + 4 + sub, ecv_n, srcl, emit);
+        if constexpr (wq == 14) qa.tail(ecv_n, srcl);
+        if constexpr (wq == 15) qb.tail(ecv_n, srcl);
+      };
+      u32x4 BF1[2][3];
+      static_for<2>([&](auto ksc) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ksc)::value;
+        static_for<24>([&](auto mc) __attribute__((always_inline)) {
+          constexpr int m = decltype(mc)::value, pr = m >> 2, tile = m & 3;
+          constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
+          const u32x4 av = XF[ks][tile >> 1][PA[pr]];
+          const u32x4 bv = ks == 0 ? BF0[tile & 1][PB[pr]] : BF1[tile & 1][PB[pr]];
+          if constexpr (tile == 0) dw00 = mfma_bf16(av, bv, dw00);
+          else if constexpr (tile == 1) dw01 = mfma_bf16(av, bv, dw01);
+          else if constexpr (tile == 2) dw10 = mfma_bf16(av, bv, dw10);
+          else dw11 = mfma_bf16(av, bv, dw11);
+          if constexpr (ks == 0 && m >= 6 && m < 12) {     // fragments of k-step 1, one (tile, piece) per MFMA
+            constexpr int v = m - 6;
+            read_bf(BF1, std::integral_constant<int, 1>{}, std::integral_constant<int, v / 3>{},
+                    std::integral_constant<int, v % 3>{}, cur_off);
+          }
+          if constexpr (ST && ks == 0 && m >= 12 && m < 20) {   // dX(i-1): one 16-byte store per MFMA
+            constexpr int v = m - 12, q = v & 3, nt = v >> 2;
+            const f32x16& c = nt ? c1 : c0;
+            const f32x4 val = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+            stv4(dxp + 32 * nt + 8 * q, val);
+          }
+          if constexpr (AGG) agg_half(std::integral_constant<int, 32 * ks + m>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (AGG) {
+          static_for<8>([&](auto rc) __attribute__((always_inline)) {
+            agg_half(std::integral_constant<int, 32 * ks + 24 + decltype(rc)::value>{});
+          });
+        }
+      });
+      if constexpr (AGG) {
+        emit(qa);
+        emit(qb);
+      }
+      wave_sync();
+    };
+
+    // ---- phase B: dX(i)^T MFMAs  ||  x(i+1) -> fragments, x(i+2) loads  ||  g(i+2), CSR(i+2) -> LDS, g(i+3), CSR(i+3)
+    //      loads  ||  fragments of dFW(i+1), k-step 0 ---------------------------------------------------------------
+    auto phase_b = [&](auto mv_tag, int i) __attribute__((always_inline)) {
+      constexpr bool MV = decltype(mv_tag)::value;
+      const unsigned cur_off = cur ? (unsigned)DFWP_BYTES : 0u;
+      const unsigned nxt_off = cur ? 0u : (unsigned)DFWP_BYTES;
+      int2* ecv_c = ecv0 + cur * ecv_stride;     // CSR(i) is dead: receives CSR(i+2)
+      int* tab_c = tab0 + cur * (FN + 4);
+      const float* xs = x + (long)gidx(i + 2) * N * D + xlane;
+      const float* gsrc = g + (long)gidx(i + 3) * N * D;
+      int base_n = 0, cnt_n = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+      u32x4 FA[4][3];     // dFW(i) fragments [k-step][piece]
+      u32x4 WL[4][2][2];  // W p2 / p3 fragments [k-step][piece - 1][tile]
+      auto read_fa = [&](auto ksc) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ksc)::value;
+        static_for<3>([&](auto pc) __attribute__((always_inline)) {
+          constexpr int p = decltype(pc)::value;
+          FA[ks][p] = lds_ld128(LB[ks] + cur_off + ((ks >> 1) << 8) + p * PL_BYTES);
+        });
+        static_for<4>([&](auto vc) __attribute__((always_inline)) {
+          constexpr int pc = decltype(vc)::value >> 1, nt = decltype(vc)::value & 1;
+          WL[ks][pc][nt] = lds_ld128(wtab + (pc * 8 + nt * 4 + ks) * 1024);
+        });
+      };
+      read_fa(std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<48>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value, ks = m / 12, pr = (m % 12) >> 1, nt = m & 1;
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+        const u32x4 wv = PB[pr] == 0 ? WF1[nt][ks] : WL[ks][PB[pr] - 1][nt];
+        if constexpr (nt == 0) c0 = mfma_bf16(wv, FA[ks][PA[pr]], c0);
+        else c1 = mfma_bf16(wv, FA[ks][PA[pr]], c1);
+        if constexpr (m % 12 == 1 && ks < 3) read_fa(std::integral_constant<int, ks + 1>{});   // one k-step ahead
+        if constexpr (MV && m < 16) split_x(std::integral_constant<int, m>{});      // x(i+1) -> fragments
+        if constexpr (MV && m >= 16 && m < 32) {                                     // x(i+2) in flight
+          constexpr int q0 = 2 * (m - 16);
+          static_for<2>([&](auto dc) __attribute__((always_inline)) {
+            constexpr int q = q0 + decltype(dc)::value, xks = q >> 4, mt = (q >> 3) & 1, j = q & 7;
+            xr[q] = xs[(16 * xks + j) * D + 32 * mt];
+          });
+        }
+        if constexpr (MV && m >= 32 && m < 40) {          // g(i+2) -> gather tile; g(i+3) in flight
+          constexpr int q = m - 32;
+          const int i4 = lane + q * 64;
+          stv4(gt + (long)i4 * 4, gpf.v[q]);
+          gpf.v[q] = ldv4(gsrc + (long)i4 * 4);
+        }
+        if constexpr (MV && m == 40)
+          land_csr(cpf, ecv_c, tab_c, cv_t, slot_plane_word(m_a.slot), base_a, cnt_a, N, lane);
+        if constexpr (MV && m == 41) {
+          base_n = meta_base(m_b);
+          cnt_n = meta_cnt(m_b);
+          issue_cv(cpf, cv_t, base_n, cnt_n, lane);
+        }
+        if constexpr (MV && m == 42) {
+          // a REAL register move (a plain `m_a = m_b` becomes a loop phi whose copy lands behind the new load of m_b:
+          // s_waitcnt vmcnt(~0) on every prefetch load of this phase at the top of the next iteration)
+          asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+                       : "=&v"(m_a.slot), "=&v"(m_a.gp) : "v"(m_b.slot), "v"(m_b.gp));
+          issue_meta(m_b, slots_t, gptr_t, gidx(i + 4), N, lane);
+        }
+        if constexpr (MV && m >= 42) {                    // dFW(i+1), k-step 0: fragments for phase A(i+1)
+          constexpr int v = m - 42;
+          read_bf(BF0, std::integral_constant<int, 0>{}, std::integral_constant<int, v / 3>{},
+                  std::integral_constant<int, v % 3>{}, nxt_off);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (MV) {
+        base_a = base_n;
+        cnt_a = cnt_n;
+      }
+      wave_sync();
+    };
+
+    // iterations: MFMA graph i, aggregated graph i+1, stores of dX(i-1)
+    using Y = std::true_type;
+    using Nn = std::false_type;
+    if (cntw > 1) {
+      phase_a(Y{}, Nn{}, 0);
+      phase_b(Y{}, 0);
+      cur ^= 1;
+      for (int i = 1; i < cntw - 1; ++i) {
+        phase_a(Y{}, Y{}, i - 1);
+        phase_b(Y{}, i);
+        cur ^= 1;
+      }
+      // last graph i = cntw-1: its dFW is ready, nothing left to aggregate or prefetch
+      phase_a(Nn{}, Y{}, cntw - 2);
+      phase_b(Nn{}, cntw - 1);
+    } else {
+      phase_a(Nn{}, Nn{}, 0);
+      phase_b(Nn{}, 0);
+    }
+    {                                           // dX of the last graph
+      float* dxp = dx + (long)tl * N * D + li * D + 4 * hi;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v0 = {c0[4 * q], c0[4 * q + 1], c0[4 * q + 2], c0[4 * q + 3]};
+        const f32x4 v1 = {c1[4 * q], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]};
+        stv4(dxp + 8 * q, v0);
+        stv4(dxp + 32 + 8 * q, v1);
+      }
+    }
+  }
+
+  // ---- reduce the workgroup's 4 waves through LDS; one partial per workgroup ---------------------
+  __syncthreads();
+  float* park = reinterpret_cast<float*>(sl);   // the plane buffers: 24,576 B >= (4096 + 64) floats
+  static_assert(2 * DFWP_BYTES >= (FD * FD + FD) * 4, "park area");
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    park[row * FD + li] = dw00[r];
+    park[row * FD + 32 + li] = dw01[r];
+    park[(32 + row) * FD + li] = dw10[r];
+    park[(32 + row) * FD + 32 + li] = dw11[r];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float v = dbacc[j];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    dbacc[j] = v;
+  }
+  if (lane < 16) stv4(park + FD * FD + lane * 4, dbacc);
+  __syncthreads();
+  const size_t slice_f = 2 * DFWP_BYTES / 4;
   const float* slice0 = reinterpret_cast<const float*>(smem);
   float* pw = part_dw + (long)blockIdx.x * D * D;
   for (int i = tid; i < D * D; i += blockDim.x) {
@@ -1435,10 +1974,15 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
     return fail("kgcn_graphconv_bwd_f32: tensors not 16-byte aligned");
   const int mode = vec ? 2 : (((at->rows * din) & 3) == 0 && ((at->rows * dout) & 3) == 0 && aligned16(x) &&
                               aligned16(dout_grad) && (!dx || aligned16(dx))) ? 1 : 0;
-  const bool full = dx != nullptr && is_full(at->rows, din, dout) &&
-                    BWD_FULL_WPB * bwd_full_slice_bytes(at->max_nnz_per_graph) <= (size_t)kLdsBytes;
+#ifndef KGCN_BWD_PLANES
+#define KGCN_BWD_PLANES 1
+#endif
+  const size_t full_lds = KGCN_BWD_PLANES ? bwd_planes_lds_bytes(at->max_nnz_per_graph)
+                                          : BWD_FULL_WPB * bwd_full_slice_bytes(at->max_nnz_per_graph);
+  const bool full = dx != nullptr && is_full(at->rows, din, dout) && full_lds <= (size_t)kLdsBytes &&
+                    at->max_nnz_per_graph < 4096;
   const int pack = (full || is_full(at->rows, din, dout)) ? 1 : pack_factor(at->rows, at->max_nnz_per_graph, FD * FD * 4);
-  const size_t per = full ? bwd_full_slice_bytes(at->max_nnz_per_graph) : bwd_slice(at->max_nnz_per_graph * pack);
+  const size_t per = full ? full_lds / BWD_FULL_WPB : bwd_slice(at->max_nnz_per_graph * pack);
   const int wpb = full ? BWD_FULL_WPB : fused_wpb(per, FD * FD * 4);
   const int blocks = fused_grid((at->num_graphs + pack - 1) / pack, wpb);
   const int64_t need = (int64_t)blocks * ((int64_t)din * dout + dout) * 4;
@@ -1447,17 +1991,22 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
                 (long long)need);
   float* part_dw = static_cast<float*>(workspace);
   float* part_db = part_dw + (long)blocks * din * dout;
-  const size_t lds = (full ? 0 : FD * FD * 4) + (size_t)wpb * per;
+  const size_t lds = full ? full_lds : FD * FD * 4 + (size_t)wpb * per;
   static thread_local bool attr_set = false;
   if (!attr_set) {
     allow_big_lds(graphconv_bwd_full_kernel);
+    allow_big_lds(graphconv_bwd_planes_kernel);
     allow_big_lds(graphconv_bwd_kernel<2>);
     allow_big_lds(graphconv_bwd_kernel<1>);
     allow_big_lds(graphconv_bwd_kernel<0>);
     attr_set = true;
   }
   const int2* cv = reinterpret_cast<const int2*>(at->cv);
-  if (full)
+  if (full && KGCN_BWD_PLANES)
+    hipLaunchKernelGGL(graphconv_bwd_planes_kernel, dim3(blocks), dim3(64 * wpb), lds, s, at->slots,
+                       at->graph_ptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
+                       at->max_nnz_per_graph);
+  else if (full)
     hipLaunchKernelGGL(graphconv_bwd_full_kernel, dim3(blocks), dim3(64 * wpb), lds, s, at->slots,
                        at->graph_ptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
                        at->max_nnz_per_graph);
