@@ -347,45 +347,6 @@ struct PassSteps {
   }
 };
 
-// Filler schedule of one graph's aggregation for the MFMA-interleaved kernels.  The matrix pipe
-// holds ONE MFMA: the next MFMA of the stream blocks the in-order wave until the pipe frees, so only
-// the instructions placed directly behind an MFMA run in its shadow (64 cycles, ~10 issue slots).
-// Hence one small "half step" behind EVERY MFMA, and LDS-dependent half steps of a pass at least two
-// MFMAs behind their producer.
-//   halves of a pass: 0 emit(previous pass)  1 slot  2 ecv0  3 ecv1  4 tile0  5 tile1  6 fma0  7 fma1
-// Dual schedule (backward, 64 MFMAs per phase): passes A (even) and B (odd) alternate MFMA by MFMA:
-//   j = 0..63: group gq = j>>4 handles slots 8gq+sub (A, even j) and 8gq+4+sub (B, odd j), half (j&15)>>1.
-template <typename Emit>
-__device__ __forceinline__ void pass_half(PassSteps& P, int h, bool do_emit, const int* tab, int j,
-                                          const int2* ecv, const float* srcl, Emit&& emit) {
-  if (h == 0) { if (do_emit) emit(P); }
-  else if (h == 1) P.slot(tab, j);
-  else if (h == 2) P.q0 = *reinterpret_cast<const i32x4*>(ecv + P.s);
-  else if (h == 3) P.q1 = *reinterpret_cast<const i32x4*>(ecv + P.s + 2);
-  else if (h == 4) { P.x0 = ldv4(srcl + P.q0.x * FD); P.x1 = ldv4(srcl + P.q0.z * FD); }
-  else if (h == 5) { P.x2 = ldv4(srcl + P.q1.x * FD); P.x3 = ldv4(srcl + P.q1.z * FD); }
-  else if (h == 6) {
-    const float v = __int_as_float(P.q0.y);
-    P.a[0] = v * P.x0[0]; P.a[1] = v * P.x0[1]; P.a[2] = v * P.x0[2]; P.a[3] = v * P.x0[3];
-    fma4(P.a, __int_as_float(P.q0.w), P.x1);
-  } else {
-    fma4(P.a, __int_as_float(P.q1.y), P.x2);
-    fma4(P.a, __int_as_float(P.q1.w), P.x3);
-  }
-}
-template <typename Emit>
-__device__ __forceinline__ void agg_dual_half(int j, PassSteps& A, PassSteps& B, const int* tab,
-                                              const int2* ecv, const float* srcl, int sub, Emit&& emit) {
-  const int gq = j >> 4, w = j & 15;
-  if ((w & 1) == 0) pass_half(A, w >> 1, gq > 0, tab, 8 * gq + sub, ecv, srcl, emit);
-  else pass_half(B, w >> 1, gq > 0, tab, 8 * gq + 4 + sub, ecv, srcl, emit);
-}
-__device__ __forceinline__ void agg_dual_tail(int j, PassSteps& A, PassSteps& B, const int2* ecv,
-                                              const float* srcl) {
-  if ((j & 15) == 14) A.tail(ecv, srcl);
-  if ((j & 15) == 15) B.tail(ecv, srcl);
-}
-
 // Sparse aggregation of one graph out of a gather tile (row stride FD) without MFMA overlap: lane
 // (sub, cl) produces the float4 [4cl, 4cl+4) of the rows of slots j = 4p + sub.
 // emit(row, cl, acc) receives every row exactly once.
@@ -945,399 +906,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_kernel(
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// backward, FULL shape: ONE wave per SIMD (4 waves per CU, up to 512 VGPRs and 36 KB LDS each), a
-// two-graph-deep software pipeline so that nothing the wave needs is ever in flight when it needs it.
-// Both contractions run on the bf16 matrix pipe (exact 3-way split, 6 products; 96 MFMAs of 32 cycles per
-// graph instead of 128 f32 MFMAs of 64 cycles on the VALU datapath), and because that pipe runs BESIDE
-// the vector ALU only when the instruction stream alternates, every MFMA carries a slice of the
-// phase's other work behind it:
-//   phase A: per k-step (16 nodes): 32 operand values read + split, then 24 MFMAs of dW(i) += x(i)^T
-//            dFW(i), each followed by one half step of the aggregation dFW(i+1) = A^T g(i+1) (two passes
-//            in flight, skewed, for LDS latency) and, for the first 16, two row stores of dX(i-1);
-//   phase B: 48 MFMAs of dX(i) = dFW(i) W^T -- A fragments split one k-step ahead, B fragments = the W
-//            pieces resident in 96 registers (no W^T in LDS) -- each followed by one slice of:
-//            x(i+1), g(i+2), CSR(i+2) registers -> LDS and the global loads of x(i+2), g(i+3), CSR(i+3)
-//            (a full iteration of flight time).
-// Measured on cfg2 (tools/phase_probe.py): 9,970 cycles per graph and wave (phase A 6,370, B 3,600) vs
-// 13,300 with f32 MFMAs; without the dX stores 7,100 -- the kernel now moves with the HBM write traffic.
-// LDS per wave: dFW[2] (odd stride), x tile, g tile (+ zero row), CSR[2].
-// ------------------------------------------------------------------------------------------------
 constexpr int BWD_FULL_WPB = 4;
-// how dX leaves the chip (see phase A): 0 = dword stores out of the C layout of dX = dFW W^T, 1 = 16-byte stores out
-// of the C layout of dX^T = W dFW^T (32-byte segments), 2 = that layout staged through LDS, whole rows as 1 KiB stores
-#ifndef KGCN_DX_STORE
-#define KGCN_DX_STORE 2
-#endif
-
-__host__ __device__ inline size_t bwd_full_slice_bytes(int max_nnz) {
-  return 2 * (((size_t)A_BWD * 4 + 15) & ~(size_t)15) + (size_t)FN * FD * 4 + (size_t)(FN + 1) * FD * 4 +
-         2 * (ecv_bytes(max_nnz) + RP_BYTES);
-}
-
-__global__ __launch_bounds__(256, 1) void graphconv_bwd_full_kernel(
-    const int* __restrict__ slots_t, const int* __restrict__ gptr_t, const int2* __restrict__ cv_t,
-    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ g,
-    float* __restrict__ dx, float* __restrict__ part_dw, float* __restrict__ part_db, int T,
-    int max_nnz) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int N = FN, D = FD;
-  constexpr size_t DFW_B = ((size_t)A_BWD * 4 + 15) & ~(size_t)15;
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 31, hi = lane >> 5;
-  const int sub = lane >> 4, cl = lane & 15;
-  unsigned char* sl = smem + (size_t)wave * bwd_full_slice_bytes(max_nnz);
-  float* dfw0 = reinterpret_cast<float*>(sl);
-  float* dfw1 = reinterpret_cast<float*>(sl + DFW_B);
-  float* xt = reinterpret_cast<float*>(sl + 2 * DFW_B);
-  float* gt = xt + FN * FD;                                   // [FN+1][FD], row FN stays zero
-  int2* ecv0 = reinterpret_cast<int2*>(gt + (FN + 1) * FD);
-  const size_t ecv_stride = ecv_bytes(max_nnz) / 8;
-  int* tab0 = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(ecv0) + 2 * ecv_bytes(max_nnz));
-
-  for (int i = lane; i < D; i += 64) gt[FN * FD + i] = 0.f;
-  // B fragments of dX = dFW W^T, resident for the whole kernel: lane (li, hi), tile nt, k-step ks holds
-  // W^T[k][32 nt + li] = W[32 nt + li][k] for k = 16 ks + 8 hi + j -- 8 contiguous floats of a W row --
-  // as three bf16 pieces
-  u32x4 WF[2][4][3];
-  static_for<8>([&](auto c) __attribute__((always_inline)) {
-    constexpr int nt = decltype(c)::value >> 2, ks = decltype(c)::value & 3;
-    const float* src = w + (32 * nt + li) * D + 16 * ks + 8 * hi;
-    const f32x4 lo = ldv4(src), hi4 = ldv4(src + 4);
-    const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-    Frag3 f;
-    split8(v, f);
-    WF[nt][ks][0] = f.p1; WF[nt][ks][1] = f.p2; WF[nt][ks][2] = f.p3;
-  });
-
-  f32x16 dw00, dw01, dw10, dw11;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { dw00[r] = 0.f; dw01[r] = 0.f; dw10[r] = 0.f; dw11[r] = 0.f; }
-  f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
-
-  const int nwaves = gridDim.x * BWD_FULL_WPB;
-  const int t0 = __builtin_amdgcn_readfirstlane(blockIdx.x * BWD_FULL_WPB + wave);
-  if (t0 < T) {
-    const int cntw = (T - 1 - t0) / nwaves + 1;              // graphs of this wave
-    const int tl = t0 + (cntw - 1) * nwaves;                  // its last graph
-#ifdef KGCN_ABL_HOT   // ablation: every wave keeps re-reading / re-writing its first two graphs (cache resident)
-    auto gidx = [&](int k) { const int t = t0 + (k & 1) * nwaves; return t < tl ? t : tl; };
-#else
-    auto gidx = [&](int k) { const int t = t0 + k * nwaves; return t < tl ? t : tl; };  // clamped
-#endif
-    const float* srcl = gt + cl * 4;
-
-    TileRegs gpf, xpf;
-    CsrRegs cpf;
-    MetaRegs m_a, m_b;   // m_a: graph whose g/CSR are in flight; m_b: the one after it
-    // ---- prologue: graph 0 aggregated without overlap; the pipeline state of iteration 0 -------
-    issue_meta(m_a, slots_t, gptr_t, gidx(0), N, lane);
-    int base_a = meta_base(m_a), cnt_a = meta_cnt(m_a);
-    issue_tile<true>(gpf, g + (long)gidx(0) * N * D, 512, lane);
-    issue_cv(cpf, cv_t, base_a, cnt_a, lane);
-    issue_tile<true>(xpf, x + (long)gidx(0) * N * D, 512, lane);
-    issue_meta(m_b, slots_t, gptr_t, gidx(1), N, lane);
-    land_tile<true>(gpf, gt, FD, 512, 16, lane);
-    land_csr(cpf, ecv0, tab0, cv_t, m_a.slot, base_a, cnt_a, N, lane);
-    wave_sync();
-    // g(1), CSR(1) in flight
-    m_a = m_b;
-    base_a = meta_base(m_a);
-    cnt_a = meta_cnt(m_a);
-    issue_tile<true>(gpf, g + (long)gidx(1) * N * D, 512, lane);
-    issue_cv(cpf, cv_t, base_a, cnt_a, lane);
-    issue_meta(m_b, slots_t, gptr_t, gidx(2), N, lane);
-    aggregate_rows<true>(ecv0, tab0, gt, N, D, lane, [&](int r, int c4, f32x4 acc) {
-      float* d = dfw0 + r * BLD + c4 * 4;
-      d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2]; d[3] = acc[3];
-      dbacc += acc;
-    });
-    wave_sync();
-    // x(0) -> xt, x(1) in flight; g(1), CSR(1) -> LDS (buffer 1); g(2), CSR(2) in flight
-    land_tile<true>(xpf, xt, FD, 512, 16, lane);
-    issue_tile<true>(xpf, x + (long)gidx(1) * N * D, 512, lane);
-    land_tile<true>(gpf, gt, FD, 512, 16, lane);
-    land_csr(cpf, ecv0 + ecv_stride, tab0 + (FN + 4), cv_t, m_a.slot, base_a, cnt_a, N, lane);
-    m_a = m_b;
-    base_a = meta_base(m_a);
-    cnt_a = meta_cnt(m_a);
-    issue_tile<true>(gpf, g + (long)gidx(2) * N * D, 512, lane);
-    issue_cv(cpf, cv_t, base_a, cnt_a, lane);
-    issue_meta(m_b, slots_t, gptr_t, gidx(3), N, lane);
-    wave_sync();
-
-    // dX accumulators: dX(i) is produced in phase B(i) and leaves the chip behind the first MFMAs of
-    // phase A(i+1) (32 row stores)
-    f32x16 c0 = {}, c1 = {};
-    int cur = 0;     // dFW / CSR buffer of the MFMA graph i; the aggregated graph i+1 uses cur^1
-
-    // ---- phase A: dW(i) MFMAs  ||  aggregation of graph i+1 (one half step per MFMA) -------------
-    auto phase_a = [&](auto agg_tag, auto st_tag, int iprev) __attribute__((always_inline)) {
-      constexpr bool AGG = decltype(agg_tag)::value, ST = decltype(st_tag)::value;
-      float* dxp = dx + (long)gidx(iprev) * N * D;
-      const float* dfc = cur ? dfw1 : dfw0;
-      float* dfn = cur ? dfw0 : dfw1;
-      const int2* ecv_n = ecv0 + (cur ^ 1) * ecv_stride;
-      const int* tab_n = tab0 + (cur ^ 1) * (FN + 4);
-      PassSteps qa, qb;
-      auto emit = [&](const PassSteps& q) {   // finished pass -> dFW(i+1) tile (odd stride), dbias
-        float* d = dfn + q.row * BLD + cl * 4;
-        d[0] = q.a[0]; d[1] = q.a[1]; d[2] = q.a[2]; d[3] = q.a[3];
-        add4(dbacc, q.a);
-      };
-      // 2 k-steps x [32 operand values read + split, then 24 bf16 MFMAs (6 split products x 4 accumulator
-      // tiles)].  The matrix pipe runs beside the vector ALU, but an in-order wave only overlaps them when
-      // the instruction stream alternates (tools/mfma_shadow_bf16.hip): ONE aggregation half step of graph
-      // i+1 sits behind every MFMA, so consecutive LDS-dependent halves of a pass are two MFMAs apart.
-      static_for<2>([&](auto ksc) __attribute__((always_inline)) {
-        constexpr int ks = decltype(ksc)::value;
-        u32x4 F[4][3];                           // [operand: x lo, x hi, dFW lo, dFW hi][piece]
-        static_for<16>([&](auto qc) __attribute__((always_inline)) {
-          constexpr int Q = decltype(qc)::value, OP = Q >> 2, J = Q & 3;
-          const int n = hi * 16 + 8 * ks + 2 * J;          // lane (li, hi): columns li / 32+li, 8 nodes
-          const float* src = (OP < 2 ? xt + n * FD : dfc + n * BLD) + (OP & 1) * 32 + li;
-          unsigned q1, q2, q3;
-          split_pair(src[0], src[OP < 2 ? FD : BLD], q1, q2, q3);
-          F[OP][0][J] = q1; F[OP][1][J] = q2; F[OP][2][J] = q3;
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<24>([&](auto mc) __attribute__((always_inline)) {
-          constexpr int m = decltype(mc)::value, pr = m >> 2, tile = m & 3;
-          constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
-          const u32x4 av = F[tile >> 1][PA[pr]], bv = F[2 + (tile & 1)][PB[pr]];
-          if constexpr (tile == 0) dw00 = mfma_bf16(av, bv, dw00);
-          else if constexpr (tile == 1) dw01 = mfma_bf16(av, bv, dw01);
-          else if constexpr (tile == 2) dw10 = mfma_bf16(av, bv, dw10);
-          else dw11 = mfma_bf16(av, bv, dw11);
-#ifndef KGCN_ABL_NO_ST
-#if KGCN_DX_STORE == 0
-          if constexpr (ST && ks == 0 && m < 16) {          // dX(i-1): two row stores per MFMA
-            const int row = (m & 3) + 8 * (m >> 2) + 4 * hi;
-            dxp[row * D + li] = c0[m];
-            dxp[row * D + 32 + li] = c1[m];
-          }
-#elif KGCN_DX_STORE == 1
-          // dX(i-1) in the C layout of dX^T = W dFW^T: lane (li, hi) holds row li, floats 8q + 4hi .. +3 of each
-          // 32-wide half: one 16-byte store behind every second MFMA (32-byte segments per row)
-          if constexpr (ST && ks == 0 && m < 16 && (m & 1) == 0) {
-            constexpr int q = (m >> 1) & 3, nt = m >> 3;
-            const f32x16& c = nt ? c1 : c0;
-            const f32x4 v = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
-            stv4(dxp + li * D + 32 * nt + 8 * q + 4 * hi, v);
-          }
-#else
-          // dX(i-1): C layout of dX^T = W dFW^T (lane = row li, 16-byte chunk ch = 8 nt + 2 q + hi) -> the dead
-          // dFW buffer `dfn` (the aggregation of graph i+1 starts writing it at MFMA 16), chunk position XORed
-          // with the row so that both the 8-lane write groups and the 16-lane read groups are conflict free
-          // -> whole rows as 1 KiB stores
-          if constexpr (ST && ks == 0 && m < 4) {
-            static_for<2>([&](auto hc) __attribute__((always_inline)) {
-              constexpr int cc = 2 * m + decltype(hc)::value, q = cc & 3, nt = cc >> 2;
-              const f32x16& c = nt ? c1 : c0;
-              const f32x4 v = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
-              stv4(dfn + li * FD + (((8 * nt + 2 * q + hi) ^ (li & 15)) << 2), v);
-            });
-          }
-          if constexpr (ST && ks == 0 && m >= 5 && m < 13) {
-            constexpr int q = m - 5;
-            const int i4 = lane + q * 64, r = i4 >> 4, ch = i4 & 15;
-            stv4(dxp + (long)i4 * 4, ldv4(dfn + r * FD + ((ch ^ (r & 15)) << 2)));
-          }
-#endif
-#endif
-#ifndef KGCN_ABL_NO_AGG
-          if constexpr (AGG) {
-            constexpr int j = 32 * ks + m;
-            agg_dual_half(j, qa, qb, tab_n, ecv_n, srcl, sub, emit);
-            agg_dual_tail(j, qa, qb, ecv_n, srcl);
-          }
-#endif
-          __builtin_amdgcn_sched_barrier(0);
-        });
-#ifndef KGCN_ABL_NO_AGG
-        if constexpr (AGG) {
-          static_for<8>([&](auto rc) __attribute__((always_inline)) {
-            constexpr int j = 32 * ks + 24 + decltype(rc)::value;
-            agg_dual_half(j, qa, qb, tab_n, ecv_n, srcl, sub, emit);
-            agg_dual_tail(j, qa, qb, ecv_n, srcl);
-          });
-        }
-#endif
-      });
-#ifndef KGCN_ABL_NO_AGG
-      if constexpr (AGG) {
-        emit(qa);
-        emit(qb);
-      }
-#endif
-      wave_sync();
-    };
-
-    // ---- phase B: dX(i) MFMAs into set `c`  ||  stores of dX(i-1) from set `p`  ||
-    //      x(i+1), g(i+2), CSR(i+2) -> LDS  ||  loads of x(i+2), g(i+3), CSR(i+3) --------------------
-    auto phase_b = [&](auto mv_tag, int i) __attribute__((always_inline)) {
-      constexpr bool MV = decltype(mv_tag)::value;
-      const float* dfc = cur ? dfw1 : dfw0;
-      int2* ecv_c = ecv0 + cur * ecv_stride;     // CSR(i) is dead: receives CSR(i+2)
-      int* tab_c = tab0 + cur * (FN + 4);
-      const float* xsrc = x + (long)gidx(i + 2) * N * D;
-      const float* gsrc = g + (long)gidx(i + 3) * N * D;
-      int base_n = 0, cnt_n = 0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
-      // dX(i) = dFW(i) W^T: A fragments = row li of dFW(i), k = 16 ks + 8 hi + j (split here, k-step ks+1
-      // behind the MFMAs of k-step ks); B fragments = the resident W pieces.  48 bf16 MFMAs, and behind
-      // each of them one slice of the phase's memory work:
-      //   MFMA 16..23: x(i+1) -> LDS, x(i+2) load            24..31: g(i+2) -> LDS, g(i+3) load
-      //   MFMA 32..34: CSR(i+2) -> LDS, CSR(i+3) / meta loads
-      u32x4 FA[4][3];
-      auto split_a = [&](auto ksc) __attribute__((always_inline)) {
-        constexpr int ks = decltype(ksc)::value;
-        const float* src = dfc + li * BLD + 16 * ks + 8 * hi;
-        static_for<4>([&](auto jc) __attribute__((always_inline)) {
-          constexpr int J = decltype(jc)::value;
-          unsigned q1, q2, q3;
-          split_pair(src[2 * J], src[2 * J + 1], q1, q2, q3);
-          FA[ks][0][J] = q1; FA[ks][1][J] = q2; FA[ks][2][J] = q3;
-        });
-      };
-      split_a(std::integral_constant<int, 0>{});
-      __builtin_amdgcn_sched_barrier(0);
-      static_for<48>([&](auto mc) __attribute__((always_inline)) {
-        constexpr int m = decltype(mc)::value, ks = m / 12, pr = (m % 12) >> 1, nt = m & 1;
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-#if KGCN_DX_STORE == 0
-        if constexpr (nt == 0) c0 = mfma_bf16(FA[ks][PA[pr]], WF[0][ks][PB[pr]], c0);
-        else c1 = mfma_bf16(FA[ks][PA[pr]], WF[1][ks][PB[pr]], c1);
-#else
-        // operands swapped: the accumulators hold dX^T = W dFW^T, i.e. lane (li, hi) owns 4 CONSECUTIVE floats of
-        // row li per register quad -- 16-byte pieces instead of single dwords
-        if constexpr (nt == 0) c0 = mfma_bf16(WF[0][ks][PB[pr]], FA[ks][PA[pr]], c0);
-        else c1 = mfma_bf16(WF[1][ks][PB[pr]], FA[ks][PA[pr]], c1);
-#endif
-#ifdef KGCN_ABL_NOSPLITB   // timing ablation (wrong results): phase B reuses the fragments of k-step 0
-        if constexpr (m % 12 == 0 && ks < 3) { FA[ks + 1][0] = FA[0][0]; FA[ks + 1][1] = FA[0][1]; FA[ks + 1][2] = FA[0][2]; }
-#else
-        if constexpr (m % 12 == 0 && ks < 3) split_a(std::integral_constant<int, ks + 1>{});
-#endif
-#ifndef KGCN_ABL_NO_MV
-        if constexpr (MV && m >= 16 && m < 24) {          // x(i+1): registers -> x tile; x(i+2) in flight
-          constexpr int q = m - 16;
-          const int i4 = lane + q * 64;
-          stv4(xt + (i4 >> 4) * FD + (i4 & 15) * 4, xpf.v[q]);
-          xpf.v[q] = ldv4(xsrc + (long)i4 * 4);
-        }
-        if constexpr (MV && m >= 24 && m < 32) {          // g(i+2) -> gather tile; g(i+3) in flight
-          constexpr int q = m - 24;
-          const int i4 = lane + q * 64;
-          stv4(gt + (i4 >> 4) * FD + (i4 & 15) * 4, gpf.v[q]);
-          gpf.v[q] = ldv4(gsrc + (long)i4 * 4);
-        }
-        if constexpr (MV && m == 32) land_csr(cpf, ecv_c, tab_c, cv_t, m_a.slot, base_a, cnt_a, N, lane);
-        if constexpr (MV && m == 33) {
-          base_n = meta_base(m_b);
-          cnt_n = meta_cnt(m_b);
-          issue_cv(cpf, cv_t, base_n, cnt_n, lane);
-        }
-        if constexpr (MV && m == 34) {
-          // a REAL register move, placed here: a plain `m_a = m_b` becomes a loop phi whose copy the
-          // compiler puts on the back edge, behind the new load of m_b -- i.e. s_waitcnt vmcnt(~0) on
-          // every prefetch load of this phase at the top of the next iteration
-          asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
-                       : "=&v"(m_a.slot), "=&v"(m_a.gp) : "v"(m_b.slot), "v"(m_b.gp));
-          issue_meta(m_b, slots_t, gptr_t, gidx(i + 4), N, lane);
-        }
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      if constexpr (MV) {
-        base_a = base_n;
-        cnt_a = cnt_n;
-      }
-      wave_sync();
-    };
-
-    // iterations: MFMA graph i, aggregated graph i+1, stores of dX(i-1)
-    using Y = std::true_type;
-    using Nn = std::false_type;
-    PROBE_DECL
-    if (cntw > 1) {
-      phase_a(Y{}, Nn{}, 0);
-      phase_b(Y{}, 0);
-      cur ^= 1;
-      PROBE(0)
-      for (int i = 1; i < cntw - 1; ++i) {
-        phase_a(Y{}, Y{}, i - 1);
-        PROBE(1)
-        phase_b(Y{}, i);
-        PROBE(2)
-        cur ^= 1;
-      }
-      // last graph i = cntw-1: its dFW is ready, nothing left to aggregate or prefetch
-      phase_a(Nn{}, Y{}, cntw - 2);
-      phase_b(Nn{}, cntw - 1);
-    } else {
-      phase_a(Nn{}, Nn{}, 0);
-      phase_b(Nn{}, 0);
-    }
-    PROBE_FLUSH(blockIdx.x * BWD_FULL_WPB + wave)
-    {                                           // dX of the last graph
-      float* dxp = dx + (long)tl * N * D;
-#if KGCN_DX_STORE == 0
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        dxp[row * D + li] = c0[r];
-        dxp[row * D + 32 + li] = c1[r];
-      }
-#else
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 v0 = {c0[4 * q], c0[4 * q + 1], c0[4 * q + 2], c0[4 * q + 3]};
-        const f32x4 v1 = {c1[4 * q], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]};
-        stv4(dxp + li * D + 8 * q + 4 * hi, v0);
-        stv4(dxp + li * D + 32 + 8 * q + 4 * hi, v1);
-      }
-#endif
-    }
-  }
-
-  // ---- reduce the workgroup's 4 waves through LDS; one partial per workgroup ---------------------
-  __syncthreads();
-  float* park = reinterpret_cast<float*>(sl);   // dFW[2] = 16,640 B >= (4096 + 64) floats
-  static_assert(2 * (((size_t)A_BWD * 4 + 15) & ~(size_t)15) >= (FD * FD + FD) * 4, "park area");
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-    park[row * FD + li] = dw00[r];
-    park[row * FD + 32 + li] = dw01[r];
-    park[(32 + row) * FD + li] = dw10[r];
-    park[(32 + row) * FD + 32 + li] = dw11[r];
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float v = dbacc[j];
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    dbacc[j] = v;
-  }
-  if (lane < 16) stv4(park + FD * FD + lane * 4, dbacc);
-  __syncthreads();
-  const size_t slice_f = bwd_full_slice_bytes(max_nnz) / 4;
-  const float* slice0 = reinterpret_cast<const float*>(smem);
-  float* pw = part_dw + (long)blockIdx.x * D * D;
-  for (int i = tid; i < D * D; i += blockDim.x) {
-    float s = 0.f;
-    for (int wv = 0; wv < BWD_FULL_WPB; ++wv) s += slice0[wv * slice_f + i];
-    pw[i] = s;
-  }
-  if (tid < D) {
-    float s = 0.f;
-    for (int wv = 0; wv < BWD_FULL_WPB; ++wv) s += slice0[wv * slice_f + D * D + tid];
-    part_db[(long)blockIdx.x * D + tid] = s;
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // backward, FULL shape, "planes" version: every fp32 -> 3 x bf16 split happens ONCE, at the producer.
@@ -1376,7 +945,14 @@ __host__ __device__ inline size_t bwd_planes_lds_bytes(int max_nnz) {
   return PLANES_ALL + WTAB_BYTES + BWD_WPB_ * bwd_planes_wave_bytes(max_nnz);
 }
 
+// Values that are only consumed a phase later (x fragments, the dbias sums): without a use at the place of their
+// definition, machine sinking moves the whole computation across the conditional blocks of the CSR landing into ONE clump
+// in front of the consumer (176 + 32 VALU ops behind a single MFMA, ~1,000 cycles per graph).  An empty volatile asm
+// with the values as in/out operands is such a use.
+#define KGCN_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+#define KGCN_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short i16x4 __attribute__((ext_vector_type(4)));
 #define KGCN_LDS __attribute__((address_space(3)))
 __device__ __forceinline__ unsigned lds_off(const void* p) {
@@ -1519,27 +1095,57 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_planes_kernel(
     auto gidx = [&](int k) { const int t = t0 + k * nwaves; return t < tl ? t : tl; };  // clamped
 #endif
     const float* srcl = gt + cl * 4;
-    const int xlane = (8 * hi) * D + li;                      // lane share of the x fragment addresses
+    const int xlane = (8 * hi) * D + 2 * li;                  // lane share of the x fragment addresses (floats)
 
     TileRegs gpf;
     CsrRegs cpf;
     MetaRegs m_a, m_b;   // m_a: graph whose g/CSR are in flight; m_b: the one after it
-    float xr[32];        // x tile in flight, A-fragment layout of dW: xr[(2 ks + mt) * 8 + j]
+    // x tile in flight in the A-fragment layout of dW.  Row li of M tile mt is feature 2 li + mt (the rows of dW come out
+    // interleaved; undone when the accumulators are parked), so a lane's two tiles are ADJACENT floats: one 8-byte
+    // load per node, xr[8 ks + j] = x[16 ks + 8 hi + j][2 li .. 2 li + 1] -- 16 loads, each two full 256-byte rows
+    f32x2 xr[16];
+    float sr0[16], ss0[16], sr1[16], sv0[16], sv1[16];   // split_pair of unit u = 2 (4 ks + J) + mt cut in two halves (one per MFMA slot)
     u32x4 XF[2][2][3];   // x(i) fragments [k-step][feature half mt][piece]
     u32x4 BF0[2][3];     // dFW(i) fragments of k-step 0 [feature half nt][piece] (read one phase ahead)
 
-    auto issue_x = [&](int k) __attribute__((always_inline)) {
-      const float* xs = x + (long)gidx(k) * N * D + xlane;
-      static_for<32>([&](auto qc) __attribute__((always_inline)) {
-        constexpr int q = decltype(qc)::value, ks = q >> 4, mt = (q >> 3) & 1, j = q & 7;
-        xr[q] = xs[(16 * ks + j) * D + 32 * mt];
-      });
+    // xb: this lane's pointer into the tile (tile base + xlane); the two 4 KiB halves get their own 64-bit lane pointer,
+    // everything else is an immediate (a 32-bit unsigned lane offset per load made the compiler hoist sixteen 64-bit
+    // indices out of the loop -- and spill them)
+    auto load_x = [&](const float* xb, auto qc) __attribute__((always_inline)) {
+      constexpr int q = decltype(qc)::value;
+      // two wave-uniform bases 4 KiB apart + one lane offset + an immediate (13-bit signed) per load: no address registers
+      xr[q] = *reinterpret_cast<const f32x2*>((q >> 3 ? xb + 16 * D : xb) + (q & 7) * D);
     };
-    auto split_x = [&](auto qc) __attribute__((always_inline)) {   // pair q of 16: values 2q, 2q+1 of xr
-      constexpr int q = decltype(qc)::value, ks = q >> 3, mt = (q >> 2) & 1, J = q & 3;
-      unsigned q1, q2, q3;
-      split_pair(xr[2 * q], xr[2 * q + 1], q1, q2, q3);
-      XF[ks][mt][0][J] = q1; XF[ks][mt][1][J] = q2; XF[ks][mt][2][J] = q3;
+    auto issue_x = [&](int k) __attribute__((always_inline)) {
+      const float* xb = x + (long)gidx(k) * N * D + xlane;
+      static_for<16>([&](auto qc) __attribute__((always_inline)) { load_x(xb, qc); });
+    };
+    // half hh of unit u: nodes (2J, 2J+1) of k-step ks, tile mt -> XF[ks][mt][.][J]
+    auto split_x_half = [&](auto uc, auto hc) __attribute__((always_inline)) {
+      constexpr int u = decltype(uc)::value, hh = decltype(hc)::value, P = u >> 1, mt = u & 1, ks = P >> 2, J = P & 3;
+      const unsigned msk = 0xffff0000u;
+      if constexpr (hh == 0) {
+        // The tile in flight is loop carried (loaded one iteration ahead) and must not compete for the 256 VALU-addressable
+        // registers: with it there the allocator split its live range -- new loads into fresh registers, copies on the
+        // back edge -- and the copies drew s_waitcnt vmcnt(10) right behind the loads (~1,000 cycles per graph).  The
+        // "a" operand keeps it in the accumulator file, which loads can target; one v_accvgpr_read per value moves it out.
+        float v0, v1;
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v0) : "a"(xr[8 * ks + 2 * J][mt]));
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v1) : "a"(xr[8 * ks + 2 * J + 1][mt]));
+        sv0[u] = v0; sv1[u] = v1;
+        const float h0 = __uint_as_float(__float_as_uint(v0) & msk), h1 = __uint_as_float(__float_as_uint(v1) & msk);
+        sr0[u] = v0 - h0;
+        sr1[u] = v1 - h1;
+        ss0[u] = sr0[u] - __uint_as_float(__float_as_uint(sr0[u]) & msk);
+        KGCN_PIN3(sr0[u], sr1[u], ss0[u]);
+      } else {
+        const float v0 = sv0[u], v1 = sv1[u];
+        const float s1 = sr1[u] - __uint_as_float(__float_as_uint(sr1[u]) & msk);
+        XF[ks][mt][0][J] = __builtin_amdgcn_perm(__float_as_uint(v1), __float_as_uint(v0), 0x07060302u);
+        XF[ks][mt][1][J] = __builtin_amdgcn_perm(__float_as_uint(sr1[u]), __float_as_uint(sr0[u]), 0x07060302u);
+        XF[ks][mt][2][J] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(ss0[u]), 0x07060302u);
+        KGCN_PIN3(XF[ks][mt][0][J], XF[ks][mt][1][J], XF[ks][mt][2][J]);
+      }
     };
     auto read_bf = [&](u32x4 (&BF)[2][3], auto ksc, auto ntc, auto pcc, unsigned buf_off) __attribute__((always_inline)) {
       constexpr int ks = decltype(ksc)::value, nt = decltype(ntc)::value, pc = decltype(pcc)::value;
@@ -1557,6 +1163,7 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_planes_kernel(
       lds_st64(ad + PL_BYTES, q2, r2);
       lds_st64(ad + 2 * PL_BYTES, q3, r3);
       add4(dbacc, q.a);
+      KGCN_PIN4(dbacc[0], dbacc[1], dbacc[2], dbacc[3]);
     };
 
     // ---- prologue: graph 0 aggregated without overlap; the pipeline state of iteration 0 -------
@@ -1598,7 +1205,10 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_planes_kernel(
     }
     wave_sync();
     // x(0) -> fragments, x(1) in flight; g(1), CSR(1) -> LDS (buffer 1); g(2), CSR(2) in flight
-    static_for<16>([&](auto qc) __attribute__((always_inline)) { split_x(qc); });
+    static_for<16>([&](auto uc) __attribute__((always_inline)) {
+      split_x_half(uc, std::integral_constant<int, 0>{});
+      split_x_half(uc, std::integral_constant<int, 1>{});
+    });
     __builtin_amdgcn_sched_barrier(0);
     issue_x(1);
     land_tile<true>(gpf, gt, FD, 512, 16, lane);
@@ -1617,8 +1227,22 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_planes_kernel(
     wave_sync();
 
     f32x16 c0 = {}, c1 = {};   // dX(i)^T, produced in phase B(i), stored behind the first MFMAs of phase A(i+1)
+    u32x4 FA[4][3];            // phase B: dFW(i) fragments [k-step][piece]
+    u32x4 WL[4][2][2];         // phase B: W p2 / p3 fragments [k-step][piece - 1][tile]
+    auto read_fa_at = [&](auto ksc, unsigned buf_off) __attribute__((always_inline)) {
+      constexpr int ks = decltype(ksc)::value;
+      static_for<3>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value;
+        FA[ks][p] = lds_ld128(LB[ks] + buf_off + ((ks >> 1) << 8) + p * PL_BYTES);
+      });
+      static_for<4>([&](auto vc) __attribute__((always_inline)) {
+        constexpr int pc = decltype(vc)::value >> 1, nt = decltype(vc)::value & 1;
+        WL[ks][pc][nt] = lds_ld128(wtab + (pc * 8 + nt * 4 + ks) * 1024);
+      });
+    };
     int cur = 0;               // plane / CSR buffer of the MFMA graph i; the aggregated graph i+1 uses cur^1
 
+    PROBE_DECL
     // ---- phase A: dW(i) MFMAs  ||  aggregation of graph i+1 -> planes(cur^1)  ||  stores of dX(i-1) ----------
     auto phase_a = [&](auto agg_tag, auto st_tag, int iprev) __attribute__((always_inline)) {
       constexpr bool AGG = decltype(agg_tag)::value, ST = decltype(st_tag)::value;
@@ -1641,20 +1265,24 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_planes_kernel(
         constexpr int ks = decltype(ksc)::value;
         static_for<24>([&](auto mc) __attribute__((always_inline)) {
           constexpr int m = decltype(mc)::value, pr = m >> 2, tile = m & 3;
-          constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
-          const u32x4 av = XF[ks][tile >> 1][PA[pr]];
-          const u32x4 bv = ks == 0 ? BF0[tile & 1][PB[pr]] : BF1[tile & 1][PB[pr]];
+          // smallest terms first; k-step 1 takes the dFW pieces in the order p3, p2, p1 so that its fragments can be read
+          // into the registers the pieces of k-step 0 leave (p3 after product 2, p2 after product 4)
+          constexpr int PA0[6] = {2, 1, 0, 1, 0, 0}, PB0[6] = {0, 1, 2, 0, 1, 0};
+          constexpr int PA1[6] = {0, 1, 2, 0, 1, 0}, PB1[6] = {2, 1, 0, 1, 0, 0};
+          constexpr int pa = ks == 0 ? PA0[pr] : PA1[pr], pb = ks == 0 ? PB0[pr] : PB1[pr];
+          const u32x4 av = XF[ks][tile >> 1][pa];
+          const u32x4 bv = ks == 0 ? BF0[tile & 1][pb] : BF1[tile & 1][pb];
           if constexpr (tile == 0) dw00 = mfma_bf16(av, bv, dw00);
           else if constexpr (tile == 1) dw01 = mfma_bf16(av, bv, dw01);
           else if constexpr (tile == 2) dw10 = mfma_bf16(av, bv, dw10);
           else dw11 = mfma_bf16(av, bv, dw11);
-          if constexpr (ks == 0 && m >= 6 && m < 12) {     // fragments of k-step 1, one (tile, piece) per MFMA
-            constexpr int v = m - 6;
-            read_bf(BF1, std::integral_constant<int, 1>{}, std::integral_constant<int, v / 3>{},
-                    std::integral_constant<int, v % 3>{}, cur_off);
+          if constexpr (ks == 0 && (m == 12 || m == 13 || m == 20 || m == 21 || m == 22 || m == 23)) {
+            constexpr int pc = m < 14 ? 2 : m < 22 ? 1 : 0;   // fragments of k-step 1: p3, p2, p1 (one tile per MFMA)
+            read_bf(BF1, std::integral_constant<int, 1>{}, std::integral_constant<int, (m & 1)>{},
+                    std::integral_constant<int, pc>{}, cur_off);
           }
-          if constexpr (ST && ks == 0 && m >= 12 && m < 20) {   // dX(i-1): one 16-byte store per MFMA
-            constexpr int v = m - 12, q = v & 3, nt = v >> 2;
+          if constexpr (ST && ks == 0 && m >= 2 && m < 10) {   // dX(i-1): one 16-byte store per MFMA
+            constexpr int v = m - 2, q = v & 3, nt = v >> 2;
             const f32x16& c = nt ? c1 : c0;
             const f32x4 val = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
             stv4(dxp + 32 * nt + 8 * q, val);
@@ -1662,12 +1290,19 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_planes_kernel(
           if constexpr (AGG) agg_half(std::integral_constant<int, 32 * ks + m>{});
           __builtin_amdgcn_sched_barrier(0);
         });
+#ifndef KGCN_PROBE_TAIL
+        if constexpr (ks == 0) { PROBE(6) }
+#endif
         if constexpr (AGG) {
           static_for<8>([&](auto rc) __attribute__((always_inline)) {
             agg_half(std::integral_constant<int, 32 * ks + 24 + decltype(rc)::value>{});
           });
         }
+#ifndef KGCN_PROBE_TAIL
+        if constexpr (ks == 0) { PROBE(7) }
+#endif
       });
+      read_fa_at(std::integral_constant<int, 0>{}, cur_off);   // phase B(i), k-step 0: in flight behind the last emits
       if constexpr (AGG) {
         emit(qa);
         emit(qb);
@@ -1683,26 +1318,12 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_planes_kernel(
       const unsigned nxt_off = cur ? 0u : (unsigned)DFWP_BYTES;
       int2* ecv_c = ecv0 + cur * ecv_stride;     // CSR(i) is dead: receives CSR(i+2)
       int* tab_c = tab0 + cur * (FN + 4);
-      const float* xs = x + (long)gidx(i + 2) * N * D + xlane;
-      const float* gsrc = g + (long)gidx(i + 3) * N * D;
+      const float* xb = x + (long)gidx(i + 2) * N * D + xlane;
+      const float* gsrc = g + (long)gidx(i + 3) * N * D + 4 * lane;
       int base_n = 0, cnt_n = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
-      u32x4 FA[4][3];     // dFW(i) fragments [k-step][piece]
-      u32x4 WL[4][2][2];  // W p2 / p3 fragments [k-step][piece - 1][tile]
-      auto read_fa = [&](auto ksc) __attribute__((always_inline)) {
-        constexpr int ks = decltype(ksc)::value;
-        static_for<3>([&](auto pc) __attribute__((always_inline)) {
-          constexpr int p = decltype(pc)::value;
-          FA[ks][p] = lds_ld128(LB[ks] + cur_off + ((ks >> 1) << 8) + p * PL_BYTES);
-        });
-        static_for<4>([&](auto vc) __attribute__((always_inline)) {
-          constexpr int pc = decltype(vc)::value >> 1, nt = decltype(vc)::value & 1;
-          WL[ks][pc][nt] = lds_ld128(wtab + (pc * 8 + nt * 4 + ks) * 1024);
-        });
-      };
-      read_fa(std::integral_constant<int, 0>{});
-      __builtin_amdgcn_sched_barrier(0);
+      auto read_fa = [&](auto ksc) __attribute__((always_inline)) { read_fa_at(ksc, cur_off); };
       static_for<48>([&](auto mc) __attribute__((always_inline)) {
         constexpr int m = decltype(mc)::value, ks = m / 12, pr = (m % 12) >> 1, nt = m & 1;
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
@@ -1710,34 +1331,45 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_planes_kernel(
         if constexpr (nt == 0) c0 = mfma_bf16(wv, FA[ks][PA[pr]], c0);
         else c1 = mfma_bf16(wv, FA[ks][PA[pr]], c1);
         if constexpr (m % 12 == 1 && ks < 3) read_fa(std::integral_constant<int, ks + 1>{});   // one k-step ahead
-        if constexpr (MV && m < 16) split_x(std::integral_constant<int, m>{});      // x(i+1) -> fragments
-        if constexpr (MV && m >= 16 && m < 32) {                                     // x(i+2) in flight
-          constexpr int q0 = 2 * (m - 16);
-          static_for<2>([&](auto dc) __attribute__((always_inline)) {
-            constexpr int q = q0 + decltype(dc)::value, xks = q >> 4, mt = (q >> 3) & 1, j = q & 7;
-            xr[q] = xs[(16 * xks + j) * D + 32 * mt];
-          });
+        // x(i+1) -> fragments: one half split_pair per MFMA (a whole one is 11 VALU ops: more than the 32 cycles of an
+        // MFMA cover); the two 8-byte registers of a node pair are reloaded with x(i+2) as soon as both tiles are split
+        if constexpr (MV && m < 32)
+          split_x_half(std::integral_constant<int, (m >> 1)>{}, std::integral_constant<int, (m & 1)>{});
+        if constexpr (MV && m >= 4 && m < 36 && ((m & 3) < 2)) {
+          constexpr int P = (m >> 2) - 1, ks_ = P >> 2, J = P & 3;
+          load_x(xb, std::integral_constant<int, 8 * ks_ + 2 * J + (m & 3)>{});
         }
-        if constexpr (MV && m >= 32 && m < 40) {          // g(i+2) -> gather tile; g(i+3) in flight
-          constexpr int q = m - 32;
-          const int i4 = lane + q * 64;
-          stv4(gt + (long)i4 * 4, gpf.v[q]);
-          gpf.v[q] = ldv4(gsrc + (long)i4 * 4);
+        if constexpr (MV && m >= 36 && m < 44) {          // g(i+2) -> gather tile; g(i+3) in flight
+          constexpr int q = m - 36;
+          stv4(gt + 4 * lane + q * 256, gpf.v[q]);
+          gpf.v[q] = ldv4((q >> 2 ? gsrc + 1024 : gsrc) + (q & 3) * 256);
         }
-        if constexpr (MV && m == 40)
+        if constexpr (MV && m == 44)
           land_csr(cpf, ecv_c, tab_c, cv_t, slot_plane_word(m_a.slot), base_a, cnt_a, N, lane);
-        if constexpr (MV && m == 41) {
+        if constexpr (MV && m == 45) {
           base_n = meta_base(m_b);
           cnt_n = meta_cnt(m_b);
           issue_cv(cpf, cv_t, base_n, cnt_n, lane);
         }
-        if constexpr (MV && m == 42) {
+        if constexpr (MV && m == 46) {
           // a REAL register move (a plain `m_a = m_b` becomes a loop phi whose copy lands behind the new load of m_b:
           // s_waitcnt vmcnt(~0) on every prefetch load of this phase at the top of the next iteration)
           asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
                        : "=&v"(m_a.slot), "=&v"(m_a.gp) : "v"(m_b.slot), "v"(m_b.gp));
           issue_meta(m_b, slots_t, gptr_t, gidx(i + 4), N, lane);
         }
+#ifdef KGCN_PROBE_TAIL
+        if constexpr (m == 35) { PROBE(1) }
+        if constexpr (m == 39) { PROBE(2) }
+        if constexpr (m == 43) { PROBE(3) }
+        if constexpr (m == 44) { PROBE(4) }
+        if constexpr (m == 45) { PROBE(6) }
+        if constexpr (m == 46) { PROBE(7) }
+#else
+        if constexpr (m == 11) { PROBE(2) }
+        if constexpr (m == 23) { PROBE(3) }
+        if constexpr (m == 35) { PROBE(4) }
+#endif
         if constexpr (MV && m >= 42) {                    // dFW(i+1), k-step 0: fragments for phase A(i+1)
           constexpr int v = m - 42;
           read_bf(BF0, std::integral_constant<int, 0>{}, std::integral_constant<int, v / 3>{},
@@ -1759,9 +1391,21 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_planes_kernel(
       phase_a(Y{}, Nn{}, 0);
       phase_b(Y{}, 0);
       cur ^= 1;
+      PROBE(0)
+      // The peeled first iteration needs more registers than the loop, so the loop's fragment registers come back from
+      // scratch in the preheader.  A reload that is still pending at the loop header makes the compiler put its wait THERE,
+      // where the back edge shares it -- as vmcnt(0): it drained the prefetch of every iteration.  A use in front of the
+      // loop moves the wait out of it.
+      asm volatile("" : "+v"(XF[0][0][0]), "+v"(XF[0][0][1]), "+v"(XF[0][0][2]), "+v"(XF[0][1][0]), "+v"(XF[0][1][1]),
+                        "+v"(XF[0][1][2]), "+v"(XF[1][0][0]), "+v"(XF[1][0][1]), "+v"(XF[1][0][2]), "+v"(XF[1][1][0]),
+                        "+v"(XF[1][1][1]), "+v"(XF[1][1][2]));
+      asm volatile("" : "+v"(BF0[0][0]), "+v"(BF0[0][1]), "+v"(BF0[0][2]), "+v"(BF0[1][0]), "+v"(BF0[1][1]),
+                        "+v"(BF0[1][2]), "+v"(FA[0][0]), "+v"(FA[0][1]), "+v"(FA[0][2]));
       for (int i = 1; i < cntw - 1; ++i) {
         phase_a(Y{}, Y{}, i - 1);
+        PROBE(1)
         phase_b(Y{}, i);
+        PROBE(5)
         cur ^= 1;
       }
       // last graph i = cntw-1: its dFW is ready, nothing left to aggregate or prefetch
@@ -1771,6 +1415,7 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_planes_kernel(
       phase_a(Nn{}, Nn{}, 0);
       phase_b(Nn{}, 0);
     }
+    PROBE_FLUSH(blockIdx.x * BWD_FULL_WPB + wave)
     {                                           // dX of the last graph
       float* dxp = dx + (long)tl * N * D + li * D + 4 * hi;
 #pragma unroll
@@ -1790,10 +1435,10 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_planes_kernel(
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-    park[row * FD + li] = dw00[r];
-    park[row * FD + 32 + li] = dw01[r];
-    park[(32 + row) * FD + li] = dw10[r];
-    park[(32 + row) * FD + 32 + li] = dw11[r];
+    park[(2 * row) * FD + li] = dw00[r];            // row `row` of M tile mt is input feature 2 row + mt
+    park[(2 * row) * FD + 32 + li] = dw01[r];
+    park[(2 * row + 1) * FD + li] = dw10[r];
+    park[(2 * row + 1) * FD + 32 + li] = dw11[r];
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -1974,11 +1619,7 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
     return fail("kgcn_graphconv_bwd_f32: tensors not 16-byte aligned");
   const int mode = vec ? 2 : (((at->rows * din) & 3) == 0 && ((at->rows * dout) & 3) == 0 && aligned16(x) &&
                               aligned16(dout_grad) && (!dx || aligned16(dx))) ? 1 : 0;
-#ifndef KGCN_BWD_PLANES
-#define KGCN_BWD_PLANES 1
-#endif
-  const size_t full_lds = KGCN_BWD_PLANES ? bwd_planes_lds_bytes(at->max_nnz_per_graph)
-                                          : BWD_FULL_WPB * bwd_full_slice_bytes(at->max_nnz_per_graph);
+  const size_t full_lds = bwd_planes_lds_bytes(at->max_nnz_per_graph);
   const bool full = dx != nullptr && is_full(at->rows, din, dout) && full_lds <= (size_t)kLdsBytes &&
                     at->max_nnz_per_graph < 4096;
   const int pack = (full || is_full(at->rows, din, dout)) ? 1 : pack_factor(at->rows, at->max_nnz_per_graph, FD * FD * 4);
@@ -1994,7 +1635,6 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
   const size_t lds = full ? full_lds : FD * FD * 4 + (size_t)wpb * per;
   static thread_local bool attr_set = false;
   if (!attr_set) {
-    allow_big_lds(graphconv_bwd_full_kernel);
     allow_big_lds(graphconv_bwd_planes_kernel);
     allow_big_lds(graphconv_bwd_kernel<2>);
     allow_big_lds(graphconv_bwd_kernel<1>);
@@ -2002,12 +1642,8 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
     attr_set = true;
   }
   const int2* cv = reinterpret_cast<const int2*>(at->cv);
-  if (full && KGCN_BWD_PLANES)
+  if (full)
     hipLaunchKernelGGL(graphconv_bwd_planes_kernel, dim3(blocks), dim3(64 * wpb), lds, s, at->slots,
-                       at->graph_ptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
-                       at->max_nnz_per_graph);
-  else if (full)
-    hipLaunchKernelGGL(graphconv_bwd_full_kernel, dim3(blocks), dim3(64 * wpb), lds, s, at->slots,
                        at->graph_ptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
                        at->max_nnz_per_graph);
   else if (mode == 2)

@@ -13,9 +13,12 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 out = os.path.join(ROOT, "gpurun_out", "libkgcn_probe.so")
-src = [os.path.join(ROOT, "kgcn_amd", "csrc", f) for f in ("misc.hip", "spmm.hip", "dense.hip", "fused.hip", "pack.hip")]
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                       "-DKGCN_PROBE", "-fno-slp-vectorize", "-o", out] + [a for a in sys.argv[1:] if a.startswith("-D")] + src)
+src = [os.path.join(ROOT, "kgcn_amd", "csrc", f) for f in ("misc.hip", "spmm.hip", "dense.hip", "gemm3.hip", "fused.hip", "pack.hip", "gat.hip")]
+if os.environ.get("KGCN_PROBE_LIB"):      # prebuilt (tools/variants.sh build probe "-DKGCN_PROBE")
+    out = os.environ["KGCN_PROBE_LIB"]
+else:
+  subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                         "-DKGCN_PROBE", "-fno-slp-vectorize", "-o", out] + [a for a in sys.argv[1:] if a.startswith("-D")] + src)
 sys.argv = [a for a in sys.argv if not a.startswith("-D")]
 import kgcn_amd._lib as L
 L.LIB_PATH = out
@@ -44,7 +47,8 @@ p = lambda t: ctypes.c_void_p(t.data_ptr())
 names_f = ["loop-top", "land x + issue x(next)", "aggregate(t-1) + store", "land CSR + issue + split + mfma(t)", "FW->LDS"]
 names_g = ["loop top", "land g + CSR", "aggregate -> dFW", "land x + issue prefetch", "dW (split + bf16 mfma)", "dX mfma",
            "dX -> LDS -> HBM"]
-names_b = ["prologue+iter0", "phase A: dW mfma || aggregate(i+1) || dX(i-1) stores", "phase B: dX mfma || land/issue next tiles"]
+names_b = ["prologue+iter0", "A: k-step 1 MFMAs + trailing halves + emits", "B: MFMA 0-11", "B: MFMA 12-23", "B: MFMA 24-35",
+           "B: MFMA 36-47", "A: k-step 0, 24 MFMA slots", "A: k-step 0 trailing halves"]
 for which in ("fwd", "bwd"):
     for rep in range(3):
         probe.zero_()
