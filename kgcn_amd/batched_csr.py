@@ -58,6 +58,8 @@ class BatchedCSR:
         self._make_t = None             # thunks set by gather(): build A^T / the padded copy on demand
         self._make_p4 = None
         self._graph_counts = None       # host int64 [T]: stored entries per graph
+        self._tperm = None              # cache of transpose_perm()
+        self._refillable = False        # static_like(): contents change under the same object
         self.slots = None               # row_pad == 4: int32 [T*M] slot table (see include/kgcn_hip.h)
         self.graph_ptr = None           # row_pad == 4: int32 [T+1]
 
@@ -140,8 +142,15 @@ class BatchedCSR:
             self._t._t = self
         if self._t is None:
             if self._struct_src is not None:
-                bt = self._struct_src.transpose()          # pattern of A^T (cached there)
-                vt = self._vals if bt.perm is None else self._vals[bt.perm]
+                src = self._struct_src
+                bt = src.transpose()                       # pattern of A^T (cached there)
+                # the values must follow the entries into A^T order.  A host-built A^T knows that order (bt.perm,
+                # None = unchanged); a gathered / static container does not (its A^T is a segmented copy of the
+                # dataset's A^T): there the permutation is computed on the device from the pattern itself
+                if src._host is not None:
+                    vt = self._vals if bt.perm is None else self._vals[bt.perm]
+                else:
+                    vt = self._vals[src.transpose_perm()]
                 t = bt.with_values(vt)
             else:
                 g, r, c, v = self._host
@@ -150,6 +159,25 @@ class BatchedCSR:
             t._t = self
             self._t = t
         return self._t
+
+    def transpose_perm(self):
+        """Device int64 [nnz]: position in the CSR of A^T -> position in this CSR, for the entry order transpose()
+        produces (entries of a transposed row in ascending original row, ties in original order).  Computed from the
+        device arrays (a stable sort of the keys (graph, col, row)); cached unless the container is a refillable one."""
+        import torch
+        if self._tperm is not None and not self._refillable:
+            return self._tperm
+        if self.row_pad:
+            raise NotImplementedError("transpose_perm() is defined on the plain layout")
+        nnz, M, K = self.nnz, self.rows, self.cols
+        dev = self.rowptr.device
+        e = torch.arange(nnz, device=dev, dtype=torch.int64)
+        grow = torch.searchsorted(self.rowptr[1:].long(), e, right=True)          # global row t*M + r of every entry
+        key = (torch.div(grow, M, rounding_mode="floor") * K + self.cv[:, 0].long()) * M + grow % M
+        perm = torch.argsort(key, stable=True)
+        if not self._refillable:
+            self._tperm = perm
+        return perm
 
     def padded4(self):
         """Row-padded copy for the fused GraphConv kernels (kgcn_csr_batch.row_pad = 4): every row
@@ -239,6 +267,12 @@ class BatchedCSR:
             T = int(sel_dev.shape[0])
             if (out.num_graphs, out.rows, out.cols, out.row_pad) != (T, self.rows, self.cols, self.row_pad):
                 raise ValueError("static container does not match the batch shape")
+            worst = max(self.max_nnz, 4 * self.rows if self.row_pad else 0)
+            if out.nnz < T * worst or not hasattr(out, "_gptr_buf"):
+                raise ValueError("refill target must come from static_like(this container, %d): it holds %d entries, "
+                                 "the worst case is %d" % (T, out.nnz, T * worst))
+            if sel_dev.dtype != torch.int32 or not sel_dev.is_cuda:
+                raise ValueError("sel_dev must be a device int32 tensor (indices validated by the caller)")
             wsb = _lib.lib.kgcn_csr_gather_workspace_bytes(T)
             _lib.check(_lib.lib.kgcn_csr_gather_graphs(
                 self.desc(), sel_dev.data_ptr(), T, out.rowptr.data_ptr(), out.cv.data_ptr() if out.nnz else 0, out.nnz,
@@ -302,6 +336,7 @@ class BatchedCSR:
         i32 = dict(device=dev, dtype=torch.int32)
         out = cls(torch.zeros(T * M + 1, **i32), torch.zeros((T * worst, 2), **i32), T, M, src.cols, worst,
                   row_pad=src.row_pad)
+        out._refillable = True
         out._gptr_buf = torch.zeros(T + 1, **i32)
         out._ws = torch.empty(max(_lib.lib.kgcn_csr_gather_workspace_bytes(T), 4) // 4, **i32)
         if src.row_pad:

@@ -11,6 +11,7 @@ import torch
 
 from . import ops
 from .batched_csr import BatchedAdjacency
+from .bspmm_call import _diff_values
 
 
 class BatchedConv:
@@ -28,7 +29,14 @@ class BatchedConv:
         rhs = torch.stack(rows)
         K, CD = rhs.shape[1], rhs.shape[2]
         D = CD // C
-        adj = sp_matrices if isinstance(sp_matrices, BatchedAdjacency) else \
-            BatchedAdjacency.from_adjs(sp_matrices, device=rhs.device)
-        out = ops.bconv(adj, rhs.reshape(B * K, CD).contiguous(), D)
+        values = None
+        if isinstance(sp_matrices, BatchedAdjacency):
+            adj = sp_matrices
+        else:
+            adj = BatchedAdjacency.from_adjs(sp_matrices, device=rhs.device)
+            # differentiable .values (kgcn/bconv_call.py:55-67 registers d values for every graph-channel)
+            per_ch = [_diff_values([sp_matrices[b][ch] for b in range(B)], adj.channels[ch]) for ch in range(C)]
+            if any(v is not None for v in per_ch):
+                values = per_ch
+        out = ops.bconv(adj, rhs.reshape(B * K, CD).contiguous(), D, values)
         return list(out.reshape(B, adj.n_nodes, D).unbind(0))

@@ -92,32 +92,60 @@ def bspmm(csr, rhs, values=None):
 # -------------------------------------------------------------------------------------------------
 class _BConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rhs, adj, d):
+    def forward(ctx, rhs, adj, d, *values):
+        # values: nothing, or one tensor per channel -- the channel's adjacency values as differentiable inputs
+        # (fp32 [nnz_c], CSR order), None for a channel whose stored values are used
         rhs = _f32c(rhs, "rhs")
         C = adj.num_channels
         T, M, K = adj.num_graphs, adj.n_nodes, adj.channels[0].cols
         if rhs.shape != (T * K, C * d):
             raise _lib.KgcnHipError("rhs must be [T*K, C*D] = [%d, %d], got %s" % (T * K, C * d, tuple(rhs.shape)))
+        if values:
+            if len(values) != C:
+                raise _lib.KgcnHipError("one value tensor (or None) per adjacency channel is required")
+            adj = BatchedAdjacency([ch if v is None else ch.with_values(_f32c(v, "values"))
+                                    for ch, v in zip(adj.channels, values)])
         out = torch.empty((T * M, d), device=rhs.device, dtype=torch.float32)
         check(lib.kgcn_bconv_f32(adj.desc_array(False), C, ptr(rhs), C * d, K * C * d, d, d,
                                  ptr(out), d, M * d, current_stream()), "kgcn_bconv_f32")
         ctx.adj, ctx.d = adj, d
+        ctx.nvalues = len(values)
+        ctx.save_for_backward(rhs)
         return out
 
     @staticmethod
     def backward(ctx, g):
         adj, d = ctx.adj, ctx.d
+        (rhs,) = ctx.saved_tensors
         g = _f32c(g, "grad")
         C = adj.num_channels
         T, M, K = adj.num_graphs, adj.n_nodes, adj.channels[0].cols
-        d_rhs = torch.empty((T * K, C * d), device=g.device, dtype=torch.float32)
-        for c, ch in enumerate(adj.channels):        # addn_grad: g fans out to every channel
-            bspmm_raw(ch.transpose(), g, d, d_rhs, out_ld=C * d, out_gs=K * C * d, out_col=c * d)
-        return d_rhs, None, None
+        d_rhs = None
+        if ctx.needs_input_grad[0]:
+            d_rhs = torch.empty((T * K, C * d), device=g.device, dtype=torch.float32)
+            for c, ch in enumerate(adj.channels):        # addn_grad: g fans out to every channel
+                bspmm_raw(ch.transpose(), g, d, d_rhs, out_ld=C * d, out_gs=K * C * d, out_col=c * d)
+        d_vals = []
+        for c in range(ctx.nvalues):
+            # kgcn/bconv_call.py:55-67: d values[t][e] = <addn_grad[t][row_e], b[t][col_e]> per graph-channel -- one
+            # gather-multiply-reduce launch per channel over the whole batch, the channel's columns of rhs as b
+            if not ctx.needs_input_grad[3 + c]:
+                d_vals.append(None)
+                continue
+            ch = adj.channels[c]
+            dv = torch.empty((ch.nnz,), device=g.device, dtype=torch.float32)
+            check(lib.kgcn_spmm_values_grad_f32(ch.desc(), ptr(g), d, M * d, rhs.data_ptr() + 4 * c * d, C * d,
+                                                K * C * d, d, ptr(dv), current_stream()),
+                  "kgcn_spmm_values_grad_f32(bconv)")
+            d_vals.append(dv)
+        return (d_rhs, None, None) + tuple(d_vals)
 
 
-def bconv(adj, rhs_cat, d):
-    return _BConv.apply(rhs_cat, adj, d)
+def bconv(adj, rhs_cat, d, values=None):
+    """values: optional list with one differentiable fp32 [nnz_c] tensor (CSR order) or None per channel."""
+    if values is None:
+        return _BConv.apply(rhs_cat, adj, d)
+    return _BConv.apply(rhs_cat, adj, d, *values)
 
 
 # -------------------------------------------------------------------------------------------------

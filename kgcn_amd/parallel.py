@@ -5,8 +5,10 @@ torch.distributed (backend "nccl" is RCCL on ROCm; "gloo" in the CPU tests).  Th
 multi-device path at all; this is the build's addition.
 
 The payload is latency-bound (tens of microseconds), so everything goes in ONE flat fp32 bucket
-and one collective; the mean over ranks matches the reference's reduce_mean over the (global)
-padded batch when shards are equal-sized (quirk Q5).
+and one collective.  The reference's loss is reduce_mean over the PADDED batch (quirk Q5,
+example_model/model.py:58-61): rank r's local mean over its B_r padded graphs enters the global mean
+with weight B_r / sum(B) -- `shard_weight` -- so unequal shards (shard_range hands out sizes that
+differ by one) still reproduce the single-process gradients; equal shards reduce to the plain mean.
 """
 import torch
 import torch.distributed as dist
@@ -19,11 +21,22 @@ def shard_range(num_graphs, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_weight(local_graphs, global_graphs):
+    """Weight of this rank's LOCAL-mean gradients in the global mean over the padded batch (Q5)."""
+    if global_graphs <= 0:
+        raise ValueError("global batch is empty")
+    return float(local_graphs) / float(global_graphs)
+
+
 class GradBucket:
     """One flat fp32 gradient bucket for a fixed parameter list."""
 
     def __init__(self, params):
         self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("GradBucket: empty parameter list -- the layers create their parameters on the first "
+                             "forward pass (Keras build semantics, kgcn/layers.py:48-62); run one forward or call "
+                             "layer.build(input_shape) before collecting model.parameters()")
         self.sizes = [p.numel() for p in self.params]
         self.total = sum(self.sizes)
         self._flat = None
@@ -40,10 +53,13 @@ class GradBucket:
             off += n
         return out
 
-    def all_reduce_mean(self, group=None):
-        """flat <- concat(grads); all_reduce (mean over ranks); scatter back into .grad (in place).
-        Four launches per step whatever the number of parameters: one multi-tensor pack, the collective,
-        one scale, one multi-tensor unpack -- the payload is latency-bound, so launches are what it costs."""
+    def all_reduce_mean(self, group=None, weight=None):
+        """flat <- concat(grads); all_reduce; scatter back into .grad (in place).  weight=None: plain mean over the
+        ranks (equal shards).  weight=w_r (shard_weight: local padded graphs / global padded graphs): sum_r w_r g_r,
+        the gradient of the reference's reduce_mean over the global padded batch for shards of any size.
+        Four launches per step whatever the number of parameters: one multi-tensor pack, one scale, the collective,
+        one multi-tensor unpack -- the payload is latency-bound, so launches are what it costs.  Capturable: inside
+        a hipGraph capture the collective is recorded on the capturing stream like any kernel."""
         grads = [p.grad for p in self.params]
         if any(g is None for g in grads):
             raise RuntimeError("GradBucket: a parameter has no gradient")
@@ -52,7 +68,9 @@ class GradBucket:
         torch._foreach_copy_(views, grads)
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         if world > 1:
+            flat.mul_(1.0 / world if weight is None else float(weight))
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-            flat.div_(world)
+        elif weight is not None and float(weight) != 1.0:
+            raise ValueError("a single rank owns the whole batch: its weight must be 1")
         torch._foreach_copy_(grads, views)
         return flat

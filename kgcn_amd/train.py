@@ -11,6 +11,9 @@ class TFAdam:
 
     def __init__(self, params, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, capturable=False):
         self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("TFAdam: empty parameter list -- the layers create their parameters on the first forward "
+                             "pass (Keras build semantics); run one forward before collecting model.parameters()")
         self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
         self.t = 0
         self.m = [torch.zeros_like(p) for p in self.params]
@@ -49,15 +52,17 @@ class TFAdam:
             torch._foreach_add_(self.params, upd, alpha=-lr_t)
 
 
-def train_step(model, optimizer, loss_fn, features, adjs, labels, mask, bucket=None, **fwd_kwargs):
+def train_step(model, optimizer, loss_fn, features, adjs, labels, mask, bucket=None, shard_weight=None,
+               **fwd_kwargs):
     """sess.run([train_step, cost_sum]) of one mini-batch; `bucket` (kgcn_amd.parallel.GradBucket)
-    averages the gradients over data-parallel ranks before the update."""
+    combines the gradients of the data-parallel ranks before the update (shard_weight: this rank's share
+    of the global padded batch, kgcn_amd.parallel.shard_weight; None = equal shards)."""
     optimizer.zero_grad()
     logits = model(features, adjs, **fwd_kwargs)
     cost_opt, cost_sum = loss_fn(logits, labels, mask)
     cost_opt.backward()
     if bucket is not None:
-        bucket.all_reduce_mean()
+        bucket.all_reduce_mean(weight=shard_weight)
     optimizer.step()
     return float(cost_sum.detach()), logits.detach()
 
@@ -74,9 +79,13 @@ class GraphedTrainStep:
 
     model(features, adjacency, **fwd_kwargs) -> logits;  loss_fn(logits, labels, mask) -> (cost_opt, cost_sum)."""
 
-    def __init__(self, model, optimizer, loss_fn, static_batch, labels, mask, warmup=3, **fwd_kwargs):
+    def __init__(self, model, optimizer, loss_fn, static_batch, labels, mask, warmup=3, bucket=None,
+                 shard_weight=None, **fwd_kwargs):
+        """bucket / shard_weight: data parallel -- the ONE all-reduce of the flat gradient bucket (RCCL) is captured
+        in the graph between backward and the Adam update, so a replay is still a single host call per step."""
         if not optimizer.capturable:
             raise ValueError("GraphedTrainStep needs TFAdam(capturable=True)")
+        self.bucket, self.shard_weight = bucket, shard_weight
         self.model, self.opt, self.loss_fn, self.sb = model, optimizer, loss_fn, static_batch
         self.labels, self.mask, self.kw = labels, mask, fwd_kwargs
         self.cost_sum = self.logits = None
@@ -106,6 +115,8 @@ class GraphedTrainStep:
         logits = self.model(self.sb.features, self.sb.adjacency, **self.kw)
         cost_opt, cost_sum = self.loss_fn(logits, self.labels, self.mask)
         cost_opt.backward()
+        if self.bucket is not None:
+            self.bucket.all_reduce_mean(weight=self.shard_weight)
         self.opt.step()
         self.cost_sum, self.logits = cost_sum.detach(), logits.detach()
 

@@ -179,6 +179,47 @@ def test_op_wrappers_api():
         close(r[b].grad, rg[b], what="d rhs[%d]" % b)
 
 
+def test_bconv_and_bspmdt_values_gradients():
+    """kgcn/bconv_call.py:55-67 and kgcn/batched_call.py:66-73 register a gradient for the sparse VALUES of every
+    graph-channel (gather rows of the output gradient, gather rows of the dense operand, multiply, reduce): through
+    BatchedConv().call / BatchedSpMDT().call with differentiable .values, against the oracle's restatement.
+    (The reference's Bspmdt version indexes ROWS of the stacked operand where it means per-graph blocks -- b[i] for
+    i < numTensors, batched_call.py:58 -- and would not broadcast; the mathematically meant gradient is taken.)"""
+    from kgcn_amd.bconv_call import BatchedConv
+    from kgcn_amd.batched_call import BatchedSpMDT
+    import collections
+    STV = collections.namedtuple("SparseTensorValue", ["indices", "values", "dense_shape"])
+    x, adjs = synthetic_batch("b30", "split")               # 6 channels, 10 real + 20 dummy graphs
+    rng = np.random.default_rng(21)
+    B, C, D = 30, 6, 12
+    dense = [[rng.standard_normal((10, D)).astype(np.float32) for _ in range(C)] for _ in range(B)]
+    g = rng.standard_normal((B, 10, D)).astype(np.float32)
+    vals = [[t32(adjs[b][c][1]).requires_grad_(c != 4) for c in range(C)] for b in range(B)]   # channel 4: constants
+    sp = [[STV(adjs[b][c][0], vals[b][c], adjs[b][c][2]) for c in range(C)] for b in range(B)]
+    td = [[t32(d).requires_grad_(True) for d in row] for row in dense]
+    out = BatchedConv().call(sp, td)
+    close(torch.stack(out), np.stack(K.bconv(adjs, dense)), what="bconv fwd")
+    (torch.stack(out) * t32(g)).sum().backward()
+    vg, rg = K.bconv_grad(adjs, dense, list(g))
+    for b in range(B):
+        for c in range(C):
+            close(td[b][c].grad, rg[b][c], what="bconv d rhs[%d][%d]" % (b, c))
+            if c == 4:
+                assert vals[b][c].grad is None
+            else:
+                close(vals[b][c].grad, vg[b][c], what="bconv d values[%d][%d]" % (b, c))
+    # Bspmdt: one stacked dense operand, list of outputs
+    stacked = np.concatenate([dense[b][3] for b in range(B)], 0)
+    v3 = [t32(adjs[b][3][1]).requires_grad_(True) for b in range(B)]
+    ts = t32(stacked).requires_grad_(True)
+    o = BatchedSpMDT().call([STV(adjs[b][3][0], v3[b], adjs[b][3][2]) for b in range(B)], ts)
+    (torch.stack(o) * t32(g)).sum().backward()
+    vg3, rg3 = K.bspmdt_grad([adjs[b][3] for b in range(B)], stacked, list(g))
+    close(ts.grad, rg3, what="bspmdt d rhs")
+    for b in range(B):
+        close(v3[b].grad, vg3[b], what="bspmdt d values[%d]" % b)
+
+
 # ---------------------------------------------------------------------------------------------
 # dense contraction (GraphDense)
 # ---------------------------------------------------------------------------------------------
@@ -314,6 +355,101 @@ def test_graphconv_fused(N, din, dout, T):
     close(out2, ref, rel=1e-6, what="unfused fwd")
 
 
+def _row_close(got, ref, rel, what):
+    """every row within rel * (largest magnitude of that reference row): inputs spanning 60 decades make one global
+    maximum meaningless"""
+    got = got.detach().cpu().numpy().astype(np.float64)
+    ref = np.asarray(ref, np.float64)
+    scale = np.abs(ref).max(axis=-1, keepdims=True)
+    bad = np.abs(got - ref) > rel * scale + 1e-37
+    assert not bad.any(), "%s: %d elements beyond %.1e of their row maximum (worst %.3e)" % (
+        what, int(bad.sum()), rel, float((np.abs(got - ref) / (scale + 1e-300)).max()))
+
+
+@pytest.mark.parametrize("case", ["exponents", "full_significands", "denormals"])
+def test_bf16_split_edge_values(case):
+    """The fused FULL-shape kernels contract on the bf16 matrix pipe with an exact 3-way split of every fp32 operand
+    (kgcn_common.h split_pair) and claim fp32 accuracy.  Stress the claim where a split could lose bits: per-row
+    exponents from 1e-18 to 1e18 (dW multiplies them by gradients of 1e-9 .. 1e9: 1e27 stays finite), operands with all 24 significand bits set (every piece saturated, every cross
+    product non-zero), and fp32 denormals (their low pieces are bf16 denormals).  Reference: fp64 oracle; second HIP
+    implementation: the unfused f32-MFMA dense kernel + Bspmm (kgcn_dense_fwd_f32, exact fp32 products)."""
+    from kgcn_amd import BatchedCSR, ops
+    rng = np.random.default_rng({"exponents": 1, "full_significands": 2, "denormals": 3}[case])
+    T, N, D = 130, 32, 64
+    adjs = K.synth_mol_graphs(rng, T, N, 3, normalize=True)
+    x = rng.standard_normal((T, N, D)).astype(np.float32)
+    g = rng.standard_normal((T, N, D)).astype(np.float32)
+    w = K.glorot_uniform(rng, D, D)
+    if case == "exponents":
+        # one scale per node row of x (all inside one graph) and per graph of g (dW sums products of both); within a row all 64 values share the scale, so every output row has a well defined size
+        x *= (10.0 ** rng.uniform(-18, 18, size=(T, N, 1))).astype(np.float32)
+        g *= (10.0 ** rng.uniform(-9, 9, size=(T, 1, 1))).astype(np.float32)
+    elif case == "full_significands":
+        ones = lambda a: (a.view(np.uint32) | np.uint32(0x007fffff)).view(np.float32)
+        x, g, w = ones(x), ones(g), ones(w)
+    else:
+        tiny = np.float32(2.0 ** -140)                         # fp32 denormals (the smallest normal is 2^-126)
+        x[:, ::2, :] = (x[:, ::2, :] * tiny).astype(np.float32)
+        assert (np.abs(x[:, ::2, :]) < 2.0 ** -126).all() and (x[:, ::2, :] != 0).any()
+    b = np.zeros((1, D), np.float32)
+    csr = BatchedCSR.from_coo_list([a[0] for a in adjs], rows=N, cols=N, device=dev())
+    tx, tw, tb = t32(x).requires_grad_(True), t32(w).requires_grad_(True), t32(b).requires_grad_(True)
+    out = ops.graphconv_fused(tx, tw, tb, csr)
+    out.backward(t32(g))
+    ref = K.graphconv_fwd_fast(x, adjs, [w], [b])
+    dx, dw, db = K.graphconv_bwd_fast(x, adjs, [w], g)
+    assert np.isfinite(ref).all() and np.isfinite(dx).all() and np.isfinite(dw[0]).all()
+    _row_close(out, ref, 2e-6, case + ": fused fwd")
+    _row_close(tx.grad, dx, 2e-6, case + ": fused dX")
+    if case != "exponents":          # dW / dbias mix rows of every scale: only meaningful against their own maximum
+        close(tw.grad, dw[0], atol=0, rel=2e-6, what=case + ": fused dW")
+        close(tb.grad, db[0], atol=0, rel=2e-6, what=case + ": fused dbias")
+    else:
+        _row_close(tw.grad, dw[0], 1e-5, case + ": fused dW")
+    ux = t32(x).requires_grad_(True)
+    out_u = ops.bspmm(csr, ops.dense(ux.reshape(T * N, D), t32(w), t32(b))).reshape(T, N, D)
+    _row_close(out_u, ref, 2e-6, case + ": unfused fwd")
+    # the two HIP implementations agree to a few fp32 roundings of the row maximum
+    _row_close(out, out_u.detach().cpu().numpy(), 3e-6, case + ": fused vs unfused")
+
+
+def test_bf16_split_non_finite_inputs():
+    """Documented behaviour (include/kgcn_hip.h): the split of +-inf is (inf, nan, nan), so a non-finite
+    input value makes every output element that depends on it NaN or +-inf (the f32 kernels and TF give +-inf or NaN
+    there), and leaves every other element untouched -- never a silently finite wrong value."""
+    from kgcn_amd import BatchedCSR, ops
+    rng = np.random.default_rng(11)
+    T, N, D = 66, 32, 64
+    adjs = K.synth_mol_graphs(rng, T, N, 3)
+    x = rng.standard_normal((T, N, D)).astype(np.float32)
+    w = K.glorot_uniform(rng, D, D)
+    b = np.zeros((1, D), np.float32)
+    g = rng.standard_normal((T, N, D)).astype(np.float32)
+    bad = [(5, 7, 3, np.inf), (5, 9, 60, -np.inf), (40, 0, 0, np.nan)]
+    xb = x.copy()
+    for t, n, k, v in bad:
+        xb[t, n, k] = v
+    csr = BatchedCSR.from_coo_list([a[0] for a in adjs], rows=N, cols=N, device=dev())
+    tx, tw, tb = t32(xb).requires_grad_(True), t32(w).requires_grad_(True), t32(b).requires_grad_(True)
+    out = ops.graphconv_fused(tx, tw, tb, csr)
+    out.backward(t32(g))
+    ref = K.graphconv_fwd_fast(x, adjs, [w], [b])                  # clean reference
+    touched = np.zeros((T, N), bool)                               # output rows that aggregate a poisoned node
+    for t, n, _, _ in bad:
+        idx = np.asarray(adjs[t][0][0]).reshape(-1, 2)
+        touched[t, idx[idx[:, 1] == n, 0]] = True
+    o = out.detach().cpu().numpy()
+    assert not np.isfinite(o[touched]).any(), "an output row that aggregates a non-finite node must be non-finite"
+    np.testing.assert_allclose(o[~touched], ref[~touched], rtol=0, atol=1e-5)
+    # backward: dX = (A^T g) W^T does not depend on x at all; dW = sum x^T dFW is non-finite in the poisoned rows of x
+    dx, _, _ = K.graphconv_bwd_fast(x, adjs, [w], g)
+    np.testing.assert_allclose(tx.grad.cpu().numpy(), dx, rtol=0, atol=1e-5)
+    dwn = tw.grad.cpu().numpy()
+    rows = sorted({k for _, _, k, _ in bad})
+    assert not np.isfinite(dwn[rows]).any()
+    assert np.isfinite(np.delete(dwn, rows, axis=0)).all()
+
+
 def test_graphconv_layer_uses_fused_and_matches():
     from kgcn_amd import layers
     rng = np.random.default_rng(3)
@@ -377,8 +513,22 @@ def test_graph_gather_and_ragged_dense():
     x = rng.standard_normal((6, 10, 8)).astype(np.float32)
     en = np.array([10, 3, 0, 7, 1, 10])
     d = layers.GraphDense(5)
-    y = d(t32(x), enabled_node_nums=en)
-    close(y, K.graphdense_ragged_fwd(x, d.kernel.detach().cpu().numpy(), d.bias.detach().cpu().numpy(), en))
+    tx = t32(x).requires_grad_(True)
+    y = d(tx, enabled_node_nums=en)
+    with torch.no_grad():
+        d.bias.copy_(t32(rng.standard_normal(5)))
+    y = d(tx, enabled_node_nums=en)
+    kern, bias = d.kernel.detach().cpu().numpy(), d.bias.detach().cpu().numpy()
+    close(y, K.graphdense_ragged_fwd(x, kern, bias, en))
+    # backward of the ragged path (kgcn/layers.py:243-254: Dense over the valid rows only, zero padding after the
+    # split): gradients flow through the valid rows only -- the oracle's dense backward on the masked output gradient
+    gy = rng.standard_normal(y.shape).astype(np.float32)
+    y.backward(t32(gy))
+    mask = (np.arange(10)[None, :] < en[:, None])[:, :, None]
+    dx, dk, db = K.graphdense_bwd(x, kern, gy * mask)
+    close(tx.grad, dx, what="ragged GraphDense dX")
+    close(d.kernel.grad, dk, rel=1e-6, what="ragged GraphDense dkernel")
+    close(d.bias.grad, db, rel=1e-6, what="ragged GraphDense dbias")
 
 
 @pytest.mark.parametrize("channels,D", [("plain", 3), ("split", 50), ("norm", 64)])
@@ -464,7 +614,35 @@ def test_cfg2_full_size_properties():
     sw = float(wu.grad.abs().max())
     assert float((wg.grad - wu.grad).abs().max()) <= 2e-5 * sw
     assert float((bg.grad - bu.grad).abs().max()) <= 2e-5 * float(bu.grad.abs().max())
-    # a random sample of graphs against the oracle
+    # the WHOLE batch against the C restatement (oracle/kgcn_ref.c, fp32, OpenMP over graphs; about a second): out and dX
+    # element-wise, dW / dbias -- sums over 3.2 M rows, where the cross-wave / cross-workgroup accumulation of the fused
+    # backward could go wrong -- relative to their largest element (absolute 1e-5 is not meaningful for
+    # sums over 1e5 graphs)
+    from oracle import ref_c
+    xh, gh, wh, bh = (t.detach().cpu().numpy() for t in (x, g, w, b))
+    ro = ref_c.graphconv_fwd(wl["off"], wl["idx"], wl["val"], xh, wh, bh)
+    rdx, rdw, rdb = ref_c.graphconv_bwd(wl["off"], wl["idx"], wl["val"], xh, wh, gh)
+    close(out_f, ro, rel=2e-6, what="cfg2 full batch fwd vs C oracle")
+    close(xg.grad, rdx, rel=2e-6, what="cfg2 full batch dX vs C oracle")
+    # the C oracle itself accumulates dW in fp32 over 100k graphs (per-thread partials): compare both with an fp64
+    # reduction of the oracle's per-graph products on a 4,096-graph prefix, and with each other on the whole batch
+    close(wg.grad, rdw.reshape(64, 64), rel=2e-5, what="cfg2 full batch dW vs C oracle")
+    close(bg.grad.reshape(-1), rdb.reshape(-1), rel=2e-5, what="cfg2 full batch dbias vs C oracle")
+    Tp = 4096
+    offp = wl["off"][:Tp + 1]
+    nz = int(offp[-1])
+    adjs_p = wl["adjs_of"](range(Tp))
+    _, dw64, db64 = K.graphconv_bwd_fast(xh[:Tp], adjs_p, [wh], gh[:Tp])
+    xq = x[:Tp].clone().requires_grad_(True)
+    wq, bq = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    from kgcn_amd import BatchedCSR
+    gi = np.repeat(np.arange(Tp), np.diff(offp))
+    csr_p = BatchedCSR.from_arrays(gi, wl["idx"][:nz, 0].astype(np.int64), wl["idx"][:nz, 1].astype(np.int64),
+                                   wl["val"][:nz], Tp, 32, 32, device=dev())
+    ops.graphconv_fused(xq, wq, bq, csr_p).backward(g[:Tp])
+    close(wq.grad, dw64[0], rel=2e-6, what="cfg2 4096-graph dW vs fp64 oracle")
+    close(bq.grad.reshape(-1), db64[0].reshape(-1), rel=2e-6, what="cfg2 4096-graph dbias vs fp64 oracle")
+    # a random sample of graphs against the fp64 oracle
     pick = np.random.default_rng(0).choice(T, 64, replace=False)
     adjs = wl["adjs_of"](pick)
     ref = K.graphconv_fwd_fast(x[pick].cpu().numpy(), adjs, [w.cpu().numpy()], [b.cpu().numpy()])
@@ -582,6 +760,55 @@ def test_integrated_gradients_features_and_adjacency():
     close(one["adjs"], np.concatenate([d[0] for d in dvals]), atol=2e-6, what="d score / d values")
 
 
+@pytest.mark.parametrize("route", ["gathered", "static"])
+def test_values_gradient_on_device_assembled_batches(route):
+    """d values / d features through GraphConv when the batch was assembled on the device (DeviceGraphDataset.batch,
+    StaticBatch): the backward runs A^T with the differentiable values permuted into A^T's entry order, which for a
+    gathered container has to be derived on the device (BatchedCSR.transpose_perm).  ASYMMETRIC adjacency with unsorted
+    columns, so a wrong permutation changes d features."""
+    from kgcn_amd import layers, visualization
+    from kgcn_amd.data_util import DeviceGraphDataset, FlatAdjacency
+    rng = np.random.default_rng(23)
+    G, N, F, Dh = 12, 10, 3, 8
+    mats = []
+    for _ in range(G):
+        n = int(rng.integers(8, 25))
+        idx = np.stack([rng.integers(0, N, n), rng.integers(0, N, n)], 1).astype(np.int32)   # duplicates allowed
+        mats.append((idx, rng.standard_normal(n).astype(np.float32), [N, N]))
+    feats = rng.standard_normal((G, N, F)).astype(np.float32)
+    ds = DeviceGraphDataset([FlatAdjacency.from_coo_list(mats, n_nodes=N)], feats, device=dev())
+    pick = np.array([7, 2, 2, 11, 0])
+    if route == "gathered":
+        adj, tx = ds.batch(pick, batch_size=6)                   # one dummy graph
+    else:
+        sb = ds.static_batch(6).load(pick)
+        adj, tx = sb.adjacency, sb.features
+    badjs = [[mats[i]] for i in pick] + [[(np.zeros((0, 2), np.int32), np.zeros(0, np.float32), [N, N])]]
+    xb = np.concatenate([feats[pick], np.zeros((1, N, F), np.float32)])
+    conv = layers.GraphConv(Dh, 1).to(dev())
+    conv(tx, adj=adj)
+    w, b = [conv.w[0].detach().cpu().numpy()], [conv.bias[0].detach().cpu().numpy()]
+    ro = rng.standard_normal(Dh).astype(np.float32)
+    tro = t32(ro)
+
+    def score_fn(feat, a):
+        return (layers.GraphGather()(torch.sigmoid(conv(feat, adj=a))) @ tro).sum()
+
+    one = visualization.integrated_gradients(score_fn, tx, adj, method="grad")
+    dx, dvals = K.probe_score_grads(xb, badjs, w, b, ro)
+    close(one["features"], dx, atol=2e-6, what="d score / d features (%s batch)" % route)
+    # the container stores a graph's entries in CSR order (stable by row); the oracle returns them in COO order
+    got = one["adjs"].cpu().numpy()
+    pos = 0
+    for (idx, _, _), dv in zip([m[0] for m in badjs], dvals):
+        order = np.argsort(np.asarray(idx).reshape(-1, 2)[:, 0], kind="stable")
+        n = order.shape[0]
+        np.testing.assert_allclose(got[pos:pos + n], np.asarray(dv[0])[order], rtol=0, atol=2e-6)
+        pos += n
+    # a static container is sized for the worst case: positions beyond the batch's entries belong to no graph
+    assert pos == got.shape[0] if route == "gathered" else pos <= got.shape[0]
+
+
 # ---------------------------------------------------------------------------------------------
 # GAT (kgcn/layers.py:477-542)
 # ---------------------------------------------------------------------------------------------
@@ -671,5 +898,15 @@ def test_batch_graphconv_block_diagonal():
     assert tuple(out.shape) == (G * N, Dout) and tuple(layer.bias.shape) == (Dout,)
     ref = K.batch_graphconv_fwd(net, coo, layer.w.detach().cpu().numpy(), layer.bias.detach().cpu().numpy())
     close(out, ref, rel=2e-6, what="BatchGraphConv")
-    out.sum().backward()
-    assert torch.isfinite(tn.grad).all() and torch.isfinite(layer.w.grad).all()
+    # backward: relu mask on the aggregated pre-activation, then the GraphConv gradients (fp64 restatement)
+    gy = rng.standard_normal(ref.shape).astype(np.float32)
+    out.backward(t32(gy))
+    w64, b64 = layer.w.detach().cpu().numpy().astype(np.float64), layer.bias.detach().cpu().numpy().astype(np.float64)
+    gm = gy.astype(np.float64) * (ref > 0)
+    dfw = K.spmm_coo(coo, gm, adjoint_a=True)
+    close(tn.grad, dfw @ w64.T, rel=2e-6, what="BatchGraphConv d net")
+    close(layer.w.grad, net.astype(np.float64).T @ dfw, rel=2e-6, what="BatchGraphConv d kernel")
+    close(layer.bias.grad, dfw.sum(0), rel=2e-6, what="BatchGraphConv d bias")
+    # no pre-activation may sit so close to the relu kink that fp32 and fp64 disagree on the mask
+    pre = K.spmm_coo(coo, net.astype(np.float64) @ w64 + b64.reshape(1, -1))
+    assert np.abs(pre).min() > 1e-6

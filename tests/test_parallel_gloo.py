@@ -63,6 +63,63 @@ def test_dp_gradient_allreduce_world2(tmp_path):
     assert spans[0][0] == 0 and spans[0][1] == spans[1][0] and spans[1][1] == 24
 
 
+def _worker_unequal(rank, world, port, outdir):
+    """Unequal shards with padded dummy graphs (quirk Q5): the loss is a MEAN over the padded batch, so rank r's
+    local-mean gradients enter with weight B_r / B; the weighted bucket must equal the single-process gradients of
+    the mean loss over the whole padded batch."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kgcn_amd.parallel import GradBucket, shard_range, shard_weight
+    from oracle import kgcn_oracle as K
+    rng = np.random.default_rng(1)
+    real, T = 20, 25                                          # 20 real graphs padded to a batch of 25 (feed.py:123-126)
+    adjs = K.synth_mol_graphs(rng, real, 16, 2)
+    empty = [(np.zeros((0, 2), np.int32), np.zeros(0, np.float32), [16, 16])]
+    adjs = adjs + [empty for _ in range(T - real)]
+    x = np.concatenate([rng.standard_normal((real, 16, 8)), np.zeros((T - real, 16, 8))])
+    w = [rng.standard_normal((8, 12))]
+    b = [rng.standard_normal((1, 12))]
+    g_sum = rng.standard_normal((T, 16, 12))                  # d(sum loss)/d out; the mean loss divides by the batch
+    lo, hi = shard_range(T, rank, world)                      # 13 / 12 graphs
+    _, dw, db = K.graphconv_bwd(x[lo:hi], adjs[lo:hi], w, b, g_sum[lo:hi] / (hi - lo))     # local mean loss
+    pw = torch.nn.Parameter(torch.tensor(w[0], dtype=torch.float32))
+    pb = torch.nn.Parameter(torch.tensor(b[0], dtype=torch.float32))
+    pw.grad = torch.tensor(dw[0], dtype=torch.float32)
+    pb.grad = torch.tensor(db[0], dtype=torch.float32)
+    GradBucket([pw, pb]).all_reduce_mean(weight=shard_weight(hi - lo, T))
+    _, dw_all, db_all = K.graphconv_bwd(x, adjs, w, b, g_sum / T)                           # global mean loss
+    ok = (np.allclose(pw.grad.numpy(), dw_all[0], rtol=1e-5, atol=1e-5)
+          and np.allclose(pb.grad.numpy(), db_all[0], rtol=1e-5, atol=1e-5))
+    # the plain mean is NOT the same thing for 13 / 12 graphs
+    plain = (hi - lo) != T // world or T % world == 0
+    with open(os.path.join(outdir, "rank%d.txt" % rank), "w") as f:
+        f.write("%d %d %d %d" % (int(ok), lo, hi, int(plain)))
+    dist.destroy_process_group()
+
+
+def test_dp_unequal_shards_weighted_mean_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker_unequal, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sizes = []
+    for r in range(world):
+        ok, lo, hi, _ = open(tmp_path / ("rank%d.txt" % r)).read().split()
+        assert ok == "1", "rank %d: weighted bucket differs from the gradients of the global mean loss" % r
+        sizes.append(int(hi) - int(lo))
+    assert sorted(sizes) == [12, 13]
+
+
+def test_empty_parameter_lists_are_refused():
+    from kgcn_amd.parallel import GradBucket
+    from kgcn_amd.train import TFAdam
+    import pytest
+    with pytest.raises(ValueError, match="first forward"):
+        GradBucket([])
+    with pytest.raises(ValueError, match="first forward"):
+        TFAdam([])
+
+
 def test_shard_range_tiles_any_batch():
     from kgcn_amd.parallel import shard_range
     for n in (0, 1, 7, 8, 100_000, 100_003):
