@@ -14,9 +14,15 @@ before the timed region.  Weak scaling: every rank owns its own 100k graphs.
            --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the fused backward) against
-the 8 TB/s HBM peak using the ALGORITHMIC bytes of DESIGN.md; `cpu_baseline` times the C
-restatement of the reference algorithm (oracle/kgcn_ref.c, OpenMP over graphs) on the host cores
-on a bounded sample of the same workload.
+the 8 TB/s HBM peak using the ALGORITHMIC bytes of DESIGN.md, with median / p10 / p90 of the per-launch
+HIP-event times; `roofline.spmm_kernel` prices the batched SpMM alone (kgcn_bspmm_f32 forward
+and adjoint on the same batch, 17,316 B/graph -- the kernel the north-star 60 % target is stated on), timed
+after the K steps; `cpu_baseline` times the C restatement of the reference algorithm (oracle/kgcn_ref.c,
+OpenMP over graphs) on the host cores on a bounded sample of the same workload, next to a reference-SHAPED
+leg (per-graph scipy CSR @ (X W + b) loop, the op structure of kgcn/layers.py:107-116).
+
+--scaling weak (default): every rank owns --graphs graphs.  --scaling strong: --graphs is the GLOBAL batch,
+sharded contiguously over the ranks (kgcn_amd.parallel.shard_range); gradients combine with the shard weights.
 """
 import argparse
 import json
@@ -132,9 +138,31 @@ def cpu_baseline(wl, budget_s=12.0, sample=20000):
         el = time.perf_counter() - t0
         if el >= budget_s and reps >= 3:
             break
-    return {"value": T * reps / el, "unit": "graphs/sec", "cores": threads, "kind": "port",
-            "sample": "%d graphs x %d passes of GraphConv fwd+bwd (oracle/kgcn_ref.c, OpenMP %d "
-                      "threads, fp32), %.1f s" % (T, reps, threads, el)}
+    res = {"value": T * reps / el, "unit": "graphs/sec", "cores": threads, "kind": "port",
+           "sample": "%d graphs x %d passes of GraphConv fwd+bwd (oracle/kgcn_ref.c, OpenMP %d "
+                     "threads, fp32), %.1f s" % (T, reps, threads, el)}
+    # reference-shaped leg: one scipy CSR SpMM and one tiny GEMM per graph, forward and the a-6 / a-7
+    # backward, single thread -- the op structure of kgcn/layers.py:107-116, not its TF executor
+    import scipy.sparse as sp
+    Ts = min(2000, T)
+    mats = [sp.csr_matrix((val[off[t]:off[t + 1]], (idx[off[t]:off[t + 1], 0], idx[off[t]:off[t + 1], 1])),
+                          shape=(N_NODES, N_NODES)) for t in range(Ts)]
+    t0, done = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 4.0:
+        dw = np.zeros_like(w)
+        db = np.zeros((1, w.shape[1]), np.float32)
+        for t in range(Ts):
+            out = mats[t] @ (x[t] @ w + b)                                        # noqa: F841
+            dfw = mats[t].T @ g[t]
+            dx = dfw @ w.T                                                        # noqa: F841
+            dw += x[t].T @ dfw
+            db += dfw.sum(0, keepdims=True)
+        done += Ts
+    el2 = time.perf_counter() - t0
+    res["reference_shaped"] = {"value": done / el2, "unit": "graphs/sec", "cores": 1,
+                               "sample": "%d graphs, per-graph scipy.sparse CSR @ (X W + b) + backward, numpy fp32, "
+                                         "1 thread, %.1f s" % (done, el2)}
+    return res
 
 
 # ---------------------------------------------------------------------------------------------
@@ -147,6 +175,8 @@ def main():
     ap.add_argument("--normalize", action="store_true", help="Kipf-normalised adjacency values")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="dense GEMM + Bspmm kernels instead of the fused layer")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --graphs per GPU; strong: --graphs in total, sharded over the GPUs")
     args = ap.parse_args()
 
     import torch
@@ -167,9 +197,14 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from kgcn_amd import layers
-    from kgcn_amd.parallel import GradBucket
+    from kgcn_amd.parallel import GradBucket, shard_range, shard_weight
 
-    T = args.graphs
+    if args.scaling == "strong":
+        lo, hi = shard_range(args.graphs, rank, world)          # contiguous shard of ONE global batch
+        T, T_global = hi - lo, args.graphs
+    else:
+        T, T_global = args.graphs, args.graphs * world
+    weight = shard_weight(T, T_global) if world > 1 else None
     wl = make_cfg2(T, device, seed=1234 + rank, normalize=args.normalize)
     csr = wl["csr"]
     layer = layers.GraphConv(FEAT, 1).to(device)
@@ -198,7 +233,7 @@ def main():
         if events:
             events[2].record()
         if bucket is not None:
-            bucket.all_reduce_mean()
+            bucket.all_reduce_mean(weight=weight)
 
     # setup: prime the caching allocator, the lazily built A^T / row-padded containers, the LDS attributes
     # and the clocks (the GPU idles at 107 MHz and needs some tens of milliseconds of load to reach its
@@ -226,49 +261,93 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the batched SpMM alone (the kernel of the north-star 60 % target): forward and adjoint launches on the same batch,
+    # after the timed region, clocks still in their sustained state
+    spmm = None
+    if rank == 0 and not args.unfused:
+        from kgcn_amd import ops
+        x2d, g2d = wl["x"].detach().reshape(T * N_NODES, FEAT), g.reshape(T * N_NODES, FEAT)
+        o2d = torch.empty_like(x2d)
+        csr_t = csr.transpose()
+        sev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(max(args.steps, 20))]
+        for _ in range(5):
+            ops.bspmm_raw(csr, x2d, FEAT, o2d)
+            ops.bspmm_raw(csr_t, g2d, FEAT, o2d)
+        for e in sev:
+            e[0].record()
+            ops.bspmm_raw(csr, x2d, FEAT, o2d)
+            e[1].record()
+            ops.bspmm_raw(csr_t, g2d, FEAT, o2d)
+            e[2].record()
+        torch.cuda.synchronize()
+        spmm = ([e[0].elapsed_time(e[1]) for e in sev], [e[1].elapsed_time(e[2]) for e in sev])
+
+    def stats(ms):
+        ms = sorted(ms)
+        n = len(ms)
+        return {"median_ms": ms[n // 2], "p10_ms": ms[n // 10], "p90_ms": ms[(9 * n) // 10], "mean_ms": float(np.mean(ms))}
+
     if rank == 0:
-        traffic_bwd = traffic_fwd = None
+        traffic = {}
         tpath = os.path.join(ROOT, "profiles", "traffic_cfg2.json")
         if os.path.exists(tpath) and not args.unfused:
             tj = json.load(open(tpath))
             if tj.get("graphs_per_launch") == T:      # PMC-measured HBM bytes of the same launch shape
-                traffic_bwd = tj["graphconv_bwd_full_kernel"]["bytes"]
-                traffic_fwd = tj["graphconv_fwd_full_kernel"]["bytes"]
-        fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-        bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+                traffic = {k: v.get("bytes") for k, v in tj.items() if isinstance(v, dict)}
+        fwd_st = stats([e[0].elapsed_time(e[1]) for e in ev])
+        bwd_st = stats([e[1].elapsed_time(e[2]) for e in ev])
+        fwd_ms, bwd_ms = fwd_st["mean_ms"], bwd_st["mean_ms"]
         ab = algorithmic_bytes(N_NODES, FEAT, FEAT, wl["nnz_per_graph"])
         bwd_gbs = ab["bwd"] * T / (bwd_ms * 1e-3) / 1e9
         fwd_gbs = ab["fwd"] * T / (fwd_ms * 1e-3) / 1e9
+        traffic_bwd = traffic.get("graphconv_bwd_planes_kernel")
+        traffic_fwd = traffic.get("graphconv_fwd_full_kernel")
+        spmm_entry = None
+        if spmm is not None:
+            sb = 2 * 4 * N_NODES * FEAT + ab["csr"]
+            sf, sa = stats(spmm[0]), stats(spmm[1])
+            spmm_entry = {"kernel": "spmm_tile_kernel (kgcn_bspmm_f32: Bspmm / Bspmdt / Bconv)", "bound": "hbm",
+                          "algorithmic_bytes_per_graph": sb, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "forward": dict(sf, achieved=sb * T / (sf["median_ms"] * 1e-3) / 1e9,
+                                          frac=sb * T / (sf["median_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS),
+                          "adjoint": dict(sa, achieved=sb * T / (sa["median_ms"] * 1e-3) / 1e9,
+                                          frac=sb * T / (sa["median_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS),
+                          "traffic": traffic.get("spmm_tile_kernel")}
         res = {
             "metric": "graphs/sec GraphConv fwd+bwd, 32-node mol graphs x64 feat",
-            "value": T * world * args.steps / elapsed,
+            "value": T_global * args.steps / elapsed,
             "unit": "graphs/sec",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "cfg2: %d random 32-node graphs per GPU (tree+3 edges+self loops, "
                                    "nnz=100), 64-dim features, 1 adjacency channel, GraphConv "
                                    "fwd+bwd (dX,dW,dbias)%s" % (T, ", unfused kernels" if args.unfused else ""),
-                       "graphs_per_gpu": T, "n_nodes": N_NODES, "din": FEAT, "dout": FEAT,
+                       "graphs_per_gpu": T, "graphs_global": T_global, "n_nodes": N_NODES, "din": FEAT, "dout": FEAT,
                        "nnz_per_graph": wl["nnz_per_graph"], "parallelism": "dp%d" % world,
+                       "collective": None if world == 1 else "one RCCL all-reduce of the flat [dW, dbias] bucket "
+                                                            "(%d floats) per step over %d ranks (backend %s)"
+                                                            % (bucket.total, dist.get_world_size(), dist.get_backend()),
                        "adjacency_values": "kipf" if args.normalize else "ones"},
             "roofline": {"bound": "hbm",
                          "kernel": "dense_wgrad+bspmm (unfused)" if args.unfused else
-                                   "graphconv_bwd_full_kernel (+1 reduce_partials launch, ~5 us, in the event bracket)",
+                                   "graphconv_bwd_planes_kernel (+1 reduce_partials launch, ~5 us, in the event bracket)",
                          "achieved": bwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": bwd_gbs / HBM_PEAK_GBS, "traffic": traffic_bwd,
+                         "launch_ms": bwd_st,
                          "traffic_note": "HBM bytes per launch, rocprofv3 PMC (profiles/traffic_cfg2.json); "
                                          "algorithmic bytes per launch = %d" % int(ab["bwd"] * T),
                          "algorithmic_bytes_per_graph": ab["bwd"], "avg_launch_ms": bwd_ms,
                          "fwd_kernel": {"achieved": fwd_gbs, "frac": fwd_gbs / HBM_PEAK_GBS,
                                         "algorithmic_bytes_per_graph": ab["fwd"], "avg_launch_ms": fwd_ms,
-                                        "traffic": traffic_fwd},
+                                        "launch_ms": fwd_st, "traffic": traffic_fwd},
+                         "spmm_kernel": spmm_entry,
                          "layer_frac_of_hbm_peak": ab["layer"] * T / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         if world == 1 and not args.no_cpu_baseline:
