@@ -228,6 +228,29 @@ int64_t kgcn_dot_workspace_bytes(int64_t n);
 int kgcn_dot_f32(const float* a, const float* b, int64_t n, float* out, void* workspace,
                  int64_t workspace_bytes, void* stream);
 
+/* -- GraphBatchNormalization (kgcn/layers.py:170-220) --------------------------------------- */
+/* Keras BatchNormalization over the VALID node rows of a padded batch x [T, N, D]: rows n < enabled[t] of graph t
+ * (enabled == NULL: every row; the reference gathers those rows, normalises the stacked [rows, D] matrix per feature and
+ * pads the result back with zeros, :196-210 / :211-216).
+ *   kgcn_graph_bn_stats_f32   mean[c], var[c] (population variance, two passes like tf.nn.moments) over the valid rows --
+ *                             the batch statistics of training mode
+ *   kgcn_graph_bn_apply_f32   y = gamma (x - mean) / sqrt(var + eps) + beta on valid rows, 0 on padding rows; with the
+ *                             moving statistics this is inference mode (the TF1 default phase)
+ *   kgcn_graph_bn_bwd_f32     dgamma = sum g xhat, dbeta = sum g, and dx (may be NULL):
+ *                             training != 0: gamma rstd (g - dbeta/n - xhat dgamma/n);  training == 0: gamma rstd g
+ * mean / var / gamma / beta / dgamma / dbeta: device [D].  workspace: kgcn_graph_bn_workspace_bytes(D) bytes; reductions
+ * are deterministic (per-workgroup partials, fixed-order second stage). */
+int64_t kgcn_graph_bn_workspace_bytes(int32_t d);
+int kgcn_graph_bn_stats_f32(const float* x, int64_t graphs, int32_t n_nodes, int32_t d, const int32_t* enabled,
+                            float* mean, float* var, void* workspace, int64_t workspace_bytes, void* stream);
+int kgcn_graph_bn_apply_f32(const float* x, int64_t graphs, int32_t n_nodes, int32_t d, const int32_t* enabled,
+                            const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                            float* y, void* stream);
+int kgcn_graph_bn_bwd_f32(const float* x, const float* grad, int64_t graphs, int32_t n_nodes, int32_t d,
+                          const int32_t* enabled, const float* mean, const float* var, const float* gamma, float eps,
+                          int32_t training, float* dx, float* dgamma, float* dbeta, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@ the C ABI of include/kgcn_hip.h; importing the package fails if that library is 
 """
 from . import _lib  # noqa: F401  -- loud failure when libkgcn_hip.so is missing
 from . import layers, ops
-from .batched_csr import BatchedAdjacency, BatchedCSR, as_batched_adjacency
+from .batched_csr import BatchedAdjacency, BatchedCSR, PackedAdjacencyCache, as_batched_adjacency
 
-__all__ = ["layers", "ops", "BatchedAdjacency", "BatchedCSR", "as_batched_adjacency"]
+__all__ = ["layers", "ops", "BatchedAdjacency", "BatchedCSR", "PackedAdjacencyCache", "as_batched_adjacency"]
 __version__ = "0.1.0"

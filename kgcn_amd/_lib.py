@@ -84,6 +84,14 @@ SIGNATURES = {
                                                  ctypes.c_void_p]),
     "kgcn_graph_gather_bwd_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i32, c_f32p,
                                                  ctypes.c_void_p]),
+    "kgcn_graph_bn_workspace_bytes": (c_i64, [c_i32]),
+    "kgcn_graph_bn_stats_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i32, c_i32p, c_f32p, c_f32p, ctypes.c_void_p, c_i64,
+                                               ctypes.c_void_p]),
+    "kgcn_graph_bn_apply_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i32, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                               ctypes.c_float, c_f32p, ctypes.c_void_p]),
+    "kgcn_graph_bn_bwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i64, c_i32, c_i32, c_i32p, c_f32p, c_f32p, c_f32p,
+                                             ctypes.c_float, c_i32, c_f32p, c_f32p, c_f32p, ctypes.c_void_p, c_i64,
+                                             ctypes.c_void_p]),
     "kgcn_dot_workspace_bytes": (c_i64, [c_i64]),
     "kgcn_dot_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i64, c_f32p, ctypes.c_void_p, c_i64,
                                     ctypes.c_void_p]),

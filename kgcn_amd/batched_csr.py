@@ -453,23 +453,70 @@ class BatchedAdjacency:
         return arr
 
 
-_PACK_CACHE = {}
+class PackedAdjacencyCache:
+    """Explicit, bounded cache of packed adjacency batches for callers that feed the reference's list-of-lists
+    adjs[b][ch] (kgcn/feed.py:112-126 builds a fresh list of the SAME arrays every step, kgcn/core.py:267-269 feeds it).
+
+    Keyed on CONTENT, not identity: a CRC of every index and value array (plus shapes), so mutating an entry in place
+    -- which the reference's align_size / split_adj / normalize_adj all do -- yields a different key and a fresh pack.
+    LRU of `max_entries` batches (device memory is held only for those); invalidate() drops everything.  The module
+    instance `pack_cache` is what layers use for list inputs; set `kgcn_amd.batched_csr.pack_cache = None` to pack on
+    every call, or hold a BatchedAdjacency yourself (BatchedAdjacency.from_adjs) and pass that -- no lookup at all."""
+
+    def __init__(self, max_entries=8):
+        import collections
+        self.max_entries = int(max_entries)
+        self._d = collections.OrderedDict()
+        self.hits = self.misses = 0
+
+    @staticmethod
+    def fingerprint(adj, n_nodes, device):
+        import zlib
+        crc = 0
+        count = 0
+        for row in adj:
+            for m in row:
+                idx, val, shape = _as_triple(m)
+                if hasattr(val, "requires_grad") and val.requires_grad:
+                    return None                         # differentiable values: never cached
+                ia, va = np.ascontiguousarray(_to_numpy(idx)), np.ascontiguousarray(_to_numpy(val))
+                crc = zlib.crc32(ia.view(np.uint8).reshape(-1), crc)
+                crc = zlib.crc32(va.view(np.uint8).reshape(-1), crc)
+                crc = zlib.crc32(np.asarray([ia.shape[0], int(shape[0]), int(shape[1])], np.int64).view(np.uint8), crc)
+                count += 1
+        return (crc, count, len(adj), n_nodes, str(device))
+
+    def get(self, adj, n_nodes=None, device="cuda"):
+        key = self.fingerprint(adj, n_nodes, device)
+        if key is not None and key in self._d:
+            self._d.move_to_end(key)
+            self.hits += 1
+            return self._d[key]
+        packed = BatchedAdjacency.from_adjs(adj, n_nodes=n_nodes, device=device)
+        self.misses += 1
+        if key is not None and self.max_entries > 0:
+            self._d[key] = packed
+            while len(self._d) > self.max_entries:
+                self._d.popitem(last=False)
+        return packed
+
+    def invalidate(self):
+        self._d.clear()
+
+    def __len__(self):
+        return len(self._d)
+
+
+pack_cache = PackedAdjacencyCache()
 
 
 def as_batched_adjacency(adj, n_nodes=None, device="cuda"):
-    """Accept a BatchedAdjacency, a BatchedCSR (single channel) or the reference's adjs[b][ch]
-    list-of-lists; the packed form of a list is cached on the list's identity (the reference
-    re-feeds the same Python objects every epoch)."""
+    """Accept a BatchedAdjacency, a BatchedCSR (single channel) or the reference's adjs[b][ch] list-of-lists (packed
+    through `pack_cache`, a content-keyed LRU -- see PackedAdjacencyCache)."""
     if isinstance(adj, BatchedAdjacency):
         return adj
     if isinstance(adj, BatchedCSR):
         return BatchedAdjacency([adj])
-    key = (id(adj), len(adj), n_nodes, str(device))
-    hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0] is adj:
-        return hit[1]
-    packed = BatchedAdjacency.from_adjs(adj, n_nodes=n_nodes, device=device)
-    if len(_PACK_CACHE) > 64:
-        _PACK_CACHE.clear()
-    _PACK_CACHE[key] = (adj, packed)
-    return packed
+    if pack_cache is None:
+        return BatchedAdjacency.from_adjs(adj, n_nodes=n_nodes, device=device)
+    return pack_cache.get(adj, n_nodes=n_nodes, device=device)

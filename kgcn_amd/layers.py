@@ -385,33 +385,78 @@ class BatchGraphConv(nn.Module):
         return torch.relu(ops.bspmm(csr, fw))
 
 
-class GraphBatchNormalization(nn.Module):
-    """kgcn/layers.py:170-220 with Keras' learning phase at its TF1 default (quirk Q6): the wrapped
-    BatchNormalization normalises with its moving statistics (mean 0, variance 1, epsilon 1e-3):
-        y = gamma * x / sqrt(1 + 1e-3) + beta
-    on the valid node rows (the first enabled_node_nums[b] of every graph, :196-210; all rows when
-    enabled_node_nums is None, :211-216) and zero on the padding rows."""
+_learning_phase = 0
 
-    def __init__(self, bn_name=None, eps=1e-3, **kwargs):
+
+def set_learning_phase(value):
+    """K.set_learning_phase: 0 = inference behaviour (the TF1 default the reference runs under),
+    1 = training behaviour of the Keras layers wrapped by this module (GraphBatchNormalization)."""
+    global _learning_phase
+    if value not in (0, 1, False, True):
+        raise ValueError("learning phase must be 0 or 1")
+    _learning_phase = int(value)
+
+
+def learning_phase():
+    return _learning_phase
+
+
+class GraphBatchNormalization(nn.Module):
+    """kgcn/layers.py:170-220: tf.keras.layers.BatchNormalization (momentum 0.99, epsilon 1e-3, gamma ones, beta zeros,
+    moving mean 0 / variance 1 -- Keras defaults, TF-internal) over the VALID node rows -- the first
+    enabled_node_nums[b] rows of every graph (:196-210; all rows when it is None, :211-216) -- zeros on the padding rows.
+
+    Mode (quirk Q6): the reference calls the Keras layer without `training=`, so the Keras LEARNING PHASE decides; its
+    `training` keyword is handed to the constructor as `trainable` (:205, :215), i.e. it only freezes gamma / beta.
+      phase 0 (default, what TF1 graph mode gives the reference): normalise with the moving statistics,
+          y = gamma (x - moving_mean) / sqrt(moving_variance + eps) + beta;
+      phase 1 (layers.set_learning_phase(1), or learning_phase=1 on the layer): batch statistics over the valid rows
+          (population variance, as tf.nn.moments), moving <- moving * momentum + batch * (1 - momentum), and the
+          backward differentiates through the statistics.
+    Statistics, normalisation and backward are HIP kernels (kgcn_graph_bn_*_f32, csrc/bn.hip)."""
+
+    def __init__(self, bn_name=None, eps=1e-3, momentum=0.99, learning_phase=None, **kwargs):
         super().__init__()
         self.bn_name = bn_name
         self.eps = eps
+        self.momentum = momentum
+        self.learning_phase = learning_phase        # None: follow layers.set_learning_phase()
         self.gamma = None
         self.beta = None
 
     def compute_output_shape(self, input_shape):
         return input_shape
 
+    def build(self, input_shape, device=None):
+        d = int(input_shape[-1])
+        dev = device if device is not None else "cuda"
+        self.gamma = nn.Parameter(torch.ones(d, device=dev))
+        self.beta = nn.Parameter(torch.zeros(d, device=dev))
+        self.register_buffer("moving_mean", torch.zeros(d, device=dev))
+        self.register_buffer("moving_variance", torch.ones(d, device=dev))
+
     def forward(self, x, enabled_node_nums=None, shape=None, max_node_num=None, training=True):
         if self.gamma is None:
-            self.gamma = nn.Parameter(torch.ones(x.shape[-1], device=x.device))
-            self.beta = nn.Parameter(torch.zeros(x.shape[-1], device=x.device))
-        y = x * (self.gamma / math.sqrt(1.0 + self.eps)) + self.beta
+            self.build(x.shape, x.device)
+        squeeze = x.dim() == 2
+        if squeeze:
+            x = x.unsqueeze(0)
+        en = None
         if enabled_node_nums is not None:
-            n = x.shape[1]
-            en = torch.as_tensor(enabled_node_nums, device=x.device).reshape(-1, 1)
-            y = y * (torch.arange(n, device=x.device).reshape(1, n) < en).to(y.dtype).unsqueeze(-1)
-        return y
+            en = torch.as_tensor(enabled_node_nums, device=x.device).to(torch.int32).reshape(-1).contiguous()
+            if en.numel() != x.shape[0]:
+                raise ValueError("enabled_node_nums has %d entries for a batch of %d graphs" % (en.numel(), x.shape[0]))
+        gamma, beta = (self.gamma, self.beta) if training else (self.gamma.detach(), self.beta.detach())
+        phase = _learning_phase if self.learning_phase is None else int(self.learning_phase)
+        if phase:
+            mean, var = ops.graph_bn_stats(x.detach(), en)
+            with torch.no_grad():
+                self.moving_mean.mul_(self.momentum).add_(mean, alpha=1.0 - self.momentum)
+                self.moving_variance.mul_(self.momentum).add_(var, alpha=1.0 - self.momentum)
+            y = ops.graph_bn(x, gamma, beta, mean, var, en, self.eps, True)
+        else:
+            y = ops.graph_bn(x, gamma, beta, self.moving_mean, self.moving_variance, en, self.eps, False)
+        return y[0] if squeeze else y
 
 
 class GraphGather(nn.Module):
@@ -425,6 +470,6 @@ class GraphGather(nn.Module):
 
 
 __all__ = ["GraphConv", "GraphDense", "GINAggregate", "GraphGather", "GraphMaxPooling",
-           "GraphBatchNormalization", "GAT", "GraphDecoderInnerProd",
+           "GraphBatchNormalization", "set_learning_phase", "learning_phase", "GAT", "GraphDecoderInnerProd",
            "GraphDecoderDistMult", "DistMult", "BatchGraphConv", "load_bspmm",
            "BatchedAdjacency"]

@@ -264,3 +264,43 @@ def test_graphed_train_step_other_models(kind):
         costs.append(float(cs_g))
         assert abs(cs_e - costs[-1]) < 2e-4 * max(1.0, abs(cs_e)), (kind, it, cs_e, costs[-1])
     assert costs[-1] < costs[0]
+
+
+def test_model_py_layer_calls_through_the_kgcn_import_path():
+    """The layer-call sequence of example_model/model.py:41-55, written against `import kgcn.layers` exactly as the
+    reference writes it (keyword adj=, enabled_node_nums / max_node_num on the BN layer), must run on the HIP path and
+    reproduce the model oracle's logits."""
+    import kgcn.layers
+    from kgcn_amd import models
+    z = load_golden("g3_synthetic_feed_b30.npz")
+    adjs = unflatten_adjs(z, "adj_")
+    x = z["features"]
+    p = M.init_params(np.random.default_rng(6), 3)
+    net = {"conv": [kgcn.layers.GraphConv(50, 1) for _ in range(3)], "bn": kgcn.layers.GraphBatchNormalization(),
+           "dense": kgcn.layers.GraphDense(50), "out": models.KerasDense(2)}
+
+    def build_model(features, adj):
+        layer = features
+        layer = net["conv"][0](layer, adj=adj)
+        layer = torch.sigmoid(layer)
+        layer = net["conv"][1](layer, adj=adj)
+        layer = torch.sigmoid(layer)
+        layer = net["conv"][2](layer, adj=adj)
+        layer = net["bn"](layer, max_node_num=features.shape[1], enabled_node_nums=None)
+        layer = torch.sigmoid(layer)
+        layer = net["dense"](layer)
+        layer = torch.sigmoid(layer)
+        layer = kgcn.layers.GraphGather()(layer)
+        return net["out"](layer)
+
+    build_model(t32(x), adjs)                          # Keras build semantics: parameters appear on the first call
+    with torch.no_grad():
+        for i, conv in enumerate(net["conv"], 1):
+            conv.w[0].copy_(t32(p["w%d" % i][0])); conv.bias[0].copy_(t32(p["b%d" % i][0]))
+        net["bn"].gamma.copy_(t32(p["gamma"])); net["bn"].beta.copy_(t32(p["beta"]))
+        net["dense"].kernel.copy_(t32(p["dk"])); net["dense"].bias.copy_(t32(p["db"]))
+        net["out"].kernel.copy_(t32(p["ok"])); net["out"].bias.copy_(t32(p["ob"]))
+    logits = build_model(t32(x), adjs)
+    c = M.forward(p, x.astype(np.float64), adjs, z["labels"].astype(np.float64), z["mask"].astype(np.float64))
+    close(logits, c["logits"], atol=2e-5, what="logits through kgcn.layers")
+    assert type(net["conv"][0]).__module__ == "kgcn_amd.layers"

@@ -531,6 +531,59 @@ def test_graph_gather_and_ragged_dense():
     close(d.bias.grad, db, rel=1e-6, what="ragged GraphDense dbias")
 
 
+@pytest.mark.parametrize("D,ragged", [(50, True), (64, True), (3, False), (256, True), (300, False)])
+def test_graph_batch_normalization_both_phases(D, ragged):
+    """kgcn/layers.py:170-220 in both Keras learning phases (quirk Q6), ragged enabled_node_nums incl. an empty graph:
+    forward, the moving-statistics update, and the backward (through the batch statistics in phase 1) against the
+    literal gather / normalise / split / pad restatement of the oracle."""
+    from kgcn_amd import layers
+    rng = np.random.default_rng(D)
+    B, N = 9, 12
+    x = (rng.standard_normal((B, N, D)) * 3 + 5 * rng.standard_normal(D)).astype(np.float32)    # per-feature offsets
+    en = np.array([12, 3, 0, 7, 1, 12, 5, 9, 2]) if ragged else None
+    gam = rng.standard_normal(D).astype(np.float32)
+    bet = rng.standard_normal(D).astype(np.float32)
+    gy = rng.standard_normal((B, N, D)).astype(np.float32)
+    for phase in (0, 1):
+        bn = layers.GraphBatchNormalization(learning_phase=phase)
+        bn.build((B, N, D), dev())
+        mm0 = rng.standard_normal(D).astype(np.float32)
+        mv0 = rng.uniform(0.5, 2.0, D).astype(np.float32)
+        with torch.no_grad():
+            bn.gamma.copy_(t32(gam)); bn.beta.copy_(t32(bet))
+            bn.moving_mean.copy_(t32(mm0)); bn.moving_variance.copy_(t32(mv0))
+        tx = t32(x).requires_grad_(True)
+        y = bn(tx, max_node_num=N, enabled_node_nums=en)
+        ry, mean, var, nmm, nmv = K.graph_bn_fwd(x, gam, bet, mm0, mv0, en, training=bool(phase))
+        close(y, ry, atol=2e-5, what="BN fwd phase %d" % phase)
+        close(bn.moving_mean, nmm, atol=1e-5, what="moving mean phase %d" % phase)
+        close(bn.moving_variance, nmv, atol=1e-5, rel=1e-6, what="moving variance phase %d" % phase)
+        y.backward(t32(gy))
+        dx, dg, db = K.graph_bn_bwd(x, gam, mean, var, gy, en, training=bool(phase))
+        close(tx.grad, dx, atol=2e-5, what="BN dx phase %d" % phase)
+        close(bn.gamma.grad, dg, atol=1e-5, rel=2e-6, what="BN dgamma phase %d" % phase)
+        close(bn.beta.grad, db, atol=1e-5, rel=2e-6, what="BN dbeta phase %d" % phase)
+        if en is not None:                                   # padding rows: exactly zero, forward and backward
+            pad = np.arange(N)[None, :] >= en[:, None]
+            assert float(y.detach()[torch.as_tensor(pad, device=dev())].abs().max()) == 0.0
+            assert float(tx.grad[torch.as_tensor(pad, device=dev())].abs().max()) == 0.0
+    # the module-level learning phase (K.set_learning_phase) is what a layer without its own setting follows, and the
+    # reference's `training` keyword only freezes gamma / beta (it is Keras' `trainable`, layers.py:205)
+    bn = layers.GraphBatchNormalization()
+    try:
+        layers.set_learning_phase(1)
+        tx = t32(x).requires_grad_(True)
+        y1 = bn(tx, enabled_node_nums=en, training=False)
+        close(y1, K.graph_bn_fwd(x, np.ones(D), np.zeros(D), np.zeros(D), np.ones(D), en, training=True)[0], atol=2e-5)
+        y1.sum().backward()
+        assert bn.gamma.grad is None and tx.grad is not None
+    finally:
+        layers.set_learning_phase(0)
+    close(bn(t32(x), enabled_node_nums=en),
+          K.graph_bn_fwd(x, np.ones(D), np.zeros(D), bn.moving_mean.cpu().numpy(), bn.moving_variance.cpu().numpy(), en)[0],
+          atol=2e-5, what="phase 0 uses the updated moving statistics")
+
+
 @pytest.mark.parametrize("channels,D", [("plain", 3), ("split", 50), ("norm", 64)])
 def test_graph_maxpooling(channels, D):
     """kgcn/layers.py:122-153 (row N3): values on a coarse grid so that ties -- between entries and

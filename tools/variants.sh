@@ -13,7 +13,7 @@ if [ "$mode" = build ]; then
     ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-slp-vectorize $flags \
         -c $CS/fused.hip -o $REPO/build/variants/fused_$name.o 2> $REPO/build/variants/$name.log &&
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $REPO/build/variants/libkgcn_$name.so \
-        $CS/misc.o $CS/spmm.o $CS/dense.o $CS/gemm3.o $REPO/build/variants/fused_$name.o $CS/pack.o $CS/gat.o &&
+        $CS/misc.o $CS/spmm.o $CS/dense.o $CS/gemm3.o $REPO/build/variants/fused_$name.o $CS/pack.o $CS/gat.o $CS/bn.o &&
       echo "built $name" || { echo "FAILED $name"; tail -5 $REPO/build/variants/$name.log; } ) &
   done
   wait
