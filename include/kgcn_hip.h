@@ -228,6 +228,41 @@ int64_t kgcn_dot_workspace_bytes(int64_t n);
 int kgcn_dot_f32(const float* a, const float* b, int64_t n, float* out, void* workspace,
                  int64_t workspace_bytes, void* stream);
 
+/* -- activations fused into the producing kernels -------------------------------------------- */
+/* The reference's models wrap the layers in tf.sigmoid / tf.nn.relu / tf.tanh (example_model/model.py:43-53,
+ * model_multitask.py:52-60, sparse.py:76, model_gin.py:47-50): one elementwise TF op -- one read and one write of the
+ * activation tensor -- per layer and direction.  Here the activation rides in the epilogue of the kernel that produces
+ * the tensor, and its derivative (expressed in the layer OUTPUT: sigmoid a(1-a), relu a > 0, tanh 1 - a^2) in the
+ * prologue of the adjoint aggregation. */
+#define KGCN_ACT_NONE 0
+#define KGCN_ACT_SIGMOID 1
+#define KGCN_ACT_RELU 2
+#define KGCN_ACT_TANH 3
+/* kgcn_bconv_f32 followed by act:  out[t] = act( sum_c A_c[t] @ rhs_c[t] ) */
+int kgcn_bconv_act_f32(const kgcn_csr_batch* a_ch, int32_t num_channels, const float* rhs, int64_t rhs_ld,
+                       int64_t rhs_graph_stride, int64_t rhs_channel_stride, int32_t d, float* out, int64_t out_ld,
+                       int64_t out_graph_stride, int32_t act, void* stream);
+/* backward of that layer through one channel (pass the A^T container):
+ *   out[t] = beta*out[t] + A[t] @ ( grad[t] (.) act'(act_out[t]) )      grad, act_out: same layout (ld, graph stride) */
+int kgcn_bspmm_dact_f32(const kgcn_csr_batch* a, const float* grad, const float* act_out, int64_t ld,
+                        int64_t graph_stride, int32_t d, int32_t act, float* out, int64_t out_ld,
+                        int64_t out_graph_stride, float beta, void* stream);
+/* kgcn_dense_fwd_f32 followed by act:  y = act(x @ w(^T) + bias) */
+int kgcn_dense_fwd_act_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w, int64_t w_ld,
+                           int32_t trans_w, const float* bias, float* y, int32_t dout, int64_t y_ld, int32_t act,
+                           void* stream);
+/* The same contraction with a caller-provided workspace of kgcn_dense_fwd_workspace_bytes(din, dout) bytes (0 for
+ * layers that do not use one): wide layers (dout > 128, din >= 64: the 256-wide layers of example_model/
+ * model_multitask.py:51-57 and sparse.py:30) then run the register-resident bf16-split GEMM of csrc/gemm4.hip, whose
+ * weight operand is split once per call into a fragment table in that workspace.  workspace == NULL: kgcn_dense_fwd_act_f32. */
+int64_t kgcn_dense_fwd_workspace_bytes(int32_t din, int32_t dout);
+int kgcn_dense_fwd_ws_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w, int64_t w_ld,
+                          int32_t trans_w, const float* bias, float* y, int32_t dout, int64_t y_ld, int32_t act,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+/* stand-alone forms: y = act(x) over n floats; dpre = grad (.) act'(act_out) (dpre may alias grad) */
+int kgcn_act_fwd_f32(const float* x, int64_t n, int32_t act, float* y, void* stream);
+int kgcn_act_bwd_f32(const float* act_out, const float* grad, int64_t n, int32_t act, float* dpre, void* stream);
+
 /* -- GraphBatchNormalization (kgcn/layers.py:170-220) --------------------------------------- */
 /* Keras BatchNormalization over the VALID node rows of a padded batch x [T, N, D]: rows n < enabled[t] of graph t
  * (enabled == NULL: every row; the reference gathers those rows, normalises the stacked [rows, D] matrix per feature and

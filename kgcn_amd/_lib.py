@@ -84,6 +84,17 @@ SIGNATURES = {
                                                  ctypes.c_void_p]),
     "kgcn_graph_gather_bwd_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i32, c_f32p,
                                                  ctypes.c_void_p]),
+    "kgcn_bconv_act_f32": (ctypes.c_int, [_CSRP, c_i32, c_f32p, c_i64, c_i64, c_i64, c_i32, c_f32p, c_i64, c_i64, c_i32,
+                                          ctypes.c_void_p]),
+    "kgcn_bspmm_dact_f32": (ctypes.c_int, [_CSRP, c_f32p, c_f32p, c_i64, c_i64, c_i32, c_i32, c_f32p, c_i64, c_i64,
+                                           ctypes.c_float, ctypes.c_void_p]),
+    "kgcn_dense_fwd_act_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i64, c_f32p, c_i64, c_i32, c_f32p, c_f32p, c_i32,
+                                              c_i64, c_i32, ctypes.c_void_p]),
+    "kgcn_dense_fwd_workspace_bytes": (c_i64, [c_i32, c_i32]),
+    "kgcn_dense_fwd_ws_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i64, c_f32p, c_i64, c_i32, c_f32p, c_f32p, c_i32,
+                                             c_i64, c_i32, ctypes.c_void_p, c_i64, ctypes.c_void_p]),
+    "kgcn_act_fwd_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_f32p, ctypes.c_void_p]),
+    "kgcn_act_bwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i64, c_i32, c_f32p, ctypes.c_void_p]),
     "kgcn_graph_bn_workspace_bytes": (c_i64, [c_i32]),
     "kgcn_graph_bn_stats_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i32, c_i32p, c_f32p, c_f32p, ctypes.c_void_p, c_i64,
                                                ctypes.c_void_p]),

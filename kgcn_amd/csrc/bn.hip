@@ -93,7 +93,8 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, long rows, int n_nodes, int d,
                                                        const int* __restrict__ enabled, const float* __restrict__ mean,
                                                        const float* __restrict__ var, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float eps, float* __restrict__ y) {
+                                                       const float* __restrict__ beta, float eps, float* __restrict__ y,
+                                                       int act) {
   const int dv = VEC ? d >> 2 : d;
   const long total = rows * dv;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
       valid = (int)(r - t * n_nodes) < enabled[t];
     }
     if constexpr (VEC) {
+      // the activation of the model follows the zero padding (tf.sigmoid(bn(...)): padding rows become act(0))
       f32x4 o = {0.f, 0.f, 0.f, 0.f};
       if (valid) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * d + c);
@@ -114,11 +116,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
           o[j] = (v[j] - mean[c + j]) * rs * gamma[c + j] + beta[c + j];
         }
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = act_fwd(o[j], act);
       *reinterpret_cast<f32x4*>(y + r * d + c) = o;
     } else {
       float o = 0.f;
       if (valid) o = (x[r * d + c] - mean[c]) * (1.0f / __builtin_sqrtf(var[c] + eps)) * gamma[c] + beta[c];
-      y[r * d + c] = o;
+      y[r * d + c] = act_fwd(o, act);
     }
   }
 }
@@ -156,6 +160,14 @@ static int bn_grid(long work) {
   return b < 1 ? 1 : (int)b;
 }
 
+// workgroups of a column reduction: ~8 row passes each (a pass covers 256 / min(d, 256) rows), at most BN_BLOCKS
+static int bn_blocks(long rows, int d) {
+  const int rpp = 256 / (d < 256 ? d : 256);
+  long nb = (rows + 8L * rpp - 1) / (8L * rpp);
+  if (nb > BN_BLOCKS) nb = BN_BLOCKS;
+  return nb < 1 ? 1 : (int)nb;
+}
+
 static int bn_check(const char* who, const float* x, int64_t graphs, int32_t n_nodes, int32_t d) {
   if (graphs < 0 || n_nodes <= 0 || d <= 0) return fail("%s: bad shape T=%lld N=%d D=%d", who, (long long)graphs, n_nodes, d);
   if (graphs > 0 && !x) return fail("%s: x is NULL", who);
@@ -181,9 +193,7 @@ extern "C" int kgcn_graph_bn_stats_f32(const float* x, int64_t graphs, int32_t n
   hipStream_t s = as_stream(stream);
   const long rows = (long)graphs * n_nodes;
   float* part = static_cast<float*>(workspace);
-  int nb = (int)((rows + 255) / 256);
-  if (nb > BN_BLOCKS) nb = BN_BLOCKS;
-  if (nb < 1) nb = 1;
+  int nb = bn_blocks(rows, d);
   hipLaunchKernelGGL(bn_colreduce_kernel<0>, dim3(nb), dim3(256), 0, s, x, nullptr, rows, n_nodes, d, enabled, nullptr,
                      nullptr, 0.f, part, nullptr);
   if (int rc = launch_reduce_partials(part, nb, d, mean, s)) return rc;
@@ -205,10 +215,10 @@ extern "C" int kgcn_graph_bn_apply_f32(const float* x, int64_t graphs, int32_t n
   const bool vec = (d % 4 == 0) && aligned16(x) && aligned16(y);
   if (vec)
     hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(bn_grid(rows * (d / 4))), dim3(256), 0, as_stream(stream), x, rows, n_nodes,
-                       d, enabled, mean, var, gamma, beta, eps, y);
+                       d, enabled, mean, var, gamma, beta, eps, y, KGCN_ACT_NONE);
   else
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(bn_grid(rows * d)), dim3(256), 0, as_stream(stream), x, rows, n_nodes, d,
-                       enabled, mean, var, gamma, beta, eps, y);
+                       enabled, mean, var, gamma, beta, eps, y, KGCN_ACT_NONE);
   return check_launch("bn_apply_kernel");
 }
 
@@ -227,9 +237,7 @@ extern "C" int kgcn_graph_bn_bwd_f32(const float* x, const float* grad, int64_t 
   float* part1 = part0 + (long)BN_BLOCKS * d;
   long* count = reinterpret_cast<long*>(reinterpret_cast<char*>(workspace) +
                                         ((((size_t)2 * BN_BLOCKS * d) * 4 + 15) & ~(size_t)15));
-  int nb = (int)((rows + 255) / 256);
-  if (nb > BN_BLOCKS) nb = BN_BLOCKS;
-  if (nb < 1) nb = 1;
+  int nb = bn_blocks(rows, d);
   hipLaunchKernelGGL(bn_colreduce_kernel<2>, dim3(nb), dim3(256), 0, s, x, grad, rows, n_nodes, d, enabled, mean, var, eps,
                      part0, part1);
   if (int rc = launch_reduce_partials(part0, nb, d, dbeta, s)) return rc;
@@ -242,4 +250,50 @@ extern "C" int kgcn_graph_bn_bwd_f32(const float* x, const float* grad, int64_t 
                          var, gamma, dgamma, dbeta, eps, training, count, dx);
   }
   return check_launch("bn_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Activations that have no producer kernel to ride in (after the fused GraphConv kernels, after BN in training mode) and
+// the backward of every fused activation:  dpre = grad (.) act'(act_out), in place when dpre == grad.
+// ------------------------------------------------------------------------------------------------
+namespace kgcn {
+template <bool BWD>
+__global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ a, const float* __restrict__ g, long n, int act,
+                                                  float* __restrict__ o) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 av = reinterpret_cast<const f32x4*>(a)[i];
+    f32x4 r;
+    if constexpr (BWD) {
+      const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = gv[j] * act_dout(av[j], act);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = act_fwd(av[j], act);
+    }
+    reinterpret_cast<f32x4*>(o)[i] = r;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    o[i] = BWD ? g[i] * act_dout(a[i], act) : act_fwd(a[i], act);
+}
+}  // namespace kgcn
+
+extern "C" int kgcn_act_fwd_f32(const float* x, int64_t n, int32_t act, float* y, void* stream) {
+  if (act < KGCN_ACT_NONE || act > KGCN_ACT_TANH) return fail("kgcn_act_fwd_f32: unknown activation code %d", act);
+  if (n <= 0) return 0;
+  if (!x || !y) return fail("kgcn_act_fwd_f32: NULL operand");
+  if (!aligned16(x) || !aligned16(y)) return fail("kgcn_act_fwd_f32: tensors not 16-byte aligned");
+  hipLaunchKernelGGL(act_kernel<false>, dim3(bn_grid(n / 4 + 1)), dim3(256), 0, as_stream(stream), x, nullptr, (long)n, act, y);
+  return check_launch("act_kernel");
+}
+
+extern "C" int kgcn_act_bwd_f32(const float* act_out, const float* grad, int64_t n, int32_t act, float* dpre, void* stream) {
+  if (act < KGCN_ACT_NONE || act > KGCN_ACT_TANH) return fail("kgcn_act_bwd_f32: unknown activation code %d", act);
+  if (n <= 0) return 0;
+  if (!act_out || !grad || !dpre) return fail("kgcn_act_bwd_f32: NULL operand");
+  if (!aligned16(act_out) || !aligned16(grad) || !aligned16(dpre)) return fail("kgcn_act_bwd_f32: tensors not 16-byte aligned");
+  hipLaunchKernelGGL(act_kernel<true>, dim3(bn_grid(n / 4 + 1)), dim3(256), 0, as_stream(stream), act_out, grad, (long)n, act,
+                     dpre);
+  return check_launch("act_kernel");
 }

@@ -20,7 +20,11 @@
 namespace kgcn {
 
 int launch_gemm3_fwd(const float* x, long m, int din, long x_ld, const float* w, long w_ld, int trans_w,
-                     const float* bias, float* y, int dout, long y_ld, hipStream_t s);
+                     const float* bias, float* y, int dout, long y_ld, int act, hipStream_t s);
+int64_t gemm4_workspace_bytes(int din, int dout);
+int launch_gemm4_fwd(const float* x, long m, int din, long x_ld, const float* w, long w_ld, int trans_w,
+                     const float* bias, float* y, int dout, long y_ld, int act, void* workspace, long* rows_done,
+                     hipStream_t s);
 int launch_gemm3_wgrad(const float* x, long x_ld, const float* dy, long dy_ld, long m, int din, int dout,
                        float* part_dw, float* part_db, int nblocks, hipStream_t s);
 
@@ -32,7 +36,7 @@ constexpr int XS_LD = BK + 4;  // +16 B pad: conflict-free ds_read_b128 of A fra
 __global__ __launch_bounds__(256) void dense_fwd_kernel(
     const float* __restrict__ x, long m, int din, long x_ld, const float* __restrict__ w,
     long w_ld, int trans_w, const float* __restrict__ bias, float* __restrict__ y, int dout,
-    long y_ld) {
+    long y_ld, int act) {
   __shared__ __attribute__((aligned(16))) float Xs[BM * XS_LD];
   __shared__ __attribute__((aligned(16))) float Ws[BK * BN];
 
@@ -105,11 +109,17 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(
   const float bv0 = (bias && c0 < dout) ? bias[c0] : 0.f;
   const float bv1 = (bias && c1 < dout) ? bias[c1] : 0.f;
 #pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] += bv0; acc1[r] += bv1; }
+  if (act != KGCN_ACT_NONE) {                          // one uniform branch around the whole activation
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = act_fwd(acc0[r], act); acc1[r] = act_fwd(acc1[r], act); }
+  }
+#pragma unroll
   for (int r = 0; r < 16; ++r) {
     const long row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
     if (row < m) {
-      if (c0 < dout) y[row * y_ld + c0] = acc0[r] + bv0;
-      if (c1 < dout) y[row * y_ld + c1] = acc1[r] + bv1;
+      if (c0 < dout) y[row * y_ld + c0] = acc0[r];
+      if (c1 < dout) y[row * y_ld + c1] = acc1[r];
     }
   }
 }
@@ -277,7 +287,7 @@ __device__ __forceinline__ void lds_handoff() {   // intra-wave LDS hand-off: co
 template <bool VEC>
 __global__ __launch_bounds__(512, 2) void dense_fwd_persist_kernel(
     const float* __restrict__ x, long m, int din, long x_ld, const float* __restrict__ w, long w_ld,
-    int trans_w, const float* __restrict__ bias, float* __restrict__ y, int dout, long y_ld, int kp) {
+    int trans_w, const float* __restrict__ bias, float* __restrict__ y, int dout, long y_ld, int kp, int act) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   float* Wp = reinterpret_cast<float*>(dsm);                      // [kp][64], zero padded
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -332,6 +342,10 @@ __global__ __launch_bounds__(512, 2) void dense_fwd_persist_kernel(
     lds_handoff();
     if (last_kc) {
       const long row0 = tile * 32;
+      if (act != KGCN_ACT_NONE) {                      // one uniform branch around the whole activation
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = act_fwd(acc0[r], act); acc1[r] = act_fwd(acc1[r], act); }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -472,18 +486,39 @@ int launch_reduce_partials2(const float* part, int nparts, long n, float* out, c
 
 using namespace kgcn;
 
-extern "C" int kgcn_dense_fwd_f32(const float* x, int64_t m, int32_t din, int64_t x_ld,
-                                  const float* w, int64_t w_ld, int32_t trans_w, const float* bias,
-                                  float* y, int32_t dout, int64_t y_ld, void* stream) {
+// wide layers take the bf16-split GEMMs: the register-resident kernel of gemm4.hip when the caller provides the
+// workspace for the pre-split weight fragments, the LDS-staged kernel of gemm3.hip otherwise
+static bool wide_layer(int din, int dout) { return dout > 128 && din >= 64; }
+// where the register-resident kernel measured ahead of the LDS-staged one (tools/gemm_bench.py, 204,800 rows:
+// 256 -> 256 +10% forward / +5% dX, 512 -> 256 +2% / -3%, 256 -> 512 -1%, 128 -> 256 and ragged din behind)
+static bool gemm4_pays(int din, int dout) { return din % 16 == 0 && din >= 256 && dout % 64 == 0 && dout <= 256; }
+
+static int dense_fwd_impl(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w, int64_t w_ld,
+                          int32_t trans_w, const float* bias, float* y, int32_t dout, int64_t y_ld, int act,
+                          void* workspace, int64_t workspace_bytes, void* stream) {
+  if (act < KGCN_ACT_NONE || act > KGCN_ACT_TANH) return fail("kgcn_dense_fwd_f32: unknown activation code %d", act);
   if (m < 0 || din <= 0 || dout <= 0)
     return fail("kgcn_dense_fwd_f32: bad shape m=%lld din=%d dout=%d", (long long)m, din, dout);
   if (m == 0) return 0;
   if (!x || !w || !y) return fail("kgcn_dense_fwd_f32: NULL operand");
   if (x_ld < din || y_ld < dout) return fail("kgcn_dense_fwd_f32: leading dimension too small");
   if (w_ld < (trans_w ? din : dout)) return fail("kgcn_dense_fwd_f32: w_ld too small");
+  if (wide_layer(din, dout) && gemm4_pays(din, dout) && workspace &&
+      workspace_bytes >= gemm4_workspace_bytes(din, dout) && m >= 4096) {
+    long done = 0;
+    const int rc = launch_gemm4_fwd(x, (long)m, din, (long)x_ld, w, (long)w_ld, trans_w, bias, y, dout, (long)y_ld, act,
+                                    workspace, &done, as_stream(stream));
+    if (rc > 0) return rc;
+    if (rc == 0) {                      // whole 128-row blocks done; the remaining rows (< 128) take the tiled kernel
+      if (done == m) return 0;
+      x += done * x_ld;
+      y += done * y_ld;
+      m -= done;
+    }
+  }
   // wide layers: f32-MFMA bound -> the bf16-split GEMM (gemm3.hip)
-  if (dout > 128 && din >= 64)
-    return launch_gemm3_fwd(x, (long)m, din, (long)x_ld, w, (long)w_ld, trans_w, bias, y, dout, (long)y_ld,
+  if (wide_layer(din, dout))
+    return launch_gemm3_fwd(x, (long)m, din, (long)x_ld, w, (long)w_ld, trans_w, bias, y, dout, (long)y_ld, act,
                             as_stream(stream));
   {
     // fast path: weight panel [din_pad x 64] resident in LDS next to 8 per-wave x tiles
@@ -505,10 +540,10 @@ extern "C" int kgcn_dense_fwd_f32(const float* x, int64_t m, int32_t din, int64_
       dim3 grid((unsigned)blocks, (unsigned)((dout + 63) / 64));
       if (vec)
         hipLaunchKernelGGL(dense_fwd_persist_kernel<true>, grid, dim3(64 * P_WAVES), lds, as_stream(stream), x,
-                           (long)m, din, (long)x_ld, w, (long)w_ld, trans_w, bias, y, dout, (long)y_ld, kp);
+                           (long)m, din, (long)x_ld, w, (long)w_ld, trans_w, bias, y, dout, (long)y_ld, kp, act);
       else
         hipLaunchKernelGGL(dense_fwd_persist_kernel<false>, grid, dim3(64 * P_WAVES), lds, as_stream(stream), x,
-                           (long)m, din, (long)x_ld, w, (long)w_ld, trans_w, bias, y, dout, (long)y_ld, kp);
+                           (long)m, din, (long)x_ld, w, (long)w_ld, trans_w, bias, y, dout, (long)y_ld, kp, act);
       return check_launch("dense_fwd_persist_kernel");
     }
   }
@@ -516,8 +551,31 @@ extern "C" int kgcn_dense_fwd_f32(const float* x, int64_t m, int32_t din, int64_
   if (gx > 0x7fffffffL) return fail("kgcn_dense_fwd_f32: m too large");
   dim3 grid((unsigned)gx, (unsigned)((dout + BN - 1) / BN));
   hipLaunchKernelGGL(dense_fwd_kernel, grid, dim3(256), 0, as_stream(stream), x, (long)m, din,
-                     (long)x_ld, w, (long)w_ld, trans_w, bias, y, dout, (long)y_ld);
+                     (long)x_ld, w, (long)w_ld, trans_w, bias, y, dout, (long)y_ld, act);
   return check_launch("dense_fwd_kernel");
+}
+
+extern "C" int kgcn_dense_fwd_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w, int64_t w_ld,
+                                  int32_t trans_w, const float* bias, float* y, int32_t dout, int64_t y_ld,
+                                  void* stream) {
+  return dense_fwd_impl(x, m, din, x_ld, w, w_ld, trans_w, bias, y, dout, y_ld, KGCN_ACT_NONE, nullptr, 0, stream);
+}
+
+extern "C" int64_t kgcn_dense_fwd_workspace_bytes(int32_t din, int32_t dout) {
+  if (din <= 0 || dout <= 0 || !wide_layer(din, dout) || !gemm4_pays(din, dout)) return 0;
+  return gemm4_workspace_bytes(din, dout);
+}
+
+extern "C" int kgcn_dense_fwd_ws_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w, int64_t w_ld,
+                                     int32_t trans_w, const float* bias, float* y, int32_t dout, int64_t y_ld,
+                                     int32_t act, void* workspace, int64_t workspace_bytes, void* stream) {
+  return dense_fwd_impl(x, m, din, x_ld, w, w_ld, trans_w, bias, y, dout, y_ld, act, workspace, workspace_bytes, stream);
+}
+
+extern "C" int kgcn_dense_fwd_act_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w,
+                                      int64_t w_ld, int32_t trans_w, const float* bias, float* y, int32_t dout,
+                                      int64_t y_ld, int32_t act, void* stream) {
+  return dense_fwd_impl(x, m, din, x_ld, w, w_ld, trans_w, bias, y, dout, y_ld, act, nullptr, 0, stream);
 }
 
 extern "C" int64_t kgcn_dense_wgrad_workspace_bytes(int64_t m, int32_t din, int32_t dout) {

@@ -945,12 +945,6 @@ __host__ __device__ inline size_t bwd_planes_lds_bytes(int max_nnz) {
   return PLANES_ALL + WTAB_BYTES + BWD_WPB_ * bwd_planes_wave_bytes(max_nnz);
 }
 
-// Values that are only consumed a phase later (x fragments, the dbias sums): without a use at the place of their
-// definition, machine sinking moves the whole computation across the conditional blocks of the CSR landing into ONE clump
-// in front of the consumer (176 + 32 VALU ops behind a single MFMA, ~1,000 cycles per graph).  An empty volatile asm
-// with the values as in/out operands is such a use.
-#define KGCN_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
-#define KGCN_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short i16x4 __attribute__((ext_vector_type(4)));

@@ -135,7 +135,7 @@ __device__ __forceinline__ void g3_write(u32x4* table, int tile, int q, int li, 
 template <bool XVEC>
 __global__ __launch_bounds__(512, 2) void gemm3_fwd_kernel(
     const float* __restrict__ x, long m, int din, long x_ld, const float* __restrict__ w, long w_ld, int trans_w,
-    const float* __restrict__ bias, float* __restrict__ y, int dout, long y_ld) {
+    const float* __restrict__ bias, float* __restrict__ y, int dout, long y_ld, int act) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   u32x4* lds = reinterpret_cast<u32x4*>(dsm);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -274,7 +274,15 @@ __global__ __launch_bounds__(512, 2) void gemm3_fwd_kernel(
       });
     });
     G3P(1)
-    if (k0c + 1 == nkc) {                                // last chunk of the tile: y <- acc
+    if (k0c + 1 == nkc) {                                // last chunk of the tile: y <- act(acc)
+      if (act != KGCN_ACT_NONE) {                        // ONE uniform branch: the plain epilogue stays what it was
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = act_fwd(acc[mt][nt][r], act);
+      }
       const long row0 = t0 * G3_BM + 64 * wr;
       const int cb = n0 + 64 * wc;
       if (row0 + 64 <= m && cb + 64 <= dout) {
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_fwd_kernel(
 }
 
 int launch_gemm3_fwd(const float* x, long m, int din, long x_ld, const float* w, long w_ld, int trans_w,
-                     const float* bias, float* y, int dout, long y_ld, hipStream_t s) {
+                     const float* bias, float* y, int dout, long y_ld, int act, hipStream_t s) {
   static thread_local bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_fwd_kernel<true>),
@@ -338,10 +346,10 @@ int launch_gemm3_fwd(const float* x, long m, int din, long x_ld, const float* w,
   const bool xvec = (din % 4 == 0) && (x_ld % 4 == 0) && aligned16(x);
   if (xvec)
     hipLaunchKernelGGL(gemm3_fwd_kernel<true>, grid, dim3(512), G3_LDS, s, x, m, din, x_ld, w, w_ld, trans_w, bias, y,
-                       dout, y_ld);
+                       dout, y_ld, act);
   else
     hipLaunchKernelGGL(gemm3_fwd_kernel<false>, grid, dim3(512), G3_LDS, s, x, m, din, x_ld, w, w_ld, trans_w, bias, y,
-                       dout, y_ld);
+                       dout, y_ld, act);
   return check_launch("gemm3_fwd_kernel");
 }
 

@@ -62,6 +62,31 @@ __device__ __forceinline__ void static_for(Fn&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+// Values that are only consumed much later (fragments of the next k-step / phase, running sums): without a use at the
+// place of their definition, machine sinking moves the whole computation across intervening blocks into ONE clump in
+// front of the consumer.  An empty volatile asm with the values as in/out operands is such a use.
+#define KGCN_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+#define KGCN_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+
+// ---- activations fused into producer epilogues (KGCN_ACT_* of include/kgcn_hip.h) ----------------------------
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  if (act == KGCN_ACT_SIGMOID) return 1.0f / (1.0f + __expf(-v));
+  if (act == KGCN_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == KGCN_ACT_TANH) {
+    const float e = __expf(-2.0f * fabsf(v));
+    const float t = (1.0f - e) / (1.0f + e);
+    return v < 0.f ? -t : t;
+  }
+  return v;
+}
+// derivative expressed in the activation OUTPUT a (what a backward pass has at hand)
+__device__ __forceinline__ float act_dout(float a, int act) {
+  if (act == KGCN_ACT_SIGMOID) return a * (1.0f - a);
+  if (act == KGCN_ACT_RELU) return a > 0.f ? 1.0f : 0.f;
+  if (act == KGCN_ACT_TANH) return 1.0f - a * a;
+  return 1.0f;
+}
+
 // ---- fp32 contraction on the bf16 matrix pipe: exact 3-way split ------------------------------------
 // gfx950 runs v_mfma_f32_32x32x2_f32 at the VALU rate AND on the VALU datapath (nothing overlaps it:
 // tools/mfma_shadow.hip), while v_mfma_f32_32x32x16_bf16 is 16x faster per flop and runs beside VALU

@@ -24,45 +24,84 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 // ------------------------------------------------------------------------------------------------
-// LDS-staged tile kernel: one wave (= one 64-thread workgroup) per graph.
-// LDS layout: tile[K*d] | ecv[max_nnz] (int2) | rp[M+1]
+// What one launch aggregates:  out[t] = act( beta*out[t] + sum_c A_c[t] @ (rhs_c[t] (.) act'(aout[t])) ).
+//   * up to MAX_CH adjacency channels in ONE launch (tf.add_n over the channels, kgcn/layers.py:115; the degree split
+//     of kgcn/data_util.py:76-122 has 6): the output is written once instead of read-modify-written per channel,
+//   * act (KGCN_ACT_*): the activation the model applies to the layer output (tf.sigmoid / tf.nn.relu / tf.tanh around
+//     GraphConv in example_model/*.py) as an epilogue -- saves one read + one write of the activation tensor,
+//   * dact + aout: backward of such a layer.  The incoming gradient is multiplied by act'(.) expressed in the saved
+//     layer OUTPUT (sigmoid: a(1-a), relu: a > 0, tanh: 1 - a^2) while it is gathered, so d pre-activation never
+//     exists in HBM.
 // ------------------------------------------------------------------------------------------------
+constexpr int MAX_CH = 8;
+struct SpmmChannels {
+  const int* rowptr[MAX_CH];
+  const int2* cv[MAX_CH];
+  int max_nnz[MAX_CH];
+  int n;
+  long rhs_cs;           // element offset between the rhs operands of consecutive channels
+};
+
+// ------------------------------------------------------------------------------------------------
+// LDS-staged tile kernel: one wave (= one 64-thread workgroup) per graph.
+// LDS layout per channel: tile[K*d] | ecv[max_nnz] (int2) | rp[M+1]   (all channels staged, then one row loop)
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t tile_chan_bytes(int M, int K, int d, int max_nnz) {
+  return (((size_t)K * d * 4 + (size_t)max_nnz * 8 + (size_t)(M + 1) * 4) + 15) & ~(size_t)15;
+}
+
 template <int LPR>
 __global__ __launch_bounds__(64) void spmm_tile_kernel(
-    const int* __restrict__ rowptr, const int2* __restrict__ cv, const float* __restrict__ rhs,
-    long rhs_ld, long rhs_gs, float* __restrict__ out, long out_ld, long out_gs, int M, int K,
-    int d, int max_nnz, float beta, const float* __restrict__ self_scale) {
+    SpmmChannels ch, const float* __restrict__ rhs, long rhs_ld, long rhs_gs, float* __restrict__ out, long out_ld,
+    long out_gs, int M, int K, int d, float beta, const float* __restrict__ self_scale, int act,
+    const float* __restrict__ aout, int dact) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* tile = reinterpret_cast<float*>(smem);
-  int2* ecv = reinterpret_cast<int2*>(tile + (size_t)K * d);
-  int* rp = reinterpret_cast<int*>(ecv + max_nnz);
-
   const int t = blockIdx.x;
   const int lane = threadIdx.x;
-  const int* grp = rowptr + (long)t * M;
-  const int base = grp[0];
-  const int cnt = grp[M] - base;
-
-  // ---- stage: rhs block (dwordx4, fully coalesced), CSR slice ---------------------------------
-  const float* rb = rhs + (long)t * rhs_gs;
   const int d4 = d >> 2;
   const int n4 = K * d4;
-  if (rhs_ld == d) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(rb);
-    f32x4* dst = reinterpret_cast<f32x4*>(tile);
+
+  // ---- stage: per channel the rhs block (dwordx4, fully coalesced; times act'(aout) in a backward launch) and the
+  // CSR slice ---------------------------------------------------------------------------------
+  size_t off = 0;
+  for (int c = 0; c < ch.n; ++c) {
+    float* tile = reinterpret_cast<float*>(smem + off);
+    int2* ecv = reinterpret_cast<int2*>(tile + (size_t)K * d);
+    int* rp = reinterpret_cast<int*>(ecv + ch.max_nnz[c]);
+    const int* grp = ch.rowptr[c] + (long)t * M;
+    const int base = grp[0];
+    const int cnt = grp[M] - base;
+    const float* rb = rhs + c * ch.rhs_cs + (long)t * rhs_gs;
+    if (dact == KGCN_ACT_NONE) {
+      if (rhs_ld == d) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(rb);
+        f32x4* dst = reinterpret_cast<f32x4*>(tile);
 #pragma unroll 4
-    for (int i = lane; i < n4; i += 64) dst[i] = src[i];
-  } else {
-    for (int i = lane; i < n4; i += 64) {
-      int r = i / d4, c = i - r * d4;
-      st4(tile + (size_t)i * 4, ld4(rb + (long)r * rhs_ld + c * 4));
+        for (int i = lane; i < n4; i += 64) dst[i] = src[i];
+      } else {
+        for (int i = lane; i < n4; i += 64) {
+          int r = i / d4, cc = i - r * d4;
+          st4(tile + (size_t)i * 4, ld4(rb + (long)r * rhs_ld + cc * 4));
+        }
+      }
+    } else {
+      const float* ab = aout + (long)t * rhs_gs;           // same layout as the gradient
+      for (int i = lane; i < n4; i += 64) {
+        int r = i / d4, cc = i - r * d4;
+        f32x4 v = ld4(rb + (long)r * rhs_ld + cc * 4);
+        const f32x4 a = ld4(ab + (long)r * rhs_ld + cc * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= act_dout(a[j], dact);
+        st4(tile + (size_t)i * 4, v);
+      }
     }
+    for (int i = lane; i < cnt; i += 64) ecv[i] = ch.cv[c][base + i];
+    for (int i = lane; i <= M; i += 64) rp[i] = grp[i] - base;
+    off += tile_chan_bytes(M, K, d, ch.max_nnz[c]);
   }
-  for (int i = lane; i < cnt; i += 64) ecv[i] = cv[base + i];
-  for (int i = lane; i <= M; i += 64) rp[i] = grp[i] - base;
   __syncthreads();  // single-wave workgroup: orders the LDS writes before the gathers
 
-  // ---- aggregate: 64/LPR rows at a time, LPR lanes x float4 per row ---------------------------
+  // ---- aggregate: 64/LPR rows at a time, LPR lanes x float4 per row, channels innermost ----------
   constexpr int RPW = 64 / LPR;
   const int sub = lane / LPR;
   const int cl = lane % LPR;
@@ -72,17 +111,28 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(
   for (int r0 = 0; r0 < M; r0 += RPW) {
     const int r = r0 + sub;
     if (r < M && col_ok) {
-      const int s = rp[r], e = rp[r + 1];
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int k = s; k < e; ++k) {
-        const int2 p = ecv[k];
-        const float v = __int_as_float(p.y);
-        const f32x4 x = ld4(tile + (size_t)p.x * d + cl * 4);
-        acc += v * x;
+      size_t o2 = 0;
+      for (int c = 0; c < ch.n; ++c) {
+        const float* tile = reinterpret_cast<const float*>(smem + o2);
+        const int2* ecv = reinterpret_cast<const int2*>(tile + (size_t)K * d);
+        const int* rp = reinterpret_cast<const int*>(ecv + ch.max_nnz[c]);
+        const int s = rp[r], e = rp[r + 1];
+        for (int k = s; k < e; ++k) {
+          const int2 p = ecv[k];
+          const float v = __int_as_float(p.y);
+          const f32x4 x = ld4(tile + (size_t)p.x * d + cl * 4);
+          acc += v * x;
+        }
+        if (self_scale && c == 0) acc += sscale * ld4(tile + (size_t)r * d + cl * 4);
+        o2 += tile_chan_bytes(M, K, d, ch.max_nnz[c]);
       }
-      if (self_scale) acc += sscale * ld4(tile + (size_t)r * d + cl * 4);
       float* o = ob + (long)r * out_ld + cl * 4;
       if (beta != 0.f) acc += ld4(o);
+      if (act != KGCN_ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = act_fwd(acc[j], act);
+      }
       st4(o, acc);
     }
   }
@@ -93,9 +143,9 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(
 // ------------------------------------------------------------------------------------------------
 template <int VEC>
 __global__ __launch_bounds__(256) void spmm_gather_kernel(
-    const int* __restrict__ rowptr, const int2* __restrict__ cv, const float* __restrict__ rhs,
-    long rhs_ld, long rhs_gs, float* __restrict__ out, long out_ld, long out_gs, int M,
-    long total_rows, int d, int lpr_log2, float beta, const float* __restrict__ self_scale) {
+    SpmmChannels ch, const float* __restrict__ rhs, long rhs_ld, long rhs_gs, float* __restrict__ out, long out_ld,
+    long out_gs, int M, long total_rows, int d, int lpr_log2, float beta, const float* __restrict__ self_scale, int act,
+    const float* __restrict__ aout, int dact) {
   const int lpr = 1 << lpr_log2;
   const int cl = threadIdx.x & (lpr - 1);
   const long nworkers = ((long)gridDim.x * 256) >> lpr_log2;
@@ -104,33 +154,47 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(
        row += nworkers) {
     const long t = row / M;
     const int r = (int)(row - t * M);
-    const int s = rowptr[row], e = rowptr[row + 1];
-    const float* rb = rhs + t * rhs_gs;
     float* o = out + t * out_gs + (long)r * out_ld;
     for (int c0 = cl * VEC; c0 < d; c0 += lpr * VEC) {
       float acc[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-      for (int k = s; k < e; ++k) {
-        const int2 p = cv[k];
-        const float v = __int_as_float(p.y);
-        const float* src = rb + (long)p.x * rhs_ld + c0;
-        if constexpr (VEC == 4) {
-          const f32x4 x = ld4(src);
+      for (int c = 0; c < ch.n; ++c) {
+        const int s = ch.rowptr[c][row], e = ch.rowptr[c][row + 1];
+        const float* rb = rhs + c * ch.rhs_cs + t * rhs_gs;
+        const int2* cv = ch.cv[c];
+        for (int k = s; k < e; ++k) {
+          const int2 p = cv[k];
+          const float v = __int_as_float(p.y);
+          const float* src = rb + (long)p.x * rhs_ld + c0;
+          if constexpr (VEC == 4) {
+            f32x4 x = ld4(src);
+            if (dact != KGCN_ACT_NONE) {
+              const f32x4 a = ld4(aout + t * rhs_gs + (long)p.x * rhs_ld + c0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] += v * x[j];
-        } else {
-          acc[0] += v * src[0];
+              for (int j = 0; j < 4; ++j) x[j] *= act_dout(a[j], dact);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += v * x[j];
+          } else {
+            float x = src[0];
+            if (dact != KGCN_ACT_NONE) x *= act_dout(aout[t * rhs_gs + (long)p.x * rhs_ld + c0], dact);
+            acc[0] += v * x;
+          }
         }
-      }
-      if (self_scale) {
-        const float* src = rb + (long)r * rhs_ld + c0;
+        if (self_scale && c == 0) {
+          const float* src = rb + (long)r * rhs_ld + c0;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] += sscale * src[j];
+          for (int j = 0; j < VEC; ++j) acc[j] += sscale * src[j];
+        }
       }
       if (beta != 0.f) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] += o[c0 + j];
+      }
+      if (act != KGCN_ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = act_fwd(acc[j], act);
       }
       if constexpr (VEC == 4) {
         f32x4 v4 = {acc[0], acc[1], acc[2], acc[3]};
@@ -252,34 +316,51 @@ static int ilog2_ceil(int v) {
   return l;
 }
 
-// LDS bytes the tile kernel needs for one graph
-static size_t tile_lds_bytes(int M, int K, int d, int max_nnz) {
-  return (size_t)K * d * 4 + (size_t)max_nnz * 8 + (size_t)(M + 1) * 4;
-}
-
-// Tile kernel is used when one graph's working set leaves >= 8 waves per CU resident.
-static bool tile_ok(const kgcn_csr_batch* a, const float* rhs, long rhs_ld, long rhs_gs, int d,
+// Tile kernel is used when one graph's working set (all channels of the launch) leaves >= 8 waves per CU resident.
+static bool tile_ok(const kgcn_csr_batch* a, int nch, const float* rhs, long rhs_ld, long rhs_gs, long rhs_cs, int d,
                     const float* out, long out_ld, long out_gs) {
   if (d % 4 != 0 || d > 256 || d <= 0) return false;
-  if (rhs_ld % 4 || rhs_gs % 4 || out_ld % 4 || out_gs % 4) return false;
+  if (rhs_ld % 4 || rhs_gs % 4 || out_ld % 4 || out_gs % 4 || rhs_cs % 4) return false;
   if (!aligned16(rhs) || !aligned16(out)) return false;
   if (a->rows <= 0 || a->cols <= 0) return false;
-  return tile_lds_bytes(a->rows, a->cols, d, a->max_nnz_per_graph) <= 20 * 1024;
+  size_t lds = 0;
+  for (int c = 0; c < nch; ++c) lds += tile_chan_bytes(a[c].rows, a[c].cols, d, a[c].max_nnz_per_graph);
+  return lds <= 20 * 1024;
 }
 
-int launch_spmm(const kgcn_csr_batch* a, const float* rhs, long rhs_ld, long rhs_gs, int d,
-                float* out, long out_ld, long out_gs, float beta, const float* self_scale,
-                hipStream_t stream) {
+// out[t] = act(beta*out[t] + sum_c A_c[t] @ (rhs_c[t] (.) act'(aout[t])));  a: nch channel descriptors of one batch shape
+int launch_spmm_multi(const kgcn_csr_batch* a, int nch, const float* rhs, long rhs_ld, long rhs_gs, long rhs_cs, int d,
+                      float* out, long out_ld, long out_gs, float beta, const float* self_scale, int act,
+                      const float* aout, int dact, hipStream_t stream) {
   const int T = a->num_graphs, M = a->rows, K = a->cols;
   if (T == 0 || M == 0 || d == 0) return 0;
-  const int2* cv = reinterpret_cast<const int2*>(a->cv);
-  if (tile_ok(a, rhs, rhs_ld, rhs_gs, d, out, out_ld, out_gs)) {
-    const size_t lds = tile_lds_bytes(M, K, d, a->max_nnz_per_graph);
+  if (nch > MAX_CH) {                       // more channels than one launch takes: groups of MAX_CH, accumulate
+    for (int c0 = 0; c0 < nch; c0 += MAX_CH) {
+      const int n = nch - c0 < MAX_CH ? nch - c0 : MAX_CH;
+      const bool last = c0 + n >= nch;      // the activation belongs to the last group only
+      int rc = launch_spmm_multi(a + c0, n, rhs + c0 * rhs_cs, rhs_ld, rhs_gs, rhs_cs, d, out, out_ld, out_gs,
+                                 c0 == 0 ? beta : 1.f, c0 == 0 ? self_scale : nullptr, last ? act : KGCN_ACT_NONE, aout,
+                                 dact, stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  SpmmChannels ch;
+  ch.n = nch;
+  ch.rhs_cs = rhs_cs;
+  for (int c = 0; c < nch; ++c) {
+    ch.rowptr[c] = a[c].rowptr;
+    ch.cv[c] = reinterpret_cast<const int2*>(a[c].cv);
+    ch.max_nnz[c] = a[c].max_nnz_per_graph;
+  }
+  if (tile_ok(a, nch, rhs, rhs_ld, rhs_gs, rhs_cs, d, out, out_ld, out_gs) &&
+      (dact == KGCN_ACT_NONE || aligned16(aout))) {
+    size_t lds = 0;
+    for (int c = 0; c < nch; ++c) lds += tile_chan_bytes(M, K, d, a[c].max_nnz_per_graph);
     const int lanes = d / 4;
-#define KGCN_TILE(LPR)                                                                        \
-  hipLaunchKernelGGL((spmm_tile_kernel<LPR>), dim3(T), dim3(64), lds, stream, a->rowptr, cv,  \
-                     rhs, rhs_ld, rhs_gs, out, out_ld, out_gs, M, K, d,                       \
-                     a->max_nnz_per_graph, beta, self_scale)
+#define KGCN_TILE(LPR)                                                                                              \
+  hipLaunchKernelGGL((spmm_tile_kernel<LPR>), dim3(T), dim3(64), lds, stream, ch, rhs, rhs_ld, rhs_gs, out, out_ld, \
+                     out_gs, M, K, d, beta, self_scale, act, aout, dact)
     if (lanes <= 8) KGCN_TILE(8);
     else if (lanes <= 16) KGCN_TILE(16);
     else if (lanes <= 32) KGCN_TILE(32);
@@ -289,7 +370,8 @@ int launch_spmm(const kgcn_csr_batch* a, const float* rhs, long rhs_ld, long rhs
   }
   const long total_rows = (long)T * M;
   const bool vec4 = (d % 4 == 0) && (rhs_ld % 4 == 0) && (rhs_gs % 4 == 0) && (out_ld % 4 == 0) &&
-                    (out_gs % 4 == 0) && aligned16(rhs) && aligned16(out);
+                    (out_gs % 4 == 0) && (rhs_cs % 4 == 0) && aligned16(rhs) && aligned16(out) &&
+                    (dact == KGCN_ACT_NONE || aligned16(aout));
   const int per_row = vec4 ? d / 4 : d;
   int lpr_log2 = ilog2_ceil(per_row);
   if (lpr_log2 > 6) lpr_log2 = 6;
@@ -298,14 +380,19 @@ int launch_spmm(const kgcn_csr_batch* a, const float* rhs, long rhs_ld, long rhs
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks < 1) blocks = 1;
   if (vec4)
-    hipLaunchKernelGGL((spmm_gather_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, stream,
-                       a->rowptr, cv, rhs, rhs_ld, rhs_gs, out, out_ld, out_gs, M, total_rows, d,
-                       lpr_log2, beta, self_scale);
+    hipLaunchKernelGGL((spmm_gather_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, stream, ch, rhs, rhs_ld, rhs_gs,
+                       out, out_ld, out_gs, M, total_rows, d, lpr_log2, beta, self_scale, act, aout, dact);
   else
-    hipLaunchKernelGGL((spmm_gather_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, stream,
-                       a->rowptr, cv, rhs, rhs_ld, rhs_gs, out, out_ld, out_gs, M, total_rows, d,
-                       lpr_log2, beta, self_scale);
+    hipLaunchKernelGGL((spmm_gather_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, stream, ch, rhs, rhs_ld, rhs_gs,
+                       out, out_ld, out_gs, M, total_rows, d, lpr_log2, beta, self_scale, act, aout, dact);
   return check_launch("spmm_gather_kernel");
+}
+
+int launch_spmm(const kgcn_csr_batch* a, const float* rhs, long rhs_ld, long rhs_gs, int d,
+                float* out, long out_ld, long out_gs, float beta, const float* self_scale,
+                hipStream_t stream) {
+  return launch_spmm_multi(a, 1, rhs, rhs_ld, rhs_gs, 0, d, out, out_ld, out_gs, beta, self_scale, KGCN_ACT_NONE,
+                           nullptr, KGCN_ACT_NONE, stream);
 }
 
 }  // namespace kgcn
@@ -340,13 +427,46 @@ extern "C" int kgcn_bconv_f32(const kgcn_csr_batch* a_ch, int32_t num_channels, 
   if (a_ch[0].num_graphs == 0 || a_ch[0].rows == 0 || d == 0) return 0;
   if (!rhs || !out) return fail("kgcn_bconv_f32: rhs/out is NULL");
   if (rhs_ld < d || out_ld < d) return fail("kgcn_bconv_f32: leading dimension smaller than d");
-  // channel add-n (tf.add_n, kgcn/layers.py:115): channel 0 overwrites, the others accumulate
-  for (int c = 0; c < num_channels; ++c) {
-    int rc = launch_spmm(a_ch + c, rhs + c * rhs_channel_stride, rhs_ld, rhs_graph_stride, d, out,
-                         out_ld, out_graph_stride, c == 0 ? 0.f : 1.f, nullptr, as_stream(stream));
-    if (rc) return rc;
-  }
+  // channel add-n (tf.add_n, kgcn/layers.py:115) inside the kernel: every output row is written once
+  return launch_spmm_multi(a_ch, num_channels, rhs, rhs_ld, rhs_graph_stride, rhs_channel_stride, d, out, out_ld,
+                           out_graph_stride, 0.f, nullptr, KGCN_ACT_NONE, nullptr, KGCN_ACT_NONE, as_stream(stream));
+}
+
+static int check_act(const char* who, int act) {
+  if (act < KGCN_ACT_NONE || act > KGCN_ACT_TANH) return fail("%s: unknown activation code %d", who, act);
   return 0;
+}
+
+extern "C" int kgcn_bconv_act_f32(const kgcn_csr_batch* a_ch, int32_t num_channels, const float* rhs, int64_t rhs_ld,
+                                  int64_t rhs_graph_stride, int64_t rhs_channel_stride, int32_t d, float* out,
+                                  int64_t out_ld, int64_t out_graph_stride, int32_t act, void* stream) {
+  if (num_channels <= 0) return fail("kgcn_bconv_act_f32: num_channels=%d", num_channels);
+  if (!a_ch) return fail("kgcn_bconv_act_f32: a_ch is NULL");
+  if (int rc = check_act("kgcn_bconv_act_f32", act)) return rc;
+  for (int c = 0; c < num_channels; ++c) {
+    if (int rc = validate_csr(a_ch + c, "kgcn_bconv_act_f32")) return rc;
+    if (a_ch[c].num_graphs != a_ch[0].num_graphs || a_ch[c].rows != a_ch[0].rows || a_ch[c].cols != a_ch[0].cols)
+      return fail("kgcn_bconv_act_f32: channel %d has a different batch shape", c);
+  }
+  if (a_ch[0].num_graphs == 0 || a_ch[0].rows == 0 || d == 0) return 0;
+  if (!rhs || !out) return fail("kgcn_bconv_act_f32: rhs/out is NULL");
+  if (rhs_ld < d || out_ld < d) return fail("kgcn_bconv_act_f32: leading dimension smaller than d");
+  return launch_spmm_multi(a_ch, num_channels, rhs, rhs_ld, rhs_graph_stride, rhs_channel_stride, d, out, out_ld,
+                           out_graph_stride, 0.f, nullptr, act, nullptr, KGCN_ACT_NONE, as_stream(stream));
+}
+
+extern "C" int kgcn_bspmm_dact_f32(const kgcn_csr_batch* a, const float* grad, const float* act_out, int64_t ld,
+                                   int64_t graph_stride, int32_t d, int32_t act, float* out, int64_t out_ld,
+                                   int64_t out_graph_stride, float beta, void* stream) {
+  if (int rc = validate_csr(a, "kgcn_bspmm_dact_f32")) return rc;
+  if (int rc = check_act("kgcn_bspmm_dact_f32", act)) return rc;
+  if (d < 0) return fail("kgcn_bspmm_dact_f32: d=%d < 0", d);
+  if (a->num_graphs == 0 || a->rows == 0 || d == 0) return 0;
+  if (!grad || !out || (act != KGCN_ACT_NONE && !act_out)) return fail("kgcn_bspmm_dact_f32: NULL operand");
+  if (ld < d || out_ld < d) return fail("kgcn_bspmm_dact_f32: leading dimension smaller than d");
+  if (beta != 0.f && beta != 1.f) return fail("kgcn_bspmm_dact_f32: beta must be 0 or 1");
+  return launch_spmm_multi(a, 1, grad, ld, graph_stride, 0, d, out, out_ld, out_graph_stride, beta, nullptr,
+                           KGCN_ACT_NONE, act_out, act, as_stream(stream));
 }
 
 extern "C" int kgcn_gin_aggregate_f32(const kgcn_csr_batch* a_ch, int32_t num_channels,

@@ -90,11 +90,16 @@ def _pack(adj, inputs):
 class GraphConv(nn.Module):
     """kgcn/layers.py:32-119.  Out[b] = sum_c A[b][c] @ (X[b] @ kernel_c + bias_c)."""
 
-    def __init__(self, output_dim, adj_channel_num, initializer="glorot_uniform", **kwargs):
+    def __init__(self, output_dim, adj_channel_num, initializer="glorot_uniform", activation=None, **kwargs):
+        """activation (extension, default None = the reference's layer): 'sigmoid' / 'relu' / 'tanh' -- the elementwise
+        op the reference's MODELS apply to the layer output (example_model/model.py:43 tf.sigmoid(layer), sparse.py:76
+        tf.nn.relu) -- computed in the epilogue of the aggregation kernel instead of a separate pass over HBM."""
         super().__init__()
         self.output_dim = int(output_dim)
         self.adj_channel_num = int(adj_channel_num)
         self.initializer = initializer
+        self.activation = activation
+        ops.act_code(activation)
         self.w = nn.ParameterList()
         self.bias = nn.ParameterList()
         self.built = False
@@ -120,6 +125,22 @@ class GraphConv(nn.Module):
         B, N, din = inputs.shape
         C, dout = self.adj_channel_num, self.output_dim
         x2d = inputs.reshape(B * N, din)
+        act = self.activation
+        if a.values is not None or enabled_bconv or enabled_bspmm or enabled_batched:
+            # the reference-structured branches keep the reference's op boundaries: activation as its own op
+            return ops.activation(self._forward_reference_branches(inputs, a, x2d, B, N, din, C, dout), act)
+        # default branch (kgcn/layers.py:105-116), MI355X form: the whole layer in one kernel when
+        # the shape fits the fused kernel, else one GEMM with concatenated kernels + fused
+        # multi-channel aggregation (one launch for all channels, activation in its epilogue).
+        if C == 1 and ops.graphconv_fused_supported(a.channels[0], din, dout):
+            return ops.activation(ops.graphconv_fused(inputs, self.w[0], self.bias[0], a.channels[0]), act)
+        if C == 1:
+            fw = ops.dense(x2d, self.w[0], self.bias[0])
+        else:
+            fw = ops.dense(x2d, torch.cat(list(self.w), dim=1), torch.cat(list(self.bias), dim=1))
+        return ops.bconv(a, fw, dout, activation=act).reshape(B, N, dout)
+
+    def _forward_reference_branches(self, inputs, a, x2d, B, N, din, C, dout):
         if a.values is not None:
             # adjacency values are differentiable inputs (integrated gradients over `adjs`,
             # kgcn/visualization.py:207-210): one Bspmm per channel with its d values gradient
@@ -144,25 +165,20 @@ class GraphConv(nn.Module):
             # kgcn/layers.py:91-104: one [B*N, Din] GEMM + Bspmdt per channel, reduce_sum
             o = [ops.bspmm(a.channels[c], ops.dense(x2d, self.w[c], self.bias[c])) for c in range(C)]
             return torch.stack(o).sum(0).reshape(B, N, dout) if C > 1 else o[0].reshape(B, N, dout)
-        # default branch (kgcn/layers.py:105-116), MI355X form: the whole layer in one kernel when
-        # the shape fits the fused kernel, else one GEMM with concatenated kernels + fused
-        # multi-channel aggregation.
-        if C == 1 and ops.graphconv_fused_supported(a.channels[0], din, dout):
-            return ops.graphconv_fused(inputs, self.w[0], self.bias[0], a.channels[0])
-        if C == 1:
-            fw = ops.dense(x2d, self.w[0], self.bias[0])
-        else:
-            fw = ops.dense(x2d, torch.cat(list(self.w), dim=1), torch.cat(list(self.bias), dim=1))
-        return ops.bconv(a, fw, dout).reshape(B, N, dout)
+        raise AssertionError("unreachable")
 
 
 class GraphDense(nn.Module):
     """kgcn/layers.py:223-265: Keras Dense applied to every node row; kernel [Din, Dout]
     glorot-uniform, bias [Dout] zeros, no activation (Keras defaults)."""
 
-    def __init__(self, output_dim, use_bias=True, kernel_initializer="glorot_uniform", **kwargs):
+    def __init__(self, output_dim, use_bias=True, kernel_initializer="glorot_uniform", activation=None, **kwargs):
+        """activation (extension, default None): the elementwise op the models apply to the output
+        (model_gin.py:47 tf.nn.relu(GraphDense(...)), model.py:53 tf.sigmoid) in the GEMM epilogue."""
         super().__init__()
         self.output_dim = int(output_dim)
+        self.activation = activation
+        ops.act_code(activation)
         self.use_bias = use_bias
         self.kernel_initializer = kernel_initializer
         self.kernel = None
@@ -183,13 +199,16 @@ class GraphDense(nn.Module):
         if not self.built:
             self.build(inputs.shape, inputs.device)
         B, N, din = inputs.shape
+        if enabled_node_nums is None:
+            return ops.dense(inputs.reshape(B * N, din), self.kernel, self.bias,
+                             activation=self.activation).reshape(B, N, self.output_dim)
         y = ops.dense(inputs.reshape(B * N, din), self.kernel, self.bias).reshape(B, N, self.output_dim)
         if enabled_node_nums is not None:
             # ragged path (kgcn/layers.py:243-254): rows >= enabled_node_nums[b] are zero padding
             en = torch.as_tensor(enabled_node_nums, device=inputs.device).reshape(B, 1)
             mask = (torch.arange(N, device=inputs.device).reshape(1, N) < en).to(y.dtype)
             y = y * mask.unsqueeze(-1)
-        return y
+        return ops.activation(y, self.activation)          # the model's activation follows the zero padding
 
 
 class GINAggregate(nn.Module):

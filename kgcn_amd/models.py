@@ -1,6 +1,9 @@
 """Model definitions mirroring the reference's model plugins line for line in LAYER CALLS
-(SURVEY 8f, row N1).  Only the layers of the hot path run in HIP kernels (kgcn_amd.layers);
-activations, the loss and the BatchNorm affine are elementwise torch ops around them.
+(SURVEY 8f, row N1).  The layers of the hot path run in HIP kernels (kgcn_amd.layers); the elementwise
+activation the reference writes as its own TF op after a layer (tf.sigmoid(layer), tf.nn.relu(layer)) is
+handed to the layer as `activation=` and computed in the epilogue of the kernel that produces the tensor
+(aggregation or GEMM) -- same function, one pass over HBM less per layer; where a BatchNormalization sits
+between layer and activation it is one HIP elementwise kernel (ops.activation).  The loss is torch.
 
   GCN  -- example_model/model.py:41-61      GraphConv(50) x3, BN, GraphDense(50), GraphGather, Dense(2)
   GIN  -- example_model/model_gin.py:40-67  2 x [GINAggregate, GraphDense(50) x2], Gather x2, Dense(2)
@@ -55,25 +58,22 @@ class GCN(nn.Module):
 
     def __init__(self, adj_channel_num=1, num_classes=2):
         super().__init__()
-        self.conv1 = layers.GraphConv(50, adj_channel_num)
-        self.conv2 = layers.GraphConv(50, adj_channel_num)
+        self.conv1 = layers.GraphConv(50, adj_channel_num, activation="sigmoid")    # :42-43 tf.sigmoid(layer)
+        self.conv2 = layers.GraphConv(50, adj_channel_num, activation="sigmoid")    # :44-45
         self.conv3 = layers.GraphConv(50, adj_channel_num)
         self.bn = GraphBatchNormalization()
-        self.dense = layers.GraphDense(50)
+        self.dense = layers.GraphDense(50, activation="sigmoid")                    # :52-53
         self.gather = layers.GraphGather()
         self.out = KerasDense(num_classes)
 
     def forward(self, features, adjs, enabled_node_nums=None):
         layer = self.conv1(features, adj=adjs)
-        layer = torch.sigmoid(layer)
         layer = self.conv2(layer, adj=adjs)
-        layer = torch.sigmoid(layer)
         layer = self.conv3(layer, adj=adjs)
         layer = self.bn(layer, max_node_num=features.shape[1], enabled_node_nums=enabled_node_nums)
-        layer = torch.sigmoid(layer)
+        layer = ops.activation(layer, "sigmoid")
         # K.layers.Dropout(dropout_rate): identity (Q6)
         layer = self.dense(layer)
-        layer = torch.sigmoid(layer)
         layer = self.gather(layer)
         return self.out(layer)
 
@@ -84,7 +84,7 @@ class GIN(nn.Module):
     def __init__(self, adj_channel_num=1, num_classes=2):
         super().__init__()
         self.agg = nn.ModuleList([layers.GINAggregate(adj_channel_num) for _ in range(2)])
-        self.dense = nn.ModuleList([layers.GraphDense(50) for _ in range(4)])
+        self.dense = nn.ModuleList([layers.GraphDense(50, activation="relu") for _ in range(4)])   # :45-54 tf.nn.relu
         self.gather = layers.GraphGather()
         self.out = KerasDense(num_classes)
 
@@ -93,8 +93,8 @@ class GIN(nn.Module):
         outs = []
         for blk in range(2):
             layer = self.agg[blk](layer, adj=adjs)
-            layer = torch.relu(self.dense[2 * blk](layer))
-            layer = torch.relu(self.dense[2 * blk + 1](layer))
+            layer = self.dense[2 * blk](layer)
+            layer = self.dense[2 * blk + 1](layer)
             outs.append(layer)
         read_out = [self.gather(o) for o in outs]
         return self.out(torch.cat(read_out, dim=1))
@@ -125,23 +125,23 @@ class MultitaskGCN(nn.Module):
 
     def __init__(self, adj_channel_num=1, label_dim=12):
         super().__init__()
-        self.conv1 = layers.GraphConv(256, adj_channel_num)
-        self.conv2 = layers.GraphConv(256, adj_channel_num)
-        self.dense1 = layers.GraphDense(256)
+        self.conv1 = layers.GraphConv(256, adj_channel_num, activation="sigmoid")   # :51-52
+        self.conv2 = layers.GraphConv(256, adj_channel_num, activation="sigmoid")   # :53-54
+        self.dense1 = layers.GraphDense(256, activation="sigmoid")                  # :55-56
         self.conv3 = layers.GraphConv(50, adj_channel_num)
         self.bn = layers.GraphBatchNormalization()
-        self.dense2 = layers.GraphDense(50)
+        self.dense2 = layers.GraphDense(50, activation="sigmoid")                   # :61-62
         self.gather = layers.GraphGather()
         self.out = KerasDense(label_dim)
 
     def forward(self, features, adjs, enabled_node_nums=None):
-        layer = torch.sigmoid(self.conv1(features, adj=adjs))
-        layer = torch.sigmoid(self.conv2(layer, adj=adjs))
-        layer = torch.sigmoid(self.dense1(layer))
+        layer = self.conv1(features, adj=adjs)
+        layer = self.conv2(layer, adj=adjs)
+        layer = self.dense1(layer)
         layer = self.conv3(layer, adj=adjs)
         layer = self.bn(layer, max_node_num=features.shape[1], enabled_node_nums=enabled_node_nums)
-        layer = torch.sigmoid(layer)
-        layer = torch.sigmoid(self.dense2(layer))
+        layer = ops.activation(layer, "sigmoid")
+        layer = self.dense2(layer)
         layer = self.gather(layer)
         return self.out(layer)                      # prediction = sigmoid(logits)
 
@@ -153,7 +153,8 @@ class SparseGCN(nn.Module):
     def __init__(self, num_classes, adj_channel_num=1, out_dims=(256, 256, 256), dense_dim=256,
                  batch_normalize=False, max_pool=False):
         super().__init__()
-        self.convs = nn.ModuleList([layers.GraphConv(o, adj_channel_num) for o in out_dims])
+        fuse = None if (batch_normalize or max_pool) else "relu"        # relu directly behind the layer: in its epilogue
+        self.convs = nn.ModuleList([layers.GraphConv(o, adj_channel_num, activation=fuse) for o in out_dims])
         self.pools = nn.ModuleList([layers.GraphMaxPooling(adj_channel_num) for _ in out_dims]) if max_pool else None
         self.bns = nn.ModuleList([layers.GraphBatchNormalization() for _ in out_dims]) if batch_normalize else None
         self.dense = layers.GraphDense(dense_dim)
@@ -169,8 +170,9 @@ class SparseGCN(nn.Module):
                 net = self.pools[i](net, batch.adjacency)
             if self.bns is not None:
                 net = self.bns[i](net)
-            net = torch.relu(net)
-        net = torch.relu(self.bn(self.dense(net)))[0]
+            if conv.activation is None:
+                net = ops.activation(net, "relu")
+        net = ops.activation(self.bn(self.dense(net)), "relu")[0]
         net = ops.bspmm(batch.segments, net.unsqueeze(0))       # per-molecule node sum (:83-94)
         net = torch.tanh(net.reshape(len(batch.sizes), -1))
         return self.out(net)                                    # probabilities = softmax(logits)

@@ -15,6 +15,18 @@ from ._lib import check, current_stream, lib, ptr, require_gpu
 from .batched_csr import BatchedAdjacency, BatchedCSR
 
 
+ACT_CODES = {None: 0, "none": 0, "linear": 0, "sigmoid": 1, "relu": 2, "tanh": 3}
+
+
+def act_code(activation):
+    """KGCN_ACT_* code of an activation given by name (the ones the reference's models use: tf.sigmoid, tf.nn.relu,
+    tf.tanh) or None."""
+    try:
+        return ACT_CODES[activation]
+    except KeyError:
+        raise ValueError("unsupported activation %r (None, 'sigmoid', 'relu', 'tanh')" % (activation,)) from None
+
+
 def _f32c(t, name):
     require_gpu(t, name)
     if t.dtype != torch.float32:
@@ -92,9 +104,11 @@ def bspmm(csr, rhs, values=None):
 # -------------------------------------------------------------------------------------------------
 class _BConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rhs, adj, d, *values):
+    def forward(ctx, rhs, adj, d, act, *values):
         # values: nothing, or one tensor per channel -- the channel's adjacency values as differentiable inputs
         # (fp32 [nnz_c], CSR order), None for a channel whose stored values are used
+        # act: KGCN_ACT_* code applied to the aggregated output inside the kernel (its derivative, expressed in the
+        # output, rides in the adjoint aggregation of the backward)
         rhs = _f32c(rhs, "rhs")
         C = adj.num_channels
         T, M, K = adj.num_graphs, adj.n_nodes, adj.channels[0].cols
@@ -106,17 +120,17 @@ class _BConv(torch.autograd.Function):
             adj = BatchedAdjacency([ch if v is None else ch.with_values(_f32c(v, "values"))
                                     for ch, v in zip(adj.channels, values)])
         out = torch.empty((T * M, d), device=rhs.device, dtype=torch.float32)
-        check(lib.kgcn_bconv_f32(adj.desc_array(False), C, ptr(rhs), C * d, K * C * d, d, d,
-                                 ptr(out), d, M * d, current_stream()), "kgcn_bconv_f32")
-        ctx.adj, ctx.d = adj, d
+        check(lib.kgcn_bconv_act_f32(adj.desc_array(False), C, ptr(rhs), C * d, K * C * d, d, d,
+                                     ptr(out), d, M * d, int(act), current_stream()), "kgcn_bconv_act_f32")
+        ctx.adj, ctx.d, ctx.act = adj, d, int(act)
         ctx.nvalues = len(values)
-        ctx.save_for_backward(rhs)
+        ctx.save_for_backward(rhs, out if act else rhs)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        adj, d = ctx.adj, ctx.d
-        (rhs,) = ctx.saved_tensors
+        adj, d, act = ctx.adj, ctx.d, ctx.act
+        rhs, aout = ctx.saved_tensors
         g = _f32c(g, "grad")
         C = adj.num_channels
         T, M, K = adj.num_graphs, adj.n_nodes, adj.channels[0].cols
@@ -124,12 +138,19 @@ class _BConv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             d_rhs = torch.empty((T * K, C * d), device=g.device, dtype=torch.float32)
             for c, ch in enumerate(adj.channels):        # addn_grad: g fans out to every channel
-                bspmm_raw(ch.transpose(), g, d, d_rhs, out_ld=C * d, out_gs=K * C * d, out_col=c * d)
+                if act:                                  # d pre-activation = g * act'(out), formed while it is gathered
+                    check(lib.kgcn_bspmm_dact_f32(ch.transpose().desc(), ptr(g), ptr(aout), d, M * d, d, act,
+                                                  d_rhs.data_ptr() + 4 * c * d, C * d, K * C * d, 0.0, current_stream()),
+                          "kgcn_bspmm_dact_f32")
+                else:
+                    bspmm_raw(ch.transpose(), g, d, d_rhs, out_ld=C * d, out_gs=K * C * d, out_col=c * d)
+        if act and ctx.nvalues and any(ctx.needs_input_grad[4:]):
+            g = activation_backward(aout, g, act)        # d values needs d pre-activation as a tensor
         d_vals = []
         for c in range(ctx.nvalues):
             # kgcn/bconv_call.py:55-67: d values[t][e] = <addn_grad[t][row_e], b[t][col_e]> per graph-channel -- one
             # gather-multiply-reduce launch per channel over the whole batch, the channel's columns of rhs as b
-            if not ctx.needs_input_grad[3 + c]:
+            if not ctx.needs_input_grad[4 + c]:
                 d_vals.append(None)
                 continue
             ch = adj.channels[c]
@@ -138,22 +159,66 @@ class _BConv(torch.autograd.Function):
                                                 K * C * d, d, ptr(dv), current_stream()),
                   "kgcn_spmm_values_grad_f32(bconv)")
             d_vals.append(dv)
-        return (d_rhs, None, None) + tuple(d_vals)
+        return (d_rhs, None, None, None) + tuple(d_vals)
 
 
-def bconv(adj, rhs_cat, d, values=None):
-    """values: optional list with one differentiable fp32 [nnz_c] tensor (CSR order) or None per channel."""
+def bconv(adj, rhs_cat, d, values=None, activation=None):
+    """values: optional list with one differentiable fp32 [nnz_c] tensor (CSR order) or None per channel.
+    activation: None / 'sigmoid' / 'relu' / 'tanh' applied to the aggregated output inside the kernel."""
+    act = act_code(activation)
     if values is None:
-        return _BConv.apply(rhs_cat, adj, d)
-    return _BConv.apply(rhs_cat, adj, d, *values)
+        return _BConv.apply(rhs_cat, adj, d, act)
+    return _BConv.apply(rhs_cat, adj, d, act, *values)
+
+
+# -------------------------------------------------------------------------------------------------
+# stand-alone activation (where no producer kernel can carry it) and the backward of every fused activation
+# -------------------------------------------------------------------------------------------------
+def activation_backward(act_out, grad, act):
+    """grad * act'(.) with the derivative expressed in the activation OUTPUT; returns a new tensor."""
+    act_out, grad = _f32c(act_out, "activation output"), _f32c(grad, "grad")
+    dpre = torch.empty_like(grad)
+    check(lib.kgcn_act_bwd_f32(ptr(act_out), ptr(grad), grad.numel(), int(act), ptr(dpre), current_stream()),
+          "kgcn_act_bwd_f32")
+    return dpre
+
+
+class _Activation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        x = _f32c(x, "inputs")
+        y = torch.empty_like(x)
+        check(lib.kgcn_act_fwd_f32(ptr(x), x.numel(), int(act), ptr(y), current_stream()), "kgcn_act_fwd_f32")
+        ctx.act = int(act)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return activation_backward(y, g, ctx.act), None
+
+
+def activation(x, name):
+    """tf.sigmoid / tf.nn.relu / tf.tanh as one HIP elementwise kernel (forward) and one (backward)."""
+    act = act_code(name)
+    return x if act == 0 else _Activation.apply(x, act)
 
 
 # -------------------------------------------------------------------------------------------------
 # dense contraction
 # -------------------------------------------------------------------------------------------------
+def _dense_ws(din, dout, device):
+    """Workspace of the wide-layer GEMM (pre-split weight fragments): (bytes, tensor or None)."""
+    wsb = lib.kgcn_dense_fwd_workspace_bytes(din, dout)
+    if wsb <= 0:
+        return 0, None
+    return wsb, torch.empty((wsb // 4,), device=device, dtype=torch.float32)
+
+
 class _Dense(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x2d, w, bias):
+    def forward(ctx, x2d, w, bias, act=0):
         x2d, w = _f32c(x2d, "x"), _f32c(w, "w")
         m, din = x2d.shape
         dout = w.shape[1]
@@ -163,24 +228,29 @@ class _Dense(torch.autograd.Function):
         if b is not None and b.numel() != dout:
             raise _lib.KgcnHipError("bias has %d elements, expected %d" % (b.numel(), dout))
         y = torch.empty((m, dout), device=x2d.device, dtype=torch.float32)
-        check(lib.kgcn_dense_fwd_f32(ptr(x2d), m, din, din, ptr(w), dout, 0, ptr(b), ptr(y), dout,
-                                     dout, current_stream()), "kgcn_dense_fwd_f32")
-        ctx.save_for_backward(x2d, w)
+        wsb, wsp = _dense_ws(din, dout, x2d.device)
+        check(lib.kgcn_dense_fwd_ws_f32(ptr(x2d), m, din, din, ptr(w), dout, 0, ptr(b), ptr(y), dout,
+                                        dout, int(act), ptr(wsp), wsb, current_stream()), "kgcn_dense_fwd_ws_f32")
+        ctx.act = int(act)
+        ctx.save_for_backward(x2d, w, y if act else x2d)
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x2d, w = ctx.saved_tensors
+        x2d, w, yact = ctx.saved_tensors
         gy = _f32c(gy, "grad")
+        if ctx.act:                                  # d pre-activation, read by both GEMMs of the backward
+            gy = activation_backward(yact, gy, ctx.act)
         m, din = x2d.shape
         dout = w.shape[1]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x2d)
             # dx = gy @ w^T : w [din, dout] used transposed
-            check(lib.kgcn_dense_fwd_f32(ptr(gy), m, dout, dout, ptr(w), dout, 1, None, ptr(dx),
-                                         din, din, current_stream()), "kgcn_dense_fwd_f32(dx)")
+            wsb, wsp = _dense_ws(dout, din, gy.device)
+            check(lib.kgcn_dense_fwd_ws_f32(ptr(gy), m, dout, dout, ptr(w), dout, 1, None, ptr(dx),
+                                            din, din, 0, ptr(wsp), wsb, current_stream()), "kgcn_dense_fwd_ws_f32(dx)")
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.bias_shape is not None and ctx.needs_input_grad[2]
         if need_w or need_b:
@@ -193,11 +263,12 @@ class _Dense(torch.autograd.Function):
                   "kgcn_dense_wgrad_f32")
             if db is not None:
                 db = db.reshape(ctx.bias_shape)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def dense(x2d, w, bias=None):
-    return _Dense.apply(x2d, w, bias)
+def dense(x2d, w, bias=None, activation=None):
+    """y = act(x2d @ w + bias); the activation rides in the GEMM epilogue."""
+    return _Dense.apply(x2d, w, bias, act_code(activation))
 
 
 # -------------------------------------------------------------------------------------------------
@@ -445,7 +516,7 @@ def graph_gather(x):
     return _Gather.apply(x)
 
 
-__all__ = ["BatchedCSR", "BatchedAdjacency", "bspmm", "bspmm_raw", "bconv", "dense",
+__all__ = ["BatchedCSR", "BatchedAdjacency", "bspmm", "bspmm_raw", "bconv", "dense", "activation", "act_code",
            "graphconv_fused", "graphconv_fused_supported", "gin_aggregate", "graph_gather",
            "graph_maxpool", "gat", "gram"]
 

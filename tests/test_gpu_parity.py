@@ -179,6 +179,79 @@ def test_op_wrappers_api():
         close(r[b].grad, rg[b], what="d rhs[%d]" % b)
 
 
+def _np_act(v, name):
+    if name == "sigmoid":
+        return 1.0 / (1.0 + np.exp(-v))
+    if name == "relu":
+        return np.maximum(v, 0)
+    if name == "tanh":
+        return np.tanh(v)
+    return v
+
+
+def _np_dact(a, name):
+    return {"sigmoid": a * (1 - a), "relu": (a > 0).astype(np.float64), "tanh": 1 - a * a}.get(name, np.ones_like(a))
+
+
+@pytest.mark.parametrize("act", ["sigmoid", "relu", "tanh"])
+@pytest.mark.parametrize("N,D,channels", [(10, 16, "split"), (10, 50, "split"), (50, 256, "one"), (10, 64, "norm")])
+def test_fused_activation_aggregation(act, N, D, channels):
+    """out = act(sum_c A_c @ rhs_c) in ONE launch (channel loop + activation epilogue; tile kernel for small graphs with
+    d % 4 == 0, gather kernel otherwise) and its backward (act' formed while the gradient is gathered), against the
+    oracle: bconv followed by the model's elementwise op (example_model/model.py:42-43)."""
+    from kgcn_amd import BatchedAdjacency, ops
+    rng = np.random.default_rng(N * D)
+    if channels == "one":
+        B = 40
+        adjs = K.synth_mol_graphs(rng, B, N, 3, normalize=True)
+    else:
+        _, adjs = synthetic_batch("b30", channels)
+        B = 30
+    C = len(adjs[0])
+    rhs = [[rng.standard_normal((N, D)).astype(np.float32) for _ in range(C)] for _ in range(B)]
+    g = rng.standard_normal((B, N, D)).astype(np.float32)
+    adj = BatchedAdjacency.from_adjs(adjs, n_nodes=N, device=dev())
+    cat = np.stack([np.concatenate(r, 1) for r in rhs]).reshape(B * N, C * D)
+    tr = t32(cat).requires_grad_(True)
+    out = ops.bconv(adj, tr, D, activation=act)
+    pre = np.stack(K.bconv(adjs, rhs))
+    ref = _np_act(pre, act)
+    close(out.reshape(B, N, D), ref, rel=1e-6, what="act(bconv) " + act)
+    out.backward(t32(g).reshape(B * N, D))
+    _, rg = K.bconv_grad(adjs, rhs, list(g * _np_dact(ref, act)))
+    want = np.stack([np.concatenate(r, 1) for r in rg]).reshape(B * N, C * D)
+    close(tr.grad, want, rel=1e-6, what="d rhs through act(bconv) " + act)
+
+
+@pytest.mark.parametrize("act", ["sigmoid", "relu", "tanh"])
+@pytest.mark.parametrize("M,din,dout", [(300, 50, 50), (1000, 64, 64), (777, 81, 256), (513, 256, 256), (64, 512, 96)])
+def test_fused_activation_dense(act, M, din, dout):
+    """y = act(x W + b) in the GEMM epilogue of all three dense kernels (f32-MFMA tiled / persistent, bf16-split), and
+    the backward through it, against numpy."""
+    from kgcn_amd import ops
+    rng = np.random.default_rng(M + din)
+    x = rng.standard_normal((M, din)).astype(np.float32)
+    w = K.glorot_uniform(rng, din, dout)
+    b = rng.standard_normal(dout).astype(np.float32)
+    g = rng.standard_normal((M, dout)).astype(np.float32)
+    tx, tw, tb = t32(x).requires_grad_(True), t32(w).requires_grad_(True), t32(b).requires_grad_(True)
+    y = ops.dense(tx, tw, tb, activation=act)
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    ref = _np_act(x64 @ w64 + b, act)
+    close(y, ref, rel=2e-6, what="act(dense) " + act)
+    y.backward(t32(g))
+    gz = g * _np_dact(ref, act)
+    close(tx.grad, gz @ w64.T, rel=2e-6, what="dx")
+    close(tw.grad, x64.T @ gz, rel=1e-5, what="dw")
+    close(tb.grad, gz.sum(0), rel=1e-5, what="db")
+    # the stand-alone activation op
+    tz = t32(x).requires_grad_(True)
+    a = ops.activation(tz, act)
+    close(a, _np_act(x64, act), rel=1e-6)
+    a.backward(t32(x))
+    close(tz.grad, x64 * _np_dact(_np_act(x64, act), act), rel=1e-6)
+
+
 def test_bconv_and_bspmdt_values_gradients():
     """kgcn/bconv_call.py:55-67 and kgcn/batched_call.py:66-73 register a gradient for the sparse VALUES of every
     graph-channel (gather rows of the output gradient, gather rows of the dense operand, multiply, reduce): through

@@ -82,15 +82,15 @@ def cfg5():
     adj = BatchedAdjacency([BatchedCSR.from_coo_list(mats, rows=N, cols=N, device=dev)])
     x = torch.randn(B, N, Dm, device=dev, requires_grad=True)
     gin = [layers.GINAggregate(1).to(dev) for _ in range(2)]
-    dn = [layers.GraphDense(Dm).to(dev) for _ in range(4)]
+    dn = [layers.GraphDense(Dm, activation="relu").to(dev) for _ in range(4)]      # tf.nn.relu(GraphDense(..)), model_gin.py:45-54
     gather = layers.GraphGather()
 
     def fwd():
         h, outs = x, []
         for blk in range(2):
             h = gin[blk](h, adj=adj)
-            h = torch.relu(dn[2 * blk](h))
-            h = torch.relu(dn[2 * blk + 1](h))
+            h = dn[2 * blk](h)
+            h = dn[2 * blk + 1](h)
             outs.append(gather(h))
         return torch.cat(outs, 1)
     fwd()
