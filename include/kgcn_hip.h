@@ -252,9 +252,10 @@ int kgcn_dense_fwd_act_f32(const float* x, int64_t m, int32_t din, int64_t x_ld,
                            int32_t trans_w, const float* bias, float* y, int32_t dout, int64_t y_ld, int32_t act,
                            void* stream);
 /* The same contraction with a caller-provided workspace of kgcn_dense_fwd_workspace_bytes(din, dout) bytes (0 for
- * layers that do not use one): wide layers (dout > 128, din >= 64: the 256-wide layers of example_model/
- * model_multitask.py:51-57 and sparse.py:30) then run the register-resident bf16-split GEMM of csrc/gemm4.hip, whose
- * weight operand is split once per call into a fragment table in that workspace.  workspace == NULL: kgcn_dense_fwd_act_f32. */
+ * layers that do not use one): for wide layers (dout > 128, din >= 192: the 256-wide layers of example_model/
+ * model_multitask.py:51-57 and sparse.py:30) the weight operand is split once per call into a bf16 fragment table in
+ * that workspace (csrc/wtable.hip) which the GEMM reads instead of splitting W in every workgroup.
+ * workspace == NULL: kgcn_dense_fwd_act_f32. */
 int64_t kgcn_dense_fwd_workspace_bytes(int32_t din, int32_t dout);
 int kgcn_dense_fwd_ws_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w, int64_t w_ld,
                           int32_t trans_w, const float* bias, float* y, int32_t dout, int64_t y_ld, int32_t act,

@@ -15,16 +15,23 @@
 // The K index is permuted (half hi = l>>5 owns k in [16*hi, 16*hi+16) of every 32-wide chunk) so
 // that a lane's 16 A values are contiguous in LDS (4 x ds_read_b128 instead of 16 x ds_read_b32);
 // A and B use the same permutation, so the sum over k is unchanged.
+#include <cstdlib>
+#include <cstring>
+
 #include "kgcn_common.h"
 
 namespace kgcn {
 
 int launch_gemm3_fwd(const float* x, long m, int din, long x_ld, const float* w, long w_ld, int trans_w,
-                     const float* bias, float* y, int dout, long y_ld, int act, hipStream_t s);
-int64_t gemm4_workspace_bytes(int din, int dout);
-int launch_gemm4_fwd(const float* x, long m, int din, long x_ld, const float* w, long w_ld, int trans_w,
-                     const float* bias, float* y, int dout, long y_ld, int act, void* workspace, long* rows_done,
-                     hipStream_t s);
+                     const float* bias, float* y, int dout, long y_ld, int act, const void* table, hipStream_t s);
+bool narrow_fwd_ok(const float* x, int din, long x_ld, const float* y, int dout, long y_ld);
+int launch_narrow_fwd(const float* x, long m, int din, const float* w, long w_ld, int trans_w, const float* bias,
+                      float* y, int dout, int act, hipStream_t s);
+bool narrow_wgrad_ok(const float* x, int din, long x_ld, const float* dy, int dout, long dy_ld);
+int launch_narrow_wgrad(const float* x, const float* dy, long m, int din, int dout, float* part_dw, float* part_db,
+                        int nblocks, hipStream_t s);
+int64_t wtable_bytes(int din, int dout);
+void launch_wtable_split(const float* w, long w_ld, int trans_w, int din, int dout, void* workspace, hipStream_t s);
 int launch_gemm3_wgrad(const float* x, long x_ld, const float* dy, long dy_ld, long m, int din, int dout,
                        float* part_dw, float* part_db, int nblocks, hipStream_t s);
 
@@ -486,12 +493,12 @@ int launch_reduce_partials2(const float* part, int nparts, long n, float* out, c
 
 using namespace kgcn;
 
-// wide layers take the bf16-split GEMMs: the register-resident kernel of gemm4.hip when the caller provides the
-// workspace for the pre-split weight fragments, the LDS-staged kernel of gemm3.hip otherwise
-static bool wide_layer(int din, int dout) { return dout > 128 && din >= 64; }
-// where the register-resident kernel measured ahead of the LDS-staged one (tools/gemm_bench.py, 204,800 rows:
-// 256 -> 256 +10% forward / +5% dX, 512 -> 256 +2% / -3%, 256 -> 512 -1%, 128 -> 256 and ragged din behind)
-static bool gemm4_pays(int din, int dout) { return din % 16 == 0 && din >= 256 && dout % 64 == 0 && dout <= 256; }
+// wide layers take the bf16-split GEMM of gemm3.hip (W pre-split into the fragment table of wtable.hip when the caller
+// provides the workspace for it)
+static bool wide_layer(int din, int dout) { return dout > 128 && din >= 32; }
+// where reading W pre-split from the fragment table measured ahead of splitting it inside the kernel (tools/gemm_bench.py,
+// 204,800 rows: 256 -> 256 +15% forward / +5% dX, 512 -> 256 +5% / -3%, 256 -> 512 +2%; 128 -> 256 -14%: few k-steps)
+static bool table_pays(int din, int dout) { return wide_layer(din, dout) && din >= 192; }
 
 static int dense_fwd_impl(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w, int64_t w_ld,
                           int32_t trans_w, const float* bias, float* y, int32_t dout, int64_t y_ld, int act,
@@ -503,23 +510,22 @@ static int dense_fwd_impl(const float* x, int64_t m, int32_t din, int64_t x_ld, 
   if (!x || !w || !y) return fail("kgcn_dense_fwd_f32: NULL operand");
   if (x_ld < din || y_ld < dout) return fail("kgcn_dense_fwd_f32: leading dimension too small");
   if (w_ld < (trans_w ? din : dout)) return fail("kgcn_dense_fwd_f32: w_ld too small");
-  if (wide_layer(din, dout) && gemm4_pays(din, dout) && workspace &&
-      workspace_bytes >= gemm4_workspace_bytes(din, dout) && m >= 4096) {
-    long done = 0;
-    const int rc = launch_gemm4_fwd(x, (long)m, din, (long)x_ld, w, (long)w_ld, trans_w, bias, y, dout, (long)y_ld, act,
-                                    workspace, &done, as_stream(stream));
-    if (rc > 0) return rc;
-    if (rc == 0) {                      // whole 128-row blocks done; the remaining rows (< 128) take the tiled kernel
-      if (done == m) return 0;
-      x += done * x_ld;
-      y += done * y_ld;
-      m -= done;
+  // wide layers: f32-MFMA bound -> the bf16-split GEMM (gemm3.hip).  With a workspace W is split ONCE into a fragment
+  // table (wtable.hip) that the waves read from L2, and the kernel's staging only splits x.
+  if (wide_layer(din, dout)) {
+    static const char* route = getenv("KGCN_DENSE_ROUTE");         // development: "gemm3" = never use the table
+    const void* table = nullptr;
+    if (!(route && !strcmp(route, "gemm3")) && table_pays(din, dout) && workspace &&
+        workspace_bytes >= wtable_bytes(din, dout) && m >= 1024) {
+      launch_wtable_split(w, (long)w_ld, trans_w, din, dout, workspace, as_stream(stream));
+      table = workspace;
     }
-  }
-  // wide layers: f32-MFMA bound -> the bf16-split GEMM (gemm3.hip)
-  if (wide_layer(din, dout))
-    return launch_gemm3_fwd(x, (long)m, din, (long)x_ld, w, (long)w_ld, trans_w, bias, y, dout, (long)y_ld, act,
+    return launch_gemm3_fwd(x, (long)m, din, (long)x_ld, w, (long)w_ld, trans_w, bias, y, dout, (long)y_ld, act, table,
                             as_stream(stream));
+  }
+  // 50-wide layers: flat tile movement (narrow.hip)
+  if (narrow_fwd_ok(x, din, (long)x_ld, y, dout, (long)y_ld))
+    return launch_narrow_fwd(x, (long)m, din, w, (long)w_ld, trans_w, bias, y, dout, act, as_stream(stream));
   {
     // fast path: weight panel [din_pad x 64] resident in LDS next to 8 per-wave x tiles
     const int kp = ((din + 63) / 64) * 64;
@@ -562,14 +568,27 @@ extern "C" int kgcn_dense_fwd_f32(const float* x, int64_t m, int32_t din, int64_
 }
 
 extern "C" int64_t kgcn_dense_fwd_workspace_bytes(int32_t din, int32_t dout) {
-  if (din <= 0 || dout <= 0 || !wide_layer(din, dout) || !gemm4_pays(din, dout)) return 0;
-  return gemm4_workspace_bytes(din, dout);
+  if (din <= 0 || dout <= 0 || !table_pays(din, dout)) return 0;
+  return wtable_bytes(din, dout);
 }
 
 extern "C" int kgcn_dense_fwd_ws_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w, int64_t w_ld,
                                      int32_t trans_w, const float* bias, float* y, int32_t dout, int64_t y_ld,
                                      int32_t act, void* workspace, int64_t workspace_bytes, void* stream) {
   return dense_fwd_impl(x, m, din, x_ld, w, w_ld, trans_w, bias, y, dout, y_ld, act, workspace, workspace_bytes, stream);
+}
+
+// dW and dbias partials of one layer in ONE launch (either output may be NULL)
+static int launch_reduce_pair(const float* part_dw, long n_dw, float* dw, const float* part_db, long n_db, float* dbias,
+                              int nparts, hipStream_t s) {
+  if (dw && dbias) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n_dw + n_db + 31) / 32)), dim3(256), 0, s, part_dw,
+                       nparts, n_dw, dw, part_db, n_db, dbias);
+    return check_launch("reduce_partials_kernel");
+  }
+  if (dw) return launch_reduce_partials(part_dw, nparts, n_dw, dw, s);
+  if (dbias) return launch_reduce_partials(part_db, nparts, n_db, dbias, s);
+  return 0;
 }
 
 extern "C" int kgcn_dense_fwd_act_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w,
@@ -617,11 +636,15 @@ extern "C" int kgcn_dense_wgrad_f32(const float* x, int64_t x_ld, const float* d
     float* part_db = part_dw + nb * din * dout;
     if (int rc = launch_gemm3_wgrad(x, (long)x_ld, dy, (long)dy_ld, (long)m, din, dout, part_dw, part_db, (int)nb, s))
       return rc;
-    if (dw)
-      if (int rc = launch_reduce_partials(part_dw, (int)nb, (long)din * dout, dw, s)) return rc;
-    if (dbias)
-      if (int rc = launch_reduce_partials(part_db, (int)nb, dout, dbias, s)) return rc;
-    return 0;
+    return launch_reduce_pair(part_dw, (long)din * dout, dw, part_db, dout, dbias, (int)nb, s);
+  }
+  if (narrow_wgrad_ok(x, din, (long)x_ld, dy, dout, (long)dy_ld)) {
+    // 50-wide layers: flat tile movement (narrow.hip), one partial per workgroup
+    nchunks = persist_blocks(m);
+    float* part_dw = static_cast<float*>(workspace);
+    float* part_db = part_dw + (long)nchunks * din * dout;
+    if (int rc = launch_narrow_wgrad(x, dy, (long)m, din, dout, part_dw, part_db, nchunks, s)) return rc;
+    return launch_reduce_pair(part_dw, (long)din * dout, dw, part_db, dout, dbias, nchunks, s);
   }
   {
     // persistent kernel: one workgroup (8 waves) per CU and per 64x64 output block
@@ -649,11 +672,7 @@ extern "C" int kgcn_dense_wgrad_f32(const float* x, int64_t x_ld, const float* d
       hipLaunchKernelGGL(dense_wgrad_persist_kernel<false>, grid, dim3(64 * P_WAVES), lds_use, s, x, (long)x_ld, dy,
                          (long)dy_ld, (long)m, din, dout, part_dw, part_db);
     if (int rc = check_launch("dense_wgrad_persist_kernel")) return rc;
-    if (dw)
-      if (int rc = launch_reduce_partials(part_dw, nchunks, (long)din * dout, dw, s)) return rc;
-    if (dbias)
-      if (int rc = launch_reduce_partials(part_db, nchunks, dout, dbias, s)) return rc;
-    return 0;
+    return launch_reduce_pair(part_dw, (long)din * dout, dw, part_db, dout, dbias, nchunks, s);
   }
   wgrad_plan(m, &rpc, &nchunks);
   float* part_dw = static_cast<float*>(workspace);

@@ -1321,7 +1321,8 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_planes_kernel(
       static_for<48>([&](auto mc) __attribute__((always_inline)) {
         constexpr int m = decltype(mc)::value, ks = m / 12, pr = (m % 12) >> 1, nt = m & 1;
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-        const u32x4 wv = PB[pr] == 0 ? WF1[nt][ks] : WL[ks][PB[pr] - 1][nt];
+        constexpr int wl = PB[pr] == 0 ? 0 : PB[pr] - 1;
+        const u32x4 wv = PB[pr] == 0 ? WF1[nt][ks] : WL[ks][wl][nt];
         if constexpr (nt == 0) c0 = mfma_bf16(wv, FA[ks][PA[pr]], c0);
         else c1 = mfma_bf16(wv, FA[ks][PA[pr]], c1);
         if constexpr (m % 12 == 1 && ks < 3) read_fa(std::integral_constant<int, ks + 1>{});   // one k-step ahead

@@ -72,7 +72,7 @@ struct G3Coord {
   bool wvec;           // transposed source with 16-byte aligned rows and din % 4 == 0
 };
 
-template <bool XVEC>
+template <bool XVEC, bool WTAB = false>
 __device__ __forceinline__ void g3_issue(G3Raw& r, const G3Coord& c, const float* __restrict__ w, int din, int k0) {
   // loads read clamped (always valid) addresses; masking happens when the data is split (g3_land), so no
   // select sits between a load and its first real use
@@ -87,6 +87,7 @@ __device__ __forceinline__ void g3_issue(G3Raw& r, const G3Coord& c, const float
       r.xb[j] = c.xrow[k + 4 + j < din ? k + 4 + j : 0];
     }
   }
+  if constexpr (WTAB) return;      // W arrives pre-split from the fragment table
   if (c.wvec) {          // transposed source, rows 16-byte aligned: 8 k-values = 2 x 16 bytes
     const int ka = k0 + 8 * c.qw[0], kb = k0 + 8 * c.qw[1];
     const f32x4 a0 = *reinterpret_cast<const f32x4*>(w + c.wbase[0] + (ka < din ? ka : 0));
@@ -132,7 +133,11 @@ __device__ __forceinline__ void g3_write(u32x4* table, int tile, int q, int li, 
   d[0] = f.p1; d[G3_FB] = f.p2; d[2 * G3_FB] = f.p3;
 }
 
-template <bool XVEC>
+// WTAB: W comes pre-split from the fragment table of wtable.hip (wtable_split_kernel: one 1 KiB lane-linear block per
+// (k-step, 32-column tile, piece), L2 resident): every wave reads the B fragments of its two column tiles straight into
+// registers one k-step ahead -- no W loads, no W split (2/3 of the staging arithmetic), no W LDS traffic; LDS holds the
+// x pieces only (48 KB).  `w` is then the table.
+template <bool XVEC, bool WTAB>
 __global__ __launch_bounds__(512, 2) void gemm3_fwd_kernel(
     const float* __restrict__ x, long m, int din, long x_ld, const float* __restrict__ w, long w_ld, int trans_w,
     const float* __restrict__ bias, float* __restrict__ y, int dout, long y_ld, int act) {
@@ -185,16 +190,38 @@ __global__ __launch_bounds__(512, 2) void gemm3_fwd_kernel(
   G3Raw ra, rb;
   Frag3 fx, f0, f1;
   // prologue: chunk 0 staged without overlap, chunk 1 requested
+  // WTAB: B fragments of (k-step g, this wave's column tiles); k-steps beyond the table (din % 32 in 1..16) and column
+  // tiles beyond it (dout % 64 in 1..32 under a 256-column block) are clamped: their products meet zero x pieces or
+  // unstored columns
+  constexpr int LBUF = WTAB ? G3_XP : G3_XP + G3_WP;     // u32x4 entries of one LDS buffer
+  const u32x4* wtab = reinterpret_cast<const u32x4*>(w);
+  const int tab_nt = ((dout + 63) / 64) * 2, tab_ks = (din + 15) / 16;
+  u32x4 B0[2][3], B1[2][3];
+  auto load_b = [&](u32x4 (&Bd)[2][3], int g) __attribute__((always_inline)) {
+    const int gg = g < tab_ks ? g : tab_ks - 1;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      int nt = (n0 + 64 * wc) / 32 + t2;
+      nt = nt < tab_nt ? nt : tab_nt - 1;
+      const u32x4* e = wtab + ((long)(gg * tab_nt + nt) * 3) * 64 + lane;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) Bd[t2][p] = e[64 * p];
+    }
+  };
   set_tile(t0);
-  g3_issue<XVEC>(ra, co, w, din, k0c * G3_BK);
-  static_for<12>([&](auto sc) __attribute__((always_inline)) {
+  g3_issue<XVEC, WTAB>(ra, co, w, din, k0c * G3_BK);
+  static_for<(WTAB ? 4 : 12)>([&](auto sc) __attribute__((always_inline)) {
     g3_split_step<decltype(sc)::value>(ra, co, din, k0c * G3_BK, fx, f0, f1);
   });
   g3_write(lds, xr >> 5, co.qx, xr & 31, fx);
-  g3_write(lds + G3_XP, (tid & 255) >> 5, co.qw[0], tid & 31, f0);
-  g3_write(lds + G3_XP, (tid & 255) >> 5, co.qw[1], tid & 31, f1);
+  if constexpr (!WTAB) {
+    g3_write(lds + G3_XP, (tid & 255) >> 5, co.qw[0], tid & 31, f0);
+    g3_write(lds + G3_XP, (tid & 255) >> 5, co.qw[1], tid & 31, f1);
+  } else {
+    load_b(B0, 0);
+  }
   set_tile(t1 < ntiles ? t1 : t0);
-  g3_issue<XVEC>(rb, co, w, din, (t1 < ntiles ? k1c : k0c) * G3_BK);
+  g3_issue<XVEC, WTAB>(rb, co, w, din, (t1 < ntiles ? k1c : k0c) * G3_BK);
   __syncthreads();
 
   f32x16 acc[2][2];
@@ -224,10 +251,12 @@ __global__ __launch_bounds__(512, 2) void gemm3_fwd_kernel(
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[mt][nt][r] = bcol[nt];
     }
-    const u32x4* xp = lds + buf * (G3_XP + G3_WP);
+    const u32x4* xp = lds + buf * LBUF;
     const u32x4* wp = xp + G3_XP;
-    u32x4* xq = lds + (buf ^ 1) * (G3_XP + G3_WP);
+    u32x4* xq = lds + (buf ^ 1) * LBUF;
     u32x4* wq = xq + G3_XP;
+    // k-step after this chunk's second one: first of the next chunk of the tile, or of the next tile (k-step 0)
+    const int gnext = (k0c + 1 < nkc) ? 2 * (k0c + 1) : 0;
     G3Coord cs = co;
     cs.rowok = rowok_split;
     G3P(0)
@@ -239,14 +268,22 @@ __global__ __launch_bounds__(512, 2) void gemm3_fwd_kernel(
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
           A[t2][p] = xp[g3_slot(2 * wr + t2, ks, p, li, hi)];
-          B[t2][p] = wp[g3_slot(2 * wc + t2, ks, p, li, hi)];
+          if constexpr (!WTAB) B[t2][p] = wp[g3_slot(2 * wc + t2, ks, p, li, hi)];
+          else B[t2][p] = ks == 0 ? B0[t2][p] : B1[t2][p];
         }
       static_for<24>([&](auto mc) __attribute__((always_inline)) {
         constexpr int mm = decltype(mc)::value, pr = mm >> 2, tl4 = mm & 3, slot = 24 * ks + mm;
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
         acc[tl4 >> 1][tl4 & 1] = mfma_bf16(A[tl4 >> 1][PA[pr]], B[tl4 & 1][PB[pr]], acc[tl4 >> 1][tl4 & 1]);
         // ---- one slice of the staging work behind every MFMA (the matrix pipe runs beside the VALU) ----
-        if constexpr (slot < 12) {
+        if constexpr (WTAB && mm == 1) {
+          // the other fragment set <- the k-step after this one (its previous contents were consumed one k-step ago)
+          if constexpr (ks == 0) load_b(B1, 2 * k0c + 1);
+          else load_b(B0, gnext);
+        }
+        if constexpr (WTAB && slot >= 4 && slot < 12) {
+        } else if constexpr (WTAB && (slot == 13 || slot == 14)) {
+        } else if constexpr (slot < 12) {
           g3_split_step<slot>(RS, cs, din, ks1, fx, f0, f1);
         } else if constexpr (slot == 12) {
           g3_write(xq, xr >> 5, co.qx, xr & 31, fx);
@@ -257,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_fwd_kernel(
         } else if constexpr (slot == 16) {
           co.xrow = xrow_l;
           co.rowok = rowok_l;
-          g3_issue<XVEC>(RL, co, w, din, kl * G3_BK);
+          g3_issue<XVEC, WTAB>(RL, co, w, din, kl * G3_BK);
         } else if constexpr (slot == 18) {
           // one more chunk of x on its way from HBM: a single k chunk per workgroup in flight (16 KB) caps the
           // read rate at ~2 TB/s (latency x bytes in flight); this 4-byte load per 32-byte piece pulls the line
@@ -331,25 +368,42 @@ __global__ __launch_bounds__(512, 2) void gemm3_fwd_kernel(
   G3P_FLUSH
 }
 
+// table == nullptr: W is split inside the kernel; else `table` is the fragment table of wtable.hip for (w, trans_w)
 int launch_gemm3_fwd(const float* x, long m, int din, long x_ld, const float* w, long w_ld, int trans_w,
-                     const float* bias, float* y, int dout, long y_ld, int act, hipStream_t s) {
+                     const float* bias, float* y, int dout, long y_ld, int act, const void* table, hipStream_t s) {
   static thread_local bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_fwd_kernel<true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_fwd_kernel<true, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_fwd_kernel<false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_fwd_kernel<false, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_fwd_kernel<true, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_fwd_kernel<false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     attr_set = true;
   }
   const long ntiles = (m + G3_BM - 1) / G3_BM;
-  const dim3 grid((unsigned)(ntiles < kNumCU ? ntiles : kNumCU), (unsigned)((dout + G3_BN - 1) / G3_BN));
   const bool xvec = (din % 4 == 0) && (x_ld % 4 == 0) && aligned16(x);
+  if (table) {
+    const dim3 grid((unsigned)(ntiles < kNumCU ? ntiles : kNumCU), (unsigned)((dout + G3_BN - 1) / G3_BN));
+    const size_t lds = 2 * (size_t)G3_XP * 16;
+    const float* tw = static_cast<const float*>(table);
+    if (xvec)
+      hipLaunchKernelGGL((gemm3_fwd_kernel<true, true>), grid, dim3(512), lds, s, x, m, din, x_ld, tw, w_ld, trans_w, bias,
+                         y, dout, y_ld, act);
+    else
+      hipLaunchKernelGGL((gemm3_fwd_kernel<false, true>), grid, dim3(512), lds, s, x, m, din, x_ld, tw, w_ld, trans_w,
+                         bias, y, dout, y_ld, act);
+    return check_launch("gemm3_fwd_kernel");
+  }
+  const dim3 grid((unsigned)(ntiles < kNumCU ? ntiles : kNumCU), (unsigned)((dout + G3_BN - 1) / G3_BN));
   if (xvec)
-    hipLaunchKernelGGL(gemm3_fwd_kernel<true>, grid, dim3(512), G3_LDS, s, x, m, din, x_ld, w, w_ld, trans_w, bias, y,
-                       dout, y_ld, act);
+    hipLaunchKernelGGL((gemm3_fwd_kernel<true, false>), grid, dim3(512), G3_LDS, s, x, m, din, x_ld, w, w_ld, trans_w,
+                       bias, y, dout, y_ld, act);
   else
-    hipLaunchKernelGGL(gemm3_fwd_kernel<false>, grid, dim3(512), G3_LDS, s, x, m, din, x_ld, w, w_ld, trans_w, bias, y,
-                       dout, y_ld, act);
+    hipLaunchKernelGGL((gemm3_fwd_kernel<false, false>), grid, dim3(512), G3_LDS, s, x, m, din, x_ld, w, w_ld, trans_w,
+                       bias, y, dout, y_ld, act);
   return check_launch("gemm3_fwd_kernel");
 }
 

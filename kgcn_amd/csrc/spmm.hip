@@ -47,93 +47,141 @@ struct SpmmChannels {
 // LDS layout per channel: tile[K*d] | ecv[max_nnz] (int2) | rp[M+1]   (all channels staged, then one row loop)
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ inline size_t tile_chan_bytes(int M, int K, int d, int max_nnz) {
-  return (((size_t)K * d * 4 + (size_t)max_nnz * 8 + (size_t)(M + 1) * 4) + 15) & ~(size_t)15;
+  return ((((size_t)K * d * 4 + 7) & ~(size_t)7) + (size_t)max_nnz * 8 + (size_t)(M + 1) * 4 + 15) & ~(size_t)15;
 }
 
-template <int LPR>
+// VEC floats per lane (4: dwordx4 everywhere; 2: widths like 50 that are even but not a multiple of 4).  blockIdx.y selects
+// a slice of ds columns of a wide operand (d = 256: four slices of 64 keep the tile within the LDS budget of 8 waves per
+// CU; each row of a slice is still one contiguous 256-byte segment).
+template <int VEC> struct SpVec;
+template <> struct SpVec<4> { using T = f32x4; };
+template <> struct SpVec<2> { using T = f32x2; };
+
+template <int LPR, int VEC>
 __global__ __launch_bounds__(64) void spmm_tile_kernel(
     SpmmChannels ch, const float* __restrict__ rhs, long rhs_ld, long rhs_gs, float* __restrict__ out, long out_ld,
-    long out_gs, int M, int K, int d, float beta, const float* __restrict__ self_scale, int act,
+    long out_gs, int M, int K, int ds, int nslices, float beta, const float* __restrict__ self_scale, int act,
     const float* __restrict__ aout, int dact) {
+  using V = typename SpVec<VEC>::T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int t = blockIdx.x;
+  // slices of one graph are neighbours in the grid: they run at the same time and share the DRAM pages of its rows
+  const int t = blockIdx.x / nslices;
+  const int col0 = (blockIdx.x - t * nslices) * ds;
   const int lane = threadIdx.x;
-  const int d4 = d >> 2;
-  const int n4 = K * d4;
+  const int dv = ds / VEC;
+  const int nv = K * dv;
+  const int step_r = 64 / dv, step_c = 64 - step_r * dv;
+  auto ldv = [](const float* p) { return *reinterpret_cast<const V*>(p); };
+  auto stv = [](float* p, V v) { *reinterpret_cast<V*>(p) = v; };
 
-  // ---- stage: per channel the rhs block (dwordx4, fully coalesced; times act'(aout) in a backward launch) and the
-  // CSR slice ---------------------------------------------------------------------------------
+  // ---- stage: per channel the rhs block (vector loads, fully coalesced; times act'(aout) in a backward launch) and
+  // the CSR slice -----------------------------------------------------------------------------
   size_t off = 0;
   for (int c = 0; c < ch.n; ++c) {
     float* tile = reinterpret_cast<float*>(smem + off);
-    int2* ecv = reinterpret_cast<int2*>(tile + (size_t)K * d);
+    int2* ecv = reinterpret_cast<int2*>(smem + off + (((size_t)K * ds * 4 + 7) & ~(size_t)7));
     int* rp = reinterpret_cast<int*>(ecv + ch.max_nnz[c]);
     const int* grp = ch.rowptr[c] + (long)t * M;
     const int base = grp[0];
     const int cnt = grp[M] - base;
-    const float* rb = rhs + c * ch.rhs_cs + (long)t * rhs_gs;
+    const float* rb = rhs + c * ch.rhs_cs + (long)t * rhs_gs + col0;
     if (dact == KGCN_ACT_NONE) {
-      if (rhs_ld == d) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(rb);
-        f32x4* dst = reinterpret_cast<f32x4*>(tile);
+      if (rhs_ld == ds) {
+        const V* src = reinterpret_cast<const V*>(rb);
+        V* dst = reinterpret_cast<V*>(tile);
 #pragma unroll 4
-        for (int i = lane; i < n4; i += 64) dst[i] = src[i];
+        for (int i = lane; i < nv; i += 64) dst[i] = src[i];
       } else {
-        for (int i = lane; i < n4; i += 64) {
-          int r = i / d4, cc = i - r * d4;
-          st4(tile + (size_t)i * 4, ld4(rb + (long)r * rhs_ld + cc * 4));
+        int r = lane / dv, cc = lane - r * dv;             // (row, vector) of element i, walked without dividing
+        int i = lane;
+        for (; i + 192 < nv; i += 256) {                   // four loads in flight per lane
+          V v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            v[u] = ldv(rb + (long)r * rhs_ld + cc * VEC);
+            r += step_r; cc += step_c;
+            if (cc >= dv) { cc -= dv; ++r; }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) stv(tile + (size_t)(i + 64 * u) * VEC, v[u]);
+        }
+        for (; i < nv; i += 64) {
+          stv(tile + (size_t)i * VEC, ldv(rb + (long)r * rhs_ld + cc * VEC));
+          r += step_r; cc += step_c;
+          if (cc >= dv) { cc -= dv; ++r; }
         }
       }
     } else {
-      const float* ab = aout + (long)t * rhs_gs;           // same layout as the gradient
-      for (int i = lane; i < n4; i += 64) {
-        int r = i / d4, cc = i - r * d4;
-        f32x4 v = ld4(rb + (long)r * rhs_ld + cc * 4);
-        const f32x4 a = ld4(ab + (long)r * rhs_ld + cc * 4);
+      const float* ab = aout + (long)t * rhs_gs + col0;    // same layout as the gradient
+      int r = lane / dv, cc = lane - r * dv;
+      int i = lane;
+      for (; i + 192 < nv; i += 256) {                     // eight loads in flight per lane
+        V v[4], a[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= act_dout(a[j], dact);
-        st4(tile + (size_t)i * 4, v);
+        for (int u = 0; u < 4; ++u) {
+          v[u] = ldv(rb + (long)r * rhs_ld + cc * VEC);
+          a[u] = ldv(ab + (long)r * rhs_ld + cc * VEC);
+          r += step_r; cc += step_c;
+          if (cc >= dv) { cc -= dv; ++r; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[u][j] *= act_dout(a[u][j], dact);
+          stv(tile + (size_t)(i + 64 * u) * VEC, v[u]);
+        }
+      }
+      for (; i < nv; i += 64) {
+        V v = ldv(rb + (long)r * rhs_ld + cc * VEC);
+        const V a = ldv(ab + (long)r * rhs_ld + cc * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] *= act_dout(a[j], dact);
+        stv(tile + (size_t)i * VEC, v);
+        r += step_r; cc += step_c;
+        if (cc >= dv) { cc -= dv; ++r; }
       }
     }
     for (int i = lane; i < cnt; i += 64) ecv[i] = ch.cv[c][base + i];
     for (int i = lane; i <= M; i += 64) rp[i] = grp[i] - base;
-    off += tile_chan_bytes(M, K, d, ch.max_nnz[c]);
+    off += tile_chan_bytes(M, K, ds, ch.max_nnz[c]);
   }
   __syncthreads();  // single-wave workgroup: orders the LDS writes before the gathers
 
-  // ---- aggregate: 64/LPR rows at a time, LPR lanes x float4 per row, channels innermost ----------
+  // ---- aggregate: 64/LPR rows at a time, LPR lanes x VEC floats per row, channels innermost ------
   constexpr int RPW = 64 / LPR;
   const int sub = lane / LPR;
   const int cl = lane % LPR;
-  const bool col_ok = cl * 4 < d;
+  const bool col_ok = cl * VEC < ds;
   const float sscale = self_scale ? self_scale[0] : 0.f;
-  float* ob = out + (long)t * out_gs;
+  float* ob = out + (long)t * out_gs + col0;
   for (int r0 = 0; r0 < M; r0 += RPW) {
     const int r = r0 + sub;
     if (r < M && col_ok) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      V acc;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
       size_t o2 = 0;
       for (int c = 0; c < ch.n; ++c) {
         const float* tile = reinterpret_cast<const float*>(smem + o2);
-        const int2* ecv = reinterpret_cast<const int2*>(tile + (size_t)K * d);
+        const int2* ecv = reinterpret_cast<const int2*>(smem + o2 + (((size_t)K * ds * 4 + 7) & ~(size_t)7));
         const int* rp = reinterpret_cast<const int*>(ecv + ch.max_nnz[c]);
         const int s = rp[r], e = rp[r + 1];
         for (int k = s; k < e; ++k) {
           const int2 p = ecv[k];
           const float v = __int_as_float(p.y);
-          const f32x4 x = ld4(tile + (size_t)p.x * d + cl * 4);
+          const V x = ldv(tile + (size_t)p.x * ds + cl * VEC);
           acc += v * x;
         }
-        if (self_scale && c == 0) acc += sscale * ld4(tile + (size_t)r * d + cl * 4);
-        o2 += tile_chan_bytes(M, K, d, ch.max_nnz[c]);
+        if (self_scale && c == 0) acc += sscale * ldv(tile + (size_t)r * ds + cl * VEC);
+        o2 += tile_chan_bytes(M, K, ds, ch.max_nnz[c]);
       }
-      float* o = ob + (long)r * out_ld + cl * 4;
-      if (beta != 0.f) acc += ld4(o);
+      float* o = ob + (long)r * out_ld + cl * VEC;
+      if (beta != 0.f) acc += ldv(o);
       if (act != KGCN_ACT_NONE) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = act_fwd(acc[j], act);
+        for (int j = 0; j < VEC; ++j) acc[j] = act_fwd(acc[j], act);
       }
-      st4(o, acc);
+      stv(o, acc);
     }
   }
 }
@@ -317,15 +365,31 @@ static int ilog2_ceil(int v) {
 }
 
 // Tile kernel is used when one graph's working set (all channels of the launch) leaves >= 8 waves per CU resident.
-static bool tile_ok(const kgcn_csr_batch* a, int nch, const float* rhs, long rhs_ld, long rhs_gs, long rhs_cs, int d,
-                    const float* out, long out_ld, long out_gs) {
-  if (d % 4 != 0 || d > 256 || d <= 0) return false;
-  if (rhs_ld % 4 || rhs_gs % 4 || out_ld % 4 || out_gs % 4 || rhs_cs % 4) return false;
-  if (!aligned16(rhs) || !aligned16(out)) return false;
-  if (a->rows <= 0 || a->cols <= 0) return false;
-  size_t lds = 0;
-  for (int c = 0; c < nch; ++c) lds += tile_chan_bytes(a[c].rows, a[c].cols, d, a[c].max_nnz_per_graph);
-  return lds <= 20 * 1024;
+// Can the LDS-staged kernel take this launch, and how?  vec = floats per lane (4, or 2 for even widths), slices = column
+// slices of d/slices floats each (one workgroup per graph and slice) so that a tile stays within 20 KiB (8 waves / CU).
+struct TilePlan { bool ok; int vec; int slices; };
+static TilePlan tile_plan(const kgcn_csr_batch* a, int nch, const float* rhs, long rhs_ld, long rhs_gs, long rhs_cs,
+                          int d, const float* out, long out_ld, long out_gs, const float* aout) {
+  TilePlan p = {false, 4, 1};
+  if (d <= 0 || d > 1024 || a->rows <= 0 || a->cols <= 0) return p;
+  const long all = rhs_ld | rhs_gs | out_ld | out_gs | rhs_cs | d;
+  const uintptr_t ptrs = reinterpret_cast<uintptr_t>(rhs) | reinterpret_cast<uintptr_t>(out) |
+                         reinterpret_cast<uintptr_t>(aout);
+  if (all % 4 == 0 && ptrs % 16 == 0) p.vec = 4;
+  else if (all % 2 == 0 && ptrs % 8 == 0) p.vec = 2;
+  else return p;
+  for (int sl = 1; sl <= 16; sl *= 2) {
+    if (d % sl != 0 || (d / sl) % p.vec != 0 || (sl > 1 && d / sl < 32)) break;
+    if (d / sl > 64 * p.vec) continue;                  // one wave covers a row of the slice
+    size_t lds = 0;
+    for (int c = 0; c < nch; ++c) lds += tile_chan_bytes(a[c].rows, a[c].cols, d / sl, a[c].max_nnz_per_graph);
+    if (lds <= 20 * 1024) {
+      p.ok = true;
+      p.slices = sl;
+      return p;
+    }
+  }
+  return p;
 }
 
 // out[t] = act(beta*out[t] + sum_c A_c[t] @ (rhs_c[t] (.) act'(aout[t])));  a: nch channel descriptors of one batch shape
@@ -353,18 +417,27 @@ int launch_spmm_multi(const kgcn_csr_batch* a, int nch, const float* rhs, long r
     ch.cv[c] = reinterpret_cast<const int2*>(a[c].cv);
     ch.max_nnz[c] = a[c].max_nnz_per_graph;
   }
-  if (tile_ok(a, nch, rhs, rhs_ld, rhs_gs, rhs_cs, d, out, out_ld, out_gs) &&
-      (dact == KGCN_ACT_NONE || aligned16(aout))) {
+  const TilePlan plan = tile_plan(a, nch, rhs, rhs_ld, rhs_gs, rhs_cs, d, out, out_ld, out_gs, dact ? aout : nullptr);
+  if (plan.ok && (long)T * plan.slices <= 0x7fffffffL) {
+    const int ds = d / plan.slices;
     size_t lds = 0;
-    for (int c = 0; c < nch; ++c) lds += tile_chan_bytes(M, K, d, a[c].max_nnz_per_graph);
-    const int lanes = d / 4;
-#define KGCN_TILE(LPR)                                                                                              \
-  hipLaunchKernelGGL((spmm_tile_kernel<LPR>), dim3(T), dim3(64), lds, stream, ch, rhs, rhs_ld, rhs_gs, out, out_ld, \
-                     out_gs, M, K, d, beta, self_scale, act, aout, dact)
-    if (lanes <= 8) KGCN_TILE(8);
-    else if (lanes <= 16) KGCN_TILE(16);
-    else if (lanes <= 32) KGCN_TILE(32);
-    else KGCN_TILE(64);
+    for (int c = 0; c < nch; ++c) lds += tile_chan_bytes(M, K, ds, a[c].max_nnz_per_graph);
+    const int lanes = ds / plan.vec;
+    const dim3 grid((unsigned)(T * plan.slices));
+#define KGCN_TILE(LPR, VEC)                                                                                        \
+  hipLaunchKernelGGL((spmm_tile_kernel<LPR, VEC>), grid, dim3(64), lds, stream, ch, rhs, rhs_ld, rhs_gs, out, out_ld, \
+                     out_gs, M, K, ds, plan.slices, beta, self_scale, act, aout, dact)
+    if (plan.vec == 4) {
+      if (lanes <= 8) KGCN_TILE(8, 4);
+      else if (lanes <= 16) KGCN_TILE(16, 4);
+      else if (lanes <= 32) KGCN_TILE(32, 4);
+      else KGCN_TILE(64, 4);
+    } else {
+      if (lanes <= 8) KGCN_TILE(8, 2);
+      else if (lanes <= 16) KGCN_TILE(16, 2);
+      else if (lanes <= 32) KGCN_TILE(32, 2);
+      else KGCN_TILE(64, 2);
+    }
 #undef KGCN_TILE
     return check_launch("spmm_tile_kernel");
   }

@@ -1,0 +1,165 @@
+"""Per-entry-point roofline of one step: every compute call through the C ABI is bracketed by HIP events on the
+calling stream (device idle before the call, so the time is the call's own kernels plus one launch latency, ~3 us)
+and priced with its ALGORITHMIC traffic and arithmetic from the arguments alone:
+
+  bytes  operands read once + results written once (fp32), CSR structure 8 B / stored entry + 4 B / row
+  flops  2 m din dout for a contraction, 2 nnz d for an aggregation
+
+  frac_hbm  = bytes / t / 8 TB/s           frac_mfma = flops / t / 157.3 TFLOP/s  (the f32 matrix rate: the kernels of
+  gemm3.hip run the exact 3 x bf16 split on the bf16 pipe, 2.5 PF / 6 products = 417 TF, and may exceed 1.0 here)
+
+usage (tools/config_bench.py --roofline):  rec = instrument(); step(); rows = rec.rows()"""
+import ctypes
+
+import torch
+
+from kgcn_amd import _lib
+
+HBM = 8.0e12
+F32_MFMA = 157.3e12
+
+
+def _csr(arg, i=0):
+    if isinstance(arg, _lib.CsrBatch):
+        return arg
+    if hasattr(arg, "_obj"):
+        o = arg._obj
+        return o[i] if isinstance(o, ctypes.Array) else o
+    if isinstance(arg, ctypes.Array):
+        return arg[i]
+    return arg[i] if i else arg.contents
+
+
+def _csr_bytes(a):
+    return 8 * a.nnz + 4 * a.num_graphs * (a.rows + 1)
+
+
+def _spmm(a, d, n_rhs=1, extra_reads=0):
+    T = a.num_graphs
+    return 4 * d * (n_rhs * T * a.cols + (1 + extra_reads) * T * a.rows) + _csr_bytes(a), 2 * a.nnz * d
+
+
+def _cost(name, a):
+    """(bytes, flops, shape text) from the positional arguments of entry point `name`."""
+    if name == "kgcn_bspmm_f32":
+        c = _csr(a[0]); b, f = _spmm(c, a[4])
+        return b, f, "T=%d %dx%d nnz=%d d=%d" % (c.num_graphs, c.rows, c.cols, c.nnz, a[4])
+    if name in ("kgcn_bconv_f32", "kgcn_bconv_act_f32"):
+        C, d = a[1], a[6]
+        b = f = 0
+        for i in range(C):
+            c = _csr(a[0], i)
+            bi, fi = _spmm(c, d)
+            b += bi - 4 * d * c.num_graphs * c.rows; f += fi
+        c = _csr(a[0], 0)
+        b += 4 * d * c.num_graphs * c.rows
+        return b, f, "C=%d T=%d %dx%d d=%d" % (C, c.num_graphs, c.rows, c.cols, d)
+    if name == "kgcn_bspmm_dact_f32":
+        c = _csr(a[0]); d = a[5]
+        b, f = _spmm(c, d, n_rhs=2)
+        return b, f, "T=%d %dx%d nnz=%d d=%d act=%d" % (c.num_graphs, c.rows, c.cols, c.nnz, d, a[6])
+    if name == "kgcn_spmm_values_grad_f32":
+        c = _csr(a[0]); d = a[7]
+        return 4 * d * c.num_graphs * (c.rows + c.cols) + 12 * c.nnz, 2 * c.nnz * d, "nnz=%d d=%d" % (c.nnz, d)
+    if name in ("kgcn_dense_fwd_f32", "kgcn_dense_fwd_act_f32", "kgcn_dense_fwd_ws_f32"):
+        m, din, dout = a[1], a[2], a[9]
+        return 4 * (m * din + m * dout + din * dout), 2 * m * din * dout, "m=%d %d->%d%s" % (m, din, dout, " T" if a[6] else "")
+    if name == "kgcn_dense_wgrad_f32":
+        m, din, dout = a[4], a[5], a[6]
+        return 4 * (m * din + m * dout + din * dout), 2 * m * din * dout, "m=%d %dx%d" % (m, din, dout)
+    if name == "kgcn_graphconv_fwd_f32":
+        c = _csr(a[0]); din, dout = a[4], a[5]
+        rows = c.num_graphs * c.rows
+        return 4 * rows * (din + dout) + _csr_bytes(c), 2 * rows * din * dout + 2 * c.nnz * dout, \
+            "T=%d N=%d %d->%d" % (c.num_graphs, c.rows, din, dout)
+    if name == "kgcn_graphconv_bwd_f32":
+        c = _csr(a[0]); din, dout = a[4], a[5]
+        rows = c.num_graphs * c.rows
+        dx = a[6] is not None
+        return 4 * rows * (din + dout + (din if dx else 0)) + _csr_bytes(c), \
+            (4 if dx else 2) * rows * din * dout + 2 * c.nnz * dout, "T=%d N=%d %d->%d" % (c.num_graphs, c.rows, din, dout)
+    if name == "kgcn_gin_aggregate_f32":
+        c = _csr(a[0]); d = a[3]
+        b, f = _spmm(c, d)
+        return b, f * a[1], "C=%d T=%d N=%d d=%d" % (a[1], c.num_graphs, c.rows, d)
+    if name == "kgcn_graph_gather_fwd_f32":
+        B, N, d = a[1], a[2], a[3]
+        return 4 * (B * N * d + B * d), B * N * d, "B=%d N=%d d=%d" % (B, N, d)
+    if name == "kgcn_graph_gather_bwd_f32":
+        B, N, d = a[1], a[2], a[3]
+        return 4 * (B * N * d + B * d), 0, "B=%d N=%d d=%d" % (B, N, d)
+    if name == "kgcn_act_fwd_f32":
+        return 8 * a[1], 0, "n=%d act=%d" % (a[1], a[2])
+    if name == "kgcn_act_bwd_f32":
+        return 12 * a[2], 0, "n=%d act=%d" % (a[2], a[3])
+    if name == "kgcn_dot_f32":
+        return 8 * a[2], 2 * a[2], "n=%d" % a[2]
+    if name == "kgcn_graph_bn_stats_f32":
+        return 4 * a[1] * a[2] * a[3], 3 * a[1] * a[2] * a[3], "T=%d N=%d d=%d" % (a[1], a[2], a[3])
+    if name == "kgcn_graph_bn_apply_f32":
+        return 8 * a[1] * a[2] * a[3], 2 * a[1] * a[2] * a[3], "T=%d N=%d d=%d" % (a[1], a[2], a[3])
+    if name == "kgcn_graph_bn_bwd_f32":
+        n = a[2] * a[3] * a[4]
+        return (12 if a[11] is not None else 8) * n, 6 * n, "T=%d N=%d d=%d training=%d" % (a[2], a[3], a[4], a[10])
+    if name in ("kgcn_graph_maxpool_fwd_f32",):
+        c = _csr(a[0]); b, f = _spmm(c, a[2])
+        return b, f // 2, "T=%d N=%d d=%d" % (c.num_graphs, c.rows, a[2])
+    if name == "kgcn_csr_gather_graphs":
+        c = _csr(a[0])
+        return 16 * c.max_nnz_per_graph * a[2], 0, "sel=%d" % a[2]
+    return None
+
+
+class Recorder:
+    def __init__(self):
+        self.calls = []            # (name, shape, bytes, flops, ms)
+        self.on = False
+        self.other = set()
+
+    def rows(self):
+        """Calls of the recorded step merged by (entry point, shape), largest time first."""
+        agg = {}
+        for name, shape, b, f, ms in self.calls:
+            k = (name, shape)
+            r = agg.setdefault(k, {"entry": name, "shape": shape, "calls": 0, "us": 0.0, "bytes": 0, "flops": 0})
+            r["calls"] += 1; r["us"] += ms * 1e3; r["bytes"] += b; r["flops"] += f
+        out = []
+        for r in sorted(agg.values(), key=lambda r: -r["us"]):
+            t = r["us"] * 1e-6
+            r["us"] = round(r["us"], 1)
+            r["GB_per_s"] = round(r["bytes"] / t / 1e9, 1)
+            r["TFLOP_per_s"] = round(r["flops"] / t / 1e12, 2)
+            r["frac_hbm"] = round(r["bytes"] / t / HBM, 3)
+            r["frac_mfma_f32"] = round(r["flops"] / t / F32_MFMA, 3)
+            r["bound"] = "hbm" if r["frac_hbm"] >= r["frac_mfma_f32"] else "mfma"
+            out.append(r)
+        return out
+
+
+def instrument():
+    """Wrap every compute entry point of the loaded library; returns the Recorder (set .on = True around one step)."""
+    rec = Recorder()
+    lib = _lib.lib
+    for name in _lib.SIGNATURES:
+        fn = getattr(lib, name)
+        if name.endswith("_bytes") or name in ("kgcn_abi_version", "kgcn_last_error", "kgcn_build_arch",
+                                               "kgcn_graphconv_fused_supported"):
+            continue
+
+        def wrapper(*a, _fn=fn, _name=name):
+            if not rec.on:
+                return _fn(*a)
+            cost = _cost(_name, a)
+            if cost is None:
+                rec.other.add(_name)
+                return _fn(*a)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = _fn(*a)
+            e1.record()
+            e1.synchronize()
+            rec.calls.append((_name, cost[2], cost[0], cost[1], e0.elapsed_time(e1)))
+            return rc
+        setattr(lib, name, wrapper)
+    return rec

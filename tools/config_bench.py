@@ -4,7 +4,9 @@ with the per-kernel breakdown of one step from the torch profiler.  Not the head
   cfg4  model_multitask.py: batch 4096 x N=50 (variable true sizes), F=81, 12 tasks
   cfg5  model_gin.py layers at D=256 on 10-node ring graphs, batch 20000
   cfg3  sparse.py: 128 molecules x <=50 nodes block-diagonal, F=128 -> 256 x3
-usage: python tools/config_bench.py [cfg4|cfg5|cfg3 ...]"""
+With --roofline every C-ABI call of one extra step is timed on its own (tools/abi_roofline.py) and priced with its
+algorithmic bytes / flops: the per-entry-point fraction-of-peak table of profiles/r02_*_config_rooflines.json.
+usage: python tools/config_bench.py [--roofline] [cfg4|cfg5|cfg3 ...]"""
 import json
 import os
 import sys
@@ -15,6 +17,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 from oracle import kgcn_oracle as K  # noqa: E402  (graph generators only)
 from kgcn_amd import BatchedAdjacency, BatchedCSR, data_util as D, layers, models  # noqa: E402
 
@@ -42,18 +45,7 @@ def breakdown(step, top=8):
     return [{"kernel": r.key[:70], "calls": r.count, "us": round(r.device_time_total, 1)} for r in rows]
 
 
-def mol_batch(B, N, extra=2):
-    sizes = rng.integers(5, N + 1, size=B)
-    g, r, c = [], [], []
-    for b, n in enumerate(sizes):
-        idx = K.synth_mol_graphs(rng, 1, int(n), extra)[0][0][0]
-        g.append(np.full(len(idx), b)); r.append(idx[:, 0]); c.append(idx[:, 1])
-    g, r, c = np.concatenate(g), np.concatenate(r), np.concatenate(c)
-    deg = np.bincount(g * N + c, minlength=B * N).astype(np.float32)
-    deg[deg == 0] = 1
-    rs = (1.0 / np.sqrt(deg)).astype(np.float32)
-    val = rs[g * N + r] * rs[g * N + c]
-    return sizes, BatchedCSR.from_arrays(g, r, c, val, B, N, N, device=dev)
+from config_bench_util import mol_batch  # noqa: E402
 
 
 def cfg4():
@@ -127,9 +119,25 @@ def cfg3():
 
 
 res = {}
-for name in (sys.argv[1:] or ["cfg4", "cfg5", "cfg3"]):
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+rec = None
+if "--roofline" in sys.argv:
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import abi_roofline
+    rec = abi_roofline.instrument()
+for name in (args or ["cfg4", "cfg5", "cfg3"]):
     graphs, step = {"cfg4": cfg4, "cfg5": cfg5, "cfg3": cfg3}[name]()
     ms = timed(step)
     res[name] = {"graphs_per_step": graphs, "ms_per_step": round(ms, 3), "graphs_per_s": round(graphs / ms * 1e3),
-                 "top_kernels": breakdown(step)}
+                 "top_kernels": breakdown(step, top=40 if rec else 8)}
+    res[name]["kernel_us_sum"] = round(sum(k["us"] for k in res[name]["top_kernels"]), 1)
+    if rec:
+        rec.calls, rec.on = [], True
+        step()
+        torch.cuda.synchronize()
+        rec.on = False
+        rows = rec.rows()
+        res[name]["abi_calls"] = rows
+        res[name]["abi_us_sum"] = round(sum(r["us"] for r in rows), 1)
+        res[name]["abi_unpriced"] = sorted(rec.other)
 print(json.dumps(res, indent=1))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dense-contraction kernels at the widths of BASELINE configs 3-5 (GPU box): y = x W + b through the C ABI with and
-without the workspace of the register-resident kernel (gemm4 vs gemm3), dx = dy W^T, correctness against fp64, TF/s
+without the workspace of the W fragment table (gemm3 with the table vs gemm3 splitting W in the kernel), dx = dy W^T, correctness against fp64, TF/s
 (flops 2 m din dout; fp32 matrix peak 157.3 TF, bf16-split ceiling 2500 / 6 = 417 TF).
 usage: python tools/gemm_bench.py [rows]"""
 import json
@@ -60,8 +60,8 @@ for din, dout in ((256, 256), (81, 256), (128, 256), (256, 512), (512, 256)):
     ex3 = float((dx3[:4096].double() - refx).abs().max() / refx.abs().max())
     ex4 = float((dx4[:4096].double() - refx).abs().max() / refx.abs().max())
     tx3, tx4 = timeit(g3), timeit(g4)
-    res["%dx%d" % (din, dout)] = {"rows": M, "fwd_gemm3_ms": t3, "fwd_gemm4_ms": t4, "fwd_gemm3_TF": fl / t3 / 1e9, "fwd_gemm4_TF": fl / t4 / 1e9,
-                                  "fwd_err_gemm3": e3, "fwd_err_gemm4": e4, "fwd_err_gemm4_tail": e4t, "ws_bytes": wsb,
-                                  "dx_gemm3_ms": tx3, "dx_gemm4_ms": tx4, "dx_gemm3_TF": fl / tx3 / 1e9, "dx_gemm4_TF": fl / tx4 / 1e9,
-                                  "dx_err_gemm3": ex3, "dx_err_gemm4": ex4, "dx_ws_bytes": wsb2}
+    res["%dx%d" % (din, dout)] = {"rows": M, "fwd_gemm3_ms": t3, "fwd_table_ms": t4, "fwd_gemm3_TF": fl / t3 / 1e9, "fwd_table_TF": fl / t4 / 1e9,
+                                  "fwd_err_gemm3": e3, "fwd_err_table": e4, "fwd_err_table_tail": e4t, "ws_bytes": wsb,
+                                  "dx_gemm3_ms": tx3, "dx_table_ms": tx4, "dx_gemm3_TF": fl / tx3 / 1e9, "dx_table_TF": fl / tx4 / 1e9,
+                                  "dx_err_gemm3": ex3, "dx_err_table": ex4, "dx_ws_bytes": wsb2}
 print(json.dumps(res, indent=1))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds variants of libkgcn_hip.so that differ in -D flags of ONE source (VSRC, default fused) -- HERE, cross-compiled:
-#   [VSRC=gemm4] tools/variants.sh build name1 "-DFLAG=1" name2 "-DFLAG=2 -DOTHER" ...
-# and times them on the GPU box:  tools/variants.sh run name1 name2 ...   (-> gpurun_out/variants/<name>.json)
+#   [VSRC=gemm3] tools/variants.sh build name1 "-DFLAG=1" name2 "-DFLAG=2 -DOTHER" ...
+# and times them on the GPU box:  [VBENCH=narrow_probe] tools/variants.sh run name1 name2 ...   (-> gpurun_out/variants/<name>.json)
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 CS=$REPO/kgcn_amd/csrc
@@ -13,7 +13,7 @@ if [ "$mode" = build ]; then
   while [ $# -gt 0 ]; do
     name=$1; flags=$2; shift 2
     objs=""
-    for o in misc spmm dense gemm3 gemm4 fused pack gat bn; do
+    for o in misc spmm dense gemm3 wtable narrow fused pack gat bn; do
       if [ $o = $VSRC ]; then objs="$objs $REPO/build/variants/${VSRC}_$name.o"; else objs="$objs $CS/$o.o"; fi
     done
     ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast $SLP $flags \
@@ -24,7 +24,7 @@ if [ "$mode" = build ]; then
   wait
 else
   for name in "$@"; do
-    KGCN_HIP_LIB=$REPO/build/variants/libkgcn_$name.so timeout 300 python $REPO/tools/variant_bench.py \
+    KGCN_HIP_LIB=$REPO/build/variants/libkgcn_$name.so timeout 300 python $REPO/tools/${VBENCH:-variant_bench}.py \
       > $REPO/gpurun_out/variants/$name.json 2> $REPO/gpurun_out/variants/$name.err || echo "$name failed"
     echo "$name: $(cat $REPO/gpurun_out/variants/$name.json)"
   done
