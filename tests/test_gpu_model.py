@@ -2,6 +2,8 @@
 HIP path (fp32) vs the fp64 model oracle -- logits, loss, every parameter gradient, and the
 parameter trajectory over several TF-Adam steps; plus a short training run (loss must fall) through
 the product's own loaders for GCN and GIN."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -11,6 +13,7 @@ from oracle import kgcn_model_oracle as M
 from test_gpu_parity import close, dev, t32
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _set_params(model, p):
@@ -304,3 +307,62 @@ def test_model_py_layer_calls_through_the_kgcn_import_path():
     c = M.forward(p, x.astype(np.float64), adjs, z["labels"].astype(np.float64), z["mask"].astype(np.float64))
     close(logits, c["logits"], atol=2e-5, what="logits through kgcn.layers")
     assert type(net["conv"][0]).__module__ == "kgcn_amd.layers"
+
+
+_DP_GRAPH_SCRIPT = r"""
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from kgcn_amd import data_util as D, models, train, parallel
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[2]
+dev = torch.device("cuda:0")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+raw = np.load(os.path.join(sys.argv[1], "tests", "golden", "g1_synthetic_raw.npz"))
+chans, _ = D.build_adjs({"dense_adj": raw["dense_adj"].astype(np.int64), "max_node_num": 10})
+ds = D.DeviceGraphDataset(chans, raw["feature"], device=dev)
+torch.manual_seed(0)
+m_e, m_g = models.GCN(1).to(dev), models.GCN(1).to(dev)
+idx = np.arange(30)
+adj0, x0 = ds.batch(idx, 30)
+m_e(x0, adj0); m_g(x0, adj0)
+m_g.load_state_dict(m_e.state_dict())
+lab = torch.from_numpy(raw["label"][idx].astype(np.float32)).to(dev)
+mask = torch.ones(30, device=dev)
+o_e = train.TFAdam(m_e.parameters(), lr=0.01)
+o_g = train.TFAdam(m_g.parameters(), lr=0.01, capturable=True)
+bucket = parallel.GradBucket(list(m_g.parameters()))
+sb = ds.static_batch(30); sb.load(idx)
+step = train.GraphedTrainStep(m_g, o_g, models.masked_softmax_ce, sb, lab, mask, bucket=bucket,
+                              shard_weight=parallel.shard_weight(30, 30))
+out = []
+for it in range(4):
+    o_e.zero_grad()
+    cost_opt, cost_sum = models.masked_softmax_ce(m_e(x0, adj0), lab, mask)
+    cost_opt.backward()
+    o_e.step()
+    cs_g, _ = step.replay()
+    out.append([float(cost_sum), float(cs_g)])
+dmax = max(float((a - b).abs().max()) for a, b in zip(m_e.parameters(), m_g.parameters()))
+torch.cuda.synchronize()
+print("RESULT " + json.dumps({"costs": out, "param_diff": dmax}))
+dist.destroy_process_group()
+"""
+
+
+def test_graphed_step_with_captured_rccl_allreduce(tmp_path):
+    """Data-parallel step as ONE hipGraph: the bucket all-reduce (RCCL, a 1-rank group on this 1-GPU box) sits inside
+    the capture between backward and the Adam update (flat bucket, shard weight 1 for the single rank) -- replaying it
+    follows eager single-process steps."""
+    import json, socket, subprocess, sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "dp_graph.py"
+    script.write_text(_DP_GRAPH_SCRIPT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), ROOT, str(port)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    res = json.loads(line[7:])
+    for ce, cg in res["costs"]:
+        assert abs(ce - cg) < 2e-4 * max(1.0, abs(ce)), res
+    assert res["costs"][-1][1] < res["costs"][0][1]
+    assert res["param_diff"] < 2e-5, res
