@@ -287,6 +287,28 @@ int kgcn_graph_bn_bwd_f32(const float* x, const float* grad, int64_t graphs, int
                           int32_t training, float* dx, float* dgamma, float* dbeta, void* workspace,
                           int64_t workspace_bytes, void* stream);
 
+/* -- COO -> batched CSR on the device (the feed side: kgcn/feed.py:112-126 assembles the same triples in Python) ------ */
+/* (graph, row, col, val)[nnz]: device arrays in ANY order (val NULL = all ones) -> rowptr_out [T*R + 1], cv_out [nnz]
+ * (int2: column, fp32 value bits) with R = rows and the entries of a row in feed order (stable sort: duplicates stay and
+ * are summed in feed order, like the host packer), or, transposed != 0, the container of A^T: R = cols, entries of a
+ * transposed row in ascending original row.  perm_out (may be NULL): [nnz] input position of every stored entry.
+ * stats_out: device int32[2] = {max stored entries per graph, number of out-of-range triples (must be 0)}.
+ * workspace >= kgcn_coo_pack_workspace_bytes(nnz, T, rows, cols). */
+int64_t kgcn_coo_pack_workspace_bytes(int64_t nnz, int32_t num_graphs, int32_t rows, int32_t cols);
+int kgcn_coo_pack_f32(const int32_t* graph, const int32_t* row, const int32_t* col, const float* val, int64_t nnz,
+                      int32_t num_graphs, int32_t rows, int32_t cols, int32_t transposed, int32_t* rowptr_out,
+                      void* cv_out, int32_t* perm_out, int32_t* stats_out, void* workspace, int64_t workspace_bytes,
+                      void* stream);
+/* plain container (row_pad = 0, square, rows <= KGCN_PAD_COL) -> the row-padded layout of the fused GraphConv kernels:
+ * rowptr4_out [T*M + 1], cv4_out [cv4_capacity entries; nnz + 4*T*M always suffices], slots_out [T*M],
+ * graph_ptr_out [T + 1].  stats_out: device int32[3] = {max padded entries per graph, total padded entries,
+ * number of violations (row longer than 252 entries, graph longer than 65535, capacity exceeded; must be 0)}.
+ * workspace >= kgcn_csr_pad4_workspace_bytes(T, M). */
+int64_t kgcn_csr_pad4_workspace_bytes(int32_t num_graphs, int32_t rows);
+int kgcn_csr_pad4(const kgcn_csr_batch* a, int32_t* rowptr4_out, void* cv4_out, int64_t cv4_capacity,
+                  int32_t* slots_out, int32_t* graph_ptr_out, int32_t* stats_out, void* workspace,
+                  int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

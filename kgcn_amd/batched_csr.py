@@ -109,6 +109,70 @@ class BatchedCSR:
         return cls(t_rowptr, t_cv, T, M, K, max_nnz, perm=perm, host=(graph, row, col, val))
 
     @classmethod
+    def from_device_coo(cls, graph, row, col, val, num_graphs, rows, cols, _transposed=False):
+        """Build from flat COO tensors that already live on the GPU (int32 graph / row / col, fp32 val or None = ones),
+        in any order, WITHOUT a host round trip of the triples: kgcn_coo_pack_f32 (stable device radix sort, rocPRIM).
+        Same container, bit for bit, as from_arrays() on the same triples; transpose() and padded4() are built on the
+        device too (kgcn_coo_pack_f32(transposed), kgcn_csr_pad4).  One 8-byte read-back (max entries per graph -- it
+        sizes the kernels' LDS staging -- and the out-of-range count)."""
+        import torch
+        lib = _lib.lib
+        T, M, K = int(num_graphs), int(rows), int(cols)
+        dev = graph.device
+        _lib.require_gpu(graph, "graph")
+        g, r, c = (t.to(torch.int32).contiguous().reshape(-1) for t in (graph, row, col))
+        v = None if val is None else val.to(torch.float32).contiguous().reshape(-1)
+        nnz = g.numel()
+        if not (r.numel() == c.numel() == nnz and (v is None or v.numel() == nnz)):
+            raise ValueError("graph/row/col/val length mismatch")
+        R = K if _transposed else M
+        rowptr = torch.empty(T * R + 1, device=dev, dtype=torch.int32)
+        cv = torch.empty((nnz, 2), device=dev, dtype=torch.int32)
+        perm = torch.empty(nnz, device=dev, dtype=torch.int32)
+        stats = torch.empty(2, device=dev, dtype=torch.int32)
+        wsb = lib.kgcn_coo_pack_workspace_bytes(nnz, T, M, K)
+        ws = torch.empty(max(wsb, 8) // 8, device=dev, dtype=torch.int64)
+        _lib.check(lib.kgcn_coo_pack_f32(_lib.ptr(g), _lib.ptr(r), _lib.ptr(c), _lib.ptr(v), nnz, T, M, K,
+                                         1 if _transposed else 0, _lib.ptr(rowptr), cv.data_ptr() if nnz else 0,
+                                         _lib.ptr(perm) if nnz else None, _lib.ptr(stats), _lib.ptr(ws), wsb,
+                                         _lib.current_stream()), "kgcn_coo_pack_f32")
+        max_nnz, bad = (int(x) for x in stats.tolist())
+        if bad:
+            raise ValueError("%d COO entries outside [0, %d) x [0, %d) x [0, %d)" % (bad, T, M, K))
+        out = cls(rowptr, cv, T, R, M if _transposed else K, max_nnz, perm=perm.long())
+        if not _transposed:
+            def make_t():
+                t = cls.from_device_coo(g, r, c, v, T, M, K, _transposed=True)
+                return t
+            out._make_t = make_t
+        out._make_p4 = out._pad4_on_device
+        return out
+
+    def _pad4_on_device(self):
+        """Row-padded copy (padded4()) of a device-built container through kgcn_csr_pad4."""
+        import torch
+        lib = _lib.lib
+        if self.rows > self.PAD_COL or self.cols > self.PAD_COL:
+            raise ValueError("row padding is only defined for graphs of at most %d nodes" % self.PAD_COL)
+        T, M, dev = self.num_graphs, self.rows, self.rowptr.device
+        cap = self.nnz + 4 * T * M
+        rp4 = torch.empty(T * M + 1, device=dev, dtype=torch.int32)
+        cv4 = torch.empty((cap, 2), device=dev, dtype=torch.int32)
+        slots = torch.empty(T * M, device=dev, dtype=torch.int32)
+        gptr = torch.empty(T + 1, device=dev, dtype=torch.int32)
+        stats = torch.empty(3, device=dev, dtype=torch.int32)
+        wsb = lib.kgcn_csr_pad4_workspace_bytes(T, M)
+        ws = torch.empty(max(wsb, 8) // 8, device=dev, dtype=torch.int64)
+        _lib.check(lib.kgcn_csr_pad4(self.desc(), _lib.ptr(rp4), cv4.data_ptr(), cap, _lib.ptr(slots), _lib.ptr(gptr),
+                                     _lib.ptr(stats), _lib.ptr(ws), wsb, _lib.current_stream()), "kgcn_csr_pad4")
+        max_nnz, total, bad = (int(x) for x in stats.tolist())
+        if bad or max_nnz >= 65536:
+            raise ValueError("graph too dense for the packed slot table of the fused kernels")
+        p4 = BatchedCSR(rp4, cv4[:total], T, M, self.cols, max_nnz, row_pad=4)
+        p4.slots, p4.graph_ptr = slots, gptr
+        return p4
+
+    @classmethod
     def from_coo_list(cls, mats, rows=None, cols=None, device="cuda"):
         """mats: T sparse matrices in the reference's COO layout (see _as_triple).  Graphs are
         padded to the common (max) shape like kgcn/data_util.py:30-37 does with max_node_num."""
@@ -408,6 +472,12 @@ class BatchedAdjacency:
         out = BatchedAdjacency(self.channels)
         out.values = list(values)
         return out
+
+    @classmethod
+    def from_device_coo(cls, channels, num_graphs, n_nodes):
+        """channels: one (graph, row, col, val) tuple of device tensors per adjacency channel (see
+        BatchedCSR.from_device_coo) -- the whole batch packed on the GPU."""
+        return cls([BatchedCSR.from_device_coo(g, r, c, v, num_graphs, n_nodes, n_nodes) for g, r, c, v in channels])
 
     @classmethod
     def from_adjs(cls, adjs, n_nodes=None, device="cuda"):

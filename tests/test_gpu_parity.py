@@ -823,6 +823,53 @@ def test_device_batch_assembly_bit_exact(channels):
             assert torch.equal(x1.grad, x2.grad) and all(torch.equal(a, p.grad) for a, p in zip(g1, layer.parameters()))
 
 
+@pytest.mark.parametrize("T,N,nnz,dups", [(40, 10, 300, True), (1, 32, 90, False), (500, 32, 40000, True), (7, 50, 0, False),
+                                          (3, 300, 2000, True)])
+def test_device_coo_pack_bit_exact(T, N, nnz, dups):
+    """kgcn_coo_pack_f32 / kgcn_csr_pad4 vs the host packer (numpy stable sorts) on shuffled COO triples with duplicate
+    entries: A, A^T and (N <= 32) both row-padded containers are identical arrays, the entry permutation too, and the
+    kernels give identical bits through either."""
+    from kgcn_amd import BatchedCSR, layers, BatchedAdjacency
+    rng = np.random.default_rng(T * 1000 + nnz)
+    g = rng.integers(0, T, nnz); r = rng.integers(0, N, nnz); c = rng.integers(0, N, nnz)
+    if dups and nnz:
+        k = nnz // 5
+        g[:k], r[:k], c[:k] = g[-k:], r[-k:], c[-k:]                     # repeated (graph, row, col) triples
+    v = rng.standard_normal(nnz).astype(np.float32)
+    host = BatchedCSR.from_arrays(g, r, c, v, T, N, N, device=dev())
+    ti = lambda a: torch.from_numpy(np.asarray(a, np.int32)).to(dev())
+    devb = BatchedCSR.from_device_coo(ti(g), ti(r), ti(c), t32(v), T, N, N)
+    _same_container(devb, host, "A")
+    if nnz:
+        order = np.argsort(g * N + r, kind="stable")
+        assert np.array_equal(devb.perm.cpu().numpy(), order)
+    _same_container(devb.transpose(), host.transpose(), "A^T")
+    assert devb.transpose().transpose() is devb
+    if N <= 32:
+        _same_container(devb.padded4(), host.padded4(), "A p4")
+        _same_container(devb.transpose().padded4(), host.transpose().padded4(), "A^T p4")
+    if nnz:
+        x = torch.randn(T, N, 16, device=dev())
+        layer = layers.GraphConv(16, 1).to(dev())
+        x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        o1, o2 = layer(x1, adj=BatchedAdjacency([devb])), layer(x2, adj=BatchedAdjacency([host]))
+        assert torch.equal(o1, o2)
+        o1.sum().backward(); g1 = [p.grad.clone() for p in layer.parameters()]
+        layer.zero_grad(); o2.sum().backward()
+        assert torch.equal(x1.grad, x2.grad) and all(torch.equal(a, p.grad) for a, p in zip(g1, layer.parameters()))
+    ones = BatchedCSR.from_device_coo(ti(g), ti(r), ti(c), None, T, N, N)                 # val = NULL: all ones
+    assert torch.equal(ones.cv[:, 0], host.cv[:, 0]) and bool((ones.cv[:, 1].view(torch.float32) == 1).all())
+
+
+def test_device_coo_pack_rejects_out_of_range_triples():
+    from kgcn_amd import BatchedCSR
+    ti = lambda a: torch.tensor(a, dtype=torch.int32, device=dev())
+    with pytest.raises(ValueError, match="outside"):
+        BatchedCSR.from_device_coo(ti([0, 1]), ti([0, 5]), ti([0, 0]), None, 2, 4, 4)
+    with pytest.raises(ValueError, match="outside"):
+        BatchedCSR.from_device_coo(ti([0, 2]), ti([0, 1]), ti([0, 0]), None, 2, 4, 4)
+
+
 def test_device_batch_assembly_large_multiblock_scan():
     """70,000 selected graphs (> 256 x 256: the block-total scan loops) drawn with repetition from 3,000
     32-node graphs, every 7th a dummy; fused-kernel containers included."""
