@@ -23,6 +23,8 @@
 // hipBLASLt fp32: 1.07-1.13 ms); compiled-out experiments: MFMAs + y stores alone 0.68 ms, staging alone
 // 0.54 ms -- the workgroup-wide lockstep (barrier per chunk, y stores of all waves at once) keeps the
 // two from overlapping fully; that is where the remaining time is.
+#include <cstdlib>
+
 #include "kgcn_common.h"
 
 namespace kgcn {
@@ -137,17 +139,22 @@ __device__ __forceinline__ void g3_write(u32x4* table, int tile, int q, int li, 
 // (k-step, 32-column tile, piece), L2 resident): every wave reads the B fragments of its two column tiles straight into
 // registers one k-step ahead -- no W loads, no W split (2/3 of the staging arithmetic), no W LDS traffic; LDS holds the
 // x pieces only (48 KB).  `w` is then the table.
-template <bool XVEC, bool WTAB>
-__global__ __launch_bounds__(512, 2) void gemm3_fwd_kernel(
+// MW: row-waves of the workgroup.  2: 8 waves, 128-row tile (one workgroup per CU).  1 (table variant only): 4 waves, 64-row
+// tile, TWO workgroups per CU with their own barriers -- while one workgroup waits at its chunk barrier the other one's
+// waves own the pipes.
+template <bool XVEC, bool WTAB, int MW>
+__global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
     const float* __restrict__ x, long m, int din, long x_ld, const float* __restrict__ w, long w_ld, int trans_w,
     const float* __restrict__ bias, float* __restrict__ y, int dout, long y_ld, int act) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   u32x4* lds = reinterpret_cast<u32x4*>(dsm);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, hi = lane >> 5;
+  static_assert(MW == 2 || WTAB, "the 4-wave workgroup stages x only");
+  constexpr int BMT = 64 * MW;                             // rows per workgroup tile
   const int wr = wave >> 2, wc = wave & 3;
   const int n0 = blockIdx.y * G3_BN;
-  const long ntiles = (m + G3_BM - 1) / G3_BM;
+  const long ntiles = (m + BMT - 1) / BMT;
   const int nkc = (din + G3_BK - 1) / G3_BK;
   if ((long)blockIdx.x >= ntiles) return;      // uniform for the whole workgroup
 
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_fwd_kernel(
     co.wbase[t2] = (unsigned)(n < dout ? n : dout - 1) * (trans_w ? (unsigned)w_ld : 1u);
   }
   auto set_tile = [&](long tile) __attribute__((always_inline)) {
-    const long row = tile * G3_BM + xr;
+    const long row = tile * BMT + xr;
     co.rowok = row < m;
     co.xrow = x + (row < m ? row : m - 1) * x_ld;
   };
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_fwd_kernel(
     // request chunk 2 (clamped to a valid chunk when the sequence ends)
     const long tl = have2 ? t2c : (have1 ? t1 : t0);
     const int kl = have2 ? k2c : (have1 ? k1c : k0c);
-    const long rowl = tl * G3_BM + xr;
+    const long rowl = tl * BMT + xr;
     const float* xrow_l = x + (rowl < m ? rowl : m - 1) * x_ld;
     const bool rowok_l = rowl < m;
     if (k0c == 0) {
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_fwd_kernel(
           long tp; int kp;
           if (kl + 1 < nkc) { tp = tl; kp = kl + 1; } else { tp = tl + gridDim.x; kp = 0; }
           if (tp >= ntiles) { tp = tl; kp = kl; }
-          const long rowp = tp * G3_BM + xr;
+          const long rowp = tp * BMT + xr;
           const int kq = kp * G3_BK + 8 * co.qx;
           touch = x[(rowp < m ? rowp : m - 1) * x_ld + (kq < din ? kq : 0)];
         } else if constexpr (slot == 47) {
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_fwd_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = act_fwd(acc[mt][nt][r], act);
       }
-      const long row0 = t0 * G3_BM + 64 * wr;
+      const long row0 = t0 * BMT + 64 * wr;
       const int cb = n0 + 64 * wc;
       if (row0 + 64 <= m && cb + 64 <= dout) {
         // interior block (wave-uniform test): no masks, one running row pointer (the masked form below costs
@@ -373,36 +380,49 @@ int launch_gemm3_fwd(const float* x, long m, int din, long x_ld, const float* w,
                      const float* bias, float* y, int dout, long y_ld, int act, const void* table, hipStream_t s) {
   static thread_local bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_fwd_kernel<true, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_fwd_kernel<true, false, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_fwd_kernel<false, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_fwd_kernel<false, false, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_fwd_kernel<true, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_fwd_kernel<true, true, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_fwd_kernel<false, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_fwd_kernel<false, true, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     attr_set = true;
   }
   const long ntiles = (m + G3_BM - 1) / G3_BM;
   const bool xvec = (din % 4 == 0) && (x_ld % 4 == 0) && aligned16(x);
   if (table) {
-    const dim3 grid((unsigned)(ntiles < kNumCU ? ntiles : kNumCU), (unsigned)((dout + G3_BN - 1) / G3_BN));
     const size_t lds = 2 * (size_t)G3_XP * 16;
     const float* tw = static_cast<const float*>(table);
+    static const char* mw = getenv("KGCN_GEMM3_MW");         // development: "2" = the 8-wave workgroup
+    if (!(mw && mw[0] == '2')) {
+      const long nt64 = (m + 63) / 64;
+      const long cap = 2L * kNumCU;
+      const dim3 grid((unsigned)(nt64 < cap ? nt64 : cap), (unsigned)((dout + G3_BN - 1) / G3_BN));
+      if (xvec)
+        hipLaunchKernelGGL((gemm3_fwd_kernel<true, true, 1>), grid, dim3(256), lds, s, x, m, din, x_ld, tw, w_ld, trans_w,
+                           bias, y, dout, y_ld, act);
+      else
+        hipLaunchKernelGGL((gemm3_fwd_kernel<false, true, 1>), grid, dim3(256), lds, s, x, m, din, x_ld, tw, w_ld, trans_w,
+                           bias, y, dout, y_ld, act);
+      return check_launch("gemm3_fwd_kernel");
+    }
+    const dim3 grid((unsigned)(ntiles < kNumCU ? ntiles : kNumCU), (unsigned)((dout + G3_BN - 1) / G3_BN));
     if (xvec)
-      hipLaunchKernelGGL((gemm3_fwd_kernel<true, true>), grid, dim3(512), lds, s, x, m, din, x_ld, tw, w_ld, trans_w, bias,
+      hipLaunchKernelGGL((gemm3_fwd_kernel<true, true, 2>), grid, dim3(512), lds, s, x, m, din, x_ld, tw, w_ld, trans_w, bias,
                          y, dout, y_ld, act);
     else
-      hipLaunchKernelGGL((gemm3_fwd_kernel<false, true>), grid, dim3(512), lds, s, x, m, din, x_ld, tw, w_ld, trans_w,
+      hipLaunchKernelGGL((gemm3_fwd_kernel<false, true, 2>), grid, dim3(512), lds, s, x, m, din, x_ld, tw, w_ld, trans_w,
                          bias, y, dout, y_ld, act);
     return check_launch("gemm3_fwd_kernel");
   }
   const dim3 grid((unsigned)(ntiles < kNumCU ? ntiles : kNumCU), (unsigned)((dout + G3_BN - 1) / G3_BN));
   if (xvec)
-    hipLaunchKernelGGL((gemm3_fwd_kernel<true, false>), grid, dim3(512), G3_LDS, s, x, m, din, x_ld, w, w_ld, trans_w,
+    hipLaunchKernelGGL((gemm3_fwd_kernel<true, false, 2>), grid, dim3(512), G3_LDS, s, x, m, din, x_ld, w, w_ld, trans_w,
                        bias, y, dout, y_ld, act);
   else
-    hipLaunchKernelGGL((gemm3_fwd_kernel<false, false>), grid, dim3(512), G3_LDS, s, x, m, din, x_ld, w, w_ld, trans_w,
+    hipLaunchKernelGGL((gemm3_fwd_kernel<false, false, 2>), grid, dim3(512), G3_LDS, s, x, m, din, x_ld, w, w_ld, trans_w,
                        bias, y, dout, y_ld, act);
   return check_launch("gemm3_fwd_kernel");
 }

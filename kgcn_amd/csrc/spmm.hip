@@ -50,6 +50,8 @@ __host__ __device__ inline size_t tile_chan_bytes(int M, int K, int d, int max_n
   return ((((size_t)K * d * 4 + 7) & ~(size_t)7) + (size_t)max_nnz * 8 + (size_t)(M + 1) * 4 + 15) & ~(size_t)15;
 }
 
+// NW waves per workgroup: 1 for tiles up to 20 KiB (8 workgroups per CU); 4 for wide operands (d = 256, N = 50: one 51 KB
+// tile, three workgroups per CU -- every load and store instruction then covers whole 1 KiB rows).
 // VEC floats per lane (4: dwordx4 everywhere; 2: widths like 50 that are even but not a multiple of 4).  blockIdx.y selects
 // a slice of ds columns of a wide operand (d = 256: four slices of 64 keep the tile within the LDS budget of 8 waves per
 // CU; each row of a slice is still one contiguous 256-byte segment).
@@ -57,8 +59,8 @@ template <int VEC> struct SpVec;
 template <> struct SpVec<4> { using T = f32x4; };
 template <> struct SpVec<2> { using T = f32x2; };
 
-template <int LPR, int VEC>
-__global__ __launch_bounds__(64) void spmm_tile_kernel(
+template <int LPR, int VEC, int NW>
+__global__ __launch_bounds__(64 * NW) void spmm_tile_kernel(
     SpmmChannels ch, const float* __restrict__ rhs, long rhs_ld, long rhs_gs, float* __restrict__ out, long out_ld,
     long out_gs, int M, int K, int ds, int nslices, float beta, const float* __restrict__ self_scale, int act,
     const float* __restrict__ aout, int dact) {
@@ -67,10 +69,11 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(
   // slices of one graph are neighbours in the grid: they run at the same time and share the DRAM pages of its rows
   const int t = blockIdx.x / nslices;
   const int col0 = (blockIdx.x - t * nslices) * ds;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x;                 // thread of the workgroup (NW waves)
+  constexpr int NT = 64 * NW;
   const int dv = ds / VEC;
   const int nv = K * dv;
-  const int step_r = 64 / dv, step_c = 64 - step_r * dv;
+  const int step_r = NT / dv, step_c = NT - step_r * dv;
   auto ldv = [](const float* p) { return *reinterpret_cast<const V*>(p); };
   auto stv = [](float* p, V v) { *reinterpret_cast<V*>(p) = v; };
 
@@ -90,11 +93,11 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(
         const V* src = reinterpret_cast<const V*>(rb);
         V* dst = reinterpret_cast<V*>(tile);
 #pragma unroll 4
-        for (int i = lane; i < nv; i += 64) dst[i] = src[i];
+        for (int i = lane; i < nv; i += NT) dst[i] = src[i];
       } else {
         int r = lane / dv, cc = lane - r * dv;             // (row, vector) of element i, walked without dividing
         int i = lane;
-        for (; i + 192 < nv; i += 256) {                   // four loads in flight per lane
+        for (; i + 3 * NT < nv; i += 4 * NT) {                   // four loads in flight per lane
           V v[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -103,9 +106,9 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(
             if (cc >= dv) { cc -= dv; ++r; }
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) stv(tile + (size_t)(i + 64 * u) * VEC, v[u]);
+          for (int u = 0; u < 4; ++u) stv(tile + (size_t)(i + NT * u) * VEC, v[u]);
         }
-        for (; i < nv; i += 64) {
+        for (; i < nv; i += NT) {
           stv(tile + (size_t)i * VEC, ldv(rb + (long)r * rhs_ld + cc * VEC));
           r += step_r; cc += step_c;
           if (cc >= dv) { cc -= dv; ++r; }
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(
       const float* ab = aout + (long)t * rhs_gs + col0;    // same layout as the gradient
       int r = lane / dv, cc = lane - r * dv;
       int i = lane;
-      for (; i + 192 < nv; i += 256) {                     // eight loads in flight per lane
+      for (; i + 3 * NT < nv; i += 4 * NT) {                     // eight loads in flight per lane
         V v[4], a[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -128,10 +131,10 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) v[u][j] *= act_dout(a[u][j], dact);
-          stv(tile + (size_t)(i + 64 * u) * VEC, v[u]);
+          stv(tile + (size_t)(i + NT * u) * VEC, v[u]);
         }
       }
-      for (; i < nv; i += 64) {
+      for (; i < nv; i += NT) {
         V v = ldv(rb + (long)r * rhs_ld + cc * VEC);
         const V a = ldv(ab + (long)r * rhs_ld + cc * VEC);
 #pragma unroll
@@ -141,14 +144,14 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(
         if (cc >= dv) { cc -= dv; ++r; }
       }
     }
-    for (int i = lane; i < cnt; i += 64) ecv[i] = ch.cv[c][base + i];
-    for (int i = lane; i <= M; i += 64) rp[i] = grp[i] - base;
+    for (int i = lane; i < cnt; i += NT) ecv[i] = ch.cv[c][base + i];
+    for (int i = lane; i <= M; i += NT) rp[i] = grp[i] - base;
     off += tile_chan_bytes(M, K, ds, ch.max_nnz[c]);
   }
-  __syncthreads();  // single-wave workgroup: orders the LDS writes before the gathers
+  __syncthreads();  // orders the LDS writes before the gathers (NW = 1: a compiler-level barrier only)
 
   // ---- aggregate: 64/LPR rows at a time, LPR lanes x VEC floats per row, channels innermost ------
-  constexpr int RPW = 64 / LPR;
+  constexpr int RPW = NT / LPR;
   const int sub = lane / LPR;
   const int cl = lane % LPR;
   const bool col_ok = cl * VEC < ds;
@@ -367,10 +370,10 @@ static int ilog2_ceil(int v) {
 // Tile kernel is used when one graph's working set (all channels of the launch) leaves >= 8 waves per CU resident.
 // Can the LDS-staged kernel take this launch, and how?  vec = floats per lane (4, or 2 for even widths), slices = column
 // slices of d/slices floats each (one workgroup per graph and slice) so that a tile stays within 20 KiB (8 waves / CU).
-struct TilePlan { bool ok; int vec; int slices; };
+struct TilePlan { bool ok; int vec; int slices; int nw; };
 static TilePlan tile_plan(const kgcn_csr_batch* a, int nch, const float* rhs, long rhs_ld, long rhs_gs, long rhs_cs,
                           int d, const float* out, long out_ld, long out_gs, const float* aout) {
-  TilePlan p = {false, 4, 1};
+  TilePlan p = {false, 4, 1, 1};
   if (d <= 0 || d > 1024 || a->rows <= 0 || a->cols <= 0) return p;
   const long all = rhs_ld | rhs_gs | out_ld | out_gs | rhs_cs | d;
   const uintptr_t ptrs = reinterpret_cast<uintptr_t>(rhs) | reinterpret_cast<uintptr_t>(out) |
@@ -383,9 +386,10 @@ static TilePlan tile_plan(const kgcn_csr_batch* a, int nch, const float* rhs, lo
     if (d / sl > 64 * p.vec) continue;                  // one wave covers a row of the slice
     size_t lds = 0;
     for (int c = 0; c < nch; ++c) lds += tile_chan_bytes(a[c].rows, a[c].cols, d / sl, a[c].max_nnz_per_graph);
-    if (lds <= 20 * 1024) {
+    if (lds <= 20 * 1024 || (sl == 1 && lds <= 53 * 1024)) {
       p.ok = true;
       p.slices = sl;
+      p.nw = lds <= 20 * 1024 ? 1 : 4;
       return p;
     }
   }
@@ -424,20 +428,34 @@ int launch_spmm_multi(const kgcn_csr_batch* a, int nch, const float* rhs, long r
     for (int c = 0; c < nch; ++c) lds += tile_chan_bytes(M, K, ds, a[c].max_nnz_per_graph);
     const int lanes = ds / plan.vec;
     const dim3 grid((unsigned)(T * plan.slices));
-#define KGCN_TILE(LPR, VEC)                                                                                        \
-  hipLaunchKernelGGL((spmm_tile_kernel<LPR, VEC>), grid, dim3(64), lds, stream, ch, rhs, rhs_ld, rhs_gs, out, out_ld, \
-                     out_gs, M, K, ds, plan.slices, beta, self_scale, act, aout, dact)
+#define KGCN_TILE2(LPR, VEC, NW)                                                                                      \
+  hipLaunchKernelGGL((spmm_tile_kernel<LPR, VEC, NW>), grid, dim3(64 * NW), lds, stream, ch, rhs, rhs_ld, rhs_gs, out,   \
+                     out_ld, out_gs, M, K, ds, plan.slices, beta, self_scale, act, aout, dact)
+#define KGCN_TILE(LPR, VEC)                                                                                           \
+  {                                                                                                                   \
+    if (plan.nw == 1) KGCN_TILE2(LPR, VEC, 1);                                                                        \
+    else {                                                                                                            \
+      static thread_local bool big = false;                                                                           \
+      if (!big) {                                                                                                     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_tile_kernel<LPR, VEC, 4>),                       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);                            \
+        big = true;                                                                                                   \
+      }                                                                                                               \
+      KGCN_TILE2(LPR, VEC, 4);                                                                                        \
+    }                                                                                                                 \
+  }
     if (plan.vec == 4) {
-      if (lanes <= 8) KGCN_TILE(8, 4);
-      else if (lanes <= 16) KGCN_TILE(16, 4);
-      else if (lanes <= 32) KGCN_TILE(32, 4);
-      else KGCN_TILE(64, 4);
+      if (lanes <= 8) KGCN_TILE(8, 4)
+      else if (lanes <= 16) KGCN_TILE(16, 4)
+      else if (lanes <= 32) KGCN_TILE(32, 4)
+      else KGCN_TILE(64, 4)
     } else {
-      if (lanes <= 8) KGCN_TILE(8, 2);
-      else if (lanes <= 16) KGCN_TILE(16, 2);
-      else if (lanes <= 32) KGCN_TILE(32, 2);
-      else KGCN_TILE(64, 2);
+      if (lanes <= 8) KGCN_TILE(8, 2)
+      else if (lanes <= 16) KGCN_TILE(16, 2)
+      else if (lanes <= 32) KGCN_TILE(32, 2)
+      else KGCN_TILE(64, 2)
     }
+#undef KGCN_TILE2
 #undef KGCN_TILE
     return check_launch("spmm_tile_kernel");
   }

@@ -5,9 +5,9 @@
 // and stays L2 resident (0.4-1.5 MB for the layers of example_model/model_multitask.py:51-57 and sparse.py:30).
 // Rows k >= din and columns n >= dout are zero.
 //
-// (Round 2 also carried a register-resident GEMM on this table -- one wave per SIMD, a [128 x 64] block per wave, no
-// LDS operands, deferred stores through a per-wave slab.  It reached 120-127 TF at 256 -> 256 and lost to gemm3 + table
-// (127-129 TF) and on every other shape, so it was removed; tools/gemm_bench.py history in profiles/README.md.)
+// (Round 2 also tried two GEMMs that share nothing between waves on this table -- one wave per SIMD with a [128 x 64]
+// block in registers, and two waves per SIMD with [64 x 64] blocks, no LDS, no barrier.  Both lost to gemm3 + table because
+// every wave then re-splits its x rows: measurements and ablations in profiles/r02_gemm_experiments.txt.)
 #include "kgcn_common.h"
 
 namespace kgcn {
