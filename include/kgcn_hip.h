@@ -260,6 +260,15 @@ int64_t kgcn_dense_fwd_workspace_bytes(int32_t din, int32_t dout);
 int kgcn_dense_fwd_ws_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w, int64_t w_ld,
                           int32_t trans_w, const float* bias, float* y, int32_t dout, int64_t y_ld, int32_t act,
                           void* workspace, int64_t workspace_bytes, void* stream);
+/* Backward of y = act(x @ w + bias) with respect to x (w: [din x dout], ld w_ld):
+ *   dpre = grad (.) act'(act_out)   written to dpre (same layout as grad; must not alias it) -- the operand of
+ *                                   kgcn_dense_wgrad_f32 for dw / dbias,
+ *   dx   = dpre @ w^T               [m x din].
+ * For wide layers with a workspace of kgcn_dense_fwd_workspace_bytes(dout, din) bytes both happen in ONE pass of the
+ * GEMM (the derivative is applied while the gradient rows are staged); otherwise two launches. */
+int kgcn_dense_dx_dact_f32(const float* grad, const float* act_out, int64_t m, int32_t dout, int64_t ld, const float* w,
+                           int64_t w_ld, int32_t din, float* dx, int64_t dx_ld, int32_t act, float* dpre,
+                           void* workspace, int64_t workspace_bytes, void* stream);
 /* stand-alone forms: y = act(x) over n floats; dpre = grad (.) act'(act_out) (dpre may alias grad) */
 int kgcn_act_fwd_f32(const float* x, int64_t n, int32_t act, float* y, void* stream);
 int kgcn_act_bwd_f32(const float* act_out, const float* grad, int64_t n, int32_t act, float* dpre, void* stream);

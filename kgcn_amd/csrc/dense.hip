@@ -30,6 +30,8 @@ int launch_narrow_fwd(const float* x, long m, int din, const float* w, long w_ld
 bool narrow_wgrad_ok(const float* x, int din, long x_ld, const float* dy, int dout, long dy_ld);
 int launch_narrow_wgrad(const float* x, const float* dy, long m, int din, int dout, float* part_dw, float* part_db,
                         int nblocks, hipStream_t s);
+int launch_gemm3_dx_dact(const float* grad, const float* act_out, float* dpre, long m, int k, long ld, const void* table,
+                         float* dx, int n, long dx_ld, int dact, hipStream_t s);
 int64_t wtable_bytes(int din, int dout);
 void launch_wtable_split(const float* w, long w_ld, int trans_w, int din, int dout, void* workspace, hipStream_t s);
 int launch_gemm3_wgrad(const float* x, long x_ld, const float* dy, long dy_ld, long m, int din, int dout,
@@ -565,6 +567,31 @@ extern "C" int kgcn_dense_fwd_f32(const float* x, int64_t m, int32_t din, int64_
                                   int32_t trans_w, const float* bias, float* y, int32_t dout, int64_t y_ld,
                                   void* stream) {
   return dense_fwd_impl(x, m, din, x_ld, w, w_ld, trans_w, bias, y, dout, y_ld, KGCN_ACT_NONE, nullptr, 0, stream);
+}
+
+extern "C" int kgcn_dense_dx_dact_f32(const float* grad, const float* act_out, int64_t m, int32_t dout, int64_t ld,
+                                      const float* w, int64_t w_ld, int32_t din, float* dx, int64_t dx_ld, int32_t act,
+                                      float* dpre, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (act <= KGCN_ACT_NONE || act > KGCN_ACT_TANH) return fail("kgcn_dense_dx_dact_f32: activation code %d", act);
+  if (m < 0 || din <= 0 || dout <= 0)
+    return fail("kgcn_dense_dx_dact_f32: bad shape m=%lld din=%d dout=%d", (long long)m, din, dout);
+  if (m == 0) return 0;
+  if (!grad || !act_out || !w || !dx || !dpre) return fail("kgcn_dense_dx_dact_f32: NULL operand");
+  if (dpre == grad) return fail("kgcn_dense_dx_dact_f32: dpre must not alias grad");
+  if (ld < dout || dx_ld < din || w_ld < dout) return fail("kgcn_dense_dx_dact_f32: leading dimension too small");
+  // the contraction runs over the layer's OUTPUT width: K = dout, N = din, W used transposed
+  static const char* route = getenv("KGCN_DENSE_ROUTE");
+  if (!(route && !strcmp(route, "gemm3")) && table_pays(dout, din) && workspace && workspace_bytes >= wtable_bytes(dout, din) &&
+      m >= 1024) {
+    launch_wtable_split(w, (long)w_ld, 1, dout, din, workspace, as_stream(stream));
+    const int rc = launch_gemm3_dx_dact(grad, act_out, dpre, (long)m, dout, (long)ld, workspace, dx, din, (long)dx_ld, act,
+                                        as_stream(stream));
+    if (rc >= 0) return rc;
+  }
+  if (ld != dout) return fail("kgcn_dense_dx_dact_f32: rows must be contiguous (ld == dout) outside the fused form");
+  if (int rc = kgcn_act_bwd_f32(act_out, grad, m * dout, act, dpre, stream)) return rc;
+  return dense_fwd_impl(dpre, m, dout, ld, w, w_ld, 1, nullptr, dx, din, dx_ld, KGCN_ACT_NONE, workspace, workspace_bytes,
+                        stream);
 }
 
 extern "C" int64_t kgcn_dense_fwd_workspace_bytes(int32_t din, int32_t dout) {

@@ -59,6 +59,7 @@ constexpr size_t G3_LDS = 2 * (size_t)(G3_XP + G3_WP) * 16;
 // so that chunk i+2 can be requested while chunk i+1 is being split.
 struct G3Raw {
   f32x4 xa, xb;        // x[row][k0 + 8 qx .. +7]
+  f32x4 ya, yb;        // DK != 0: the saved layer output at the same positions (x is then the incoming gradient)
   float w0[8], w1[8];  // W^(T)[k0 + 8 q + j][n] for the thread's two (n, q) tasks
 };
 
@@ -74,8 +75,9 @@ struct G3Coord {
   bool wvec;           // transposed source with 16-byte aligned rows and din % 4 == 0
 };
 
-template <bool XVEC, bool WTAB = false>
-__device__ __forceinline__ void g3_issue(G3Raw& r, const G3Coord& c, const float* __restrict__ w, int din, int k0) {
+template <bool XVEC, bool WTAB = false, int DK = 0>
+__device__ __forceinline__ void g3_issue(G3Raw& r, const G3Coord& c, const float* __restrict__ w, int din, int k0,
+                                         long ydiff = 0) {
   // loads read clamped (always valid) addresses; masking happens when the data is split (g3_land), so no
   // select sits between a load and its first real use
   const int k = k0 + 8 * c.qx;
@@ -88,6 +90,10 @@ __device__ __forceinline__ void g3_issue(G3Raw& r, const G3Coord& c, const float
       r.xa[j] = c.xrow[k + j < din ? k + j : 0];
       r.xb[j] = c.xrow[k + 4 + j < din ? k + 4 + j : 0];
     }
+  }
+  if constexpr (DK != 0) {         // XVEC only
+    r.ya = *reinterpret_cast<const f32x4*>(c.xrow + ydiff + (k < din ? k : 0));
+    r.yb = *reinterpret_cast<const f32x4*>(c.xrow + ydiff + (k + 4 < din ? k + 4 : 0));
   }
   if constexpr (WTAB) return;      // W arrives pre-split from the fragment table
   if (c.wvec) {          // transposed source, rows 16-byte aligned: 8 k-values = 2 x 16 bytes
@@ -142,15 +148,47 @@ __device__ __forceinline__ void g3_write(u32x4* table, int tile, int q, int li, 
 // MW: row-waves of the workgroup.  2: 8 waves, 128-row tile (one workgroup per CU).  1 (table variant only): 4 waves, 64-row
 // tile, TWO workgroups per CU with their own barriers -- while one workgroup waits at its chunk barrier the other one's
 // waves own the pipes.
-template <bool XVEC, bool WTAB, int MW>
+// DK (table variant, XVEC): backward of an activated dense layer in ONE pass -- x is the incoming gradient g, the operand
+// of the contraction is dpre = g (.) act'(a) with a = the saved layer output (same layout, `ydiff` elements away): the
+// staging threads multiply while they split and write dpre (`pdiff` elements away from x) for the weight-gradient GEMM, so
+// the stand-alone activation-backward pass (3 x 4 bytes per element) disappears.  DK = 1: act' = c0 + c1 a + c2 a^2
+// (sigmoid 0, 1, -1; tanh 1, 0, -1), DK = 2: relu (a > 0).  Every store goes to the clamped address its load came from:
+// threads whose row or k is out of range re-store values another thread stores too.
+struct G3Dact { long ydiff, pdiff; float c0, c1, c2; };
+
+template <bool XVEC, bool WTAB, int MW, int DK = 0>
 __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
     const float* __restrict__ x, long m, int din, long x_ld, const float* __restrict__ w, long w_ld, int trans_w,
-    const float* __restrict__ bias, float* __restrict__ y, int dout, long y_ld, int act) {
+    const float* __restrict__ bias, float* __restrict__ y, int dout, long y_ld, int act, G3Dact da) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   u32x4* lds = reinterpret_cast<u32x4*>(dsm);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, hi = lane >> 5;
   static_assert(MW == 2 || WTAB, "the 4-wave workgroup stages x only");
+  static_assert(DK == 0 || (WTAB && XVEC), "the activation-derivative prologue lives in the table variant");
+  // g (.) act'(a) for the pair J of a raw set, in place (before the pair is split)
+  auto dact_pair = [&](G3Raw& R, auto jc) __attribute__((always_inline)) {
+    constexpr int J = decltype(jc)::value;
+    if constexpr (DK != 0) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float a = (J < 2) ? R.ya[2 * J + e] : R.yb[2 * J - 4 + e];
+        float g = (J < 2) ? R.xa[2 * J + e] : R.xb[2 * J - 4 + e];
+        if constexpr (DK == 1) g *= __builtin_fmaf(__builtin_fmaf(da.c2, a, da.c1), a, da.c0);
+        else g = a > 0.f ? g : 0.f;
+        if constexpr (J < 2) R.xa[2 * J + e] = g;
+        else R.xb[2 * J - 4 + e] = g;
+      }
+    }
+  };
+  auto store_dpre = [&](const G3Raw& R, const float* xrow, int k0) __attribute__((always_inline)) {
+    if constexpr (DK != 0) {
+      const int k = k0 + 8 * (tid & 3);
+      float* p = const_cast<float*>(xrow) + da.pdiff;
+      *reinterpret_cast<f32x4*>(p + (k < din ? k : 0)) = R.xa;
+      *reinterpret_cast<f32x4*>(p + (k + 4 < din ? k + 4 : 0)) = R.xb;
+    }
+  };
   constexpr int BMT = 64 * MW;                             // rows per workgroup tile
   const int wr = wave >> 2, wc = wave & 3;
   const int n0 = blockIdx.y * G3_BN;
@@ -216,10 +254,12 @@ __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
     }
   };
   set_tile(t0);
-  g3_issue<XVEC, WTAB>(ra, co, w, din, k0c * G3_BK);
+  g3_issue<XVEC, WTAB, DK>(ra, co, w, din, k0c * G3_BK, da.ydiff);
   static_for<(WTAB ? 4 : 12)>([&](auto sc) __attribute__((always_inline)) {
+    if constexpr (decltype(sc)::value < 4) dact_pair(ra, sc);
     g3_split_step<decltype(sc)::value>(ra, co, din, k0c * G3_BK, fx, f0, f1);
   });
+  store_dpre(ra, co.xrow, k0c * G3_BK);
   g3_write(lds, xr >> 5, co.qx, xr & 31, fx);
   if constexpr (!WTAB) {
     g3_write(lds + G3_XP, (tid & 255) >> 5, co.qw[0], tid & 31, f0);
@@ -228,7 +268,7 @@ __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
     load_b(B0, 0);
   }
   set_tile(t1 < ntiles ? t1 : t0);
-  g3_issue<XVEC, WTAB>(rb, co, w, din, (t1 < ntiles ? k1c : k0c) * G3_BK);
+  g3_issue<XVEC, WTAB, DK>(rb, co, w, din, (t1 < ntiles ? k1c : k0c) * G3_BK, da.ydiff);
   __syncthreads();
 
   f32x16 acc[2][2];
@@ -288,9 +328,12 @@ __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
           if constexpr (ks == 0) load_b(B1, 2 * k0c + 1);
           else load_b(B0, gnext);
         }
-        if constexpr (WTAB && slot >= 4 && slot < 12) {
+        if constexpr (WTAB && slot == 5) {
+          store_dpre(RS, cs.xrow, ks1);
+        } else if constexpr (WTAB && slot >= 4 && slot < 12) {
         } else if constexpr (WTAB && (slot == 13 || slot == 14)) {
         } else if constexpr (slot < 12) {
+          if constexpr (slot < 4) dact_pair(RS, std::integral_constant<int, slot>{});
           g3_split_step<slot>(RS, cs, din, ks1, fx, f0, f1);
         } else if constexpr (slot == 12) {
           g3_write(xq, xr >> 5, co.qx, xr & 31, fx);
@@ -301,7 +344,7 @@ __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
         } else if constexpr (slot == 16) {
           co.xrow = xrow_l;
           co.rowok = rowok_l;
-          g3_issue<XVEC, WTAB>(RL, co, w, din, kl * G3_BK);
+          g3_issue<XVEC, WTAB, DK>(RL, co, w, din, kl * G3_BK, da.ydiff);
         } else if constexpr (slot == 18) {
           // one more chunk of x on its way from HBM: a single k chunk per workgroup in flight (16 KB) caps the
           // read rate at ~2 TB/s (latency x bytes in flight); this 4-byte load per 32-byte piece pulls the line
@@ -402,29 +445,56 @@ int launch_gemm3_fwd(const float* x, long m, int din, long x_ld, const float* w,
       const dim3 grid((unsigned)(nt64 < cap ? nt64 : cap), (unsigned)((dout + G3_BN - 1) / G3_BN));
       if (xvec)
         hipLaunchKernelGGL((gemm3_fwd_kernel<true, true, 1>), grid, dim3(256), lds, s, x, m, din, x_ld, tw, w_ld, trans_w,
-                           bias, y, dout, y_ld, act);
+                           bias, y, dout, y_ld, act, G3Dact{});
       else
         hipLaunchKernelGGL((gemm3_fwd_kernel<false, true, 1>), grid, dim3(256), lds, s, x, m, din, x_ld, tw, w_ld, trans_w,
-                           bias, y, dout, y_ld, act);
+                           bias, y, dout, y_ld, act, G3Dact{});
       return check_launch("gemm3_fwd_kernel");
     }
     const dim3 grid((unsigned)(ntiles < kNumCU ? ntiles : kNumCU), (unsigned)((dout + G3_BN - 1) / G3_BN));
     if (xvec)
       hipLaunchKernelGGL((gemm3_fwd_kernel<true, true, 2>), grid, dim3(512), lds, s, x, m, din, x_ld, tw, w_ld, trans_w, bias,
-                         y, dout, y_ld, act);
+                         y, dout, y_ld, act, G3Dact{});
     else
       hipLaunchKernelGGL((gemm3_fwd_kernel<false, true, 2>), grid, dim3(512), lds, s, x, m, din, x_ld, tw, w_ld, trans_w,
-                         bias, y, dout, y_ld, act);
+                         bias, y, dout, y_ld, act, G3Dact{});
     return check_launch("gemm3_fwd_kernel");
   }
   const dim3 grid((unsigned)(ntiles < kNumCU ? ntiles : kNumCU), (unsigned)((dout + G3_BN - 1) / G3_BN));
   if (xvec)
     hipLaunchKernelGGL((gemm3_fwd_kernel<true, false, 2>), grid, dim3(512), G3_LDS, s, x, m, din, x_ld, w, w_ld, trans_w,
-                       bias, y, dout, y_ld, act);
+                       bias, y, dout, y_ld, act, G3Dact{});
   else
     hipLaunchKernelGGL((gemm3_fwd_kernel<false, false, 2>), grid, dim3(512), G3_LDS, s, x, m, din, x_ld, w, w_ld, trans_w,
-                       bias, y, dout, y_ld, act);
+                       bias, y, dout, y_ld, act, G3Dact{});
   return check_launch("gemm3_fwd_kernel");
+}
+
+// dx = (grad (.) act'(act_out)) @ W^T through the table variant, dpre written on the way (see G3Dact).  Returns -1 when the
+// shape / alignment is not one the fused form takes (the caller then runs the activation backward on its own).
+int launch_gemm3_dx_dact(const float* grad, const float* act_out, float* dpre, long m, int k, long ld, const void* table,
+                         float* dx, int n, long dx_ld, int dact, hipStream_t s) {
+  const bool ok = (k % 4 == 0) && (ld % 4 == 0) && aligned16(grad) && aligned16(act_out) && aligned16(dpre) && table &&
+                  dact != KGCN_ACT_NONE && dpre != grad;
+  if (!ok) return -1;
+  G3Dact da;
+  da.ydiff = act_out - grad;
+  da.pdiff = dpre - grad;
+  da.c0 = dact == KGCN_ACT_TANH ? 1.f : 0.f;
+  da.c1 = dact == KGCN_ACT_SIGMOID ? 1.f : 0.f;
+  da.c2 = -1.f;
+  const long nt64 = (m + 63) / 64;
+  const long cap = 2L * kNumCU;
+  const dim3 grid((unsigned)(nt64 < cap ? nt64 : cap), (unsigned)((n + G3_BN - 1) / G3_BN));
+  const size_t lds = 2 * (size_t)G3_XP * 16;
+  const float* tw = static_cast<const float*>(table);
+  if (dact == KGCN_ACT_RELU)
+    hipLaunchKernelGGL((gemm3_fwd_kernel<true, true, 1, 2>), grid, dim3(256), lds, s, grad, m, k, ld, tw, 0L, 1, nullptr, dx, n,
+                       dx_ld, KGCN_ACT_NONE, da);
+  else
+    hipLaunchKernelGGL((gemm3_fwd_kernel<true, true, 1, 1>), grid, dim3(256), lds, s, grad, m, k, ld, tw, 0L, 1, nullptr, dx, n,
+                       dx_ld, KGCN_ACT_NONE, da);
+  return check_launch("gemm3_fwd_kernel(dact)");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -240,17 +240,27 @@ class _Dense(torch.autograd.Function):
     def backward(ctx, gy):
         x2d, w, yact = ctx.saved_tensors
         gy = _f32c(gy, "grad")
-        if ctx.act:                                  # d pre-activation, read by both GEMMs of the backward
-            gy = activation_backward(yact, gy, ctx.act)
         m, din = x2d.shape
         dout = w.shape[1]
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if ctx.act and ctx.needs_input_grad[0]:
+            # d pre-activation is produced by the dX GEMM itself while it stages the gradient rows (wide layers); the
+            # weight-gradient GEMM reads it afterwards
             dx = torch.empty_like(x2d)
-            # dx = gy @ w^T : w [din, dout] used transposed
+            dpre = torch.empty_like(gy)
             wsb, wsp = _dense_ws(dout, din, gy.device)
-            check(lib.kgcn_dense_fwd_ws_f32(ptr(gy), m, dout, dout, ptr(w), dout, 1, None, ptr(dx),
-                                            din, din, 0, ptr(wsp), wsb, current_stream()), "kgcn_dense_fwd_ws_f32(dx)")
+            check(lib.kgcn_dense_dx_dact_f32(ptr(gy), ptr(yact), m, dout, dout, ptr(w), dout, din, ptr(dx), din, ctx.act,
+                                             ptr(dpre), ptr(wsp), wsb, current_stream()), "kgcn_dense_dx_dact_f32")
+            gy = dpre
+        else:
+            if ctx.act:
+                gy = activation_backward(yact, gy, ctx.act)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x2d)
+                # dx = gy @ w^T : w [din, dout] used transposed
+                wsb, wsp = _dense_ws(dout, din, gy.device)
+                check(lib.kgcn_dense_fwd_ws_f32(ptr(gy), m, dout, dout, ptr(w), dout, 1, None, ptr(dx),
+                                                din, din, 0, ptr(wsp), wsb, current_stream()), "kgcn_dense_fwd_ws_f32(dx)")
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.bias_shape is not None and ctx.needs_input_grad[2]
         if need_w or need_b:

@@ -64,6 +64,9 @@ def _cost(name, a):
     if name in ("kgcn_dense_fwd_f32", "kgcn_dense_fwd_act_f32", "kgcn_dense_fwd_ws_f32"):
         m, din, dout = a[1], a[2], a[9]
         return 4 * (m * din + m * dout + din * dout), 2 * m * din * dout, "m=%d %d->%d%s" % (m, din, dout, " T" if a[6] else "")
+    if name == "kgcn_dense_dx_dact_f32":
+        m, dout, din = a[2], a[3], a[7]
+        return 4 * (3 * m * dout + m * din + din * dout), 2 * m * din * dout, "m=%d %d->%d T dact=%d" % (m, dout, din, a[10])
     if name == "kgcn_dense_wgrad_f32":
         m, din, dout = a[4], a[5], a[6]
         return 4 * (m * din + m * dout + din * dout), 2 * m * din * dout, "m=%d %dx%d" % (m, din, dout)
