@@ -52,6 +52,14 @@ extern "C" {
  * gather an all-zero row the fused kernels keep in LDS, so they contribute exactly 0 (never 0*inf). */
 #define KGCN_PAD_COL 32
 
+/* Non-finite inputs.  The fused GraphConv kernels and the wide-layer GEMMs contract on the bf16 matrix pipe with an EXACT
+ * three-way split of every fp32 value (p1 + p2 + p3 == x bit for bit for finite x, six products per k-value); the other
+ * kernels use fp32 MFMA / FMA.  For finite inputs both agree with fp32 arithmetic to one rounding.  +-inf splits into
+ * (inf, NaN, NaN) and NaN into (NaN, NaN, NaN): every output element that depends on a non-finite input comes out
+ * non-finite (NaN where fp32 arithmetic would give +-inf is possible), every other element is unaffected -- never a
+ * silently finite wrong value (tests/test_gpu_parity.py::test_bf16_split_non_finite_inputs).  Padding entries of the
+ * row-padded layout gather an all-zero row with value 0, so they contribute exactly 0 (never 0 * inf). */
+
 typedef struct kgcn_csr_batch {
   int32_t num_graphs;        /* T */
   int32_t rows;              /* M: rows per graph (padded, uniform) */

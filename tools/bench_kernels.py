@@ -80,7 +80,7 @@ add("graphconv_fwd fused", lambda: check(lib.kgcn_graphconv_fwd_f32(p4.desc(), p
                                                                     current_stream())), ab["fwd"], 2 * N * D * D + 2 * NNZ * D)
 wsb2 = lib.kgcn_graphconv_bwd_workspace_bytes(T, D, D)
 wsp2 = torch.empty(wsb2 // 4, device=dev)
-add("graphconv_bwd fused (+2 reduce launches)",
+add("graphconv_bwd fused (+1 reduce launch)",
     lambda: check(lib.kgcn_graphconv_bwd_f32(p4t.desc(), ptr(x), ptr(w), ptr(g), D, D, ptr(dx), ptr(dw), ptr(db),
                                              ptr(wsp2), wsb2, current_stream())), ab["bwd"], 4 * N * D * D + 2 * NNZ * D)
 # device-side mini-batch assembly: T graphs gathered (shuffled) out of a resident dataset of T graphs;
