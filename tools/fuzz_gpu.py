@@ -120,6 +120,77 @@ for case in range(CASES):
                                      for s in sel], rows=N, cols=N, device=dev) if len(sel) else None
     if host is not None and not (torch.equal(got.rowptr, host.rowptr) and torch.equal(got.cv, host.cv)):
         fails.append(("gather", (N, T, len(sel)), 0, 0))
+    # ---- wide / odd-width aggregation on larger graphs: tile kernel in column slices, 4-wave tiles, float2 lanes, gather --
+    N2, T2 = int(rng.integers(1, 65)), int(rng.integers(1, 40))
+    D2 = int(rng.choice([2, 6, 50, 64, 96, 128, 130, 200, 256, 300, 512, int(rng.integers(1, 300))]))
+    C2 = int(rng.integers(1, 4))
+    chans = [rand_graphs(T2, N2, rng.uniform(0.03, 0.3), empty_every=int(rng.integers(0, 5))) for _ in range(C2)]
+    csrs = [BatchedCSR.from_coo_list([a[0] for a in ch], rows=N2, cols=N2, device=dev) for ch in chans]
+    adj2 = BatchedAdjacency(csrs)
+    rhs2 = rng.standard_normal((T2 * N2, C2 * D2)).astype(np.float32)
+    g2 = rng.standard_normal((T2 * N2, D2)).astype(np.float32)
+    actn = [None, "sigmoid", "relu", "tanh"][int(rng.integers(0, 4))]
+    tr = t32(rhs2).requires_grad_(True)
+    o2 = ops.bconv(adj2, tr, D2, activation=actn)
+    o2.backward(t32(g2))
+    pre = np.zeros((T2, N2, D2))
+    r3 = rhs2.astype(np.float64).reshape(T2, N2, C2 * D2)
+    for c in range(C2):
+        pre += np.stack(K.bspmm([a[0] for a in chans[c]], list(r3[:, :, c * D2:(c + 1) * D2])))
+    f_act = {None: lambda z: z, "sigmoid": lambda z: 1 / (1 + np.exp(-z)), "relu": lambda z: np.maximum(z, 0), "tanh": np.tanh}[actn]
+    yref = f_act(pre)
+    # relu': the mask of the kernel's OWN output (as tf.nn.relu's gradient reads its output): a pre-activation within one
+    # rounding of 0 may legitimately land on either side
+    d_act = {None: np.ones_like(yref), "sigmoid": yref * (1 - yref),
+             "relu": (o2.detach().cpu().numpy().reshape(yref.shape) > 0) * 1.0, "tanh": 1 - yref ** 2}[actn]
+    ctx = ("bconv+act", N2, D2, T2, C2, actn)
+    check("bconv act fwd", o2, yref.reshape(T2 * N2, D2), ctx=ctx)
+    gpre = (g2.reshape(T2, N2, D2) * d_act)
+    drhs = np.concatenate([np.stack(K.bspmm([a[0] for a in chans[c]], list(gpre), adjoint_a=True)) for c in range(C2)], axis=2)
+    check("bconv act bwd", tr.grad, drhs.reshape(T2 * N2, C2 * D2), ctx=ctx)
+    # ---- activated dense layers incl. the wide-layer table / fused d-activation routes (m >= 1024) -------------------------
+    M3 = int(rng.integers(1, 6000))
+    di3, do3 = int(rng.choice([50, 81, 192, 256, 320, int(rng.integers(1, 400))])), int(rng.choice([12, 50, 129, 200, 256, 512, int(rng.integers(1, 400))]))
+    act3 = ["sigmoid", "relu", "tanh"][int(rng.integers(0, 3))]
+    x3 = rng.standard_normal((M3, di3)).astype(np.float32)
+    w3 = K.glorot_uniform(rng, di3, do3); b3 = rng.standard_normal(do3).astype(np.float32)
+    g3 = rng.standard_normal((M3, do3)).astype(np.float32)
+    tx3, tw3, tb3 = t32(x3).requires_grad_(True), t32(w3).requires_grad_(True), t32(b3).requires_grad_(True)
+    y3 = ops.dense(tx3, tw3, tb3, activation=act3)
+    y3.backward(t32(g3))
+    z3 = x3.astype(np.float64) @ w3.astype(np.float64) + b3
+    a3 = {"sigmoid": 1 / (1 + np.exp(-z3)), "relu": np.maximum(z3, 0), "tanh": np.tanh(z3)}[act3]
+    gz3 = g3 * {"sigmoid": a3 * (1 - a3), "relu": (y3.detach().cpu().numpy() > 0) * 1.0, "tanh": 1 - a3 ** 2}[act3]
+    ctx = ("dense+act", M3, di3, do3, act3)
+    check("dense act fwd", y3, a3, ctx=ctx); check("dense act dx", tx3.grad, gz3 @ w3.astype(np.float64).T, ctx=ctx)
+    check("dense act dw", tw3.grad, x3.astype(np.float64).T @ gz3, rel=5e-5, ctx=ctx); check("dense act db", tb3.grad, gz3.sum(0), rel=5e-5, ctx=ctx)
+    # ---- device-side COO pack -----------------------------------------------------------------------------------------------
+    Tp, Np, nz = int(rng.integers(1, 60)), int(rng.integers(1, 65)), int(rng.integers(0, 4000))
+    gp, rp_, cp = rng.integers(0, Tp, nz), rng.integers(0, Np, nz), rng.integers(0, Np, nz)
+    vp = rng.standard_normal(nz).astype(np.float32)
+    hostp = BatchedCSR.from_arrays(gp, rp_, cp, vp, Tp, Np, Np, device=dev)
+    ti = lambda a: torch.from_numpy(np.asarray(a, np.int32)).to(dev)
+    devp = BatchedCSR.from_device_coo(ti(gp), ti(rp_), ti(cp), t32(vp), Tp, Np, Np)
+    pairs = [(devp, hostp), (devp.transpose(), hostp.transpose())]
+    if Np <= 32:
+        try:
+            hp4 = hostp.padded4()
+        except ValueError:
+            hp4 = None                                     # a row longer than 252 padded entries: both packers refuse
+        try:
+            dp4 = devp.padded4()
+        except ValueError:
+            dp4 = None
+        if (hp4 is None) != (dp4 is None):
+            fails.append(("coo pack: only one packer refused", (Tp, Np, nz), 0, 0))
+        elif hp4 is not None:
+            pairs += [(dp4, hp4)]
+    for a_, b_ in pairs:
+        same = torch.equal(a_.rowptr, b_.rowptr) and torch.equal(a_.cv, b_.cv) and a_.max_nnz == b_.max_nnz
+        if a_.row_pad:
+            same = same and torch.equal(a_.slots, b_.slots) and torch.equal(a_.graph_ptr, b_.graph_ptr)
+        if not same:
+            fails.append(("coo pack", (Tp, Np, nz, a_.row_pad), 0, 0))
 print("%d cases in %.1f s, %d failures" % (CASES, time.time() - t_start, len(fails)))
 for f in fails[:30]:
     print("  FAIL", f)
