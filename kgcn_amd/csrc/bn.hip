@@ -15,19 +15,24 @@
 namespace kgcn {
 
 int launch_reduce_partials(const float* part, int nparts, long n, float* out, hipStream_t s);
+int launch_reduce_pair(const float* part_a, long n_a, float* out_a, const float* part_b, long n_b, float* out_b, int nparts,
+                       hipStream_t s);
 
 constexpr int BN_BLOCKS = 1024;    // partial rows of the first reduction stage
 
 // MODE 0: acc0 = sum x                       (mean numerator)
 // MODE 1: acc0 = sum (x - mean)^2            (variance numerator)
 // MODE 2: acc0 = sum g, acc1 = sum g * xhat  (dbeta, dgamma), xhat = (x - mean) * rstd
+// MODE 3: MODE 2 and, in the same pass, the inference-phase dx = gamma rstd g (0 on padding rows): x and g are read once
 // Thread layout: column c = tid % cb of a block of cb <= 256 columns, row lane tid / cb of 256 / cb rows per pass:
 // consecutive threads read consecutive floats of a row.
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_colreduce_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                            long rows, int n_nodes, int d, const int* __restrict__ enabled,
                                                            const float* __restrict__ mean, const float* __restrict__ var,
-                                                           float eps, float* __restrict__ part0, float* __restrict__ part1) {
+                                                           float eps, float* __restrict__ part0, float* __restrict__ part1,
+                                                           const float* __restrict__ gamma = nullptr,
+                                                           float* __restrict__ dx = nullptr) {
   __shared__ float red[2][256];
   const int tid = threadIdx.x;
   for (int c0 = 0; c0 < d; c0 += 256) {
@@ -36,18 +41,27 @@ __global__ __launch_bounds__(256) void bn_colreduce_kernel(const float* __restri
     const int c = tid % cb, rl = tid / cb;
     float a0 = 0.f, a1 = 0.f;
     if (rl < rpp) {
-      float mu = 0.f, rs = 0.f;
+      float mu = 0.f, rs = 0.f, gr = 0.f;
       if constexpr (MODE >= 1) mu = mean[c0 + c];
-      if constexpr (MODE == 2) rs = 1.0f / __builtin_sqrtf(var[c0 + c] + eps);
+      if constexpr (MODE >= 2) rs = 1.0f / __builtin_sqrtf(var[c0 + c] + eps);
+      if constexpr (MODE == 3) gr = gamma[c0 + c] * rs;
       for (long r = (long)blockIdx.x * rpp + rl; r < rows; r += (long)gridDim.x * rpp) {
         if (enabled) {
           const long t = r / n_nodes;
-          if ((int)(r - t * n_nodes) >= enabled[t]) continue;
+          if ((int)(r - t * n_nodes) >= enabled[t]) {
+            if constexpr (MODE == 3) dx[r * d + c0 + c] = 0.f;
+            continue;
+          }
         }
         const float v = x[r * d + c0 + c];
         if constexpr (MODE == 0) a0 += v;
         if constexpr (MODE == 1) { const float dv = v - mu; a0 += dv * dv; }
-        if constexpr (MODE == 2) { const float gv = g[r * d + c0 + c]; a0 += gv; a1 += gv * ((v - mu) * rs); }
+        if constexpr (MODE >= 2) {
+          const float gv = g[r * d + c0 + c];
+          a0 += gv;
+          a1 += gv * ((v - mu) * rs);
+          if constexpr (MODE == 3) dx[r * d + c0 + c] = gr * gv;
+        }
       }
     }
     red[0][tid] = a0;
@@ -57,7 +71,7 @@ __global__ __launch_bounds__(256) void bn_colreduce_kernel(const float* __restri
       float s0 = 0.f, s1 = 0.f;
       for (int k = 0; k < rpp; ++k) { s0 += red[0][k * cb + tid]; s1 += red[1][k * cb + tid]; }
       part0[(long)blockIdx.x * d + c0 + tid] = s0;
-      if constexpr (MODE == 2) part1[(long)blockIdx.x * d + c0 + tid] = s1;
+      if constexpr (MODE >= 2) part1[(long)blockIdx.x * d + c0 + tid] = s1;
     }
     __syncthreads();
   }
@@ -238,10 +252,15 @@ extern "C" int kgcn_graph_bn_bwd_f32(const float* x, const float* grad, int64_t 
   long* count = reinterpret_cast<long*>(reinterpret_cast<char*>(workspace) +
                                         ((((size_t)2 * BN_BLOCKS * d) * 4 + 15) & ~(size_t)15));
   int nb = bn_blocks(rows, d);
+  if (dx && !training) {
+    // inference phase: dx does not depend on the reductions -> one pass over x and g
+    hipLaunchKernelGGL(bn_colreduce_kernel<3>, dim3(nb), dim3(256), 0, s, x, grad, rows, n_nodes, d, enabled, mean, var, eps,
+                       part0, part1, gamma, dx);
+    return launch_reduce_pair(part0, d, dbeta, part1, d, dgamma, nb, s);
+  }
   hipLaunchKernelGGL(bn_colreduce_kernel<2>, dim3(nb), dim3(256), 0, s, x, grad, rows, n_nodes, d, enabled, mean, var, eps,
-                     part0, part1);
-  if (int rc = launch_reduce_partials(part0, nb, d, dbeta, s)) return rc;
-  if (int rc = launch_reduce_partials(part1, nb, d, dgamma, s)) return rc;
+                     part0, part1, nullptr, nullptr);
+  if (int rc = launch_reduce_pair(part0, d, dbeta, part1, d, dgamma, nb, s)) return rc;
   if (dx) {
     // the valid-row count (scale kernel with no array to scale: d = 0)
     hipLaunchKernelGGL(bn_scale_kernel, dim3(1), dim3(256), 0, s, part0, 0, enabled, (long)graphs, n_nodes, count);

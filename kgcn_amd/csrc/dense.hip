@@ -606,8 +606,9 @@ extern "C" int kgcn_dense_fwd_ws_f32(const float* x, int64_t m, int32_t din, int
 }
 
 // dW and dbias partials of one layer in ONE launch (either output may be NULL)
-static int launch_reduce_pair(const float* part_dw, long n_dw, float* dw, const float* part_db, long n_db, float* dbias,
-                              int nparts, hipStream_t s) {
+namespace kgcn {
+int launch_reduce_pair(const float* part_dw, long n_dw, float* dw, const float* part_db, long n_db, float* dbias,
+                       int nparts, hipStream_t s) {
   if (dw && dbias) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n_dw + n_db + 31) / 32)), dim3(256), 0, s, part_dw,
                        nparts, n_dw, dw, part_db, n_db, dbias);
@@ -617,6 +618,7 @@ static int launch_reduce_pair(const float* part_dw, long n_dw, float* dw, const 
   if (dbias) return launch_reduce_partials(part_db, nparts, n_db, dbias, s);
   return 0;
 }
+}  // namespace kgcn
 
 extern "C" int kgcn_dense_fwd_act_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w,
                                       int64_t w_ld, int32_t trans_w, const float* bias, float* y, int32_t dout,

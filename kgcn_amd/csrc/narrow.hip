@@ -104,7 +104,6 @@ __global__ __launch_bounds__(512) void narrow_fwd_kernel(
     for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
 #ifndef NR_ABL_NOMFMA
     if (two) {
-#pragma unroll 4
       for (int s = 0; s < kh; ++s) {
         float a = xa[s];
         a = s < kvalid ? a : 0.f;                   // k == din of an odd din: the neighbour row's float, not ours
@@ -112,7 +111,6 @@ __global__ __launch_bounds__(512) void narrow_fwd_kernel(
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[s * 64 + 32], acc1, 0, 0, 0);
       }
     } else {
-#pragma unroll 4
       for (int s = 0; s < kh; ++s) {
         float a = xa[s];
         a = s < kvalid ? a : 0.f;

@@ -218,7 +218,10 @@ def test_fused_activation_aggregation(act, N, D, channels):
     ref = _np_act(pre, act)
     close(out.reshape(B, N, D), ref, rel=1e-6, what="act(bconv) " + act)
     out.backward(t32(g).reshape(B * N, D))
-    _, rg = K.bconv_grad(adjs, rhs, list(g * _np_dact(ref, act)))
+    # relu': read from the kernel's own output, like tf.nn.relu's gradient (a pre-activation within one rounding of 0 may
+    # land on either side in fp32)
+    aout = out.detach().cpu().numpy().reshape(np.shape(ref)).astype(np.float64) if act == "relu" else ref
+    _, rg = K.bconv_grad(adjs, rhs, list(g * _np_dact(aout, act)))
     want = np.stack([np.concatenate(r, 1) for r in rg]).reshape(B * N, C * D)
     close(tr.grad, want, rel=1e-6, what="d rhs through act(bconv) " + act)
 
@@ -241,7 +244,7 @@ def test_fused_activation_dense(act, M, din, dout):
     ref = _np_act(x64 @ w64 + b, act)
     close(y, ref, rel=2e-6, what="act(dense) " + act)
     y.backward(t32(g))
-    gz = g * _np_dact(ref, act)
+    gz = g * _np_dact(y.detach().cpu().numpy().astype(np.float64) if act == "relu" else ref, act)
     close(tx.grad, gz @ w64.T, rel=2e-6, what="dx")
     close(tw.grad, x64.T @ gz, rel=1e-5, what="dw")
     close(tb.grad, gz.sum(0), rel=1e-5, what="db")
@@ -564,8 +567,11 @@ def test_gin_aggregate(channels, D):
     out.backward(t32(g))
     dx, deps = K.gin_bwd(x, adjs, eps, g)
     close(tx.grad, dx, what="gin dx")
+    # d eps = <g, x>: one fp32 dot product over B*N*D terms -- tolerance = 8 sigma of fp32 summation noise for that length
+    terms = g.astype(np.float64) * x
+    noise = 8 * 6e-8 * np.sqrt(terms.size) * np.sqrt((terms ** 2).mean())
     for c in range(C):
-        close(layer.epsilon[c].grad, deps[c], rel=1e-6, what="gin deps")
+        close(layer.epsilon[c].grad, deps[c], rel=1e-6, atol=max(2e-5, noise), what="gin deps")
     try:                                                   # quirk Q1: accelerated branches drop eps
         _set_variant("bspmm")
         close(layer(t32(x), adj=adjs), K.gin_fwd(x, adjs, eps, with_eps=False), what="gin no-eps")

@@ -6,7 +6,9 @@ with the per-kernel breakdown of one step from the torch profiler.  Not the head
   cfg3  sparse.py: 128 molecules x <=50 nodes block-diagonal, F=128 -> 256 x3
 With --roofline every C-ABI call of one extra step is timed on its own (tools/abi_roofline.py) and priced with its
 algorithmic bytes / flops: the per-entry-point fraction-of-peak table of profiles/r02_*_config_rooflines.json.
-usage: python tools/config_bench.py [--roofline] [cfg4|cfg5|cfg3 ...]"""
+--graph additionally captures the step (all of its launches and allocations) in ONE hipGraph and times its replay: the
+step without host launch gaps.
+usage: python tools/config_bench.py [--roofline] [--graph] [cfg4|cfg5|cfg3 ...]"""
 import json
 import os
 import sys
@@ -36,6 +38,28 @@ def timed(step, reps=20, warm=3):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
+def graphed(step, reps=20):
+    """ms per replay of the step captured in one hipGraph (gradients accumulate into static .grad tensors)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
 def breakdown(step, top=8):
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
@@ -55,7 +79,7 @@ def cfg4():
     x = torch.randn(B, N, F, device=dev)
     labels = (torch.rand(B, T, device=dev) < 0.5).float()
     mask, ml = torch.ones(B, device=dev), (torch.rand(B, T, device=dev) < 0.8).float()
-    en = torch.as_tensor(sizes)
+    en = torch.as_tensor(sizes).to(dev)                  # resident: no host copy inside the step
     model = models.MultitaskGCN(1, T).to(dev)
     model(x, adj, enabled_node_nums=en)
 
@@ -131,6 +155,8 @@ for name in (args or ["cfg4", "cfg5", "cfg3"]):
     res[name] = {"graphs_per_step": graphs, "ms_per_step": round(ms, 3), "graphs_per_s": round(graphs / ms * 1e3),
                  "top_kernels": breakdown(step, top=40 if rec else 8)}
     res[name]["kernel_us_sum"] = round(sum(k["us"] for k in res[name]["top_kernels"]), 1)
+    if "--graph" in sys.argv:
+        res[name]["ms_per_step_hipgraph"] = round(graphed(step), 3)
     if rec:
         rec.calls, rec.on = [], True
         step()
