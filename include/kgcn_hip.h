@@ -304,6 +304,16 @@ int kgcn_graph_bn_bwd_f32(const float* x, const float* grad, int64_t graphs, int
                           int32_t training, float* dx, float* dgamma, float* dbeta, void* workspace,
                           int64_t workspace_bytes, void* stream);
 
+/* act(bn(x)) in one pass (the padding rows become act(0), as tf.sigmoid(bn(...)) makes them) and its backward: the incoming
+ * gradient is multiplied by act'(act_out) while it is read (act_out = the output of kgcn_graph_bn_apply_act_f32). */
+int kgcn_graph_bn_apply_act_f32(const float* x, int64_t graphs, int32_t n_nodes, int32_t d, const int32_t* enabled,
+                                const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                                int32_t act, float* y, void* stream);
+int kgcn_graph_bn_bwd_dact_f32(const float* x, const float* grad, const float* act_out, int32_t act, int64_t graphs,
+                               int32_t n_nodes, int32_t d, const int32_t* enabled, const float* mean, const float* var,
+                               const float* gamma, float eps, int32_t training, float* dx, float* dgamma, float* dbeta,
+                               void* workspace, int64_t workspace_bytes, void* stream);
+
 /* -- COO -> batched CSR on the device (the feed side: kgcn/feed.py:112-126 assembles the same triples in Python) ------ */
 /* (graph, row, col, val)[nnz]: device arrays in ANY order (val NULL = all ones) -> rowptr_out [T*R + 1], cv_out [nnz]
  * (int2: column, fp32 value bits) with R = rows and the entries of a row in feed order (stable sort: duplicates stay and

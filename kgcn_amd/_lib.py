@@ -111,6 +111,11 @@ SIGNATURES = {
     "kgcn_csr_pad4_workspace_bytes": (c_i64, [c_i32, c_i32]),
     "kgcn_csr_pad4": (ctypes.c_int, [_CSRP, c_i32p, ctypes.c_void_p, c_i64, c_i32p, c_i32p, c_i32p, ctypes.c_void_p,
                                      c_i64, ctypes.c_void_p]),
+    "kgcn_graph_bn_apply_act_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i32, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                                   ctypes.c_float, c_i32, c_f32p, ctypes.c_void_p]),
+    "kgcn_graph_bn_bwd_dact_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_i32, c_i64, c_i32, c_i32, c_i32p, c_f32p, c_f32p,
+                                                  c_f32p, ctypes.c_float, c_i32, c_f32p, c_f32p, c_f32p, ctypes.c_void_p,
+                                                  c_i64, ctypes.c_void_p]),
     "kgcn_dot_workspace_bytes": (c_i64, [c_i64]),
     "kgcn_dot_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i64, c_f32p, ctypes.c_void_p, c_i64,
                                     ctypes.c_void_p]),

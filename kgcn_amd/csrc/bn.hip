@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void bn_colreduce_kernel(const float* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ var,
                                                            float eps, float* __restrict__ part0, float* __restrict__ part1,
                                                            const float* __restrict__ gamma = nullptr,
-                                                           float* __restrict__ dx = nullptr) {
+                                                           float* __restrict__ dx = nullptr,
+                                                           const float* __restrict__ aout = nullptr, int dact = 0) {
   __shared__ float red[2][256];
   const int tid = threadIdx.x;
   for (int c0 = 0; c0 < d; c0 += 256) {
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(256) void bn_colreduce_kernel(const float* __restri
         if constexpr (MODE == 0) a0 += v;
         if constexpr (MODE == 1) { const float dv = v - mu; a0 += dv * dv; }
         if constexpr (MODE >= 2) {
-          const float gv = g[r * d + c0 + c];
+          float gv = g[r * d + c0 + c];
+          if (dact != KGCN_ACT_NONE) gv *= act_dout(aout[r * d + c0 + c], dact);   // backward of act(bn(x)): uniform branch
           a0 += gv;
           a1 += gv * ((v - mu) * rs);
           if constexpr (MODE == 3) dx[r * d + c0 + c] = gr * gv;
@@ -147,7 +149,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
                                                         const float* __restrict__ mean, const float* __restrict__ var,
                                                         const float* __restrict__ gamma, const float* __restrict__ dgamma,
                                                         const float* __restrict__ dbeta, float eps, int training,
-                                                        const long* __restrict__ count, float* __restrict__ dx) {
+                                                        const long* __restrict__ count, float* __restrict__ dx,
+                                                        const float* __restrict__ aout, int dact) {
   const long total = rows * d;
   const float inv_n = (training && *count > 0) ? 1.0f / (float)*count : 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -162,7 +165,9 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
     if (valid) {
       const float rs = 1.0f / __builtin_sqrtf(var[c] + eps);
       const float xh = (x[i] - mean[c]) * rs;
-      o = gamma[c] * rs * (g[i] - inv_n * (dbeta[c] + xh * dgamma[c]));
+      float gv = g[i];
+      if (dact != KGCN_ACT_NONE) gv *= act_dout(aout[i], dact);
+      o = gamma[c] * rs * (gv - inv_n * (dbeta[c] + xh * dgamma[c]));
     }
     dx[i] = o;
   }
@@ -219,9 +224,10 @@ extern "C" int kgcn_graph_bn_stats_f32(const float* x, int64_t graphs, int32_t n
   return check_launch("bn_stats");
 }
 
-extern "C" int kgcn_graph_bn_apply_f32(const float* x, int64_t graphs, int32_t n_nodes, int32_t d, const int32_t* enabled,
-                                       const float* mean, const float* var, const float* gamma, const float* beta,
-                                       float eps, float* y, void* stream) {
+static int bn_apply_impl(const float* x, int64_t graphs, int32_t n_nodes, int32_t d, const int32_t* enabled,
+                         const float* mean, const float* var, const float* gamma, const float* beta, float eps, float* y,
+                         int act, void* stream) {
+  if (act < KGCN_ACT_NONE || act > KGCN_ACT_TANH) return fail("kgcn_graph_bn_apply_f32: unknown activation code %d", act);
   if (int rc = bn_check("kgcn_graph_bn_apply_f32", x, graphs, n_nodes, d)) return rc;
   if (graphs == 0) return 0;
   if (!mean || !var || !gamma || !beta || !y) return fail("kgcn_graph_bn_apply_f32: NULL operand");
@@ -229,17 +235,31 @@ extern "C" int kgcn_graph_bn_apply_f32(const float* x, int64_t graphs, int32_t n
   const bool vec = (d % 4 == 0) && aligned16(x) && aligned16(y);
   if (vec)
     hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(bn_grid(rows * (d / 4))), dim3(256), 0, as_stream(stream), x, rows, n_nodes,
-                       d, enabled, mean, var, gamma, beta, eps, y, KGCN_ACT_NONE);
+                       d, enabled, mean, var, gamma, beta, eps, y, act);
   else
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(bn_grid(rows * d)), dim3(256), 0, as_stream(stream), x, rows, n_nodes, d,
-                       enabled, mean, var, gamma, beta, eps, y, KGCN_ACT_NONE);
+                       enabled, mean, var, gamma, beta, eps, y, act);
   return check_launch("bn_apply_kernel");
 }
 
-extern "C" int kgcn_graph_bn_bwd_f32(const float* x, const float* grad, int64_t graphs, int32_t n_nodes, int32_t d,
-                                     const int32_t* enabled, const float* mean, const float* var, const float* gamma,
-                                     float eps, int32_t training, float* dx, float* dgamma, float* dbeta, void* workspace,
-                                     int64_t workspace_bytes, void* stream) {
+extern "C" int kgcn_graph_bn_apply_f32(const float* x, int64_t graphs, int32_t n_nodes, int32_t d, const int32_t* enabled,
+                                       const float* mean, const float* var, const float* gamma, const float* beta,
+                                       float eps, float* y, void* stream) {
+  return bn_apply_impl(x, graphs, n_nodes, d, enabled, mean, var, gamma, beta, eps, y, KGCN_ACT_NONE, stream);
+}
+
+extern "C" int kgcn_graph_bn_apply_act_f32(const float* x, int64_t graphs, int32_t n_nodes, int32_t d,
+                                           const int32_t* enabled, const float* mean, const float* var, const float* gamma,
+                                           const float* beta, float eps, int32_t act, float* y, void* stream) {
+  return bn_apply_impl(x, graphs, n_nodes, d, enabled, mean, var, gamma, beta, eps, y, act, stream);
+}
+
+static int bn_bwd_impl(const float* x, const float* grad, const float* aout, int dact, int64_t graphs, int32_t n_nodes,
+                       int32_t d, const int32_t* enabled, const float* mean, const float* var, const float* gamma, float eps,
+                       int32_t training, float* dx, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
+                       void* stream) {
+  if (dact < KGCN_ACT_NONE || dact > KGCN_ACT_TANH) return fail("kgcn_graph_bn_bwd_f32: unknown activation code %d", dact);
+  if (dact != KGCN_ACT_NONE && !aout) return fail("kgcn_graph_bn_bwd_f32: act_out is NULL");
   if (int rc = bn_check("kgcn_graph_bn_bwd_f32", x, graphs, n_nodes, d)) return rc;
   if (!grad || !mean || !var || !gamma || !dgamma || !dbeta) return fail("kgcn_graph_bn_bwd_f32: NULL operand");
   if (!workspace || workspace_bytes < kgcn_graph_bn_workspace_bytes(d))
@@ -255,20 +275,37 @@ extern "C" int kgcn_graph_bn_bwd_f32(const float* x, const float* grad, int64_t 
   if (dx && !training) {
     // inference phase: dx does not depend on the reductions -> one pass over x and g
     hipLaunchKernelGGL(bn_colreduce_kernel<3>, dim3(nb), dim3(256), 0, s, x, grad, rows, n_nodes, d, enabled, mean, var, eps,
-                       part0, part1, gamma, dx);
+                       part0, part1, gamma, dx, aout, dact);
     return launch_reduce_pair(part0, d, dbeta, part1, d, dgamma, nb, s);
   }
   hipLaunchKernelGGL(bn_colreduce_kernel<2>, dim3(nb), dim3(256), 0, s, x, grad, rows, n_nodes, d, enabled, mean, var, eps,
-                     part0, part1, nullptr, nullptr);
+                     part0, part1, nullptr, nullptr, aout, dact);
   if (int rc = launch_reduce_pair(part0, d, dbeta, part1, d, dgamma, nb, s)) return rc;
   if (dx) {
     // the valid-row count (scale kernel with no array to scale: d = 0)
     hipLaunchKernelGGL(bn_scale_kernel, dim3(1), dim3(256), 0, s, part0, 0, enabled, (long)graphs, n_nodes, count);
     if (rows > 0)
       hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(bn_grid(rows * d)), dim3(256), 0, s, x, grad, rows, n_nodes, d, enabled, mean,
-                         var, gamma, dgamma, dbeta, eps, training, count, dx);
+                         var, gamma, dgamma, dbeta, eps, training, count, dx, aout, dact);
   }
   return check_launch("bn_bwd");
+}
+
+extern "C" int kgcn_graph_bn_bwd_f32(const float* x, const float* grad, int64_t graphs, int32_t n_nodes, int32_t d,
+                                     const int32_t* enabled, const float* mean, const float* var, const float* gamma,
+                                     float eps, int32_t training, float* dx, float* dgamma, float* dbeta, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+  return bn_bwd_impl(x, grad, nullptr, KGCN_ACT_NONE, graphs, n_nodes, d, enabled, mean, var, gamma, eps, training, dx, dgamma,
+                     dbeta, workspace, workspace_bytes, stream);
+}
+
+extern "C" int kgcn_graph_bn_bwd_dact_f32(const float* x, const float* grad, const float* act_out, int32_t act,
+                                          int64_t graphs, int32_t n_nodes, int32_t d, const int32_t* enabled,
+                                          const float* mean, const float* var, const float* gamma, float eps,
+                                          int32_t training, float* dx, float* dgamma, float* dbeta, void* workspace,
+                                          int64_t workspace_bytes, void* stream) {
+  return bn_bwd_impl(x, grad, act_out, act, graphs, n_nodes, d, enabled, mean, var, gamma, eps, training, dx, dgamma, dbeta,
+                     workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

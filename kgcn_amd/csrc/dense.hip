@@ -500,7 +500,7 @@ using namespace kgcn;
 static bool wide_layer(int din, int dout) { return dout > 128 && din >= 32; }
 // where reading W pre-split from the fragment table measured ahead of splitting it inside the kernel (tools/gemm_bench.py,
 // 204,800 rows: 256 -> 256 +15% forward / +5% dX, 512 -> 256 +5% / -3%, 256 -> 512 +2%; 128 -> 256 -14%: few k-steps)
-static bool table_pays(int din, int dout) { return wide_layer(din, dout) && din >= 192; }
+static bool table_pays(int din, int dout) { return wide_layer(din, dout) && din >= 32; }
 
 static int dense_fwd_impl(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w, int64_t w_ld,
                           int32_t trans_w, const float* bias, float* y, int32_t dout, int64_t y_ld, int act,

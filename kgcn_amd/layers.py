@@ -432,10 +432,13 @@ class GraphBatchNormalization(nn.Module):
       phase 1 (layers.set_learning_phase(1), or learning_phase=1 on the layer): batch statistics over the valid rows
           (population variance, as tf.nn.moments), moving <- moving * momentum + batch * (1 - momentum), and the
           backward differentiates through the statistics.
-    Statistics, normalisation and backward are HIP kernels (kgcn_graph_bn_*_f32, csrc/bn.hip)."""
+    Statistics, normalisation and backward are HIP kernels (kgcn_graph_bn_*_f32, csrc/bn.hip).
+    activation (not in the reference's signature): the tf.sigmoid / tf.nn.relu the model files apply to the layer's output
+    (example_model/model.py:50, model_multitask.py:60), fused into the normalise pass and the backward's reads."""
 
-    def __init__(self, bn_name=None, eps=1e-3, momentum=0.99, learning_phase=None, **kwargs):
+    def __init__(self, bn_name=None, eps=1e-3, momentum=0.99, learning_phase=None, activation=None, **kwargs):
         super().__init__()
+        self.activation = activation
         self.bn_name = bn_name
         self.eps = eps
         self.momentum = momentum
@@ -472,9 +475,9 @@ class GraphBatchNormalization(nn.Module):
             with torch.no_grad():
                 self.moving_mean.mul_(self.momentum).add_(mean, alpha=1.0 - self.momentum)
                 self.moving_variance.mul_(self.momentum).add_(var, alpha=1.0 - self.momentum)
-            y = ops.graph_bn(x, gamma, beta, mean, var, en, self.eps, True)
+            y = ops.graph_bn(x, gamma, beta, mean, var, en, self.eps, True, self.activation)
         else:
-            y = ops.graph_bn(x, gamma, beta, self.moving_mean, self.moving_variance, en, self.eps, False)
+            y = ops.graph_bn(x, gamma, beta, self.moving_mean, self.moving_variance, en, self.eps, False, self.activation)
         return y[0] if squeeze else y
 
 

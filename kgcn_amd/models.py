@@ -61,7 +61,7 @@ class GCN(nn.Module):
         self.conv1 = layers.GraphConv(50, adj_channel_num, activation="sigmoid")    # :42-43 tf.sigmoid(layer)
         self.conv2 = layers.GraphConv(50, adj_channel_num, activation="sigmoid")    # :44-45
         self.conv3 = layers.GraphConv(50, adj_channel_num)
-        self.bn = GraphBatchNormalization()
+        self.bn = GraphBatchNormalization(activation="sigmoid")                     # :48-50 tf.sigmoid(bn(...)), one pass
         self.dense = layers.GraphDense(50, activation="sigmoid")                    # :52-53
         self.gather = layers.GraphGather()
         self.out = KerasDense(num_classes)
@@ -71,7 +71,6 @@ class GCN(nn.Module):
         layer = self.conv2(layer, adj=adjs)
         layer = self.conv3(layer, adj=adjs)
         layer = self.bn(layer, max_node_num=features.shape[1], enabled_node_nums=enabled_node_nums)
-        layer = ops.activation(layer, "sigmoid")
         # K.layers.Dropout(dropout_rate): identity (Q6)
         layer = self.dense(layer)
         layer = self.gather(layer)
@@ -129,7 +128,7 @@ class MultitaskGCN(nn.Module):
         self.conv2 = layers.GraphConv(256, adj_channel_num, activation="sigmoid")   # :53-54
         self.dense1 = layers.GraphDense(256, activation="sigmoid")                  # :55-56
         self.conv3 = layers.GraphConv(50, adj_channel_num)
-        self.bn = layers.GraphBatchNormalization()
+        self.bn = layers.GraphBatchNormalization(activation="sigmoid")              # :58-60 tf.sigmoid(bn(...)), one pass
         self.dense2 = layers.GraphDense(50, activation="sigmoid")                   # :61-62
         self.gather = layers.GraphGather()
         self.out = KerasDense(label_dim)
@@ -140,7 +139,6 @@ class MultitaskGCN(nn.Module):
         layer = self.dense1(layer)
         layer = self.conv3(layer, adj=adjs)
         layer = self.bn(layer, max_node_num=features.shape[1], enabled_node_nums=enabled_node_nums)
-        layer = ops.activation(layer, "sigmoid")
         layer = self.dense2(layer)
         layer = self.gather(layer)
         return self.out(layer)                      # prediction = sigmoid(logits)
@@ -158,7 +156,7 @@ class SparseGCN(nn.Module):
         self.pools = nn.ModuleList([layers.GraphMaxPooling(adj_channel_num) for _ in out_dims]) if max_pool else None
         self.bns = nn.ModuleList([layers.GraphBatchNormalization() for _ in out_dims]) if batch_normalize else None
         self.dense = layers.GraphDense(dense_dim)
-        self.bn = layers.GraphBatchNormalization()
+        self.bn = layers.GraphBatchNormalization(activation="relu")     # tf.nn.relu(bn(dense)), one pass
         self.out = KerasDense(num_classes)
 
     def forward(self, batch):
@@ -172,7 +170,7 @@ class SparseGCN(nn.Module):
                 net = self.bns[i](net)
             if conv.activation is None:
                 net = ops.activation(net, "relu")
-        net = ops.activation(self.bn(self.dense(net)), "relu")[0]
+        net = self.bn(self.dense(net))[0]
         net = ops.bspmm(batch.segments, net.unsqueeze(0))       # per-molecule node sum (:83-94)
         net = torch.tanh(net.reshape(len(batch.sizes), -1))
         return self.out(net)                                    # probabilities = softmax(logits)

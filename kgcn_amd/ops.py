@@ -549,20 +549,20 @@ def graph_bn_stats(x, enabled=None):
 
 class _GraphBN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, mean, var, enabled, eps, training):
+    def forward(ctx, x, gamma, beta, mean, var, enabled, eps, training, act=0):
         x = _f32c(x, "inputs")
         T, N, D = x.shape
         gamma, beta = _f32c(gamma, "gamma"), _f32c(beta, "beta")
         y = torch.empty_like(x)
-        check(lib.kgcn_graph_bn_apply_f32(ptr(x), T, N, D, ptr(enabled), ptr(mean), ptr(var), ptr(gamma), ptr(beta),
-                                          float(eps), ptr(y), current_stream()), "kgcn_graph_bn_apply_f32")
-        ctx.save_for_backward(x, gamma, mean, var)
-        ctx.enabled, ctx.eps, ctx.training = enabled, float(eps), bool(training)
+        check(lib.kgcn_graph_bn_apply_act_f32(ptr(x), T, N, D, ptr(enabled), ptr(mean), ptr(var), ptr(gamma), ptr(beta),
+                                              float(eps), int(act), ptr(y), current_stream()), "kgcn_graph_bn_apply_act_f32")
+        ctx.save_for_backward(x, gamma, mean, var, y if act else x)
+        ctx.enabled, ctx.eps, ctx.training, ctx.act = enabled, float(eps), bool(training), int(act)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, gamma, mean, var = ctx.saved_tensors
+        x, gamma, mean, var, yact = ctx.saved_tensors
         g = _f32c(g, "grad")
         T, N, D = x.shape
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
@@ -570,13 +570,15 @@ class _GraphBN(torch.autograd.Function):
         dbeta = torch.empty_like(dgamma)
         wsb = lib.kgcn_graph_bn_workspace_bytes(D)
         wsp = torch.empty((wsb // 4 + 1,), device=x.device, dtype=torch.float32)
-        check(lib.kgcn_graph_bn_bwd_f32(ptr(x), ptr(g), T, N, D, ptr(ctx.enabled), ptr(mean), ptr(var), ptr(gamma),
-                                        ctx.eps, int(ctx.training), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(wsp), wsb,
-                                        current_stream()), "kgcn_graph_bn_bwd_f32")
-        return dx, dgamma, dbeta, None, None, None, None, None
+        check(lib.kgcn_graph_bn_bwd_dact_f32(ptr(x), ptr(g), ptr(yact) if ctx.act else None, ctx.act, T, N, D,
+                                             ptr(ctx.enabled), ptr(mean), ptr(var), ptr(gamma), ctx.eps, int(ctx.training),
+                                             ptr(dx), ptr(dgamma), ptr(dbeta), ptr(wsp), wsb, current_stream()),
+              "kgcn_graph_bn_bwd_dact_f32")
+        return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
-def graph_bn(x, gamma, beta, mean, var, enabled=None, eps=1e-3, training=False):
-    """y = gamma (x - mean) / sqrt(var + eps) + beta on the valid rows, 0 on the padding rows.  training=True: mean / var
-    are THIS batch's statistics and the backward differentiates through them."""
-    return _GraphBN.apply(x, gamma, beta, mean, var, enabled, eps, training)
+def graph_bn(x, gamma, beta, mean, var, enabled=None, eps=1e-3, training=False, activation=None):
+    """y = act(gamma (x - mean) / sqrt(var + eps) + beta on the valid rows, 0 on the padding rows).  training=True: mean /
+    var are THIS batch's statistics and the backward differentiates through them.  The activation rides in the same pass
+    (and its derivative in the backward's reads)."""
+    return _GraphBN.apply(x, gamma, beta, mean, var, enabled, eps, training, act_code(activation))

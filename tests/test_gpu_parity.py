@@ -664,6 +664,38 @@ def test_graph_batch_normalization_both_phases(D, ragged):
           atol=2e-5, what="phase 0 uses the updated moving statistics")
 
 
+@pytest.mark.parametrize("act", ["sigmoid", "relu", "tanh"])
+@pytest.mark.parametrize("phase", [0, 1])
+def test_graph_batch_normalization_fused_activation(act, phase):
+    """act(bn(x)) in one pass (kgcn_graph_bn_apply_act_f32) and its backward with act'(y) applied while the gradient is
+    read (kgcn_graph_bn_bwd_dact_f32) against the oracle's BN followed by the activation / its derivative; ragged batch,
+    padding rows = act(0)."""
+    from kgcn_amd import layers
+    rng = np.random.default_rng(40 + phase)
+    T, N, D = 37, 10, 50
+    x = rng.standard_normal((T, N, D)).astype(np.float32) * 2 + 0.5
+    en = rng.integers(0, N + 1, T).astype(np.int32)
+    g = rng.standard_normal((T, N, D)).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, D).astype(np.float32); beta = rng.standard_normal(D).astype(np.float32)
+    mm = rng.standard_normal(D).astype(np.float32) * 0.3; mv = rng.uniform(0.5, 2.0, D).astype(np.float32)
+    layer = layers.GraphBatchNormalization(learning_phase=phase, activation=act)
+    layer.build(x.shape, dev())
+    with torch.no_grad():
+        layer.gamma.copy_(t32(gamma)); layer.beta.copy_(t32(beta))
+        layer.moving_mean.copy_(t32(mm)); layer.moving_variance.copy_(t32(mv))
+    tx = t32(x).requires_grad_(True)
+    y = layer(tx, enabled_node_nums=torch.from_numpy(en).to(dev()))
+    y.backward(t32(g))
+    pre, mean, var, _, _ = K.graph_bn_fwd(x, gamma, beta, mm, mv, en, training=bool(phase))
+    ref = _np_act(pre, act)
+    close(y, ref, rel=2e-6, what="act(bn) " + act)
+    aout = y.detach().cpu().numpy().astype(np.float64) if act == "relu" else ref
+    dx, dgamma, dbeta = K.graph_bn_bwd(x, gamma, mean, var, g * _np_dact(aout, act), en, training=bool(phase))
+    close(tx.grad, dx, rel=1e-5, what="dx")
+    close(layer.gamma.grad, dgamma, rel=1e-5, atol=1e-4, what="dgamma")
+    close(layer.beta.grad, dbeta, rel=1e-5, atol=1e-4, what="dbeta")
+
+
 @pytest.mark.parametrize("channels,D", [("plain", 3), ("split", 50), ("norm", 64)])
 def test_graph_maxpooling(channels, D):
     """kgcn/layers.py:122-153 (row N3): values on a coarse grid so that ties -- between entries and

@@ -101,6 +101,12 @@ def _cost(name, a):
         return 4 * a[1] * a[2] * a[3], 3 * a[1] * a[2] * a[3], "T=%d N=%d d=%d" % (a[1], a[2], a[3])
     if name == "kgcn_graph_bn_apply_f32":
         return 8 * a[1] * a[2] * a[3], 2 * a[1] * a[2] * a[3], "T=%d N=%d d=%d" % (a[1], a[2], a[3])
+    if name == "kgcn_graph_bn_apply_act_f32":
+        return 8 * a[1] * a[2] * a[3], 2 * a[1] * a[2] * a[3], "T=%d N=%d d=%d act=%d" % (a[1], a[2], a[3], a[10])
+    if name == "kgcn_graph_bn_bwd_dact_f32":
+        n = a[4] * a[5] * a[6]
+        return ((12 if a[13] is not None else 8) + (4 if a[3] else 0)) * n, 6 * n, \
+            "T=%d N=%d d=%d training=%d dact=%d" % (a[4], a[5], a[6], a[12], a[3])
     if name == "kgcn_graph_bn_bwd_f32":
         n = a[2] * a[3] * a[4]
         return (12 if a[11] is not None else 8) * n, 6 * n, "T=%d N=%d d=%d training=%d" % (a[2], a[3], a[4], a[10])
