@@ -32,6 +32,9 @@ int launch_narrow_wgrad(const float* x, const float* dy, long m, int din, int do
                         int nblocks, hipStream_t s);
 int launch_gemm3_dx_dact(const float* grad, const float* act_out, float* dpre, long m, int k, long ld, const void* table,
                          float* dx, int n, long dx_ld, int dact, hipStream_t s);
+bool gemmn_pays(const float* x, int din, long x_ld, int dout);
+int launch_gemmn_fwd(const float* x, long m, int din, long x_ld, const void* table, const float* bias, float* y, int dout,
+                     long y_ld, int act, hipStream_t s);
 int64_t wtable_bytes(int din, int dout);
 void launch_wtable_split(const float* w, long w_ld, int trans_w, int din, int dout, void* workspace, hipStream_t s);
 int launch_gemm3_wgrad(const float* x, long x_ld, const float* dy, long dy_ld, long m, int din, int dout,
@@ -525,6 +528,14 @@ static int dense_fwd_impl(const float* x, int64_t m, int32_t din, int64_t x_ld, 
     return launch_gemm3_fwd(x, (long)m, din, (long)x_ld, w, (long)w_ld, trans_w, bias, y, dout, (long)y_ld, act, table,
                             as_stream(stream));
   }
+  // wide input, narrow output (256 -> 50): one 64-column block per wave on the bf16 pipe (gemmn.hip), W from the table
+  if (gemmn_pays(x, din, (long)x_ld, dout) && workspace && workspace_bytes >= wtable_bytes(din, dout) && m >= 1024) {
+    static const char* route = getenv("KGCN_DENSE_ROUTE");
+    if (!(route && !strcmp(route, "gemm3"))) {
+      launch_wtable_split(w, (long)w_ld, trans_w, din, dout, workspace, as_stream(stream));
+      return launch_gemmn_fwd(x, (long)m, din, (long)x_ld, workspace, bias, y, dout, (long)y_ld, act, as_stream(stream));
+    }
+  }
   // 50-wide layers: flat tile movement (narrow.hip)
   if (narrow_fwd_ok(x, din, (long)x_ld, y, dout, (long)y_ld))
     return launch_narrow_fwd(x, (long)m, din, w, (long)w_ld, trans_w, bias, y, dout, act, as_stream(stream));
@@ -595,7 +606,7 @@ extern "C" int kgcn_dense_dx_dact_f32(const float* grad, const float* act_out, i
 }
 
 extern "C" int64_t kgcn_dense_fwd_workspace_bytes(int32_t din, int32_t dout) {
-  if (din <= 0 || dout <= 0 || !table_pays(din, dout)) return 0;
+  if (din <= 0 || dout <= 0 || !(table_pays(din, dout) || (dout <= 64 && din >= 128 && din % 4 == 0))) return 0;
   return wtable_bytes(din, dout);
 }
 

@@ -49,6 +49,7 @@ constexpr int kLdsBytes = 160 * 1024;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- shared device helpers ---------------------------------------------------------------------------

@@ -228,7 +228,8 @@ def test_fused_activation_aggregation(act, N, D, channels):
 
 @pytest.mark.parametrize("act", ["sigmoid", "relu", "tanh"])
 @pytest.mark.parametrize("M,din,dout", [(300, 50, 50), (1000, 64, 64), (777, 81, 256), (513, 256, 256), (64, 512, 96),
-                                        (3001, 256, 256), (2050, 320, 200), (1500, 256, 512)])
+                                        (3001, 256, 256), (2050, 320, 200), (1500, 256, 512), (2000, 256, 50), (1100, 160, 64),
+                                        (1500, 132, 7)])
 def test_fused_activation_dense(act, M, din, dout):
     """y = act(x W + b) in the GEMM epilogue of all three dense kernels (f32-MFMA tiled / persistent, bf16-split), and
     the backward through it, against numpy."""
