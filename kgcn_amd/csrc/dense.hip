@@ -35,6 +35,9 @@ int launch_gemm3_dx_dact(const float* grad, const float* act_out, float* dpre, l
 bool gemmn_pays(const float* x, int din, long x_ld, int dout);
 int launch_gemmn_fwd(const float* x, long m, int din, long x_ld, const void* table, const float* bias, float* y, int dout,
                      long y_ld, int act, hipStream_t s);
+bool wgradn_ok(const float* x, int din, long x_ld, int dout);
+int launch_wgradn(const float* x, long x_ld, const float* dy, long dy_ld, long m, int din, int dout, float* part_dw,
+                  float* part_db, int nblocks, hipStream_t s);
 int64_t wtable_bytes(int din, int dout);
 void launch_wtable_split(const float* w, long w_ld, int trans_w, int din, int dout, void* workspace, hipStream_t s);
 int launch_gemm3_wgrad(const float* x, long x_ld, const float* dy, long dy_ld, long m, int din, int dout,
@@ -677,6 +680,14 @@ extern "C" int kgcn_dense_wgrad_f32(const float* x, int64_t x_ld, const float* d
     if (int rc = launch_gemm3_wgrad(x, (long)x_ld, dy, (long)dy_ld, (long)m, din, dout, part_dw, part_db, (int)nb, s))
       return rc;
     return launch_reduce_pair(part_dw, (long)din * dout, dw, part_db, dout, dbias, (int)nb, s);
+  }
+  if (wgradn_ok(x, din, (long)x_ld, dout) && m >= 4096) {
+    // wide input, narrow output (256 x 50): the whole dW block per wave on the bf16 pipe (wgradn.hip)
+    nchunks = kNumCU;
+    float* part_dw = static_cast<float*>(workspace);
+    float* part_db = part_dw + (long)nchunks * din * dout;
+    if (int rc = launch_wgradn(x, (long)x_ld, dy, (long)dy_ld, (long)m, din, dout, part_dw, part_db, nchunks, s)) return rc;
+    return launch_reduce_pair(part_dw, (long)din * dout, dw, part_db, dout, dbias, nchunks, s);
   }
   if (narrow_wgrad_ok(x, din, (long)x_ld, dy, dout, (long)dy_ld)) {
     // 50-wide layers: flat tile movement (narrow.hip), one partial per workgroup

@@ -13,7 +13,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 out = os.path.join(ROOT, "gpurun_out", "libkgcn_probe.so")
-src = [os.path.join(ROOT, "kgcn_amd", "csrc", f) for f in ("misc.hip", "spmm.hip", "dense.hip", "gemm3.hip", "wtable.hip", "gemmn.hip", "narrow.hip", "fused.hip", "pack.hip", "gat.hip", "bn.hip")]
+src = [os.path.join(ROOT, "kgcn_amd", "csrc", f) for f in ("misc.hip", "spmm.hip", "dense.hip", "gemm3.hip", "wtable.hip", "gemmn.hip", "wgradn.hip", "narrow.hip", "fused.hip", "pack.hip", "gat.hip", "bn.hip")]
 if os.environ.get("KGCN_PROBE_LIB"):      # prebuilt (tools/variants.sh build probe "-DKGCN_PROBE")
     out = os.environ["KGCN_PROBE_LIB"]
 else:
