@@ -5,96 +5,95 @@
 //
 // The f32-MFMA kernel of dense.hip cuts din into four 64-column blocks (each re-reading dy, x in 256-byte segments) and
 // spends 256 MFMAs of 64 cycles per 32 rows on a pipe it shares with the VALU: 146 us at m = 204,800 (HBM time 31 us).
-// Here one wave (one per SIMD, 512 registers) owns the WHOLE [256 x 64] block of dW in 256 accumulator registers:
-//   * the batch rows are the MFMA K dimension, 16 rows per k-step; x rows are loaded WHOLE (one 1 KiB row per instruction,
-//     a lane holds 4 columns of 8 consecutive rows = four 8-k fragments after an exact 3-way bf16 split), written to the
-//     wave's own 24 KB of LDS in fragment order (XOR-rotated by the m-tile: 4 lanes per bank group, the optimum for a
-//     1 KiB write) and read back as A fragments at the start of the k-step -- wave-local in-order LDS traffic, no barrier;
-//   * dy is loaded lane = column, 8 consecutive rows per lane: B fragments without any data movement; its column sums are
-//     accumulated on the way (dbias);
-//   * the four waves of a workgroup are summed through LDS (two rounds), one [din x dout] partial per workgroup.
+// Here a wave owns a [128 x 64] half of dW in 128 accumulator registers, two waves per SIMD (the two column halves of the
+// same rows) hide each other's vector work behind the other's MFMAs:
+//   * the batch rows are the MFMA K dimension, 16 rows per k-step with k = (row parity, row / 2) -- so that the lane layout
+//     of a coalesced load IS the fragment layout: a load instruction fetches two whole 512-byte half rows (lanes 0-31 the
+//     even row, 32-63 the odd one), eight of them give a lane 4 columns x 8 rows of its parity = four 8-k fragments after
+//     an exact 3-way bf16 split;
+//   * the fragments go through the wave's own 12 KB of LDS into operand order (entries XOR-rotated by the m-tile: 4 lanes
+//     per bank group, the optimum for a 1 KiB write) and are read back at the start of the k-step -- wave-local in-order LDS
+//     traffic, no barrier;
+//   * dy is loaded lane = column, the 8 rows of the lane's parity: B fragments without any data movement; the column-half-0
+//     waves sum it for dbias;
+//   * the row-range groups of a workgroup are summed through LDS (two rounds), one [din x dout] partial per workgroup.
 #include "kgcn_common.h"
 
 namespace kgcn {
 
-constexpr int WN_LDS_WAVE = 8 * 3 * 64 * 16;               // (m-tile, piece) x 64 lanes x 16 bytes = 24 KB
+constexpr int WN_LDS_WAVE = 4 * 3 * 64 * 16;               // (m-tile, piece) x 64 lanes x 16 bytes = 12 KB
+constexpr int WN_WAVES = 8;                                 // 4 row-range groups x 2 column halves
 
-__global__ __launch_bounds__(256, 1) void wgradn_kernel(const float* __restrict__ x, long x_ld,
+__global__ __launch_bounds__(512, 1) void wgradn_kernel(const float* __restrict__ x, long x_ld,
                                                         const float* __restrict__ dy, long dy_ld, long m, int din,
                                                         int dout, float* __restrict__ part_dw, float* __restrict__ part_db) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wn_smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int li = lane & 31, hi = lane >> 5;
+  const int grp = wave >> 1, ch = wave & 1;                  // row-range group, column half (x columns 128 ch ..)
   unsigned char* xp = wn_smem + (size_t)wave * WN_LDS_WAVE;
   const long nsteps = (m + 15) / 16;                         // k-steps of 16 rows
-  const long nwaves = (long)gridDim.x * 4;
-  const long gw = (long)blockIdx.x * 4 + wave;
-  // contiguous range of k-steps per wave
-  const long per = (nsteps + nwaves - 1) / nwaves;
-  const long s_begin = gw * per;
+  const long ngroups = (long)gridDim.x * 4;
+  const long gg = (long)blockIdx.x * 4 + grp;
+  const long per = (nsteps + ngroups - 1) / ngroups;         // contiguous range of k-steps per group
+  const long s_begin = gg * per;
   long s_end = s_begin + per;
   if (s_end > nsteps) s_end = nsteps;
 
-  // x staging: this lane's 4 columns (4 lane .. 4 lane + 3; beyond din: clamped, masked when split), m-tile lane >> 3
-  const int xcol = 4 * lane < din ? 4 * lane : 0;
-  const bool xok = 4 * lane < din;
-  const int mt_w = lane >> 3;
-  // entry of column e of this lane inside its m-tile block, XOR-rotated by the m-tile: 4 (lane & 7) + (e ^ (mt & 3))
-  const int wr_base = mt_w * 3072 + ((lane & 7) * 4) * 16;
-  // dy staging: column 32 nt + li (clamped / masked)
+  // x staging: lane = (row parity hi, 16-byte column group li): columns 128 ch + 4 li .. + 3 (beyond din: clamped, masked)
+  const int c0x = 128 * ch + 4 * li;
+  const bool xok = c0x < din;
+  const int xcol = xok ? c0x : 0;
+  const int mt_w = li >> 3;
+  // entry of column e inside its m-tile block, XOR-rotated by the m-tile: 32 hi + 4 (li & 7) + (e ^ (mt & 3))
+  const int wr_base = mt_w * 3072 + (32 * hi + (li & 7) * 4) * 16;
+  // dy staging: column 32 nt + li (clamped / masked), rows of parity hi
   const bool dok0 = li < dout, dok1 = 32 + li < dout;
   const int dc0 = dok0 ? li : 0, dc1 = dok1 ? 32 + li : 0;
 
-  f32x16 acc[8][2];
+  f32x16 acc[4][2];
 #pragma unroll
-  for (int mt = 0; mt < 8; ++mt)
+  for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
   float cs0 = 0.f, cs1 = 0.f;
 
-  f32x4 rawx[16];                                            // rows 8 g + j of the k-step: rawx[8 g + j]
-  float rawd[2][8];                                          // dy[row 8 hi + j][column of tile nt]
+  f32x4 rawx[8];                                             // rows 2 j + hi of the k-step
+  float rawd[2][8];                                          // dy[row 2 j + hi][column of tile nt]
   auto load_step = [&](long s) __attribute__((always_inline)) {
-    const long row0 = s * 16;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const long r = row0 + q;
-      rawx[q] = *reinterpret_cast<const f32x4*>(x + (r < m ? r : m - 1) * x_ld + xcol);
-    }
+    const long row0 = s * 16 + hi;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const long r = row0 + 8 * hi + j;
-      const float* dr = dy + (r < m ? r : m - 1) * dy_ld;
+      const long r = row0 + 2 * j;
+      const long rc = r < m ? r : m - 1;
+      rawx[j] = *reinterpret_cast<const f32x4*>(x + rc * x_ld + xcol);
+      const float* dr = dy + rc * dy_ld;
       rawd[0][j] = dr[dc0];
       rawd[1][j] = dr[dc1];
     }
   };
   // rawx -> pieces in LDS (fragment order); rawd -> B fragments
-  auto stage_x = [&](long s) __attribute__((always_inline)) {
-    const long row0 = s * 16;
+  auto stage = [&](long s, Frag3 (&B)[2]) __attribute__((always_inline)) {
+    const long row0 = s * 16 + hi;
+    const bool full = row0 + 14 < m;                        // every row of this lane's parity exists (uniform per half wave)
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int e = 0; e < 4; ++e) {
+      float v[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (xok && row0 + 8 * g + j < m) ? rawx[8 * g + j][e] : 0.f;
-        Frag3 f;
-        split8(v, f);
-        unsigned char* d = xp + wr_base + ((e ^ (mt_w & 3)) + 32 * g) * 16;
-        *reinterpret_cast<u32x4*>(d) = f.p1;
-        *reinterpret_cast<u32x4*>(d + 1024) = f.p2;
-        *reinterpret_cast<u32x4*>(d + 2048) = f.p3;
-      }
-  };
-  auto stage_d = [&](long s, Frag3 (&B)[2]) __attribute__((always_inline)) {
-    const long row0 = s * 16 + 8 * hi;
+      for (int j = 0; j < 8; ++j) v[j] = (xok && (full || row0 + 2 * j < m)) ? rawx[j][e] : 0.f;
+      Frag3 f;
+      split8(v, f);
+      unsigned char* d = xp + wr_base + (e ^ (mt_w & 3)) * 16;
+      *reinterpret_cast<u32x4*>(d) = f.p1;
+      *reinterpret_cast<u32x4*>(d + 1024) = f.p2;
+      *reinterpret_cast<u32x4*>(d + 2048) = f.p3;
+    }
     float v0[8], v1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const bool rok = row0 + j < m;
+      const bool rok = full || row0 + 2 * j < m;
       v0[j] = (dok0 && rok) ? rawd[0][j] : 0.f;
       v1[j] = (dok1 && rok) ? rawd[1][j] : 0.f;
       cs0 += v0[j];
@@ -107,43 +106,41 @@ __global__ __launch_bounds__(256, 1) void wgradn_kernel(const float* __restrict_
   if (s_begin < s_end) {
     Frag3 B[2];
     load_step(s_begin);
-    stage_x(s_begin);
-    stage_d(s_begin, B);
+    stage(s_begin, B);
     if (s_begin + 1 < s_end) load_step(s_begin + 1);
     for (long s = s_begin; s < s_end; ++s) {
       // A fragments of this k-step -> registers (then the LDS buffer is free for the next one)
-      u32x4 A[8][3];
+      u32x4 A[4][3];
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt)
+      for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc)
           A[mt][pc] = *reinterpret_cast<const u32x4*>(xp + (mt * 3 + pc) * 1024 + (32 * hi + (li ^ (mt & 3))) * 16);
-      static_for<96>([&](auto sc) __attribute__((always_inline)) {
+      static_for<48>([&](auto sc) __attribute__((always_inline)) {
         constexpr int q = decltype(sc)::value, mt = q / 12, r12 = q % 12, pr = r12 >> 1, nt = r12 & 1;
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
         const u32x4 bv = PB[pr] == 0 ? B[nt].p1 : PB[pr] == 1 ? B[nt].p2 : B[nt].p3;
         acc[mt][nt] = mfma_bf16(A[mt][PA[pr]], bv, acc[mt][nt]);
       });
       // the next k-step: pieces -> LDS (its A reads above are through: in-order LDS) / B registers; the one after that is
-      // requested (a whole k-step of lead)
+      // requested.  The other wave of the SIMD issues its MFMAs meanwhile.
       if (s + 1 < s_end) {
-        stage_x(s + 1);
-        stage_d(s + 1, B);
+        stage(s + 1, B);
         if (s + 2 < s_end) load_step(s + 2);
       }
     }
   }
 
-  // ---- the four waves' blocks summed through LDS: waves 2, 3 -> waves 0, 1; wave 1 -> wave 0 ------------------------
+  // ---- the four row-range groups summed through LDS: groups 2, 3 -> 0, 1; group 1 -> 0 -----------------------------------
   cs0 += __shfl_xor(cs0, 32, 64);
   cs1 += __shfl_xor(cs1, 32, 64);
-  float* red = reinterpret_cast<float*>(wn_smem);            // two slabs of [8][2][16][64] floats (64 KB each)
-  float* csr = red + 2 * 16384;                              // [4][64] column sums
-  if (hi == 0) { csr[wave * 64 + li] = cs0; csr[wave * 64 + 32 + li] = cs1; }
+  float* red = reinterpret_cast<float*>(wn_smem);            // four slabs of [4][2][16][64] floats (32 KB each)
+  float* csr = red + 4 * 8192;                               // [4 groups][64] column sums (column-half-0 waves)
+  if (ch == 0 && hi == 0) { csr[grp * 64 + li] = cs0; csr[grp * 64 + 32 + li] = cs1; }
   __syncthreads();                                           // every wave is through with its fragment region
   auto put = [&](float* slab) __attribute__((always_inline)) {
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -151,33 +148,33 @@ __global__ __launch_bounds__(256, 1) void wgradn_kernel(const float* __restrict_
   };
   auto add = [&](const float* slab) __attribute__((always_inline)) {
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] += slab[((mt * 2 + nt) * 16 + r) * 64 + lane];
   };
-  if (wave >= 2) put(red + (wave - 2) * 16384);
+  if (grp >= 2) put(red + ((grp - 2) * 2 + ch) * 8192);
   __syncthreads();
-  if (wave < 2) add(red + wave * 16384);
+  if (grp < 2) add(red + (grp * 2 + ch) * 8192);
   __syncthreads();
-  if (wave == 1) put(red);
+  if (grp == 1) put(red + ch * 8192);
   __syncthreads();
-  if (wave == 0) {
-    add(red);
+  if (grp == 0) {
+    add(red + ch * 8192);
     float* pw = part_dw + (long)blockIdx.x * din * dout;
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const int col = 32 * nt + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const int row = 128 * ch + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hi;
           if (row < din && col < dout) pw[(long)row * dout + col] = acc[mt][nt][r];
         }
       }
-    if (part_db && lane < dout)
+    if (part_db && ch == 0 && lane < dout)
       part_db[(long)blockIdx.x * dout + lane] = (csr[lane] + csr[64 + lane]) + (csr[128 + lane] + csr[192 + lane]);
   }
 }
@@ -189,7 +186,7 @@ bool wgradn_ok(const float* x, int din, long x_ld, int dout) {
 // nblocks partials ([nblocks][din*dout], [nblocks][dout]); nblocks <= kNumCU
 int launch_wgradn(const float* x, long x_ld, const float* dy, long dy_ld, long m, int din, int dout, float* part_dw,
                   float* part_db, int nblocks, hipStream_t s) {
-  const size_t frag_b = 4 * (size_t)WN_LDS_WAVE, red_b = (size_t)(2 * 16384 + 256) * 4;
+  const size_t frag_b = WN_WAVES * (size_t)WN_LDS_WAVE, red_b = (size_t)(4 * 8192 + 256) * 4;
   const size_t lds = frag_b > red_b ? frag_b : red_b;
   static thread_local bool attr_set = false;
   if (!attr_set) {
@@ -197,8 +194,8 @@ int launch_wgradn(const float* x, long x_ld, const float* dy, long dy_ld, long m
                               kLdsBytes);
     attr_set = true;
   }
-  hipLaunchKernelGGL(wgradn_kernel, dim3((unsigned)nblocks), dim3(256), lds, s, x, x_ld, dy, dy_ld, m, din, dout, part_dw,
-                     part_db);
+  hipLaunchKernelGGL(wgradn_kernel, dim3((unsigned)nblocks), dim3(64 * WN_WAVES), lds, s, x, x_ld, dy, dy_ld, m, din, dout,
+                     part_dw, part_db);
   return check_launch("wgradn_kernel");
 }
 
