@@ -33,6 +33,11 @@ def _to_numpy(a):
     return np.asarray(a)
 
 
+# from_coo_list() packs batches with at least this many stored entries on the GPU (kgcn_coo_pack_f32); smaller ones on the
+# host (a handful of tiny launches and one 8-byte read-back cost more than numpy there)
+DEVICE_PACK_MIN_NNZ = 20000
+
+
 class BatchedCSR:
     """One adjacency channel of a batch of T graphs, device resident."""
 
@@ -193,9 +198,18 @@ class BatchedCSR:
                 cs.append(idx[:, 1])
                 vs.append(val)
         cat = (lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt))
+        M, K = (rows if rows is not None else M), (cols if cols is not None else K)
+        nnz = sum(v.shape[0] for v in vs)
+        import torch
+        if nnz >= DEVICE_PACK_MIN_NNZ and torch.device(device).type == "cuda":
+            # big batches: the triples are uploaded as they are and packed on the GPU (A now; A^T and the row-padded copies
+            # on demand) -- the numpy route sorts on the host for every new batch (A^T always, A when the feed is unsorted)
+            up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(device)
+            return cls.from_device_coo(up(cat(gs, np.int32), np.int32), up(cat(rs, np.int32), np.int32),
+                                       up(cat(cs, np.int32), np.int32), up(cat(vs, np.float32), np.float32),
+                                       len(mats), M, K)
         return cls.from_arrays(cat(gs, np.int64), cat(rs, np.int64), cat(cs, np.int64),
-                               cat(vs, np.float32), len(mats), rows if rows is not None else M,
-                               cols if cols is not None else K, device=device)
+                               cat(vs, np.float32), len(mats), M, K, device=device)
 
     # ---- derived -------------------------------------------------------------------------------
     def transpose(self):

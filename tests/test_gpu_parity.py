@@ -902,6 +902,27 @@ def test_device_coo_pack_bit_exact(T, N, nnz, dups):
     assert torch.equal(ones.cv[:, 0], host.cv[:, 0]) and bool((ones.cv[:, 1].view(torch.float32) == 1).all())
 
 
+def test_coo_lists_take_the_device_packer_for_big_batches(monkeypatch):
+    """The reference-API route (lists of per-graph COO, kgcn/feed.py:112-126) packs big batches on the GPU: same containers
+    as the numpy route, bit for bit, and the same layer output."""
+    from kgcn_amd import BatchedCSR, batched_csr, ops
+    rng = np.random.default_rng(77)
+    adjs = K.synth_mol_graphs(rng, 700, 32, 3)                       # ~70k entries > DEVICE_PACK_MIN_NNZ
+    mats = [a[0] for a in adjs]
+    devb = BatchedCSR.from_coo_list(mats, rows=32, cols=32, device=dev())
+    assert devb._host is None, "expected the device packer"
+    monkeypatch.setattr(batched_csr, "DEVICE_PACK_MIN_NNZ", 10 ** 12)
+    host = BatchedCSR.from_coo_list(mats, rows=32, cols=32, device=dev())
+    assert host._host is not None
+    _same_container(devb, host, "A")
+    _same_container(devb.transpose(), host.transpose(), "A^T")
+    _same_container(devb.padded4(), host.padded4(), "A p4")
+    _same_container(devb.transpose().padded4(), host.transpose().padded4(), "A^T p4")
+    x = torch.randn(700, 32, 64, device=dev())
+    w = torch.randn(64, 64, device=dev()); b = torch.randn(64, device=dev())
+    assert torch.equal(ops.graphconv_fused(x, w, b, devb), ops.graphconv_fused(x, w, b, host))
+
+
 def test_device_coo_pack_rejects_out_of_range_triples():
     from kgcn_amd import BatchedCSR
     ti = lambda a: torch.tensor(a, dtype=torch.int32, device=dev())
