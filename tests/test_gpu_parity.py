@@ -257,6 +257,34 @@ def test_fused_activation_dense(act, M, din, dout):
     close(tz.grad, x64 * _np_dact(_np_act(x64, act), act), rel=1e-6)
 
 
+def test_dense_entry_points_with_padded_leading_dimensions():
+    """The C ABI takes leading dimensions: the wide-input / narrow-output kernels (gemmn.hip, wgradn.hip) and the wide GEMMs
+    on operands that are column slices of wider tensors (x_ld > din, y_ld > dout, dy_ld > dout)."""
+    from kgcn_amd._lib import lib, check, ptr, current_stream
+    rng = np.random.default_rng(5)
+    for M, din, dout in ((5000, 256, 50), (4200, 160, 64), (4300, 256, 256)):
+        xl, yl = din + 8, dout + 12
+        xbig = t32(rng.standard_normal((M, xl)).astype(np.float32))
+        gbig = t32(rng.standard_normal((M, yl)).astype(np.float32))
+        w = t32(K.glorot_uniform(rng, din, dout)); b = t32(rng.standard_normal(dout).astype(np.float32))
+        ybig = torch.full((M, yl), 7.0, device=dev())
+        wsb = lib.kgcn_dense_fwd_workspace_bytes(din, dout)
+        ws = torch.empty(max(wsb, 4) // 4, device=dev())
+        check(lib.kgcn_dense_fwd_ws_f32(ptr(xbig), M, din, xl, ptr(w), dout, 0, ptr(b), ptr(ybig), dout, yl, 0, ptr(ws), wsb,
+                                        current_stream()))
+        x64, w64 = xbig[:, :din].double().cpu().numpy(), w.double().cpu().numpy()
+        close(ybig[:, :dout], x64 @ w64 + b.double().cpu().numpy(), rel=2e-6, what="y (ld)")
+        assert bool((ybig[:, dout:] == 7.0).all()), "columns beyond dout were written"
+        dw = torch.empty(din, dout, device=dev()); db = torch.empty(dout, device=dev())
+        wb = lib.kgcn_dense_wgrad_workspace_bytes(M, din, dout)
+        wsw = torch.empty(max(wb, 4) // 4, device=dev())
+        check(lib.kgcn_dense_wgrad_f32(ptr(xbig), xl, ptr(gbig), yl, M, din, dout, ptr(dw), ptr(db), ptr(wsw), wb,
+                                       current_stream()))
+        g64 = gbig[:, :dout].double().cpu().numpy()
+        close(dw, x64.T @ g64, rel=1e-5, what="dw (ld)")
+        close(db, g64.sum(0), rel=1e-5, what="db (ld)")
+
+
 def test_bconv_and_bspmdt_values_gradients():
     """kgcn/bconv_call.py:55-67 and kgcn/batched_call.py:66-73 register a gradient for the sparse VALUES of every
     graph-channel (gather rows of the output gradient, gather rows of the dense operand, multiply, reduce): through
