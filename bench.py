@@ -1,32 +1,53 @@
 #!/usr/bin/env python3
-"""bench.py -- graphs/sec of GraphConv forward+backward on synthetic molecular graphs.
+"""bench.py -- graphs/sec of the kGCN hot path on synthetic molecular graphs, 1..8 MI355X.
 
-Metric (BASELINE.json): "graphs/sec GraphConv fwd+bwd, 32-node mol graphs x64 feat".
-Workload = BASELINE config 2: 100,000 random 32-node graphs per GPU (random
-spanning tree + 3 extra edges, symmetrised, + self loops => nnz = 100 exactly, values 1.0), 64-dim
-features, one adjacency channel, kernel [64,64] glorot-uniform.  One "step" = one pass of the hot
-path over that batch: kgcn_amd.layers.GraphConv forward, then backward producing dX, dW, dbias
-(+ for N > 1 one RCCL all-reduce of the flat [dW, dbias] bucket).  Inputs are resident in HBM
-before the timed region.  Weak scaling: every rank owns its own 100k graphs.
+Metric (BASELINE.json): "graphs/sec GraphConv fwd+bwd, 32-node mol graphs x64 feat, 1/2/4/8 GPU".
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--graphs G]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg4|cfg5] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the fused backward) against
-the 8 TB/s HBM peak using the ALGORITHMIC bytes of DESIGN.md, with median / p10 / p90 of the per-launch
-HIP-event times; `roofline.spmm_kernel` prices the batched SpMM alone (kgcn_bspmm_f32 forward
-and adjoint on the same batch, 17,316 B/graph -- the kernel the north-star 60 % target is stated on), timed
-after the K steps; `cpu_baseline` times the C restatement of the reference algorithm (oracle/kgcn_ref.c,
-OpenMP over graphs) on the host cores on a bounded sample of the same workload, next to a reference-SHAPED
-leg (per-graph scipy CSR @ (X W + b) loop, the op structure of kgcn/layers.py:107-116).
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment LAUNCHES ITS OWN RANKS: it re-executes
+itself under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1, a free port); under a launcher that
+already set RANK / WORLD_SIZE it just runs as the rank it is.  Rank 0 prints ONE JSON line either way.
 
---scaling weak (default): every rank owns --graphs graphs.  --scaling strong: --graphs is the GLOBAL batch,
-sharded contiguously over the ranks (kgcn_amd.parallel.shard_range); gradients combine with the shard weights.
+--config cfg2 (default; the configuration BASELINE.json's metric is quoted on): 100,000 random 32-node
+    graphs per GPU (random spanning tree + 3 extra edges, symmetrised, + self loops => nnz = 100 exactly), 64-dim
+    features, one adjacency channel, kernel [64,64].  One step = kgcn_amd.layers.GraphConv forward, then backward
+    producing dX, dW, dbias (+ for N > 1 one RCCL all-reduce of the flat [dW, dbias] bucket).
+--config cfg4 (BASELINE config 4): Tox21-shaped multitask training, example_model/model_multitask.py network, N = 50
+    padded nodes with true sizes 5..50, F = 81, 12 masked tasks; --graphs molecules resident in HBM per GPU (default
+    125,000 = 1 M / 8), one step = one mini-batch of --batch (4,096) molecules per GPU assembled on the device,
+    forward, masked sigmoid CE, backward, gradient all-reduce, TF-Adam -- captured in one hipGraph (--eager: plain
+    launches).  --padded: compute on all 50 padded rows per molecule like round 2; default: valid rows only.
+--config cfg5 (BASELINE config 5): example_model/model_gin.py network at width 256 on 10-node ring graphs
+    (data_generator/synth_generator_ring.py distribution), --graphs (20,000) graphs per GPU per step, 256-dim features;
+    one step = forward, masked softmax CE, backward, gradient all-reduce, TF-Adam.
+
+Inputs are resident in HBM before the timed region.  --scaling weak (default): every rank owns --graphs graphs /
+--batch graphs per step.  --scaling strong (cfg2): --graphs is the GLOBAL batch, sharded contiguously over the ranks
+(kgcn_amd.parallel.shard_range); gradients combine with the shard weights.
+
+`roofline` prices the dominant kernel against the 8 TB/s HBM peak (cfg2: the fused backward, ALGORITHMIC bytes of
+DESIGN.md, median / p10 / p90 of the per-launch HIP-event times inside the timed region; `roofline.spmm_kernel` prices
+the batched SpMM alone -- the kernel the north-star 60 % target is stated on).  cfg4 / cfg5: every C-ABI call of one
+extra eager step after the timed region is bracketed by HIP events and priced with its algorithmic bytes / flops
+(tools/abi_roofline.py); `roofline` is the call with the largest time.  `cpu_baseline` (cfg2, N = 1): the C
+restatement of the reference algorithm (oracle/kgcn_ref.c, OpenMP over graphs) on the host cores on a bounded sample,
+next to a reference-SHAPED leg (per-graph scipy CSR @ (X W + b) loop, the op structure of kgcn/layers.py:107-116).
+
+`collective` (N > 1): ranks, backend and RCCL version, bucket size, the all-reduce alone timed with HIP events after the
+timed region (and inside the step for cfg2), per-rank step times.
+
+--dry --device cpu --backend gloo: the launcher and the gradient exchange WITHOUT the kernels (dummy gradients of the
+configuration's parameter shapes) -- what the CPU test of the multi-rank path runs; the product path itself has no CPU
+fallback and `bench.py` without --dry needs a GPU in every rank.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,13 +61,40 @@ N_NODES = 32
 FEAT = 64
 EXTRA_EDGES = 3
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+METRIC = "graphs/sec GraphConv fwd+bwd, 32-node mol graphs x64 feat"
 
 
 # ---------------------------------------------------------------------------------------------
-# workload (vectorised version of oracle.kgcn_oracle.synth_mol_graphs; same distribution)
+# launcher: `python bench.py --gpus N` spawns its own ranks
+# ---------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_command(n, argv, port=None):
+    """The command line `python bench.py --gpus n ...` re-executes itself with (one rank per GPU)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n, argv):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    return subprocess.call(launch_command(n, argv), env=env)
+
+
+# ---------------------------------------------------------------------------------------------
+# workload generators (build-authored; the reference's synth_generator.py needs edward + TF)
 # ---------------------------------------------------------------------------------------------
 def gen_mol_graphs(T, n=N_NODES, extra=EXTRA_EDGES, seed=1234):
-    """Returns flat COO (graph, row, col) in row-major order; nnz = T * (2*(n-1+extra) + n)."""
+    """cfg2 (vectorised version of oracle.kgcn_oracle.synth_mol_graphs; same distribution).  Returns flat COO
+    (graph, row, col) in row-major order; nnz = T * (2*(n-1+extra) + n)."""
     rng = np.random.default_rng(seed)
     A = np.zeros((T, n, n), np.bool_)
     perm = rng.permuted(np.tile(np.arange(n), (T, 1)), axis=1)
@@ -78,30 +126,49 @@ def kipf_values(g, r, c, T, n):
     return (np.float32(1.0) * recip[g * n + r]) * recip[g * n + c]
 
 
-def make_cfg2(T, device, seed=1234, normalize=False):
-    import torch
-    from kgcn_amd import BatchedCSR
-    g, r, c = gen_mol_graphs(T, seed=seed)
-    val = kipf_values(g, r, c, T, N_NODES) if normalize else np.ones(g.shape[0], np.float32)
-    csr = BatchedCSR.from_arrays(g, r, c, val, T, N_NODES, N_NODES, device=device)
-    csr.transpose()
-    gen = torch.Generator(device=device)
-    gen.manual_seed(seed)
-    x = torch.randn((T, N_NODES, FEAT), device=device, dtype=torch.float32, generator=gen)
-    grad = torch.randn((T, N_NODES, FEAT), device=device, dtype=torch.float32, generator=gen)
-    wrng = np.random.default_rng(4321)                      # identical weights on every rank
-    lim = np.sqrt(6.0 / (FEAT + FEAT))
-    w = torch.as_tensor(wrng.uniform(-lim, lim, size=(FEAT, FEAT)).astype(np.float32), device=device)
-    bias = torch.zeros((1, FEAT), device=device, dtype=torch.float32)
-    off = np.zeros(T + 1, np.int64)
-    np.cumsum(np.bincount(g, minlength=T), out=off[1:])
-    idx = np.stack([r, c], axis=1).astype(np.int32)
+def gen_tox21_like(G, n=50, seed=4):
+    """cfg4: molecules of 5..n atoms on the first `size` node slots of an n-node padded graph: random tree + two extra
+    edges + self loops on the real atoms.  Returns (sizes [G], g, r, c flat COO row-major)."""
+    rng = np.random.default_rng(seed)
+    sizes = rng.integers(5, n + 1, size=G)
+    A = np.zeros((G, n, n), np.bool_)
+    ar = np.arange(G)
+    for i in range(1, n):
+        act = sizes > i
+        j = (rng.random(G) * i).astype(np.int64)
+        A[ar[act], i, j[act]] = True
+        A[ar[act], j[act], i] = True
+    for _ in range(2):
+        i = (rng.random(G) * sizes).astype(np.int64)
+        j = (rng.random(G) * sizes).astype(np.int64)
+        A[ar, i, j] = True
+        A[ar, j, i] = True
+    node = np.arange(n)
+    A[:, node, node] = node[None, :] < sizes[:, None]
+    g, r, c = np.nonzero(A)
+    return sizes, g.astype(np.int64), r.astype(np.int64), c.astype(np.int64), rng
 
-    def adjs_of(pick):
-        return [[(idx[off[t]:off[t + 1]], val[off[t]:off[t + 1]], [N_NODES, N_NODES])] for t in pick]
 
-    return dict(csr=csr, x=x, g=grad, w=w, bias=bias, off=off, idx=idx, val=val, adjs_of=adjs_of,
-                nnz_per_graph=float(g.shape[0]) / T)
+def gen_ring_graphs(G, n=10, seed=5):
+    """cfg5, the distribution of data_generator/synth_generator_ring.py:11-46: a 6-ring (even graphs) or 5-ring (odd)
+    with self loops on the ring nodes; every (noise node, ring node) pair connected with probability 0.1, symmetric;
+    noise nodes carry no self loop.  Returns flat COO (g, r, c) row-major and the labels (ring size 6 -> 0, 5 -> 1)."""
+    rng = np.random.default_rng(seed)
+    ring = np.where(np.arange(G) % 2 == 0, 6, 5)
+    node = np.arange(n)
+    in_ring = node[None, :] < ring[:, None]                                       # [G, n]
+    A = np.zeros((G, n, n), np.bool_)
+    ar = np.arange(G)
+    A[:, node, node] = in_ring
+    for i in range(6):
+        act = ring > i
+        j = np.where(i + 1 < ring, i + 1, 0)
+        A[ar[act], i, j[act]] = True
+        A[ar[act], j[act], i] = True
+    noise = (rng.random((G, n, n)) < 0.1) & (~in_ring)[:, :, None] & in_ring[:, None, :]   # (noise row, ring col)
+    A |= noise | noise.transpose(0, 2, 1)
+    g, r, c = np.nonzero(A)
+    return g.astype(np.int64), r.astype(np.int64), c.astype(np.int64), (ring == 5).astype(np.int64), rng
 
 
 # ---------------------------------------------------------------------------------------------
@@ -112,6 +179,12 @@ def algorithmic_bytes(n, din, dout, nnz):
     fwd = 4 * n * din + csr + 4 * n * dout
     bwd = 4 * n * dout + csr + 4 * n * din + 4 * n * din     # read g, CSR, read x, write dx
     return dict(csr=csr, fwd=fwd, bwd=bwd, layer=fwd + bwd)
+
+
+def stats(ms):
+    ms = sorted(ms)
+    n = len(ms)
+    return {"median_ms": ms[n // 2], "p10_ms": ms[n // 10], "p90_ms": ms[(9 * n) // 10], "mean_ms": float(np.mean(ms))}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -166,142 +239,238 @@ def cpu_baseline(wl, budget_s=12.0, sample=20000):
 
 
 # ---------------------------------------------------------------------------------------------
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--graphs", type=int, default=100_000, help="graphs per GPU per step")
-    ap.add_argument("--normalize", action="store_true", help="Kipf-normalised adjacency values")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--unfused", action="store_true", help="dense GEMM + Bspmm kernels instead of the fused layer")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: --graphs per GPU; strong: --graphs in total, sharded over the GPUs")
-    args = ap.parse_args()
+# run context
+# ---------------------------------------------------------------------------------------------
+class Ctx:
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.on_gpu = args.device == "cuda"
+        if self.on_gpu:
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs a GPU (rank %d of %d: the product path has no CPU fallback; "
+                                 "--dry --device cpu --backend gloo exercises the launcher and the collective alone)"
+                                 % (self.rank, self.world))
+            torch.cuda.set_device(self.local_rank)
+            self.device = torch.device("cuda", self.local_rank)
+        else:
+            self.device = torch.device("cpu")
+        self.backend = args.backend
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            kw = {"device_id": self.device} if self.on_gpu else {}
+            # the communication libraries print connection banners on fd 1 (gloo always, RCCL with NCCL_DEBUG): stdout
+            # is reserved for rank 0's ONE JSON line, so fd 1 points at stderr while the group is being set up
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world, **kw)
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
 
-    import torch
-    import torch.distributed as dist
+    def sync(self):
+        if self.on_gpu:
+            self.torch.cuda.synchronize()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)"
-                         % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    def barrier(self):
+        """barrier + device synchronisation on both sides (the contract's bracket of the timed region)."""
+        self.sync()
+        if self.world > 1:
+            self.dist.barrier()
+        self.sync()
 
-    from kgcn_amd import layers
-    from kgcn_amd.parallel import GradBucket, shard_range, shard_weight
+    def event(self):
+        return self.torch.cuda.Event(enable_timing=True) if self.on_gpu else None
 
-    if args.scaling == "strong":
-        lo, hi = shard_range(args.graphs, rank, world)          # contiguous shard of ONE global batch
-        T, T_global = hi - lo, args.graphs
-    else:
-        T, T_global = args.graphs, args.graphs * world
-    weight = shard_weight(T, T_global) if world > 1 else None
-    wl = make_cfg2(T, device, seed=1234 + rank, normalize=args.normalize)
-    csr = wl["csr"]
-    layer = layers.GraphConv(FEAT, 1).to(device)
-    layer.build((T, N_NODES, FEAT), device)
-    with torch.no_grad():
-        layer.w[0].copy_(wl["w"])
-        layer.bias[0].copy_(wl["bias"])
-    if args.unfused:
-        layers.enabled_batched = True
-    x = wl["x"].requires_grad_(True)
-    g = wl["g"]
-    bucket = GradBucket(list(layer.parameters())) if world > 1 else None
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], device=self.device, dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    def gather_over_ranks(self, x):
+        if self.world == 1:
+            return [x]
+        t = self.torch.tensor([x], device=self.device, dtype=self.torch.float64)
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
 
-    def step(events=None):
-        x.grad = None
-        for p in layer.parameters():
-            p.grad = None
-        if events:
-            events[0].record()
-        out = layer(x, adj=csr)
-        if events:
-            events[1].record()
-        out.backward(g)
-        if events:
-            events[2].record()
-        if bucket is not None:
-            bucket.all_reduce_mean(weight=weight)
-
-    # setup: prime the caching allocator, the lazily built A^T / row-padded containers, the LDS attributes
-    # and the clocks (the GPU idles at 107 MHz and needs some tens of milliseconds of load to reach its
-    # sustained state, profiles/r01_h_power_clocks.txt) with untimed passes -- part of initialisation, like
-    # data generation -- then the W warm-up steps of the contract
-    for _ in range(25):
-        step()
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(ev[i])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # the batched SpMM alone (the kernel of the north-star 60 % target): forward and adjoint launches on the same batch,
-    # after the timed region, clocks still in their sustained state
-    spmm = None
-    if rank == 0 and not args.unfused:
-        from kgcn_amd import ops
-        x2d, g2d = wl["x"].detach().reshape(T * N_NODES, FEAT), g.reshape(T * N_NODES, FEAT)
-        o2d = torch.empty_like(x2d)
-        csr_t = csr.transpose()
-        sev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(max(args.steps, 20))]
+    def collective_report(self, bucket, weight, in_step_us=None, reps=50):
+        """The all-reduce of the gradient bucket alone, event-timed (HIP events on the stream the collective is
+        enqueued on; host clock on CPU), after the timed region."""
+        if self.world == 1 or bucket is None:
+            return None
+        torch, dist = self.torch, self.dist
+        for p in bucket.params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
         for _ in range(5):
-            ops.bspmm_raw(csr, x2d, FEAT, o2d)
+            bucket.all_reduce_mean(weight=weight)
+        self.barrier()
+        if self.on_gpu:
+            ev = [(self.event(), self.event()) for _ in range(reps)]
+            for a, b in ev:
+                a.record()
+                bucket.all_reduce_mean(weight=weight)
+                b.record()
+            self.sync()
+            us = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+        else:
+            us = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                bucket.all_reduce_mean(weight=weight)
+                us.append((time.perf_counter() - t0) * 1e6)
+            us.sort()
+        rep = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
+               "what": "one all-reduce (sum) of the flat fp32 gradient bucket per step + pack / scale / unpack launches",
+               "bucket_floats": int(bucket.total), "bucket_bytes": int(bucket.total) * 4,
+               "allreduce_us_standalone": {"median": us[len(us) // 2], "p10": us[len(us) // 10],
+                                           "p90": us[(9 * len(us)) // 10]}}
+        if self.on_gpu:
+            try:
+                rep["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:                                       # noqa: BLE001
+                rep["rccl_version"] = "unavailable (%s)" % e
+        if in_step_us:
+            u = sorted(in_step_us)
+            rep["allreduce_us_in_step"] = {"median": u[len(u) // 2], "p10": u[len(u) // 10], "p90": u[(9 * len(u)) // 10]}
+        return rep
+
+
+# ---------------------------------------------------------------------------------------------
+# cfg2: one GraphConv layer, forward + backward (the headline)
+# ---------------------------------------------------------------------------------------------
+def make_cfg2(T, device, seed=1234, normalize=False):
+    import torch
+    from kgcn_amd import BatchedCSR
+    g, r, c = gen_mol_graphs(T, seed=seed)
+    val = kipf_values(g, r, c, T, N_NODES) if normalize else np.ones(g.shape[0], np.float32)
+    csr = BatchedCSR.from_arrays(g, r, c, val, T, N_NODES, N_NODES, device=device)
+    csr.transpose()
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    x = torch.randn((T, N_NODES, FEAT), device=device, dtype=torch.float32, generator=gen)
+    grad = torch.randn((T, N_NODES, FEAT), device=device, dtype=torch.float32, generator=gen)
+    wrng = np.random.default_rng(4321)                      # identical weights on every rank
+    lim = np.sqrt(6.0 / (FEAT + FEAT))
+    w = torch.as_tensor(wrng.uniform(-lim, lim, size=(FEAT, FEAT)).astype(np.float32), device=device)
+    bias = torch.zeros((1, FEAT), device=device, dtype=torch.float32)
+    off = np.zeros(T + 1, np.int64)
+    np.cumsum(np.bincount(g, minlength=T), out=off[1:])
+    idx = np.stack([r, c], axis=1).astype(np.int32)
+
+    def adjs_of(pick):
+        return [[(idx[off[t]:off[t + 1]], val[off[t]:off[t + 1]], [N_NODES, N_NODES])] for t in pick]
+
+    return dict(csr=csr, x=x, g=grad, w=w, bias=bias, off=off, idx=idx, val=val, adjs_of=adjs_of,
+                nnz_per_graph=float(g.shape[0]) / T)
+
+
+class Cfg2:
+    name = "cfg2"
+    n_events = 5
+
+    def __init__(self, args, ctx):
+        import torch
+        from kgcn_amd import layers
+        from kgcn_amd.parallel import GradBucket, shard_range, shard_weight
+        self.args, self.ctx = args, ctx
+        graphs = args.graphs or 100_000
+        if args.scaling == "strong":
+            lo, hi = shard_range(graphs, ctx.rank, ctx.world)        # contiguous shard of ONE global batch
+            self.T, self.T_global = hi - lo, graphs
+        else:
+            self.T, self.T_global = graphs, graphs * ctx.world
+        self.weight = shard_weight(self.T, self.T_global) if ctx.world > 1 else None
+        self.wl = make_cfg2(self.T, ctx.device, seed=1234 + ctx.rank, normalize=args.normalize)
+        self.csr = self.wl["csr"]
+        self.layer = layers.GraphConv(FEAT, 1).to(ctx.device)
+        self.layer.build((self.T, N_NODES, FEAT), ctx.device)
+        with torch.no_grad():
+            self.layer.w[0].copy_(self.wl["w"])
+            self.layer.bias[0].copy_(self.wl["bias"])
+        if args.unfused:
+            layers.enabled_batched = True
+        self.x = self.wl["x"].requires_grad_(True)
+        self.g = self.wl["g"]
+        self.bucket = GradBucket(list(self.layer.parameters())) if ctx.world > 1 else None
+        self.units_local = self.T
+        self.units_global = self.T_global
+
+    def setup_passes(self):
+        return 25
+
+    def step(self, ev=None):
+        self.x.grad = None
+        for p in self.layer.parameters():
+            p.grad = None
+        if ev:
+            ev[0].record()
+        out = self.layer(self.x, adj=self.csr)
+        if ev:
+            ev[1].record()
+        out.backward(self.g)
+        if ev:
+            ev[2].record()
+        if self.bucket is not None:
+            self.bucket.all_reduce_mean(weight=self.weight)
+            if ev:
+                ev[3].record()
+
+    def spmm_probe(self, reps):
+        """The batched SpMM alone (the kernel of the north-star 60 % target): forward and adjoint launches on the
+        same batch, after the timed region, clocks still in their sustained state."""
+        import torch
+        from kgcn_amd import ops
+        T = self.T
+        x2d, g2d = self.wl["x"].detach().reshape(T * N_NODES, FEAT), self.g.reshape(T * N_NODES, FEAT)
+        o2d = torch.empty_like(x2d)
+        csr_t = self.csr.transpose()
+        sev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(max(reps, 20))]
+        for _ in range(5):
+            ops.bspmm_raw(self.csr, x2d, FEAT, o2d)
             ops.bspmm_raw(csr_t, g2d, FEAT, o2d)
         for e in sev:
             e[0].record()
-            ops.bspmm_raw(csr, x2d, FEAT, o2d)
+            ops.bspmm_raw(self.csr, x2d, FEAT, o2d)
             e[1].record()
             ops.bspmm_raw(csr_t, g2d, FEAT, o2d)
             e[2].record()
         torch.cuda.synchronize()
-        spmm = ([e[0].elapsed_time(e[1]) for e in sev], [e[1].elapsed_time(e[2]) for e in sev])
+        return [e[0].elapsed_time(e[1]) for e in sev], [e[1].elapsed_time(e[2]) for e in sev]
 
-    def stats(ms):
-        ms = sorted(ms)
-        n = len(ms)
-        return {"median_ms": ms[n // 2], "p10_ms": ms[n // 10], "p90_ms": ms[(9 * n) // 10], "mean_ms": float(np.mean(ms))}
+    def in_step_allreduce_us(self, evs):
+        if self.bucket is None:
+            return None
+        return [e[2].elapsed_time(e[3]) * 1e3 for e in evs]
 
-    if rank == 0:
+    def report(self, evs):
+        """rank 0: config + roofline + cpu_baseline."""
+        args, T, wl = self.args, self.T, self.wl
+        spmm = None if args.unfused else self.spmm_probe(args.steps)
         traffic = {}
         tpath = os.path.join(ROOT, "profiles", "traffic_cfg2.json")
         if os.path.exists(tpath) and not args.unfused:
             tj = json.load(open(tpath))
             if tj.get("graphs_per_launch") == T:      # PMC-measured HBM bytes of the same launch shape
                 traffic = {k: v.get("bytes") for k, v in tj.items() if isinstance(v, dict)}
-        fwd_st = stats([e[0].elapsed_time(e[1]) for e in ev])
-        bwd_st = stats([e[1].elapsed_time(e[2]) for e in ev])
+        fwd_st = stats([e[0].elapsed_time(e[1]) for e in evs])
+        bwd_st = stats([e[1].elapsed_time(e[2]) for e in evs])
         fwd_ms, bwd_ms = fwd_st["mean_ms"], bwd_st["mean_ms"]
         ab = algorithmic_bytes(N_NODES, FEAT, FEAT, wl["nnz_per_graph"])
         bwd_gbs = ab["bwd"] * T / (bwd_ms * 1e-3) / 1e9
         fwd_gbs = ab["fwd"] * T / (fwd_ms * 1e-3) / 1e9
-        traffic_bwd = traffic.get("graphconv_bwd_planes_kernel")
-        traffic_fwd = traffic.get("graphconv_fwd_full_kernel")
         spmm_entry = None
         if spmm is not None:
             sb = 2 * 4 * N_NODES * FEAT + ab["csr"]
@@ -313,11 +482,380 @@ def main():
                           "adjoint": dict(sa, achieved=sb * T / (sa["median_ms"] * 1e-3) / 1e9,
                                           frac=sb * T / (sa["median_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS),
                           "traffic": traffic.get("spmm_tile_kernel")}
+        config = {"workload": "cfg2: %d random 32-node graphs per GPU (tree+3 edges+self loops, nnz=100), 64-dim "
+                              "features, 1 adjacency channel, GraphConv fwd+bwd (dX,dW,dbias)%s"
+                              % (T, ", unfused kernels" if args.unfused else ""),
+                  "graphs_per_gpu": T, "graphs_global": self.T_global, "n_nodes": N_NODES, "din": FEAT, "dout": FEAT,
+                  "nnz_per_graph": wl["nnz_per_graph"], "adjacency_values": "kipf" if args.normalize else "ones"}
+        roofline = {"bound": "hbm",
+                    "kernel": "dense_wgrad+bspmm (unfused)" if args.unfused else
+                              "graphconv_bwd_planes_kernel (+1 reduce_partials launch, ~5 us, in the event bracket)",
+                    "achieved": bwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": bwd_gbs / HBM_PEAK_GBS, "traffic": traffic.get("graphconv_bwd_planes_kernel"),
+                    "launch_ms": bwd_st,
+                    "traffic_note": "HBM bytes per launch, rocprofv3 PMC (profiles/traffic_cfg2.json); "
+                                    "algorithmic bytes per launch = %d" % int(ab["bwd"] * T),
+                    "algorithmic_bytes_per_graph": ab["bwd"], "avg_launch_ms": bwd_ms,
+                    "fwd_kernel": {"achieved": fwd_gbs, "frac": fwd_gbs / HBM_PEAK_GBS,
+                                   "algorithmic_bytes_per_graph": ab["fwd"], "avg_launch_ms": fwd_ms,
+                                   "launch_ms": fwd_st, "traffic": traffic.get("graphconv_fwd_full_kernel")},
+                    "spmm_kernel": spmm_entry,
+                    "layer_frac_of_hbm_peak": ab["layer"] * T / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        extra = {}
+        if self.ctx.world == 1 and not args.no_cpu_baseline:
+            extra["cpu_baseline"] = cpu_baseline(wl)
+        return config, roofline, extra
+
+
+# ---------------------------------------------------------------------------------------------
+# cfg4 / cfg5: model-level training steps (hipGraph-captured by default)
+# ---------------------------------------------------------------------------------------------
+def abi_roofline_of(step_fn):
+    """Every C-ABI call of ONE eager step bracketed by HIP events and priced with its algorithmic bytes / flops
+    (tools/abi_roofline.py); returns the merged rows, largest time first."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import abi_roofline
+    rec = abi_roofline.instrument()
+    step_fn()                                        # warm (allocator) with the wrappers in place
+    torch.cuda.synchronize()
+    rec.calls, rec.on = [], True
+    step_fn()
+    torch.cuda.synchronize()
+    rec.on = False
+    abi_roofline.restore(rec)
+    return rec.rows(), sorted(rec.other)
+
+
+def roofline_from_rows(rows, unpriced):
+    if not rows:
+        return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+    top = rows[0]
+    mfma = top["bound"] == "mfma"
+    return {"bound": top["bound"], "kernel": "%s [%s] x%d per step" % (top["entry"], top["shape"], top["calls"]),
+            "achieved": top["TFLOP_per_s"] if mfma else top["GB_per_s"],
+            "peak": 157.3 if mfma else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma else "GB/s",
+            "frac": top["frac_mfma_f32"] if mfma else top["frac_hbm"], "traffic": None,
+            "peak_note": "mfma rows: fp32 matrix rate 157.3 TFLOP/s (the kernels run the exact 3 x bf16 split on the bf16 "
+                         "pipe: 6 products per fp32 product, i.e. the same flops priced against 2.5 PF / 6 = 417 TF give "
+                         "frac x 0.377)" if mfma else None,
+            "avg_launch_ms": top["us"] / top["calls"] * 1e-3,
+            "per_call_table": rows, "unpriced_calls": unpriced,
+            "method": "one extra EAGER step after the timed region, every C-ABI call bracketed by HIP events on the "
+                      "calling stream, algorithmic bytes / flops from the call arguments (tools/abi_roofline.py)"}
+
+
+class _ModelStep:
+    """Shared by cfg4 / cfg5: eager or hipGraph-captured train step + the per-call roofline of one eager step."""
+    n_events = 2
+
+    def setup_passes(self):
+        return 5
+
+    def _finish(self, model, loss_fn, static_batch, labels, mask, **fwd_kwargs):
+        from kgcn_amd import parallel, train
+        ctx = self.ctx
+        self.model, self.loss_fn, self.sb, self.labels, self.mask, self.kw = model, loss_fn, static_batch, labels, mask, \
+            fwd_kwargs
+        dp = ctx.world > 1
+        self.weight = parallel.shard_weight(self.units_local, self.units_local * ctx.world) if dp else None
+        params = list(model.parameters())
+        self.bucket = parallel.GradBucket(params) if dp else None
+        self.opt = train.TFAdam(params, lr=1e-3, capturable=not self.args.eager)
+        self.graph_step = None
+        if not self.args.eager:
+            self.graph_step = train.GraphedTrainStep(model, self.opt, loss_fn, static_batch, labels, mask,
+                                                     bucket=self.bucket, shard_weight=self.weight, **fwd_kwargs)
+
+    def _eager_step(self):
+        self.opt.zero_grad(set_to_none=False)
+        logits = self.model(self.sb.features, self.sb.adjacency, **self.kw)
+        cost_opt, _ = self.loss_fn(logits, self.labels, self.mask)
+        cost_opt.backward()
+        if self.bucket is not None:
+            self.bucket.all_reduce_mean(weight=self.weight)
+        self.opt.step()
+
+    def step(self, ev=None):
+        if ev:
+            ev[0].record()
+        self.next_batch()
+        if self.graph_step is not None:
+            self.graph_step.replay()
+        else:
+            self._eager_step()
+        if ev:
+            ev[1].record()
+
+    def in_step_allreduce_us(self, evs):
+        return None
+
+    def model_roofline(self):
+        rows, unpriced = abi_roofline_of(self._eager_step)
+        return roofline_from_rows(rows, unpriced)
+
+
+class Cfg4(_ModelStep):
+    name = "cfg4"
+
+    def __init__(self, args, ctx):
+        import torch
+        from kgcn_amd import data_util as D, models
+        self.args, self.ctx = args, ctx
+        N, F, TASKS = 50, 81, 12
+        G = args.graphs or 125_000
+        B = args.batch or 4096
+        dev = ctx.device
+        t0 = time.perf_counter()
+        sizes, g, r, c, rng = gen_tox21_like(G, N, seed=4 + ctx.rank)         # every rank its own molecules
+        chan = D.normalize_adj(D.FlatAdjacency(g, r, c, np.ones(g.shape[0], np.float32), G, N))
+        valid = np.arange(N)[None, :] < sizes[:, None]
+        feats = rng.standard_normal((G, N, F)).astype(np.float32) * valid[:, :, None]
+        labels = (rng.random((G, TASKS)) < 0.3).astype(np.float32)
+        mask_label = (rng.random((G, TASKS)) < 0.8).astype(np.float32)
+        self.gen_s = time.perf_counter() - t0
+        self.rng, self.G, self.B, self.N, self.F = rng, G, B, N, F
+        self.mean_valid = float(sizes.mean())
+        self.ds = D.DeviceGraphDataset([chan], feats, device=dev, sizes=sizes)
+        self.dataset_bytes = int(feats.nbytes + 8 * g.shape[0] + 4 * (G * N + 1))
+        self.lab_d, self.ml_d = torch.from_numpy(labels).to(dev), torch.from_numpy(mask_label).to(dev)
+        self.sizes_d = torch.from_numpy(sizes).to(dev)
+        torch.manual_seed(0)                                                    # the same initial weights on every rank
+        model = models.MultitaskGCN(1, TASKS, ragged=not args.padded).to(dev)
+        sb = self.ds.static_batch(B) if args.padded else self.ds.static_ragged_batch(B)
+        sb.load(np.arange(B))
+        self.capacity = getattr(sb, "capacity", B * N)
+        self.lab_s, self.ml_s = torch.zeros((B, TASKS), device=dev), torch.zeros((B, TASKS), device=dev)
+        self.en_s = torch.zeros(B, device=dev, dtype=self.sizes_d.dtype)
+        self.en_s.copy_(self.sizes_d[:B])
+        model(sb.features, sb.adjacency, enabled_node_nums=self.en_s)           # Keras-style build
+        mask = torch.ones(B, device=dev)
+        self.units_local, self.units_global = B, B * ctx.world
+        self.perm = rng.permutation(G)
+        self.cursor = 0
+        ml_s = self.ml_s
+        self._finish(model, lambda lg, lb, mk: models.masked_sigmoid_ce(lg, lb, mk, ml_s), sb, self.lab_s, mask,
+                     enabled_node_nums=self.en_s)
+
+    def next_batch(self):
+        """Mini-batch assembly on the device (part of the step): adjacency by kgcn_csr_gather_graphs into the static
+        containers, features / labels / sizes by index_select."""
+        torch = self.ctx.torch
+        G, B = self.G, self.B
+        lo = self.cursor
+        if lo + B > G:
+            lo = self.cursor = 0
+        self.cursor += B
+        idx = self.perm[lo:lo + B]
+        it = torch.from_numpy(idx).to(self.ctx.device)
+        self.sb.load(idx)
+        self.lab_s.copy_(self.lab_d[it])
+        self.ml_s.copy_(self.ml_d[it])
+        self.en_s.copy_(self.sizes_d[it])
+
+    def report(self, evs):
+        args = self.args
+        config = {"workload": "cfg4: example_model/model_multitask.py training step (GraphConv 256, 256, GraphDense 256, "
+                              "GraphConv 50, BN, GraphDense 50, gather, Dense 12; masked sigmoid CE; TF-Adam), %d "
+                              "Tox21-shaped molecules resident per GPU, batch %d per GPU, N=50 padded (true sizes 5..50, "
+                              "mean %.1f), F=81, 12 tasks, %s, %s" % (self.G, self.B, self.mean_valid,
+                                                                       "all padded rows computed" if args.padded else
+                                                                       "valid rows only (ragged-compact)",
+                                                                       "eager launches" if args.eager else
+                                                                       "one hipGraph per step"),
+                  "graphs_resident_per_gpu": self.G, "batch_per_gpu": self.B, "batch_global": self.units_global,
+                  "n_nodes_padded": self.N, "mean_valid_nodes": self.mean_valid, "rows_per_step": self.capacity,
+                  "features": self.F, "tasks": 12,
+                  "dataset_bytes_hbm": self.dataset_bytes, "host_generation_s": round(self.gen_s, 2)}
+        return config, self.model_roofline(), {}
+
+
+class Cfg5(_ModelStep):
+    name = "cfg5"
+
+    def __init__(self, args, ctx):
+        import types
+        import torch
+        from kgcn_amd import BatchedAdjacency, BatchedCSR, models
+        self.args, self.ctx = args, ctx
+        N, D = 10, 256
+        B = args.graphs or 20_000
+        dev = ctx.device
+        g, r, c, lab, rng = gen_ring_graphs(B, N, seed=5 + ctx.rank)
+        csr = BatchedCSR.from_arrays(g, r, c, np.ones(g.shape[0], np.float32), B, N, N, device=dev)
+        adj = BatchedAdjacency([csr])
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(5 + ctx.rank)
+        x = torch.randn((B, N, D), device=dev, generator=gen)
+        labels = torch.nn.functional.one_hot(torch.from_numpy(lab), 2).float().to(dev)
+        mask = torch.ones(B, device=dev)
+        torch.manual_seed(0)
+        model = models.GIN(1, 2, width=D).to(dev)
+        model(x, adj)
+        self.B, self.nnz = B, int(g.shape[0])
+        self.units_local, self.units_global = B, B * ctx.world
+        self._finish(model, models.masked_softmax_ce, types.SimpleNamespace(features=x, adjacency=adj), labels, mask)
+
+    def next_batch(self):
+        pass                                             # the batch is resident (one fixed batch per GPU)
+
+    def report(self, evs):
+        config = {"workload": "cfg5: example_model/model_gin.py training step at width 256 (2 x [GINAggregate, GraphDense "
+                              "256 relu x2], gather x2, Dense 2; masked softmax CE; TF-Adam), %d synthetic ring graphs "
+                              "(synth_generator_ring.py distribution, N=10) per GPU per step, 256-dim features, %s"
+                              % (self.B, "eager launches" if self.args.eager else "one hipGraph per step"),
+                  "graphs_per_gpu": self.B, "n_nodes": 10, "features": 256, "nnz_per_graph": self.nnz / self.B}
+        return config, self.model_roofline(), {}
+
+
+# ---------------------------------------------------------------------------------------------
+# --dry: the multi-rank path without the kernels (launcher + bucket exchange), any device / backend
+# ---------------------------------------------------------------------------------------------
+PARAM_SHAPES = {
+    "cfg2": [(64, 64), (1, 64)],
+    "cfg4": [(81, 256), (1, 256), (256, 256), (1, 256), (256, 256), (256,), (256, 50), (1, 50), (50,), (50,), (50, 50),
+             (50,), (50, 12), (12,)],
+    "cfg5": [(), (), (256, 256), (256,), (256, 256), (256,), (256, 256), (256,), (256, 256), (256,), (512, 2), (2,)],
+}
+
+
+class Dry:
+    n_events = 2
+
+    def __init__(self, args, ctx):
+        import torch
+        from kgcn_amd.parallel import GradBucket, shard_range, shard_weight
+        self.args, self.ctx = args, ctx
+        self.name = args.config
+        graphs = args.graphs or 1000
+        if args.scaling == "strong":
+            lo, hi = shard_range(graphs, ctx.rank, ctx.world)
+            self.units_local, self.units_global = hi - lo, graphs
+        else:
+            self.units_local, self.units_global = graphs, graphs * ctx.world
+        self.weight = shard_weight(self.units_local, self.units_global) if ctx.world > 1 else None
+        self.params = [torch.nn.Parameter(torch.zeros(s, device=ctx.device)) for s in PARAM_SHAPES[args.config]]
+        self.bucket = GradBucket(self.params) if ctx.world > 1 else None
+        self.checked = 0
+
+    def setup_passes(self):
+        return 1
+
+    def step(self, ev=None):
+        torch, ctx = self.ctx.torch, self.ctx
+        if ev and ev[0] is not None:
+            ev[0].record()
+        for i, p in enumerate(self.params):                       # "local mean gradients" of rank r: (r + 1)(i + 1)
+            p.grad = torch.full_like(p, float((ctx.rank + 1) * (i + 1)))
+        if self.bucket is not None:
+            self.bucket.all_reduce_mean(weight=self.weight)
+            # sum_r w_r (r + 1)(i + 1) with w_r = B_r / B
+            from kgcn_amd.parallel import shard_range
+            if self.args.scaling == "strong":
+                ws = [(shard_range(self.units_global, r, ctx.world)[1] - shard_range(self.units_global, r, ctx.world)[0])
+                      / self.units_global for r in range(ctx.world)]
+            else:
+                ws = [1.0 / ctx.world] * ctx.world
+            want = sum(w * (r + 1) for r, w in enumerate(ws))
+            for i, p in enumerate(self.params):
+                if not torch.allclose(p.grad, torch.full_like(p, want * (i + 1)), rtol=1e-6, atol=0):
+                    raise SystemExit("dry run: rank %d parameter %d: reduced gradient %r != %r"
+                                     % (ctx.rank, i, float(p.grad.reshape(-1)[0]), want * (i + 1)))
+            self.checked += 1
+        if ev and ev[1] is not None:
+            ev[1].record()
+
+    def in_step_allreduce_us(self, evs):
+        return None
+
+    def report(self, evs):
+        config = {"workload": "DRY RUN of %s: launcher + gradient-bucket exchange only (dummy gradients of the "
+                              "configuration's parameter shapes, no kernels); value is NOT a throughput" % self.name,
+                  "dry": True, "exchanges_checked": self.checked}
+        roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+        return config, roofline, {}
+
+
+# ---------------------------------------------------------------------------------------------
+def build_parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=("cfg2", "cfg4", "cfg5"), default="cfg2")
+    ap.add_argument("--graphs", type=int, default=0,
+                    help="cfg2 / cfg5: graphs per GPU per step (100,000 / 20,000); cfg4: molecules resident per GPU (125,000)")
+    ap.add_argument("--batch", type=int, default=0, help="cfg4: molecules per GPU per step (4,096)")
+    ap.add_argument("--normalize", action="store_true", help="cfg2: Kipf-normalised adjacency values")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="cfg2: dense GEMM + Bspmm kernels instead of the fused layer")
+    ap.add_argument("--eager", action="store_true", help="cfg4 / cfg5: plain launches instead of one hipGraph per step")
+    ap.add_argument("--padded", action="store_true", help="cfg4: compute all padded rows (round-2 behaviour)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --graphs per GPU; strong (cfg2): --graphs in total, sharded over the GPUs")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="nccl = RCCL on ROCm")
+    ap.add_argument("--device", choices=("cuda", "cpu"), default="cuda")
+    ap.add_argument("--dry", action="store_true",
+                    help="launcher + gradient exchange only (no kernels); the only mode that runs without a GPU")
+    return ap
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = build_parser().parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.device == "cpu" and not args.dry:
+        raise SystemExit("--device cpu needs --dry: the product path has no CPU fallback")
+    if args.scaling == "strong" and args.config != "cfg2" and not args.dry:
+        raise SystemExit("--scaling strong is defined for cfg2 (cfg4 / cfg5 are fixed per-GPU batches)")
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        # not under a launcher: spawn one rank per GPU and let rank 0 print the line
+        raise SystemExit(self_launch(args.gpus, argv))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, env_world))
+
+    ctx = Ctx(args)
+    torch, dist = ctx.torch, ctx.dist
+    wl = Dry(args, ctx) if args.dry else {"cfg2": Cfg2, "cfg4": Cfg4, "cfg5": Cfg5}[args.config](args, ctx)
+
+    ev = [[ctx.event() for _ in range(wl.n_events)] for _ in range(args.steps)] if ctx.on_gpu else None
+    # setup: prime the caching allocator, the lazily built A^T / row-padded containers, the LDS attributes
+    # and the clocks (the GPU idles at 107 MHz and needs some tens of milliseconds of load to reach its
+    # sustained state, profiles/r01_h_power_clocks.txt) with untimed passes -- part of initialisation, like
+    # data generation -- then the W warm-up steps of the contract
+    for _ in range(wl.setup_passes()):
+        wl.step()
+    ctx.sync()
+    for _ in range(args.warmup):
+        wl.step()
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        wl.step(ev[i] if ev else None)
+    ctx.barrier()
+    local_elapsed = time.perf_counter() - t0
+    elapsed = ctx.max_over_ranks(local_elapsed)
+    per_rank = ctx.gather_over_ranks(local_elapsed / args.steps * 1e3)
+
+    in_step = wl.in_step_allreduce_us(ev) if ev else None
+    collective = ctx.collective_report(getattr(wl, "bucket", None), getattr(wl, "weight", None), in_step)
+    if collective is not None:
+        collective["per_rank_ms_per_step"] = {"min": min(per_rank), "max": max(per_rank), "all": per_rank}
+    if ctx.rank == 0:
+        config, roofline, extra = wl.report(ev)
+        config["parallelism"] = "dp%d" % ctx.world
+        config["collective"] = None if ctx.world == 1 else \
+            "one %s all-reduce of the flat gradient bucket (%d floats) per step over %d ranks" \
+            % ("RCCL" if ctx.backend == "nccl" else ctx.backend, wl.bucket.total, dist.get_world_size())
+        from kgcn_amd import _lib
+        config["library"] = {"path": os.path.relpath(_lib.LIB_PATH, ROOT), "dev_overrides": _lib.active_overrides()}
         res = {
-            "metric": "graphs/sec GraphConv fwd+bwd, 32-node mol graphs x64 feat",
-            "value": T_global * args.steps / elapsed,
+            "metric": METRIC if args.config == "cfg2" else "graphs/sec %s training step" % args.config,
+            "value": 0.0 if args.dry else wl.units_global * args.steps / elapsed,
             "unit": "graphs/sec",
-            "n_gpus": world,
+            "n_gpus": ctx.world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -326,34 +864,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "cfg2: %d random 32-node graphs per GPU (tree+3 edges+self loops, "
-                                   "nnz=100), 64-dim features, 1 adjacency channel, GraphConv "
-                                   "fwd+bwd (dX,dW,dbias)%s" % (T, ", unfused kernels" if args.unfused else ""),
-                       "graphs_per_gpu": T, "graphs_global": T_global, "n_nodes": N_NODES, "din": FEAT, "dout": FEAT,
-                       "nnz_per_graph": wl["nnz_per_graph"], "parallelism": "dp%d" % world,
-                       "collective": None if world == 1 else "one RCCL all-reduce of the flat [dW, dbias] bucket "
-                                                            "(%d floats) per step over %d ranks (backend %s)"
-                                                            % (bucket.total, dist.get_world_size(), dist.get_backend()),
-                       "adjacency_values": "kipf" if args.normalize else "ones"},
-            "roofline": {"bound": "hbm",
-                         "kernel": "dense_wgrad+bspmm (unfused)" if args.unfused else
-                                   "graphconv_bwd_planes_kernel (+1 reduce_partials launch, ~5 us, in the event bracket)",
-                         "achieved": bwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": bwd_gbs / HBM_PEAK_GBS, "traffic": traffic_bwd,
-                         "launch_ms": bwd_st,
-                         "traffic_note": "HBM bytes per launch, rocprofv3 PMC (profiles/traffic_cfg2.json); "
-                                         "algorithmic bytes per launch = %d" % int(ab["bwd"] * T),
-                         "algorithmic_bytes_per_graph": ab["bwd"], "avg_launch_ms": bwd_ms,
-                         "fwd_kernel": {"achieved": fwd_gbs, "frac": fwd_gbs / HBM_PEAK_GBS,
-                                        "algorithmic_bytes_per_graph": ab["fwd"], "avg_launch_ms": fwd_ms,
-                                        "launch_ms": fwd_st, "traffic": traffic_fwd},
-                         "spmm_kernel": spmm_entry,
-                         "layer_frac_of_hbm_peak": ab["layer"] * T / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "config": config,
+            "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(wl)
+        if collective is not None:
+            res["collective"] = collective
+        res.update(extra)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if ctx.world > 1:
         dist.destroy_process_group()
 
 

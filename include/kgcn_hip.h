@@ -336,6 +336,50 @@ int kgcn_csr_pad4(const kgcn_csr_batch* a, int32_t* rowptr4_out, void* cv4_out, 
                   int32_t* slots_out, int32_t* graph_ptr_out, int32_t* stats_out, void* workspace,
                   int64_t workspace_bytes, void* stream);
 
+/* -- ragged-compact batches: the layer stack on the VALID node rows only ------------------------------------------------ */
+/* The reference pads every graph to max_node_num rows (kgcn/data_util.py:30-37, feed.py:127-133); its ragged layers
+ * gather the first enabled_node_nums[b] rows of every graph, compute on the stacked [sum n_b, D] matrix and pad back
+ * (GraphDense kgcn/layers.py:243-254, GraphBatchNormalization :196-210).  These entry points build that stacked layout
+ * ONCE per batch so that every layer runs on it:
+ *   rows [graph_ptr[t], graph_ptr[t+1])  the n_t valid rows of batch graph t
+ *   rows [R, capacity_rows)              padding representatives: zero features, no adjacency entries; they go through
+ *                                        the layers like the padded rows of the reference's layout, so any one of them
+ *                                        holds the value ALL padded rows of the padded formulation have (GraphConv -> 0,
+ *                                        act(0), un-ragged GraphDense -> one constant row, ragged BN -> 0)
+ *   adjacency                            one block-diagonal [capacity_rows x capacity_rows] CSR (num_graphs = 1),
+ *                                        accepted by every kgcn_bspmm / kgcn_bconv entry point
+ * capacity_rows >= R + 1 is chosen by the caller (a fixed capacity lets a captured hipGraph replay batches of varying R).
+ *
+ * kgcn_ragged_plan: n_t = clamp(sizes[g], 0, rows) and e_t = stored entries in rows [0, n_t) of graph g = sel[t]
+ * (sel NULL: g = t; sel[t] < 0: an empty dummy graph); graph_ptr / entry_ptr [num_sel + 1] = their exclusive scans
+ * (graph_ptr[num_sel] = R).  src: square batched CSR of the source graphs (the batch itself or the whole dataset).
+ * workspace >= kgcn_ragged_workspace_bytes(num_sel). */
+int64_t kgcn_ragged_workspace_bytes(int32_t num_sel);
+int kgcn_ragged_plan(const kgcn_csr_batch* src, const int32_t* sizes, const int32_t* sel, int32_t num_sel,
+                     int32_t* graph_ptr, int32_t* entry_ptr, void* workspace, int64_t workspace_bytes, void* stream);
+/* dst_rowptr [capacity_rows + 1], dst_cv [dst_cv_capacity entries] <- the block-diagonal container of the selected graphs
+ * (also for A^T: pass the transposed source container with the SAME plan).  status (may be NULL): device int32, += the
+ * number of stored entries that do not fit the compact layout (rows or columns >= n_t, plan mismatch, capacity exceeded);
+ * must read 0. */
+int kgcn_ragged_compact_csr(const kgcn_csr_batch* src, const int32_t* sel, int32_t num_sel, const int32_t* graph_ptr,
+                            const int32_t* entry_ptr, int32_t capacity_rows, int32_t* dst_rowptr, int32_t* dst_cv,
+                            int64_t dst_cv_capacity, int32_t* status, void* stream);
+/* dst [capacity_rows, d] <- the valid rows of src [num_source_graphs, n_nodes, d] (feed.py:127-133 layout), zeros on the
+ * rows >= R. */
+int kgcn_ragged_compact_rows_f32(const float* src, const int32_t* sel, int32_t num_sel, int32_t n_nodes, int32_t d,
+                                 const int32_t* graph_ptr, int32_t capacity_rows, float* dst, void* stream);
+/* back to the padded layout: dst [num_graphs, n_nodes, d]; padded rows <- row fill_row of src (the padding representative)
+ * or zeros (fill_row < 0). */
+int kgcn_ragged_expand_rows_f32(const float* src, int32_t num_graphs, int32_t n_nodes, int32_t d,
+                                const int32_t* graph_ptr, int32_t fill_row, float* dst, void* stream);
+/* GraphGather (kgcn/layers.py:163-164, padding rows included: quirk Q4) on the compact layout:
+ *   out[b, :] = sum_{r in graph b} x[r, :] + (n_nodes - n_b) * x[pad_row, :]
+ * backward: dx[r] = dout[b(r)] on valid rows, dx[pad_row] = sum_b (n_nodes - n_b) dout[b], 0 on the other rows >= R. */
+int kgcn_ragged_gather_fwd_f32(const float* x, const int32_t* graph_ptr, int64_t batch, int32_t n_nodes, int32_t d,
+                               int32_t pad_row, float* out, void* stream);
+int kgcn_ragged_gather_bwd_f32(const float* dout_grad, const int32_t* graph_ptr, int64_t batch, int32_t n_nodes, int32_t d,
+                               int32_t pad_row, int32_t capacity_rows, float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

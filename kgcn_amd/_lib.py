@@ -8,8 +8,24 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# KGCN_HIP_LIB: development override (tools/variant_bench.py times alternative builds of the same library)
+# Development overrides.  KGCN_HIP_LIB: load another build of the library (tools/variant_bench.py times alternative builds).
+# KGCN_DENSE_ROUTE / KGCN_GEMM3_MW: kernel-routing knobs that the library itself only honours when it was compiled with
+# -DKGCN_DEV_KNOBS (make DEV_KNOBS=1) -- the shipped build ignores them.  Anything set here is reported by
+# active_overrides() (bench.py prints it in its JSON line) and warned about once at import, because a stray variable
+# changes summation order / which binary produced the numbers.
+DEV_ENV_VARS = ("KGCN_HIP_LIB", "KGCN_DENSE_ROUTE", "KGCN_GEMM3_MW")
 LIB_PATH = os.environ.get("KGCN_HIP_LIB") or os.path.join(_HERE, "csrc", "libkgcn_hip.so")
+
+
+def active_overrides():
+    """Development environment switches that are set in this process (name -> value); {} in a clean environment."""
+    return {k: os.environ[k] for k in DEV_ENV_VARS if os.environ.get(k)}
+
+
+if active_overrides():
+    import warnings
+    warnings.warn("kgcn_amd: development overrides active: %r (KGCN_HIP_LIB swaps the native library; the routing knobs "
+                  "act only on a -DKGCN_DEV_KNOBS build)" % (active_overrides(),), RuntimeWarning, stacklevel=2)
 
 c_f32p = ctypes.c_void_p
 c_i32p = ctypes.c_void_p
@@ -116,6 +132,17 @@ SIGNATURES = {
     "kgcn_graph_bn_bwd_dact_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_i32, c_i64, c_i32, c_i32, c_i32p, c_f32p, c_f32p,
                                                   c_f32p, ctypes.c_float, c_i32, c_f32p, c_f32p, c_f32p, ctypes.c_void_p,
                                                   c_i64, ctypes.c_void_p]),
+    "kgcn_ragged_workspace_bytes": (c_i64, [c_i32]),
+    "kgcn_ragged_plan": (ctypes.c_int, [_CSRP, c_i32p, c_i32p, c_i32, c_i32p, c_i32p, ctypes.c_void_p, c_i64,
+                                        ctypes.c_void_p]),
+    "kgcn_ragged_compact_csr": (ctypes.c_int, [_CSRP, c_i32p, c_i32, c_i32p, c_i32p, c_i32, c_i32p, c_i32p, c_i64, c_i32p,
+                                               ctypes.c_void_p]),
+    "kgcn_ragged_compact_rows_f32": (ctypes.c_int, [c_f32p, c_i32p, c_i32, c_i32, c_i32, c_i32p, c_i32, c_f32p,
+                                                    ctypes.c_void_p]),
+    "kgcn_ragged_expand_rows_f32": (ctypes.c_int, [c_f32p, c_i32, c_i32, c_i32, c_i32p, c_i32, c_f32p, ctypes.c_void_p]),
+    "kgcn_ragged_gather_fwd_f32": (ctypes.c_int, [c_f32p, c_i32p, c_i64, c_i32, c_i32, c_i32, c_f32p, ctypes.c_void_p]),
+    "kgcn_ragged_gather_bwd_f32": (ctypes.c_int, [c_f32p, c_i32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32p,
+                                                  ctypes.c_void_p]),
     "kgcn_dot_workspace_bytes": (c_i64, [c_i64]),
     "kgcn_dot_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i64, c_f32p, ctypes.c_void_p, c_i64,
                                     ctypes.c_void_p]),

@@ -541,7 +541,7 @@ class PackedAdjacencyCache:
     """Explicit, bounded cache of packed adjacency batches for callers that feed the reference's list-of-lists
     adjs[b][ch] (kgcn/feed.py:112-126 builds a fresh list of the SAME arrays every step, kgcn/core.py:267-269 feeds it).
 
-    Keyed on CONTENT, not identity: a CRC of every index and value array (plus shapes), so mutating an entry in place
+    Keyed on CONTENT, not identity: a 128-bit digest of every index and value array (plus shapes), so mutating an entry in place
     -- which the reference's align_size / split_adj / normalize_adj all do -- yields a different key and a fresh pack.
     LRU of `max_entries` batches (device memory is held only for those); invalidate() drops everything.  The module
     instance `pack_cache` is what layers use for list inputs; set `kgcn_amd.batched_csr.pack_cache = None` to pack on
@@ -555,20 +555,24 @@ class PackedAdjacencyCache:
 
     @staticmethod
     def fingerprint(adj, n_nodes, device):
-        import zlib
-        crc = 0
+        """128-bit BLAKE2b digest of every index / value byte plus the per-matrix (nnz, shape) -- a CRC32 here would let two
+        different batches of one shape collide once in ~2^32 and silently reuse the wrong CSR."""
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
         count = 0
+        meta = []
         for row in adj:
             for m in row:
                 idx, val, shape = _as_triple(m)
                 if hasattr(val, "requires_grad") and val.requires_grad:
                     return None                         # differentiable values: never cached
                 ia, va = np.ascontiguousarray(_to_numpy(idx)), np.ascontiguousarray(_to_numpy(val))
-                crc = zlib.crc32(ia.view(np.uint8).reshape(-1), crc)
-                crc = zlib.crc32(va.view(np.uint8).reshape(-1), crc)
-                crc = zlib.crc32(np.asarray([ia.shape[0], int(shape[0]), int(shape[1])], np.int64).view(np.uint8), crc)
+                h.update(ia.view(np.uint8).reshape(-1))
+                h.update(va.view(np.uint8).reshape(-1))
+                meta += [ia.shape[0], int(shape[0]), int(shape[1]), ia.dtype.num, va.dtype.num]
                 count += 1
-        return (crc, count, len(adj), n_nodes, str(device))
+        h.update(np.asarray(meta, np.int64).view(np.uint8))
+        return (h.digest(), count, len(adj), n_nodes, str(device))
 
     def get(self, adj, n_nodes=None, device="cuda"):
         key = self.fingerprint(adj, n_nodes, device)
@@ -601,6 +605,8 @@ def as_batched_adjacency(adj, n_nodes=None, device="cuda"):
         return adj
     if isinstance(adj, BatchedCSR):
         return BatchedAdjacency([adj])
+    if hasattr(adj, "graph_ptr") and hasattr(adj, "adjacency"):        # kgcn_amd.ragged.RaggedBatch: its block-diagonal form
+        return adj.adjacency
     if pack_cache is None:
         return BatchedAdjacency.from_adjs(adj, n_nodes=n_nodes, device=device)
     return pack_cache.get(adj, n_nodes=n_nodes, device=device)

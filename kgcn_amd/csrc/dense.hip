@@ -521,7 +521,7 @@ static int dense_fwd_impl(const float* x, int64_t m, int32_t din, int64_t x_ld, 
   // wide layers: f32-MFMA bound -> the bf16-split GEMM (gemm3.hip).  With a workspace W is split ONCE into a fragment
   // table (wtable.hip) that the waves read from L2, and the kernel's staging only splits x.
   if (wide_layer(din, dout)) {
-    static const char* route = getenv("KGCN_DENSE_ROUTE");         // development: "gemm3" = never use the table
+    static const char* route = dev_knob("KGCN_DENSE_ROUTE");         // development: "gemm3" = never use the table
     const void* table = nullptr;
     if (!(route && !strcmp(route, "gemm3")) && table_pays(din, dout) && workspace &&
         workspace_bytes >= wtable_bytes(din, dout) && m >= 1024) {
@@ -533,7 +533,7 @@ static int dense_fwd_impl(const float* x, int64_t m, int32_t din, int64_t x_ld, 
   }
   // wide input, narrow output (256 -> 50): one 64-column block per wave on the bf16 pipe (gemmn.hip), W from the table
   if (gemmn_pays(x, din, (long)x_ld, dout) && workspace && workspace_bytes >= wtable_bytes(din, dout) && m >= 1024) {
-    static const char* route = getenv("KGCN_DENSE_ROUTE");
+    static const char* route = dev_knob("KGCN_DENSE_ROUTE");
     if (!(route && !strcmp(route, "gemm3"))) {
       launch_wtable_split(w, (long)w_ld, trans_w, din, dout, workspace, as_stream(stream));
       return launch_gemmn_fwd(x, (long)m, din, (long)x_ld, workspace, bias, y, dout, (long)y_ld, act, as_stream(stream));
@@ -594,7 +594,7 @@ extern "C" int kgcn_dense_dx_dact_f32(const float* grad, const float* act_out, i
   if (dpre == grad) return fail("kgcn_dense_dx_dact_f32: dpre must not alias grad");
   if (ld < dout || dx_ld < din || w_ld < dout) return fail("kgcn_dense_dx_dact_f32: leading dimension too small");
   // the contraction runs over the layer's OUTPUT width: K = dout, N = din, W used transposed
-  static const char* route = getenv("KGCN_DENSE_ROUTE");
+  static const char* route = dev_knob("KGCN_DENSE_ROUTE");
   if (!(route && !strcmp(route, "gemm3")) && table_pays(dout, din) && workspace && workspace_bytes >= wtable_bytes(dout, din) &&
       m >= 1024) {
     launch_wtable_split(w, (long)w_ld, 1, dout, din, workspace, as_stream(stream));

@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
   };
   auto store_dpre = [&](const G3Raw& R, const float* xrow, int k0) __attribute__((always_inline)) {
     if constexpr (DK != 0) {
+      if (blockIdx.y != 0) return;                         // uniform: ONE column block writes d pre-activation
       const int k = k0 + 8 * (tid & 3);
       float* p = const_cast<float*>(xrow) + da.pdiff;
       *reinterpret_cast<f32x4*>(p + (k < din ? k : 0)) = R.xa;
@@ -438,7 +439,7 @@ int launch_gemm3_fwd(const float* x, long m, int din, long x_ld, const float* w,
   if (table) {
     const size_t lds = 2 * (size_t)G3_XP * 16;
     const float* tw = static_cast<const float*>(table);
-    static const char* mw = getenv("KGCN_GEMM3_MW");         // development: "2" = the 8-wave workgroup
+    static const char* mw = dev_knob("KGCN_GEMM3_MW");         // development: "2" = the 8-wave workgroup
     if (!(mw && mw[0] == '2')) {
       const long nt64 = (m + 63) / 64;
       const long cap = 2L * kNumCU;

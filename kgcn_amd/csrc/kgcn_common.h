@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <type_traits>
 #include <utility>
@@ -24,6 +25,15 @@ inline int check_launch(const char* what) {
   if (e != hipSuccess) return fail("%s: launch failed: %s", what, hipGetErrorString(e));
   return 0;
 }
+
+// Development routing knobs (KGCN_DENSE_ROUTE, KGCN_GEMM3_MW) exist only in a -DKGCN_DEV_KNOBS build (make DEV_KNOBS=1,
+// what tools/variant_bench.py / tools/gemm_route_bench.py use): the shipped library never reads the environment, so a
+// stray variable cannot change kernel routing (and with it summation order) behind the parity tests' back.
+#ifdef KGCN_DEV_KNOBS
+inline const char* dev_knob(const char* name) { return getenv(name); }
+#else
+inline const char* dev_knob(const char*) { return nullptr; }
+#endif
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -220,10 +220,25 @@ class DeviceGraphDataset:
     adjacency like kgcn/core.py:267-269 does), features by one index_select; short batches are padded
     with empty dummy graphs / zero feature rows exactly like kgcn/feed.py:112-133."""
 
-    def __init__(self, channels, features=None, device="cuda"):
+    def __init__(self, channels, features=None, device="cuda", sizes=None):
+        """sizes (optional): true node count of every graph (the reference's enabled_node_nums, kgcn/feed.py:148-151) --
+        enables static_ragged_batch(): batches assembled directly in the ragged-compact layout (kgcn_amd.ragged)."""
         import torch
         self.num_graphs = channels[0].num_graphs
         all_idx = np.arange(self.num_graphs)
+        self.sizes = self.sizes_dev = None
+        if sizes is not None:
+            self.sizes = np.asarray(sizes, np.int64).reshape(-1)
+            if self.sizes.shape[0] != self.num_graphs:
+                raise ValueError("sizes has %d entries for %d graphs" % (self.sizes.shape[0], self.num_graphs))
+            n = channels[0].n_rows
+            if self.sizes.min(initial=0) < 0 or self.sizes.max(initial=0) > n:
+                raise ValueError("sizes must lie in [0, %d]" % n)
+            for c in channels:                      # no stored entry may touch a node >= size (checked once, on the host)
+                lim = self.sizes[c.graph]
+                if c.graph.size and ((c.row >= lim).any() or (c.col >= lim).any()):
+                    raise ValueError("an adjacency entry touches a node beyond its graph's size")
+            self.sizes_dev = torch.from_numpy(self.sizes.astype(np.int32)).to(device)
         self.channels = [c.batch(all_idx, device=device) for c in channels]
         self.features = None if features is None else \
             torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).to(device)
@@ -245,6 +260,19 @@ class DeviceGraphDataset:
     def static_batch(self, batch_size, fused=True):
         """Fixed-address batch buffers for hipGraph replay (kgcn_amd.train.GraphedTrainStep)."""
         return StaticBatch(self, batch_size, fused)
+
+    def static_ragged_batch(self, batch_size, capacity=None):
+        """Fixed-address, fixed-capacity batch buffers in the ragged-compact layout (valid node rows only)."""
+        from .ragged import StaticRaggedBatch
+        return StaticRaggedBatch(self, batch_size, capacity)
+
+    def ragged_batch(self, batch_idx, batch_size=None):
+        """One mini-batch assembled on the device directly in the ragged-compact layout (exact capacity R + 1)."""
+        from .ragged import StaticRaggedBatch
+        batch_idx = np.asarray(batch_idx, np.int64).reshape(-1)
+        T = batch_idx.shape[0] if batch_size is None else int(batch_size)
+        R = int(self.sizes[batch_idx].sum())
+        return StaticRaggedBatch(self, T, capacity=(R + 1 + 3) // 4 * 4).load(batch_idx).ragged
 
 
 class StaticBatch:

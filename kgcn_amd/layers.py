@@ -256,6 +256,9 @@ class GraphMaxPooling(nn.Module):
         return input_shape
 
     def forward(self, inputs, adj=None):
+        if hasattr(adj, "graph_ptr") and hasattr(adj, "adjacency"):
+            raise ValueError("GraphMaxPooling is not defined on a ragged-compact batch (its implicit-zero rule counts the "
+                             "padded columns of the row, kgcn/layers.py:139-147): use the padded layout")
         a = _pack(adj, inputs)
         if a.num_channels != self.adj_channel_num:
             raise ValueError("layer has %d adjacency channels, adj has %d"
@@ -487,7 +490,11 @@ class GraphGather(nn.Module):
     def compute_output_shape(self, input_shape):
         return input_shape[0], input_shape[2]
 
-    def forward(self, inputs, **kwargs):
+    def forward(self, inputs, ragged=None, **kwargs):
+        """ragged: the kgcn_amd.ragged.RaggedBatch `inputs` [1, capacity, D] lives on -- per-graph sums over graph_ptr plus
+        the padded rows' share (N - n_b times the padding representative row), i.e. the padded formulation's result."""
+        if ragged is not None:
+            return ops.ragged_gather(inputs, ragged)
         return ops.graph_gather(inputs)
 
 

@@ -23,7 +23,7 @@ import math
 import torch
 from torch import nn
 
-from . import layers, ops
+from . import layers, ops, ragged as _ragged
 
 
 GraphBatchNormalization = layers.GraphBatchNormalization
@@ -56,8 +56,11 @@ def masked_softmax_ce(logits, labels, mask):
 class GCN(nn.Module):
     """example_model/model.py:30-71."""
 
-    def __init__(self, adj_channel_num=1, num_classes=2):
+    def __init__(self, adj_channel_num=1, num_classes=2, ragged=False):
+        """ragged: run on the valid node rows only when enabled_node_nums is given (kgcn_amd.ragged; same results as the
+        padded formulation, which computes every layer on all max_node_num rows)."""
         super().__init__()
+        self.ragged = bool(ragged)
         self.conv1 = layers.GraphConv(50, adj_channel_num, activation="sigmoid")    # :42-43 tf.sigmoid(layer)
         self.conv2 = layers.GraphConv(50, adj_channel_num, activation="sigmoid")    # :44-45
         self.conv3 = layers.GraphConv(50, adj_channel_num)
@@ -67,27 +70,32 @@ class GCN(nn.Module):
         self.out = KerasDense(num_classes)
 
     def forward(self, features, adjs, enabled_node_nums=None):
+        features, adjs, enabled_node_nums, rb = _ragged.enter(self.ragged, features, adjs, enabled_node_nums)
+        if rb is None:
+            adjs = layers._pack(adjs, features)         # list-of-lists feed: packed ONCE per forward, not per layer
         layer = self.conv1(features, adj=adjs)
         layer = self.conv2(layer, adj=adjs)
         layer = self.conv3(layer, adj=adjs)
         layer = self.bn(layer, max_node_num=features.shape[1], enabled_node_nums=enabled_node_nums)
         # K.layers.Dropout(dropout_rate): identity (Q6)
         layer = self.dense(layer)
-        layer = self.gather(layer)
+        layer = self.gather(layer, ragged=rb)
         return self.out(layer)
 
 
 class GIN(nn.Module):
     """example_model/model_gin.py:29-78."""
 
-    def __init__(self, adj_channel_num=1, num_classes=2):
+    def __init__(self, adj_channel_num=1, num_classes=2, width=50):
+        """width: units of the four GraphDense layers (50 in the file; BASELINE config 5 quotes the layer at 256)."""
         super().__init__()
         self.agg = nn.ModuleList([layers.GINAggregate(adj_channel_num) for _ in range(2)])
-        self.dense = nn.ModuleList([layers.GraphDense(50, activation="relu") for _ in range(4)])   # :45-54 tf.nn.relu
+        self.dense = nn.ModuleList([layers.GraphDense(width, activation="relu") for _ in range(4)])   # :45-54 tf.nn.relu
         self.gather = layers.GraphGather()
         self.out = KerasDense(num_classes)
 
     def forward(self, features, adjs, enabled_node_nums=None):
+        adjs = layers._pack(adjs, features)
         layer = features
         outs = []
         for blk in range(2):
@@ -122,8 +130,12 @@ def sparse_softmax_ce_sum(logits, labels):
 class MultitaskGCN(nn.Module):
     """example_model/model_multitask.py:32-101."""
 
-    def __init__(self, adj_channel_num=1, label_dim=12):
+    def __init__(self, adj_channel_num=1, label_dim=12, ragged=False):
+        """ragged: run on the valid node rows only when enabled_node_nums is given (kgcn_amd.ragged) -- the reference
+        computes GraphConv / GraphDense on all max_node_num rows and only its BN on the valid ones (:58-60); the results
+        are the same, the padded rows' constant contribution to GraphGather included."""
         super().__init__()
+        self.ragged = bool(ragged)
         self.conv1 = layers.GraphConv(256, adj_channel_num, activation="sigmoid")   # :51-52
         self.conv2 = layers.GraphConv(256, adj_channel_num, activation="sigmoid")   # :53-54
         self.dense1 = layers.GraphDense(256, activation="sigmoid")                  # :55-56
@@ -134,13 +146,16 @@ class MultitaskGCN(nn.Module):
         self.out = KerasDense(label_dim)
 
     def forward(self, features, adjs, enabled_node_nums=None):
+        features, adjs, enabled_node_nums, rb = _ragged.enter(self.ragged, features, adjs, enabled_node_nums)
+        if rb is None:
+            adjs = layers._pack(adjs, features)
         layer = self.conv1(features, adj=adjs)
         layer = self.conv2(layer, adj=adjs)
         layer = self.dense1(layer)
         layer = self.conv3(layer, adj=adjs)
         layer = self.bn(layer, max_node_num=features.shape[1], enabled_node_nums=enabled_node_nums)
         layer = self.dense2(layer)
-        layer = self.gather(layer)
+        layer = self.gather(layer, ragged=rb)
         return self.out(layer)                      # prediction = sigmoid(logits)
 
 
@@ -187,6 +202,7 @@ class GATNet(nn.Module):
         self.out = KerasDense(num_classes)
 
     def forward(self, features, adjs, enabled_node_nums=None):
+        adjs = layers._pack(adjs, features)
         layer = features
         block_out = []
         for i in range(3):

@@ -124,13 +124,18 @@ class _BConv(torch.autograd.Function):
                                      ptr(out), d, M * d, int(act), current_stream()), "kgcn_bconv_act_f32")
         ctx.adj, ctx.d, ctx.act = adj, d, int(act)
         ctx.nvalues = len(values)
-        ctx.save_for_backward(rhs, out if act else rhs)
+        # rhs (the [T*K, C*D] GEMM output) is only read by the d values gradient; without differentiable adjacency values
+        # it is NOT retained (one activation-sized tensor per GraphConv layer until backward otherwise)
+        ctx.keeps_rhs = bool(values) and any(ctx.needs_input_grad[4:])
+        ctx.save_for_backward(*(([rhs] if ctx.keeps_rhs else []) + ([out] if act else [])))
         return out
 
     @staticmethod
     def backward(ctx, g):
         adj, d, act = ctx.adj, ctx.d, ctx.act
-        rhs, aout = ctx.saved_tensors
+        saved = list(ctx.saved_tensors)
+        rhs = saved.pop(0) if ctx.keeps_rhs else None
+        aout = saved.pop(0) if act else None
         g = _f32c(g, "grad")
         C = adj.num_channels
         T, M, K = adj.num_graphs, adj.n_nodes, adj.channels[0].cols
@@ -526,9 +531,58 @@ def graph_gather(x):
     return _Gather.apply(x)
 
 
+class _RaggedGather(torch.autograd.Function):
+    """GraphGather on a ragged-compact batch (kgcn_amd.ragged): sum of the valid rows + (N - n_b) x the padding
+    representative row (quirk Q4: the reference's reduce_sum runs over the padded rows too)."""
+
+    @staticmethod
+    def forward(ctx, x, rb):
+        x = _f32c(x, "inputs")
+        d = x.shape[-1]
+        if x.numel() != rb.capacity * d:
+            raise _lib.KgcnHipError("inputs %s do not match the ragged batch (capacity %d rows)" % (tuple(x.shape), rb.capacity))
+        out = torch.empty((rb.num_graphs, d), device=x.device, dtype=torch.float32)
+        check(lib.kgcn_ragged_gather_fwd_f32(ptr(x), ptr(rb.graph_ptr), rb.num_graphs, rb.n_nodes, d, rb.pad_row, ptr(out),
+                                             current_stream()), "kgcn_ragged_gather_fwd_f32")
+        ctx.rb, ctx.shape = rb, tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rb = ctx.rb
+        g = _f32c(g, "grad")
+        d = ctx.shape[-1]
+        dx = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+        check(lib.kgcn_ragged_gather_bwd_f32(ptr(g), ptr(rb.graph_ptr), rb.num_graphs, rb.n_nodes, d, rb.pad_row, rb.capacity,
+                                             ptr(dx), current_stream()), "kgcn_ragged_gather_bwd_f32")
+        return dx, None
+
+
+def ragged_gather(x, rb):
+    return _RaggedGather.apply(x, rb)
+
+
+class _RaggedCompactRows(torch.autograd.Function):
+    """Padded [B, N, D] -> the valid rows [1, capacity, D] of a ragged-compact batch; the gradient goes back to the valid
+    rows of the padded tensor (zeros on its padded rows)."""
+
+    @staticmethod
+    def forward(ctx, padded, rb):
+        ctx.rb = rb
+        return rb.compact_rows(_f32c(padded, "features"))
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.rb.expand(_f32c(g, "grad"), fill="zero"), None
+
+
+def ragged_compact_rows(padded, rb):
+    return _RaggedCompactRows.apply(padded, rb)
+
+
 __all__ = ["BatchedCSR", "BatchedAdjacency", "bspmm", "bspmm_raw", "bconv", "dense", "activation", "act_code",
            "graphconv_fused", "graphconv_fused_supported", "gin_aggregate", "graph_gather",
-           "graph_maxpool", "gat", "gram"]
+           "graph_maxpool", "gat", "gram", "ragged_gather", "ragged_compact_rows"]
 
 
 # -------------------------------------------------------------------------------------------------

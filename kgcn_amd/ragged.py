@@ -1,0 +1,251 @@
+"""Ragged-compact batches: the layer stack on the VALID node rows only (csrc/ragged.hip).
+
+The reference pads every graph of a batch to max_node_num rows (kgcn/data_util.py:30-37, kgcn/feed.py:127-133) and
+hands the true sizes to the layers as `enabled_node_nums`; its ragged layers gather the valid rows, compute on the
+stacked [sum n_b, D] matrix and pad back (GraphDense kgcn/layers.py:243-254, GraphBatchNormalization :196-210), every
+other layer computes on all padded rows.  A RaggedBatch IS that stacked matrix, built once per batch, and every layer
+of the path runs on it unchanged because it is an ordinary batch of ONE graph with a block-diagonal adjacency:
+
+    features   [1, capacity, F]     rows [graph_ptr[b], graph_ptr[b+1]) = the n_b valid rows of graph b; rows >= R are
+                                    "padding representatives" (zero features, no adjacency entries)
+    adjacency  BatchedAdjacency     C channels, num_graphs = 1, [capacity x capacity] block-diagonal CSR (+ A^T)
+    row_count  int32 [1] (device)   = R; what GraphBatchNormalization / ragged GraphDense take as enabled_node_nums
+
+Why the results are those of the padded formulation: padded rows of the reference's layout never feed a valid row
+(the adjacency has no entry there), and all of them carry the SAME value at every layer -- GraphConv gives 0 (empty
+adjacency row), an activation act(0), an un-ragged GraphDense the constant row act(prev K + bias), a ragged layer 0.
+A padding representative row goes through exactly these steps, so row capacity-1 holds that value, GraphGather adds it
+(N - n_b) times (quirk Q4: the reference sums the padded rows too), and the gradient of those padded rows reaches the
+kernels / biases through the same row.  Requirement: the padded rows of the input features are zero (feed.py pads with
+zeros) and no adjacency entry touches a node >= n_b (checked on the device when the batch is built).
+Not defined on this layout: GraphMaxPooling (its implicit-zero rule counts the padded columns) and
+GraphBatchNormalization in training phase WITHOUT enabled_node_nums (its statistics would include the padded rows).
+"""
+import numpy as np
+
+from . import _lib
+from .batched_csr import BatchedAdjacency, BatchedCSR, as_batched_adjacency
+
+
+class RaggedBatch:
+    def __init__(self, adjacency, features, graph_ptr, num_graphs, n_nodes, capacity, rows=None):
+        self.adjacency = adjacency            # BatchedAdjacency, 1 graph of capacity x capacity
+        self.features = features              # torch [1, capacity, F] or None
+        self.graph_ptr = graph_ptr            # torch int32 [B + 1] (device)
+        self.num_graphs = int(num_graphs)     # B
+        self.n_nodes = int(n_nodes)           # N = max_node_num of the padded formulation
+        self.capacity = int(capacity)
+        self.rows = rows                      # host int R when known (None after a device-only refill)
+        self.pad_row = self.capacity - 1
+
+    @property
+    def row_count(self):
+        """int32 [1] device view: R (fixed address -- what a captured hipGraph reads)."""
+        return self.graph_ptr[self.num_graphs:self.num_graphs + 1]
+
+    @property
+    def device(self):
+        return self.graph_ptr.device
+
+    def gather(self, x):
+        from . import ops
+        return ops.ragged_gather(x, self)
+
+    def expand(self, x, fill="pad"):
+        """[1, capacity, D] (or [capacity, D]) -> the padded layout [B, N, D]; padded rows get the padding representative
+        row (fill='pad': what the padded formulation holds there) or zeros (fill='zero')."""
+        import torch
+        x2 = x.reshape(self.capacity, -1).contiguous()
+        d = x2.shape[1]
+        out = torch.empty((self.num_graphs, self.n_nodes, d), device=x2.device, dtype=torch.float32)
+        _lib.check(_lib.lib.kgcn_ragged_expand_rows_f32(_lib.ptr(x2), self.num_graphs, self.n_nodes, d,
+                                                        _lib.ptr(self.graph_ptr), self.pad_row if fill == "pad" else -1,
+                                                        _lib.ptr(out), _lib.current_stream()), "kgcn_ragged_expand_rows_f32")
+        return out
+
+    def compact_rows(self, padded, out=None):
+        """[B, N, D] padded tensor -> [1, capacity, D] with this batch's row map (zeros on the rows >= R)."""
+        import torch
+        padded = padded.contiguous()
+        B, N, d = padded.shape
+        if (B, N) != (self.num_graphs, self.n_nodes):
+            raise ValueError("tensor %s does not match the batch (%d graphs x %d nodes)" % (tuple(padded.shape), self.num_graphs,
+                                                                                          self.n_nodes))
+        if out is None:
+            out = torch.empty((1, self.capacity, d), device=padded.device, dtype=torch.float32)
+        _lib.check(_lib.lib.kgcn_ragged_compact_rows_f32(_lib.ptr(padded), None, B, N, d, _lib.ptr(self.graph_ptr),
+                                                         self.capacity, _lib.ptr(out), _lib.current_stream()),
+                   "kgcn_ragged_compact_rows_f32")
+        return out
+
+
+def _plan(src, sizes_dev, sel_dev, B, graph_ptr, entry_ptr, ws):
+    _lib.check(_lib.lib.kgcn_ragged_plan(src.desc(), _lib.ptr(sizes_dev), _lib.ptr(sel_dev), B, _lib.ptr(graph_ptr),
+                                         _lib.ptr(entry_ptr), _lib.ptr(ws), ws.numel() * 4, _lib.current_stream()),
+               "kgcn_ragged_plan")
+
+
+def _compact_csr(src, sel_dev, B, graph_ptr, entry_ptr, capacity, rowptr, cv, status):
+    _lib.check(_lib.lib.kgcn_ragged_compact_csr(src.desc(), _lib.ptr(sel_dev), B, _lib.ptr(graph_ptr), _lib.ptr(entry_ptr),
+                                                capacity, _lib.ptr(rowptr), cv.data_ptr() if cv.shape[0] else 0,
+                                                cv.shape[0], _lib.ptr(status), _lib.current_stream()),
+               "kgcn_ragged_compact_csr")
+
+
+def _container(rowptr, cv, capacity):
+    return BatchedCSR(rowptr, cv, 1, capacity, capacity, max(int(cv.shape[0]), 1))
+
+
+def default_capacity(sizes, batch_size, n_nodes):
+    """A row capacity that a batch of `batch_size` graphs drawn from a dataset with these sizes exceeds with negligible
+    probability (mean + 8 sigma of the sum), rounded up to a multiple of 64, never above the padded row count + 1."""
+    sizes = np.asarray(sizes, np.float64)
+    if sizes.size == 0:
+        return 64
+    cap = batch_size * sizes.mean() + 8.0 * np.sqrt(batch_size) * sizes.std() + 1
+    cap = int(-(-cap // 64) * 64)
+    return int(min(cap, -(-(batch_size * n_nodes + 1) // 64) * 64))
+
+
+def compact(features, adj, enabled_node_nums, capacity=None, check=True):
+    """Padded batch (features [B, N, F] or None, adjacency adjs[b][ch] / BatchedAdjacency, true sizes enabled_node_nums
+    [B]) -> RaggedBatch.  capacity None: R + 1 rounded up to a multiple of 4 (one host read of R when the sizes live on
+    the device).  check: read back the device-side validity count (entries touching nodes >= n_b) and raise."""
+    import torch
+    dev = features.device if features is not None else None
+    if isinstance(adj, RaggedBatch):
+        return adj
+    n_hint = None if features is None else int(features.shape[1])
+    a = as_batched_adjacency(adj, n_nodes=n_hint, device=dev if dev is not None else "cuda")
+    B, N = a.num_graphs, a.n_nodes
+    dev = a.channels[0].rowptr.device
+    if torch.is_tensor(enabled_node_nums):
+        sizes_dev = enabled_node_nums.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
+        R = None
+    else:
+        sz = np.asarray(enabled_node_nums, np.int64).reshape(-1)
+        sizes_dev = torch.from_numpy(sz.astype(np.int32)).to(dev)
+        R = int(np.clip(sz, 0, N).sum())
+    if sizes_dev.numel() != B:
+        raise ValueError("enabled_node_nums has %d entries for a batch of %d graphs" % (sizes_dev.numel(), B))
+    if capacity is None:
+        if R is None:
+            R = int(sizes_dev.clamp(0, N).sum().item())
+        capacity = (R + 1 + 3) // 4 * 4
+    elif R is not None and R + 1 > capacity:
+        raise ValueError("batch holds %d valid rows, capacity %d needs one more for the padding representative" % (R, capacity))
+    i32 = dict(device=dev, dtype=torch.int32)
+    graph_ptr = torch.empty(B + 1, **i32)
+    ws = torch.empty(max(_lib.lib.kgcn_ragged_workspace_bytes(B), 8) // 4, **i32)
+    status = torch.zeros(1, **i32)
+    chans = []
+    for ch in a.channels:
+        entry_ptr = torch.empty(B + 1, **i32)
+        _plan(ch, sizes_dev, None, B, graph_ptr, entry_ptr, ws)
+        pair = []
+        for src in (ch, ch.transpose()):
+            rowptr = torch.empty(capacity + 1, **i32)
+            cv = torch.empty((src.nnz, 2), **i32)
+            _compact_csr(src, None, B, graph_ptr, entry_ptr, capacity, rowptr, cv, status)
+            pair.append(_container(rowptr, cv, capacity))
+        pair[0]._t, pair[1]._t = pair[1], pair[0]
+        chans.append(pair[0])
+    feat = None
+    if features is not None:
+        f = features.contiguous()
+        if f.dtype != torch.float32 or tuple(f.shape[:2]) != (B, N):
+            raise ValueError("features must be float32 [%d, %d, F], got %s %s" % (B, N, f.dtype, tuple(f.shape)))
+    if check:
+        got = torch.cat([status, graph_ptr[B:B + 1]]).tolist()
+        if got[0]:
+            raise ValueError("%d adjacency entries touch nodes beyond enabled_node_nums (or do not fit): the batch has no "
+                             "ragged-compact form" % got[0])
+        if got[1] + 1 > capacity:
+            raise ValueError("batch holds %d valid rows, capacity %d needs one more" % (got[1], capacity))
+        R = got[1]
+    rb = RaggedBatch(BatchedAdjacency(chans), None, graph_ptr, B, N, capacity, rows=R)
+    if features is not None:
+        from . import ops
+        rb.features = ops.ragged_compact_rows(f, rb)        # differentiable: d features reaches the padded tensor
+    return rb
+
+
+def enter(enabled, features, adjs, enabled_node_nums):
+    """What a model's forward does first.  Returns (features, adjs, enabled_node_nums, rb): the compact tensors and the
+    RaggedBatch when the ragged-compact route applies (`adjs` already is one, or the model asked for it and the true
+    sizes are given), the arguments unchanged and rb = None otherwise."""
+    if isinstance(adjs, RaggedBatch):
+        rb = adjs
+    elif enabled and enabled_node_nums is not None:
+        rb = compact(features, adjs, enabled_node_nums)
+    else:
+        return features, adjs, enabled_node_nums, None
+    feats = rb.features
+    if features is not None and features.dim() == 3 and tuple(features.shape[:2]) == (1, rb.capacity):
+        feats = features                      # the caller's own compact tensor (e.g. requires_grad inputs)
+    return feats, rb, rb.row_count, rb
+
+
+class StaticRaggedBatch:
+    """A ragged-compact mini-batch at FIXED device addresses and a FIXED row capacity, refilled on the device from a
+    kgcn_amd.data_util.DeviceGraphDataset that knows its graphs' true sizes: load(batch_idx) runs the plan, the two
+    container copies per channel and the feature-row copy (6 launches for one channel) -- the kernels captured in a
+    hipGraph (kgcn_amd.train.GraphedTrainStep) keep reading the same pointers whatever R the new batch has.
+    .features / .adjacency are what the model takes (adjacency = the RaggedBatch)."""
+
+    def __init__(self, dataset, batch_size, capacity=None):
+        import torch
+        if dataset.sizes is None:
+            raise ValueError("the dataset was built without `sizes` (true node counts per graph)")
+        self.dataset = dataset
+        self.batch_size = B = int(batch_size)
+        N = dataset.channels[0].rows
+        self.capacity = cap = int(capacity) if capacity else default_capacity(dataset.sizes, B, N)
+        dev = dataset.channels[0].rowptr.device
+        i32 = dict(device=dev, dtype=torch.int32)
+        self._sel_dev = torch.zeros(B, **i32)
+        self._graph_ptr = torch.zeros(B + 1, **i32)
+        self._ws = torch.empty(max(_lib.lib.kgcn_ragged_workspace_bytes(B), 8) // 4, **i32)
+        self.status = torch.zeros(1, **i32)
+        self._chan = []
+        chans = []
+        for src in dataset.channels:
+            worst = B * max(src.max_nnz, 1)
+            entry_ptr = torch.zeros(B + 1, **i32)
+            pair = [_container(torch.zeros(cap + 1, **i32), torch.zeros((worst, 2), **i32), cap) for _ in range(2)]
+            pair[0]._t, pair[1]._t = pair[1], pair[0]
+            for c in pair:
+                c._refillable = True
+            self._chan.append((src, src.transpose(), entry_ptr, pair))
+            chans.append(pair[0])
+        f = dataset.features
+        feat = None if f is None else f.new_zeros((1, cap, f.shape[2]))
+        self.ragged = RaggedBatch(BatchedAdjacency(chans), feat, self._graph_ptr, B, N, cap)
+        self.features = feat
+        self.adjacency = self.ragged
+
+    def load(self, batch_idx):
+        import torch
+        ds = self.dataset
+        batch_idx = np.asarray(batch_idx, np.int64).reshape(-1)
+        B, nb = self.batch_size, batch_idx.shape[0]
+        if nb > B or (nb and (batch_idx.max() >= ds.num_graphs or batch_idx.min() < 0)):
+            raise ValueError("batch indices out of range")
+        R = int(ds.sizes[batch_idx].sum())
+        if R + 1 > self.capacity:
+            raise ValueError("batch holds %d valid rows: beyond the static capacity %d" % (R, self.capacity))
+        sel = np.full(B, -1, np.int32)
+        sel[:nb] = batch_idx
+        self._sel_dev.copy_(torch.from_numpy(sel), non_blocking=True)
+        for src, src_t, entry_ptr, pair in self._chan:
+            _plan(src, ds.sizes_dev, self._sel_dev, B, self._graph_ptr, entry_ptr, self._ws)
+            for s, c in ((src, pair[0]), (src_t, pair[1])):
+                _compact_csr(s, self._sel_dev, B, self._graph_ptr, entry_ptr, self.capacity, c.rowptr, c.cv, self.status)
+        if self.features is not None:
+            f = ds.features
+            _lib.check(_lib.lib.kgcn_ragged_compact_rows_f32(_lib.ptr(f), _lib.ptr(self._sel_dev), B, f.shape[1], f.shape[2],
+                                                             _lib.ptr(self._graph_ptr), self.capacity,
+                                                             _lib.ptr(self.features), _lib.current_stream()),
+                       "kgcn_ragged_compact_rows_f32")
+        self.ragged.rows = R
+        return self

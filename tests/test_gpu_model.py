@@ -112,10 +112,13 @@ def _grad_of(t, ref, what, rel=2e-5):
     close(t.grad, np.asarray(ref).reshape(tuple(t.shape)), atol=2e-6, rel=rel, what="grad " + what)
 
 
+@pytest.mark.parametrize("ragged", [False, True])
 @pytest.mark.parametrize("pos_weight", [None, 2.5])
-def test_model_multitask_tox21_shaped(pos_weight):
+def test_model_multitask_tox21_shaped(pos_weight, ragged):
     """12 tasks, N = 50 padded with variable true sizes, F = 81, widths 256/256/256/50/50, masked labels,
-    a dummy graph in the batch; logits, loss and every gradient vs the fp64 oracle."""
+    a dummy graph in the batch; logits, loss and every gradient vs the fp64 oracle (the PADDED formulation of the
+    reference).  ragged=True: the product computes on the valid node rows only (kgcn_amd.ragged) -- same numbers, the padded
+    rows' constant share of GraphGather and its gradient into dense2 / bias included."""
     from kgcn_amd import models
     from test_oracle_model import tox21_like_batch
     rng = np.random.default_rng(44)
@@ -125,7 +128,10 @@ def test_model_multitask_tox21_shaped(pos_weight):
         p[k] = [rng.standard_normal(p[k][0].shape) * 0.1]
     c = NETS.multitask_forward(p, x, adjs, labels, mask, mask_label, sizes, pos_weight)
     g = NETS.multitask_backward(p, c, x, adjs, labels, mask, mask_label, pos_weight)
-    model = models.MultitaskGCN(1, 12).to(dev())
+    p["c5"] = rng.standard_normal(p["c5"].shape) * 0.1                # a bias the padded rows' constant row depends on
+    c = NETS.multitask_forward(p, x, adjs, labels, mask, mask_label, sizes, pos_weight)
+    g = NETS.multitask_backward(p, c, x, adjs, labels, mask, mask_label, pos_weight)
+    model = models.MultitaskGCN(1, 12, ragged=ragged).to(dev())
     tx = t32(x).requires_grad_(True)
     en = torch.as_tensor(sizes)
     model(tx, adjs, enabled_node_nums=en)

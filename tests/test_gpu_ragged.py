@@ -1,0 +1,203 @@
+"""Ragged-compact batches (kgcn_amd.ragged, csrc/ragged.hip): the layer stack on the valid node rows only must give
+what the reference's PADDED formulation gives (kgcn/layers.py GraphConv / GraphDense on all max_node_num rows, BN on
+the valid rows :196-210, GraphGather over the padded rows :163-164).  The checker is the numpy oracle on padded tensors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kgcn_oracle as K
+from test_gpu_parity import close, dev, t32
+from test_oracle_model import tox21_like_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _block_diagonal_reference(adjs, sizes, capacity):
+    """numpy: (rowptr, col, val) of the block-diagonal CSR of the valid blocks, entries in stored order."""
+    gp = np.zeros(len(sizes) + 1, np.int64)
+    np.cumsum(sizes, out=gp[1:])
+    rows, cols, vals = [], [], []
+    for b, chans in enumerate(adjs):
+        idx, val, _ = chans[0]
+        idx = np.asarray(idx).reshape(-1, 2)
+        rows.append(idx[:, 0] + gp[b]); cols.append(idx[:, 1] + gp[b]); vals.append(np.asarray(val, np.float32))
+    r, c, v = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    order = np.argsort(r, kind="stable")
+    r, c, v = r[order], c[order], v[order]
+    rowptr = np.zeros(capacity + 1, np.int64)
+    np.cumsum(np.bincount(r, minlength=capacity), out=rowptr[1:])
+    return gp, rowptr, c, v
+
+
+@pytest.mark.parametrize("B,N,F", [(7, 12, 5), (300, 50, 81), (1, 9, 4)])
+def test_compact_layout_bit_exact(B, N, F):
+    from kgcn_amd import ragged
+    rng = np.random.default_rng(B)
+    x, adjs, _, _, _, sizes = tox21_like_batch(rng, B=B, N=N, F=F, T=2)
+    rb = ragged.compact(t32(x), adjs, sizes)
+    R = int(sizes.sum())
+    assert rb.rows == R and rb.capacity >= R + 1 and rb.capacity % 4 == 0
+    gp, rowptr, col, val = _block_diagonal_reference(adjs, sizes, rb.capacity)
+    assert np.array_equal(rb.graph_ptr.cpu().numpy(), gp)
+    assert int(rb.row_count.item()) == R
+    a = rb.adjacency.channels[0]
+    assert (a.num_graphs, a.rows, a.cols) == (1, rb.capacity, rb.capacity)
+    assert np.array_equal(a.rowptr.cpu().numpy(), rowptr)
+    E = int(rowptr[-1])
+    cv = a.cv.cpu().numpy()[:E]
+    assert np.array_equal(cv[:, 0], col) and np.array_equal(cv[:, 1].view(np.float32), val)
+    # A^T container: same entries, transposed
+    at = a.transpose()
+    rpt = at.rowptr.cpu().numpy()
+    cvt = at.cv.cpu().numpy()[:E]
+    dense = np.zeros((rb.capacity, rb.capacity), np.float64)
+    rr = np.repeat(np.arange(rb.capacity), np.diff(rowptr))
+    np.add.at(dense, (rr, col), val)
+    dense_t = np.zeros_like(dense)
+    rt = np.repeat(np.arange(rb.capacity), np.diff(rpt))
+    np.add.at(dense_t, (rt, cvt[:, 0]), cvt[:, 1].view(np.float32))
+    assert np.array_equal(dense.T, dense_t)
+    # features: valid rows stacked, zeros behind
+    f = rb.features[0].cpu().numpy()
+    want = np.zeros((rb.capacity, F), np.float32)
+    for b in range(B):
+        want[gp[b]:gp[b + 1]] = x[b, :sizes[b]]
+    assert np.array_equal(f, want)
+    # round trip to the padded layout
+    back = rb.expand(rb.features, fill="zero").cpu().numpy()
+    assert np.array_equal(back, x.astype(np.float32))
+
+
+def test_compact_rejects_entries_beyond_the_true_size():
+    from kgcn_amd import ragged
+    rng = np.random.default_rng(3)
+    x, adjs, _, _, _, sizes = tox21_like_batch(rng, B=5, N=10, F=3, T=2)
+    sizes = sizes.copy()
+    sizes[0] -= 1                                  # graph 0 now has entries on its last (no longer valid) node
+    with pytest.raises(ValueError, match="beyond enabled_node_nums"):
+        ragged.compact(t32(x), adjs, sizes)
+    with pytest.raises(ValueError, match="capacity"):
+        ragged.compact(t32(x), adjs, sizes + (np.arange(5) == 0), capacity=8)
+
+
+@pytest.mark.parametrize("d", [50, 256, 7])
+def test_ragged_gather_matches_padded_reduce_sum(d):
+    """GraphGather on the compact layout = reduce_sum over the PADDED rows when every padded row holds the padding
+    representative's value (quirk Q4); backward: valid rows get dout[b], the representative row sum_b (N - n_b) dout[b]."""
+    from kgcn_amd import layers, ragged
+    rng = np.random.default_rng(d)
+    B, N = 37, 20
+    x, adjs, _, _, _, sizes = tox21_like_batch(rng, B=B, N=N, F=3, T=2)
+    rb = ragged.compact(None, adjs, sizes)
+    h = rng.standard_normal((rb.capacity, d)).astype(np.float32)
+    th = t32(h).reshape(1, rb.capacity, d).requires_grad_(True)
+    out = layers.GraphGather()(th, ragged=rb)
+    gp = rb.graph_ptr.cpu().numpy()
+    padded = np.repeat(h[rb.pad_row][None, None, :], B, 0).repeat(N, 1).astype(np.float64)
+    for b in range(B):
+        padded[b, :sizes[b]] = h[gp[b]:gp[b + 1]]
+    close(out, K.gather_fwd(padded), atol=2e-5, what="ragged gather")
+    g = rng.standard_normal((B, d)).astype(np.float32)
+    out.backward(t32(g))
+    want = np.zeros((rb.capacity, d))
+    for b in range(B):
+        want[gp[b]:gp[b + 1]] = g[b]
+    want[rb.pad_row] = ((N - sizes)[:, None] * g.astype(np.float64)).sum(0)
+    close(th.grad[0], want, atol=1e-5, rel=1e-6, what="ragged gather backward")
+    close(rb.expand(th.detach()), padded, atol=0, what="expand with the padding representative")
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_model_py_network_ragged_equals_padded_oracle(channels):
+    """example_model/model.py's network (3 x GraphConv, BN on the valid rows, GraphDense, gather, Dense) on a padded batch
+    with true sizes: ragged-compact product path vs the padded product path vs (through test_gpu_model) the oracle --
+    logits and every parameter gradient."""
+    from kgcn_amd import models
+    rng = np.random.default_rng(5 + channels)
+    B, N, F = 40, 16, 6
+    x, adjs, labels, mask, _, sizes = tox21_like_batch(rng, B=B, N=N, F=F, T=2)
+    if channels == 2:                                   # a second channel: the transposed pattern with other values
+        adjs = [[a[0], (np.asarray(a[0][0])[:, ::-1].copy(), (np.asarray(a[0][1]) * 0.5).astype(np.float32), a[0][2])]
+                for a in adjs]
+    lab = np.eye(2)[rng.integers(0, 2, B)]
+    res = {}
+    for ragged_mode in (False, True):
+        torch.manual_seed(0)
+        model = models.GCN(channels, 2, ragged=ragged_mode).to(dev())
+        tx = t32(x).requires_grad_(True)
+        en = torch.as_tensor(sizes)
+        model(tx, adjs, enabled_node_nums=en)
+        with torch.no_grad():                            # non-trivial biases / BN parameters
+            gen = torch.Generator(device="cpu").manual_seed(1)
+            for p_ in model.parameters():
+                if p_.dim() == 1 or p_.shape[0] == 1:
+                    p_.copy_(torch.randn(p_.shape, generator=gen).to(p_.device) * 0.1 + (1.0 if p_ is model.bn.gamma else 0.0))
+        logits = model(tx, adjs, enabled_node_nums=en)
+        cost, _ = models.masked_softmax_ce(logits, t32(lab), t32(mask))
+        cost.backward()
+        res[ragged_mode] = (logits.detach().cpu().numpy(), tx.grad.cpu().numpy(),
+                            [p_.grad.cpu().numpy() for p_ in model.parameters()])
+    close(res[True][0], res[False][0], atol=2e-5, what="logits ragged vs padded")
+    close(res[True][1], res[False][1], atol=1e-6, rel=2e-5, what="d features ragged vs padded")
+    for i, (a, b) in enumerate(zip(res[True][2], res[False][2])):
+        close(a, b, atol=2e-6, rel=2e-5, what="parameter %d gradient ragged vs padded" % i)
+
+
+def test_static_ragged_batch_equals_compact_and_replays():
+    """Device-side assembly of a ragged-compact mini-batch from a resident dataset (fixed capacity, fixed addresses) equals
+    compact() of the same padded batch; the hipGraph-captured train step on it follows the eager padded step."""
+    from kgcn_amd import data_util as D, models, ragged, train
+    rng = np.random.default_rng(9)
+    G, N, F, T, B = 300, 20, 7, 3, 32
+    x, adjs, labels, mask, mask_label, sizes = tox21_like_batch(rng, B=G, N=N, F=F, T=T)
+    sizes = np.maximum(sizes, 1); x[-1, :1] = 0
+    flat = D.FlatAdjacency.from_coo_list([a[0] for a in adjs], n_nodes=N)
+    ds = D.DeviceGraphDataset([flat], x.astype(np.float32), device=dev(), sizes=np.where(np.arange(G) == G - 1, 0, sizes))
+    sizes = ds.sizes
+    srb = ds.static_ragged_batch(B)
+    assert srb.capacity % 64 == 0 and srb.capacity <= B * N + 64
+    for trial in range(3):
+        idx = rng.permutation(G)[:B - (trial == 2) * 5]            # the last one is a short batch (dummy graphs)
+        srb.load(idx)
+        assert int(srb.status.item()) == 0
+        pad_adj, pad_x = ds.batch(idx, B)
+        en = np.zeros(B, np.int64); en[:len(idx)] = sizes[idx]
+        ref = ragged.compact(pad_x, pad_adj, en, capacity=srb.capacity)
+        R = int(en.sum())
+        assert np.array_equal(srb.ragged.graph_ptr.cpu().numpy(), ref.graph_ptr.cpu().numpy())
+        for a, b in ((srb.ragged.adjacency.channels[0], ref.adjacency.channels[0]),
+                     (srb.ragged.adjacency.channels[0].transpose(), ref.adjacency.channels[0].transpose())):
+            assert np.array_equal(a.rowptr.cpu().numpy(), b.rowptr.cpu().numpy())
+            E = int(a.rowptr[-1])
+            assert np.array_equal(a.cv.cpu().numpy()[:E], b.cv.cpu().numpy()[:E])
+        assert np.array_equal(srb.features.cpu().numpy(), ref.features.detach().cpu().numpy())
+        assert srb.ragged.rows == R
+    # captured step on the static ragged batch vs eager padded steps, same batches, same initial weights
+    lab_d, ml_d = t32(labels), t32(mask_label)
+    batches = [rng.permutation(G)[:B] for _ in range(4)]
+
+    def fresh():
+        torch.manual_seed(3)
+        m = models.MultitaskGCN(1, T, ragged=True).to(dev())
+        a0, x0 = ds.batch(batches[0], B)
+        m(x0, a0, enabled_node_nums=torch.as_tensor(sizes[batches[0]]))
+        return m
+    m_e, m_g = fresh(), fresh()
+    ones = torch.ones(B, device=dev())
+    opt_e = train.TFAdam(m_e.parameters(), lr=1e-2)
+    for b in batches:
+        a, xb = ds.batch(b, B)
+        it = torch.as_tensor(b, device=dev())
+        train.train_step(m_e, opt_e, lambda lg, lb, mk: models.masked_sigmoid_ce(lg, lb, mk, ml_d[it]), xb, a, lab_d[it], ones,
+                         enabled_node_nums=torch.as_tensor(sizes[b]))
+    opt_g = train.TFAdam(m_g.parameters(), lr=1e-2, capturable=True)
+    lab_s, ml_s = torch.zeros((B, T), device=dev()), torch.zeros((B, T), device=dev())
+    srb.load(batches[0])
+    step = train.GraphedTrainStep(m_g, opt_g, lambda lg, lb, mk: models.masked_sigmoid_ce(lg, lb, mk, ml_s), srb, lab_s, ones)
+    for b in batches:
+        it = torch.as_tensor(b, device=dev())
+        srb.load(b); lab_s.copy_(lab_d[it]); ml_s.copy_(ml_d[it])
+        step.replay()
+    torch.cuda.synchronize()
+    for pe, pg in zip(m_e.parameters(), m_g.parameters()):
+        close(pg, pe.detach().cpu().numpy(), atol=2e-5, rel=1e-4, what="parameters after 4 steps: captured ragged vs eager")

@@ -124,6 +124,7 @@ class Recorder:
         self.calls = []            # (name, shape, bytes, flops, ms)
         self.on = False
         self.other = set()
+        self.originals = {}
 
     def rows(self):
         """Calls of the recorded step merged by (entry point, shape), largest time first."""
@@ -170,5 +171,13 @@ def instrument():
             e1.synchronize()
             rec.calls.append((_name, cost[2], cost[0], cost[1], e0.elapsed_time(e1)))
             return rc
+        rec.originals[name] = fn
         setattr(lib, name, wrapper)
     return rec
+
+
+def restore(rec):
+    """Put the library's own entry points back (undo instrument())."""
+    for name, fn in rec.originals.items():
+        setattr(_lib.lib, name, fn)
+    rec.originals = {}
