@@ -458,7 +458,7 @@ class Cfg2:
     def report(self, evs):
         """rank 0: config + roofline + cpu_baseline."""
         args, T, wl = self.args, self.T, self.wl
-        spmm = None if args.unfused else self.spmm_probe(args.steps)
+        spmm = None if (args.unfused or args.profile) else self.spmm_probe(args.steps)
         traffic = {}
         tpath = os.path.join(ROOT, "profiles", "traffic_cfg2.json")
         if os.path.exists(tpath) and not args.unfused:
@@ -502,7 +502,7 @@ class Cfg2:
                     "spmm_kernel": spmm_entry,
                     "layer_frac_of_hbm_peak": ab["layer"] * T / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
         extra = {}
-        if self.ctx.world == 1 and not args.no_cpu_baseline:
+        if self.ctx.world == 1 and not args.no_cpu_baseline and not args.profile:
             extra["cpu_baseline"] = cpu_baseline(wl)
         return config, roofline, extra
 
@@ -545,6 +545,11 @@ def roofline_from_rows(rows, unpriced):
                       "calling stream, algorithmic bytes / flops from the call arguments (tools/abi_roofline.py)"}
 
 
+def train_exchange(bucket, opt, weight):
+    from kgcn_amd import train
+    return train._exchange(bucket, opt, weight)
+
+
 class _ModelStep:
     """Shared by cfg4 / cfg5: eager or hipGraph-captured train step + the per-call roofline of one eager step."""
     n_events = 2
@@ -560,8 +565,9 @@ class _ModelStep:
         dp = ctx.world > 1
         self.weight = parallel.shard_weight(self.units_local, self.units_local * ctx.world) if dp else None
         params = list(model.parameters())
-        self.bucket = parallel.GradBucket(params) if dp else None
-        self.opt = train.TFAdam(params, lr=1e-3, capturable=not self.args.eager)
+        self.opt = train.TFAdam(params, lr=1e-3)
+        # the bucket IS the optimiser's flat gradient buffer: pack, all-reduce, fused update -- nothing copied back
+        self.bucket = parallel.GradBucket(params, flat=self.opt.flat) if dp else None
         self.graph_step = None
         if not self.args.eager:
             self.graph_step = train.GraphedTrainStep(model, self.opt, loss_fn, static_batch, labels, mask,
@@ -572,9 +578,7 @@ class _ModelStep:
         logits = self.model(self.sb.features, self.sb.adjacency, **self.kw)
         cost_opt, _ = self.loss_fn(logits, self.labels, self.mask)
         cost_opt.backward()
-        if self.bucket is not None:
-            self.bucket.all_reduce_mean(weight=self.weight)
-        self.opt.step()
+        self.opt.step(packed=train_exchange(self.bucket, self.opt, self.weight))
 
     def step(self, ev=None):
         if ev:
@@ -591,6 +595,8 @@ class _ModelStep:
         return None
 
     def model_roofline(self):
+        if self.args.profile:
+            return roofline_from_rows([], [])
         rows, unpriced = abi_roofline_of(self._eager_step)
         return roofline_from_rows(rows, unpriced)
 
@@ -795,6 +801,9 @@ def build_parser():
                     help="weak: --graphs per GPU; strong (cfg2): --graphs in total, sharded over the GPUs")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="nccl = RCCL on ROCm")
     ap.add_argument("--device", choices=("cuda", "cpu"), default="cuda")
+    ap.add_argument("--profile", action="store_true",
+                    help="for rocprofv3 runs: nothing after the timed region (no per-call roofline pass, no SpMM probe, no "
+                         "CPU baseline), so the trace ends with the timed steps")
     ap.add_argument("--dry", action="store_true",
                     help="launcher + gradient exchange only (no kernels); the only mode that runs without a GPU")
     return ap

@@ -374,11 +374,35 @@ int kgcn_ragged_expand_rows_f32(const float* src, int32_t num_graphs, int32_t n_
                                 const int32_t* graph_ptr, int32_t fill_row, float* dst, void* stream);
 /* GraphGather (kgcn/layers.py:163-164, padding rows included: quirk Q4) on the compact layout:
  *   out[b, :] = sum_{r in graph b} x[r, :] + (n_nodes - n_b) * x[pad_row, :]
- * backward: dx[r] = dout[b(r)] on valid rows, dx[pad_row] = sum_b (n_nodes - n_b) dout[b], 0 on the other rows >= R. */
+ * backward: dx[r] = dout[b(r)] on valid rows, dx[pad_row] = sum_b (n_nodes - n_b) dout[b] (deterministic two-stage sum;
+ * workspace >= kgcn_ragged_gather_bwd_workspace_bytes(d)), 0 on the other rows >= R. */
 int kgcn_ragged_gather_fwd_f32(const float* x, const int32_t* graph_ptr, int64_t batch, int32_t n_nodes, int32_t d,
                                int32_t pad_row, float* out, void* stream);
+int64_t kgcn_ragged_gather_bwd_workspace_bytes(int32_t d);
 int kgcn_ragged_gather_bwd_f32(const float* dout_grad, const int32_t* graph_ptr, int64_t batch, int32_t n_nodes, int32_t d,
-                               int32_t pad_row, int32_t capacity_rows, float* dx, void* stream);
+                               int32_t pad_row, int32_t capacity_rows, float* dx, void* workspace, int64_t workspace_bytes,
+                               void* stream);
+
+/* -- loss definitions and optimiser update of the model files ---------------------------------------------- */
+/* example_model/model_multitask.py:66-79:  cost[b] = mask[b] * sum_t mask_label[b,t] * ce(logits[b,t], labels[b,t]) with
+ * tf.nn.sigmoid_cross_entropy_with_logits (weighted == 0) or tf.nn.weighted_cross_entropy_with_logits(pos_weight);
+ * sums[0] = reduce_sum(cost) (cost_sum), sums[1] = reduce_mean(cost) over the PADDED batch (cost_opt, quirk Q5);
+ * dlogits [batch, tasks] = d sums[0] / d logits.  mask_label may be NULL (all ones), cost [batch] may be NULL.
+ * workspace >= kgcn_loss_workspace_bytes(batch); deterministic (block partials added in a fixed order). */
+int64_t kgcn_loss_workspace_bytes(int64_t batch);
+int kgcn_masked_sigmoid_ce_f32(const float* logits, const float* labels, const float* mask, const float* mask_label,
+                               int64_t batch, int32_t tasks, int32_t weighted, float pos_weight, float* cost, float* dlogits,
+                               float* sums, void* workspace, int64_t workspace_bytes, void* stream);
+/* example_model/model.py:56-61:  cost[b] = mask[b] * softmax_cross_entropy(labels[b], logits[b]); same outputs. */
+int kgcn_masked_softmax_ce_f32(const float* logits, const float* labels, const float* mask, int64_t batch, int32_t classes,
+                               float* cost, float* dlogits, float* sums, void* workspace, int64_t workspace_bytes,
+                               void* stream);
+/* tf.train.AdamOptimizer(lr) (kgcn/core.py:124) over one flat buffer of n floats, with t = *step_counter + 1:
+ *   lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t) (fp64);  m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g^2;
+ *   params -= lr_t m / (sqrt(v) + eps)
+ * then *step_counter += 1 (device int64: a captured hipGraph advances it on every replay). */
+int kgcn_adam_tf_f32(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                     float eps, int64_t* step_counter, void* stream);
 
 #ifdef __cplusplus
 }

@@ -141,8 +141,16 @@ SIGNATURES = {
                                                     ctypes.c_void_p]),
     "kgcn_ragged_expand_rows_f32": (ctypes.c_int, [c_f32p, c_i32, c_i32, c_i32, c_i32p, c_i32, c_f32p, ctypes.c_void_p]),
     "kgcn_ragged_gather_fwd_f32": (ctypes.c_int, [c_f32p, c_i32p, c_i64, c_i32, c_i32, c_i32, c_f32p, ctypes.c_void_p]),
+    "kgcn_ragged_gather_bwd_workspace_bytes": (c_i64, [c_i32]),
     "kgcn_ragged_gather_bwd_f32": (ctypes.c_int, [c_f32p, c_i32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32p,
-                                                  ctypes.c_void_p]),
+                                                  ctypes.c_void_p, c_i64, ctypes.c_void_p]),
+    "kgcn_loss_workspace_bytes": (c_i64, [c_i64]),
+    "kgcn_masked_sigmoid_ce_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i32, c_i32, ctypes.c_float, c_f32p,
+                                                  c_f32p, c_f32p, ctypes.c_void_p, c_i64, ctypes.c_void_p]),
+    "kgcn_masked_softmax_ce_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_i32, c_f32p, c_f32p, c_f32p,
+                                                  ctypes.c_void_p, c_i64, ctypes.c_void_p]),
+    "kgcn_adam_tf_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, ctypes.c_float, ctypes.c_float,
+                                        ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "kgcn_dot_workspace_bytes": (c_i64, [c_i64]),
     "kgcn_dot_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i64, c_f32p, ctypes.c_void_p, c_i64,
                                     ctypes.c_void_p]),

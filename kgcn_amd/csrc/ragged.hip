@@ -238,27 +238,33 @@ __global__ __launch_bounds__(256) void ragged_gather_bwd_kernel(const float* __r
   }
 }
 
-// dx[pad_row, c] = sum_b (N - n_b) g[b, c]: one workgroup per block of <= 256 columns, fixed summation order
+// part[blockIdx.x, c] = sum over this workgroup's slice of graphs of (N - n_b) g[b, c]; blockIdx.y = block of <= 256
+// columns.  A fixed-order second stage (reduce_partials) adds the slices into dx[pad_row]: deterministic.
+constexpr int kPadParts = 128;
 __global__ __launch_bounds__(256) void ragged_gather_pad_bwd_kernel(const float* __restrict__ g, const int* __restrict__ graph_ptr,
-                                                                    int B, int N, int d, int pad_row, float* __restrict__ dx) {
+                                                                    int B, int N, int d, float* __restrict__ part) {
   __shared__ float red[256];
   const int tid = threadIdx.x;
-  const int c0 = blockIdx.x * 256;
+  const int c0 = blockIdx.y * 256;
   const int cb = d - c0 < 256 ? d - c0 : 256;
   const int rpp = 256 / cb;
   const int c = tid % cb, rl = tid / cb;
+  const int per = (B + gridDim.x - 1) / gridDim.x;
+  const int b0 = blockIdx.x * per, b1 = b0 + per < B ? b0 + per : B;
   float a = 0.f;
   if (rl < rpp) {
-    for (int b = rl; b < B; b += rpp) a += (float)(N - (graph_ptr[b + 1] - graph_ptr[b])) * g[(long)b * d + c0 + c];
+    for (int b = b0 + rl; b < b1; b += rpp) a += (float)(N - (graph_ptr[b + 1] - graph_ptr[b])) * g[(long)b * d + c0 + c];
   }
   red[tid] = a;
   __syncthreads();
   if (tid < cb) {
     float s = 0.f;
     for (int k = 0; k < rpp; ++k) s += red[k * cb + tid];
-    dx[(long)pad_row * d + c0 + tid] = s;
+    part[(long)blockIdx.x * d + c0 + tid] = s;
   }
 }
+
+int launch_reduce_partials(const float* part, int nparts, long n, float* out, hipStream_t s);
 
 static unsigned grid_cap(long work_items, long cap = (long)kNumCU * 16) {
   long b = (work_items + 255) / 256;
@@ -366,18 +372,31 @@ extern "C" int kgcn_ragged_gather_fwd_f32(const float* x, const int32_t* graph_p
   return check_launch("ragged_gather_fwd_kernel");
 }
 
+extern "C" int64_t kgcn_ragged_gather_bwd_workspace_bytes(int32_t d) {
+  return d > 0 ? (int64_t)kPadParts * d * 4 : 0;
+}
+
 extern "C" int kgcn_ragged_gather_bwd_f32(const float* dout_grad, const int32_t* graph_ptr, int64_t batch, int32_t n_nodes,
-                                          int32_t d, int32_t pad_row, int32_t capacity_rows, float* dx, void* stream) {
+                                          int32_t d, int32_t pad_row, int32_t capacity_rows, float* dx, void* workspace,
+                                          int64_t workspace_bytes, void* stream) {
   if (batch < 0 || n_nodes < 0 || d < 0 || capacity_rows < 0) return fail("kgcn_ragged_gather_bwd_f32: negative argument");
   if (capacity_rows == 0 || d == 0) return 0;
   if (pad_row < 0 || pad_row >= capacity_rows) return fail("kgcn_ragged_gather_bwd_f32: pad_row outside the capacity");
   if (!graph_ptr || !dx || (!dout_grad && batch > 0)) return fail("kgcn_ragged_gather_bwd_f32: NULL operand");
   if (batch >= INT32_MAX) return fail("kgcn_ragged_gather_bwd_f32: batch too large");
+  if (!workspace || workspace_bytes < kgcn_ragged_gather_bwd_workspace_bytes(d))
+    return fail("kgcn_ragged_gather_bwd_f32: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                (long long)kgcn_ragged_gather_bwd_workspace_bytes(d));
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(ragged_gather_bwd_kernel, dim3(grid_cap((batch > 0 ? batch : 1) * kWave, (long)kNumCU * 32)), dim3(256),
                      0, s, dout_grad, graph_ptr, (int)batch, d, capacity_rows, dx);
   if (int rc = check_launch("ragged_gather_bwd_kernel")) return rc;
-  hipLaunchKernelGGL(ragged_gather_pad_bwd_kernel, dim3((d + 255) / 256), dim3(256), 0, s, dout_grad, graph_ptr, (int)batch,
-                     n_nodes, d, pad_row, dx);
-  return check_launch("ragged_gather_pad_bwd_kernel");
+  int nparts = (int)((batch + 31) / 32);
+  if (nparts > kPadParts) nparts = kPadParts;
+  if (nparts < 1) nparts = 1;
+  float* part = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(ragged_gather_pad_bwd_kernel, dim3(nparts, (d + 255) / 256), dim3(256), 0, s, dout_grad, graph_ptr,
+                     (int)batch, n_nodes, d, part);
+  if (int rc = check_launch("ragged_gather_pad_bwd_kernel")) return rc;
+  return launch_reduce_partials(part, nparts, d, dx + (long)pad_row * d, s);
 }

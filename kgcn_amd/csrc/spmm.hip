@@ -190,6 +190,111 @@ __global__ __launch_bounds__(64 * NW) void spmm_tile_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// row-chunk kernel: big matrices whose rhs block does not fit LDS -- the block-diagonal [sum N x sum N] batch of the
+// kgcn-sparse path (kgcn/data_util.py:698-845) and the ragged-compact batches (ragged.hip), VEC in {4, 2}.
+// The generic gather kernel below walks one row per lane group with THREE dependent loads per entry (rowptr -> cv ->
+// rhs row): latency-bound (0.42 of HBM peak at d = 256, 0.12 at d = 50, profiles/r03a).  Here a group of LPR lanes owns
+// ROWS = 8 consecutive rows: one coalesced load brings their 9 row offsets, one more the (column, value) pairs of all 8
+// rows (a sliding LPR-entry window held across the group's lanes, handed out with ds_bpermute), and the rhs rows of up
+// to four entries are requested back to back before the first is consumed -- two latency steps per 8 rows instead of
+// three per entry.  Neighbour rows of a block-diagonal matrix lie within one graph (<= N rows away): consecutive row
+// chunks are mapped to the SAME XCD (blockIdx -> chunk remap below), so those re-reads hit that XCD's L2.
+// ------------------------------------------------------------------------------------------------
+template <int VEC, int LPR>
+__global__ __launch_bounds__(256) void spmm_rows_kernel(
+    SpmmChannels ch, const float* __restrict__ rhs, long rhs_ld, long rhs_gs, float* __restrict__ out, long out_ld,
+    long out_gs, int M, long total_rows, int d, float beta, const float* __restrict__ self_scale, int act,
+    const float* __restrict__ aout, int dact, int blocks_per_xcd) {
+  using V = typename SpVec<VEC>::T;
+  constexpr int ROWS = 8;
+  constexpr int GPB = 256 / LPR;
+  auto ldv = [](const float* p) { return *reinterpret_cast<const V*>(p); };
+  auto stv = [](float* p, V v) { *reinterpret_cast<V*>(p) = v; };
+  // XCD-aware: workgroups are dealt round-robin to the 8 XCDs; logical chunk = (xcd, position inside the xcd)
+  const long lb = (long)(blockIdx.x & 7) * blocks_per_xcd + (blockIdx.x >> 3);
+  const int gl = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+  const long r0 = (lb * GPB + grp) * ROWS;
+  if (r0 >= total_rows) return;                      // whole lane group leaves together
+  const float sscale = self_scale ? self_scale[0] : 0.f;
+  for (int c0 = gl * VEC; c0 - gl * VEC < d; c0 += LPR * VEC) {     // one trip unless d > LPR * VEC; group-uniform count
+    const bool ok = c0 < d;
+    V acc[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[i][j] = 0.f;
+    for (int c = 0; c < ch.n; ++c) {
+      const int* rp = ch.rowptr[c];
+      const int2* cv = ch.cv[c];
+      const long ri = r0 + (gl <= ROWS ? gl : ROWS);
+      const int my = rp[ri < total_rows ? ri : total_rows];          // rows past the end: empty
+      const int e_all = __shfl(my, ROWS, LPR);
+      int wbase = __shfl(my, 0, LPR);
+      int2 w = (wbase + gl < e_all) ? cv[wbase + gl] : make_int2(0, 0);
+      const float* rc = rhs + c * ch.rhs_cs;
+      static_for<ROWS>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int s = __shfl(my, i, LPR), e = __shfl(my, i + 1, LPR);
+        const long row = r0 + i;
+        const long t = row / M;
+        const float* rb = rc + t * rhs_gs + c0;
+        const float* ab = aout + t * rhs_gs + c0;
+        for (int k = s; k < e; k += 4) {
+          const int last = (k + 4 < e ? k + 4 : e);
+          if (last > wbase + LPR) {                   // slide the window (group-uniform)
+            wbase = k;
+            w = (wbase + gl < e_all) ? cv[wbase + gl] : make_int2(0, 0);
+          }
+          V x[4], a[4];
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool valid = k + j < e;
+            const int idx = (k + j - wbase) & (LPR - 1);
+            const int col = __shfl(w.x, idx, LPR);
+            v[j] = valid ? __int_as_float(__shfl(w.y, idx, LPR)) : 0.f;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) { x[j][q] = 0.f; a[j][q] = 0.f; }
+            if (valid && ok) {
+              x[j] = ldv(rb + (long)col * rhs_ld);
+              if (dact != KGCN_ACT_NONE) a[j] = ldv(ab + (long)col * rhs_ld);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (dact != KGCN_ACT_NONE) {
+#pragma unroll
+              for (int q = 0; q < VEC; ++q) x[j][q] *= act_dout(a[j][q], dact);
+            }
+            acc[i] += v[j] * x[j];
+          }
+        }
+        if (self_scale && c == 0 && ok && row < total_rows) {
+          const int r = (int)(row - t * M);
+          acc[i] += sscale * ldv(rb + (long)r * rhs_ld);
+        }
+      });
+    }
+    static_for<ROWS>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const long row = r0 + i;
+      if (ok && row < total_rows) {
+        const long t = row / M;
+        const int r = (int)(row - t * M);
+        float* o = out + t * out_gs + (long)r * out_ld + c0;
+        V y = acc[i];
+        if (beta != 0.f) y += ldv(o);
+        if (act != KGCN_ACT_NONE) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) y[j] = act_fwd(y[j], act);
+        }
+        stv(o, y);
+      }
+    });
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // generic CSR-vector gather kernel: LPR = 2^lpr_log2 lanes per row, VEC floats per lane
 // ------------------------------------------------------------------------------------------------
 template <int VEC>
@@ -460,6 +565,31 @@ int launch_spmm_multi(const kgcn_csr_batch* a, int nch, const float* rhs, long r
     return check_launch("spmm_tile_kernel");
   }
   const long total_rows = (long)T * M;
+  {
+    // rows that do not fit an LDS tile: the row-chunk kernel when 8- or 16-byte vectors are possible
+    const long all = rhs_ld | rhs_gs | out_ld | out_gs | rhs_cs | d;
+    const uintptr_t ptrs = reinterpret_cast<uintptr_t>(rhs) | reinterpret_cast<uintptr_t>(out) |
+                           (dact ? reinterpret_cast<uintptr_t>(aout) : 0);
+    const int vec = (all % 4 == 0 && ptrs % 16 == 0) ? 4 : ((all % 2 == 0 && ptrs % 8 == 0) ? 2 : 0);
+    if (vec && total_rows < (1L << 31)) {
+      const int lanes = d / vec;
+      const int lpr = lanes <= 16 ? 16 : (lanes <= 32 ? 32 : 64);
+      const long rows_per_block = (long)(256 / lpr) * 8;
+      const long nblocks = (total_rows + rows_per_block - 1) / rows_per_block;
+      const int per_xcd = (int)((nblocks + 7) / 8);
+      const dim3 grid((unsigned)(per_xcd * 8));
+#define KGCN_ROWS(VEC, LPR)                                                                                           \
+  hipLaunchKernelGGL((spmm_rows_kernel<VEC, LPR>), grid, dim3(256), 0, stream, ch, rhs, rhs_ld, rhs_gs, out, out_ld,  \
+                     out_gs, M, total_rows, d, beta, self_scale, act, aout, dact, per_xcd)
+      if (vec == 4) {
+        if (lpr == 16) KGCN_ROWS(4, 16); else if (lpr == 32) KGCN_ROWS(4, 32); else KGCN_ROWS(4, 64);
+      } else {
+        if (lpr == 16) KGCN_ROWS(2, 16); else if (lpr == 32) KGCN_ROWS(2, 32); else KGCN_ROWS(2, 64);
+      }
+#undef KGCN_ROWS
+      return check_launch("spmm_rows_kernel");
+    }
+  }
   const bool vec4 = (d % 4 == 0) && (rhs_ld % 4 == 0) && (rhs_gs % 4 == 0) && (out_ld % 4 == 0) &&
                     (out_gs % 4 == 0) && (rhs_cs % 4 == 0) && aligned16(rhs) && aligned16(out) &&
                     (dact == KGCN_ACT_NONE || aligned16(aout));

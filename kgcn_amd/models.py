@@ -47,10 +47,9 @@ class KerasDense(nn.Module):
 
 def masked_softmax_ce(logits, labels, mask):
     """model.py:56-61: cost = mask * softmax_cross_entropy(labels, logits);
-    cost_opt = reduce_mean(cost) over the PADDED batch (quirk Q5); cost_sum = reduce_sum(cost)."""
-    logp = torch.log_softmax(logits, dim=1)
-    cost = mask * -(labels.to(logits.dtype) * logp).sum(dim=1)
-    return cost.mean(), cost.sum()
+    cost_opt = reduce_mean(cost) over the PADDED batch (quirk Q5); cost_sum = reduce_sum(cost).
+    One HIP pass (csrc/train.hip: per-graph cost, d cost_sum / d logits, fixed-order sums)."""
+    return ops.masked_softmax_ce(logits, labels, mask)
 
 
 class GCN(nn.Module):
@@ -110,15 +109,8 @@ class GIN(nn.Module):
 def masked_sigmoid_ce(logits, labels, mask, mask_label, pos_weight=None):
     """model_multitask.py:66-79: cost = mask * sum_tasks mask_label * (weighted) sigmoid cross entropy;
     cost_opt = reduce_mean over the padded batch, cost_sum = reduce_sum.  Formulas of
-    tf.nn.sigmoid_cross_entropy_with_logits / tf.nn.weighted_cross_entropy_with_logits."""
-    x, z = logits, labels.to(logits.dtype)
-    sp = torch.log1p(torch.exp(-x.abs()))
-    if pos_weight is None:
-        ce = torch.clamp(x, min=0) - x * z + sp
-    else:
-        ce = (1 - z) * x + (1 + (pos_weight - 1) * z) * (sp + torch.clamp(-x, min=0))
-    cost = mask * (mask_label * ce).sum(dim=1)
-    return cost.mean(), cost.sum()
+    tf.nn.sigmoid_cross_entropy_with_logits / tf.nn.weighted_cross_entropy_with_logits; one HIP pass (csrc/train.hip)."""
+    return ops.masked_sigmoid_ce(logits, labels, mask, mask_label, pos_weight)
 
 
 def sparse_softmax_ce_sum(logits, labels):

@@ -553,8 +553,10 @@ class _RaggedGather(torch.autograd.Function):
         g = _f32c(g, "grad")
         d = ctx.shape[-1]
         dx = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+        wsb = lib.kgcn_ragged_gather_bwd_workspace_bytes(d)
+        ws = torch.empty((wsb // 4,), device=g.device, dtype=torch.float32)
         check(lib.kgcn_ragged_gather_bwd_f32(ptr(g), ptr(rb.graph_ptr), rb.num_graphs, rb.n_nodes, d, rb.pad_row, rb.capacity,
-                                             ptr(dx), current_stream()), "kgcn_ragged_gather_bwd_f32")
+                                             ptr(dx), ptr(ws), wsb, current_stream()), "kgcn_ragged_gather_bwd_f32")
         return dx, None
 
 
@@ -580,9 +582,61 @@ def ragged_compact_rows(padded, rb):
     return _RaggedCompactRows.apply(padded, rb)
 
 
+# -------------------------------------------------------------------------------------------------
+# losses of the model files: one HIP pass (cost per graph, d cost_sum / d logits, partial sums) + one finishing block
+# -------------------------------------------------------------------------------------------------
+class _MaskedCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, mask, mask_label, kind, pos_weight):
+        x = _f32c(logits, "logits")
+        if x.dim() != 2:
+            raise _lib.KgcnHipError("logits must be [batch, width], got %s" % (tuple(x.shape),))
+        B, W = x.shape
+        z = _f32c(labels.to(torch.float32), "labels")
+        mk = _f32c(mask.to(torch.float32).reshape(-1), "mask")
+        ml = None if mask_label is None else _f32c(mask_label.to(torch.float32), "mask_label")
+        if tuple(z.shape) != (B, W) or mk.numel() != B or (ml is not None and tuple(ml.shape) != (B, W)):
+            raise _lib.KgcnHipError("labels / mask / mask_label do not match logits %s" % (tuple(x.shape),))
+        dlog = torch.empty_like(x)
+        sums = torch.empty((2,), device=x.device, dtype=torch.float32)
+        wsb = lib.kgcn_loss_workspace_bytes(B)
+        ws = torch.empty((max(wsb, 4) // 4,), device=x.device, dtype=torch.float32)
+        if kind == "sigmoid":
+            check(lib.kgcn_masked_sigmoid_ce_f32(ptr(x), ptr(z), ptr(mk), ptr(ml), B, W, 0 if pos_weight is None else 1,
+                                                 0.0 if pos_weight is None else float(pos_weight), None, ptr(dlog), ptr(sums),
+                                                 ptr(ws), wsb, current_stream()), "kgcn_masked_sigmoid_ce_f32")
+        else:
+            check(lib.kgcn_masked_softmax_ce_f32(ptr(x), ptr(z), ptr(mk), B, W, None, ptr(dlog), ptr(sums), ptr(ws), wsb,
+                                                 current_stream()), "kgcn_masked_softmax_ce_f32")
+        ctx.save_for_backward(dlog)
+        ctx.batch = B
+        return sums[1], sums[0]                    # cost_opt (mean over the padded batch, Q5), cost_sum
+
+    @staticmethod
+    def backward(ctx, g_opt, g_sum):
+        (dlog,) = ctx.saved_tensors
+        scale = None
+        if g_opt is not None:
+            scale = g_opt * (1.0 / ctx.batch)
+        if g_sum is not None:
+            scale = g_sum if scale is None else scale + g_sum
+        return (dlog * scale if scale is not None else None), None, None, None, None, None
+
+
+def masked_sigmoid_ce(logits, labels, mask, mask_label=None, pos_weight=None):
+    """example_model/model_multitask.py:66-79 -> (cost_opt, cost_sum)."""
+    return _MaskedCE.apply(logits, labels, mask, mask_label, "sigmoid", pos_weight)
+
+
+def masked_softmax_ce(logits, labels, mask):
+    """example_model/model.py:56-61 -> (cost_opt, cost_sum)."""
+    return _MaskedCE.apply(logits, labels, mask, None, "softmax", None)
+
+
 __all__ = ["BatchedCSR", "BatchedAdjacency", "bspmm", "bspmm_raw", "bconv", "dense", "activation", "act_code",
            "graphconv_fused", "graphconv_fused_supported", "gin_aggregate", "graph_gather",
-           "graph_maxpool", "gat", "gram", "ragged_gather", "ragged_compact_rows"]
+           "graph_maxpool", "gat", "gram", "ragged_gather", "ragged_compact_rows",
+           "masked_sigmoid_ce", "masked_softmax_ce"]
 
 
 # -------------------------------------------------------------------------------------------------

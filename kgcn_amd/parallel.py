@@ -31,32 +31,42 @@ def shard_weight(local_graphs, global_graphs):
 class GradBucket:
     """One flat fp32 gradient bucket for a fixed parameter list."""
 
-    def __init__(self, params):
+    def __init__(self, params, flat=None):
+        """flat: a kgcn_amd.train.FlatParameters over the same parameters (TFAdam(...).flat) -- the bucket then IS its flat
+        gradient buffer: the all-reduce runs on the buffer the fused optimiser update reads, nothing is copied back."""
+        self.flat_params = flat
+        if flat is not None:
+            params = flat.params
         self.params = [p for p in params]
         if not self.params:
             raise ValueError("GradBucket: empty parameter list -- the layers create their parameters on the first "
                              "forward pass (Keras build semantics, kgcn/layers.py:48-62); run one forward or call "
                              "layer.build(input_shape) before collecting model.parameters()")
         self.sizes = [p.numel() for p in self.params]
-        self.total = sum(self.sizes)
+        self.total = sum(self.sizes) if flat is None else flat.total
         self._flat = None
 
     def _buffer(self, like):
+        if self.flat_params is not None:
+            return self.flat_params.grad
         if self._flat is None or self._flat.device != like.device:
             self._flat = torch.empty((self.total,), dtype=torch.float32, device=like.device)
         return self._flat
 
     def _views(self, flat):
+        if self.flat_params is not None:
+            return self.flat_params.grad_views
         out, off = [], 0
         for p, n in zip(self.params, self.sizes):
             out.append(flat[off:off + n].view(p.shape))
             off += n
         return out
 
-    def all_reduce_mean(self, group=None, weight=None):
+    def all_reduce_mean(self, group=None, weight=None, unpack=True):
         """flat <- concat(grads); all_reduce; scatter back into .grad (in place).  weight=None: plain mean over the
         ranks (equal shards).  weight=w_r (shard_weight: local padded graphs / global padded graphs): sum_r w_r g_r,
         the gradient of the reference's reduce_mean over the global padded batch for shards of any size.
+        unpack=False: the reduced gradients stay in the flat buffer (the fused optimiser update reads it there).
         Four launches per step whatever the number of parameters: one multi-tensor pack, one scale, the collective,
         one multi-tensor unpack -- the payload is latency-bound, so launches are what it costs.  Capturable: inside
         a hipGraph capture the collective is recorded on the capturing stream like any kernel."""
@@ -72,5 +82,6 @@ class GradBucket:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         elif weight is not None and float(weight) != 1.0:
             raise ValueError("a single rank owns the whole batch: its weight must be 1")
-        torch._foreach_copy_(grads, views)
+        if unpack:
+            torch._foreach_copy_(grads, views)
         return flat

@@ -4,23 +4,73 @@ session harness (checkpoints, early stopping, metrics files are out of scope).""
 import torch
 
 
+class FlatParameters:
+    """All parameters of a model in ONE flat fp32 buffer (each tensor at a 256-byte aligned offset, the nn.Parameters
+    re-pointed at views of it) next to a same-shaped flat gradient buffer: the optimiser update is one kernel over the
+    buffer, and the data-parallel exchange all-reduces the gradient buffer as it is (kgcn_amd.parallel.GradBucket shares
+    it) -- no per-tensor launches.  The parameters keep their identity (model.parameters() still yields them); moving the
+    model to another device afterwards would break the sharing."""
+    ALIGN = 64                                   # floats
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("FlatParameters: empty parameter list -- the layers create their parameters on the first forward "
+                             "pass (Keras build semantics); run one forward before collecting model.parameters()")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise ValueError("the fused optimiser needs device-resident parameters (kgcn_amd has no CPU path)")
+        self.offsets, off = [], 0
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise ValueError("all parameters must be float32 on one device")
+            self.offsets.append(off)
+            off += -(-p.numel() // self.ALIGN) * self.ALIGN
+        self.total = off
+        self.data = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.views, self.grad_views = [], []
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                v = self.data[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                self.views.append(v)
+                self.grad_views.append(self.grad[o:o + p.numel()].view(p.shape))
+
+    def pack_grads(self):
+        """flat gradient buffer <- the parameters' .grad tensors (ONE multi-tensor copy launch)."""
+        grads = [p.grad for p in self.params]
+        if any(g is None for g in grads):
+            raise RuntimeError("FlatParameters: a parameter has no gradient")
+        torch._foreach_copy_(self.grad_views, grads)
+        return self.grad
+
+
 class TFAdam:
     """tf.train.AdamOptimizer(lr) (kgcn/core.py:124), defaults beta1 .9, beta2 .999, eps 1e-8:
         lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t);  p -= lr_t * m / (sqrt(v) + eps)
-    -- "epsilon hat" OUTSIDE the bias-corrected square root, unlike torch.optim.Adam."""
+    -- "epsilon hat" OUTSIDE the bias-corrected square root, unlike torch.optim.Adam.
+    The update of the WHOLE model is one HIP kernel over the flat parameter buffer (kgcn_adam_tf_f32, csrc/train.hip); the
+    step counter lives in device memory, so a captured hipGraph advances it on replay (`capturable` is accepted for
+    compatibility: the update is always capturable)."""
 
-    def __init__(self, params, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, capturable=False):
-        self.params = [p for p in params]
-        if not self.params:
+    def __init__(self, params, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, capturable=True):
+        params = [p for p in params]
+        if not params:
             raise ValueError("TFAdam: empty parameter list -- the layers create their parameters on the first forward "
                              "pass (Keras build semantics); run one forward before collecting model.parameters()")
+        self.flat = FlatParameters(params)
+        self.params = self.flat.params
         self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
         self.t = 0
-        self.m = [torch.zeros_like(p) for p in self.params]
-        self.v = [torch.zeros_like(p) for p in self.params]
-        # capturable: the step counter lives on the device, so that a captured hipGraph advances it
-        self.capturable = capturable
-        self._t_dev = torch.zeros((), dtype=torch.float64, device=self.params[0].device) if capturable else None
+        self._m = torch.zeros_like(self.flat.data)
+        self._v = torch.zeros_like(self.flat.data)
+        # per-parameter views of the moment buffers (state inspection / save-restore)
+        self.m = [self._m[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.flat.offsets)]
+        self.v = [self._v[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.flat.offsets)]
+        self.capturable = True
+        self._t_dev = torch.zeros((), dtype=torch.int64, device=self.flat.data.device)
 
     def zero_grad(self, set_to_none=True):
         if set_to_none or any(p.grad is None for p in self.params):
@@ -30,26 +80,27 @@ class TFAdam:
             torch._foreach_zero_([p.grad for p in self.params])
 
     @torch.no_grad()
-    def step(self):
-        """One update of every parameter with multi-tensor (_foreach) ops: 8 launches for the whole model
-        instead of 9 per parameter -- at the reference's batch size the step is launch-bound."""
+    def step(self, packed=False):
+        """One update of every parameter: [one multi-tensor copy of the .grad tensors into the flat gradient buffer unless
+        `packed` says a GradBucket sharing the buffer already did it] + the update kernel + the counter tick."""
+        from . import _lib
+        if not packed:
+            self.flat.pack_grads()
         self.t += 1
-        grads = [p.grad for p in self.params]
-        torch._foreach_mul_(self.m, self.b1)
-        torch._foreach_add_(self.m, grads, alpha=1.0 - self.b1)
-        torch._foreach_mul_(self.v, self.b2)
-        torch._foreach_addcmul_(self.v, grads, grads, value=1.0 - self.b2)
-        denom = torch._foreach_sqrt(self.v)
-        torch._foreach_add_(denom, self.eps)
-        upd = torch._foreach_div(self.m, denom)
-        if self.capturable:
-            self._t_dev += 1
-            lr_t = (self.lr * torch.sqrt(1.0 - self.b2 ** self._t_dev) / (1.0 - self.b1 ** self._t_dev)).float()
-            torch._foreach_mul_(upd, lr_t)
-            torch._foreach_sub_(self.params, upd)
-        else:
-            lr_t = self.lr * (1.0 - self.b2 ** self.t) ** 0.5 / (1.0 - self.b1 ** self.t)
-            torch._foreach_add_(self.params, upd, alpha=-lr_t)
+        _lib.check(_lib.lib.kgcn_adam_tf_f32(_lib.ptr(self.flat.data), _lib.ptr(self.flat.grad), _lib.ptr(self._m),
+                                             _lib.ptr(self._v), self.flat.total, float(self.lr), float(self.b1),
+                                             float(self.b2), float(self.eps), _lib.ptr(self._t_dev), _lib.current_stream()),
+                   "kgcn_adam_tf_f32")
+
+
+def _exchange(bucket, optimizer, shard_weight):
+    """Data-parallel gradient exchange in front of the update; returns True when the flat gradient buffer of the optimiser
+    already holds the reduced gradients (bucket built on optimizer.flat)."""
+    if bucket is None:
+        return False
+    shared = getattr(bucket, "flat_params", None) is optimizer.flat
+    bucket.all_reduce_mean(weight=shard_weight, unpack=not shared)
+    return shared
 
 
 def train_step(model, optimizer, loss_fn, features, adjs, labels, mask, bucket=None, shard_weight=None,
@@ -61,9 +112,7 @@ def train_step(model, optimizer, loss_fn, features, adjs, labels, mask, bucket=N
     logits = model(features, adjs, **fwd_kwargs)
     cost_opt, cost_sum = loss_fn(logits, labels, mask)
     cost_opt.backward()
-    if bucket is not None:
-        bucket.all_reduce_mean(weight=shard_weight)
-    optimizer.step()
+    optimizer.step(packed=_exchange(bucket, optimizer, shard_weight))
     return float(cost_sum.detach()), logits.detach()
 
 
@@ -111,13 +160,14 @@ class GraphedTrainStep:
             static_batch.prune_unused()
 
     def _eager(self):
-        self.opt.zero_grad(set_to_none=False)
+        # gradients are NOT accumulated into persistent .grad tensors (one add launch per parameter): .grad is dropped, the
+        # backward's own result tensors become the new .grad (static addresses inside the captured graph's memory pool) and
+        # one multi-tensor copy packs them into the flat buffer the update kernel / the all-reduce read
+        self.opt.zero_grad(set_to_none=True)
         logits = self.model(self.sb.features, self.sb.adjacency, **self.kw)
         cost_opt, cost_sum = self.loss_fn(logits, self.labels, self.mask)
         cost_opt.backward()
-        if self.bucket is not None:
-            self.bucket.all_reduce_mean(weight=self.shard_weight)
-        self.opt.step()
+        self.opt.step(packed=_exchange(self.bucket, self.opt, self.shard_weight))
         self.cost_sum, self.logits = cost_sum.detach(), logits.detach()
 
     def replay(self):

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Per-kernel table of the TIMED steps of a tools/profile_config.sh directory (rocprofv3 rocpd databases).
+
+The timed region of `bench.py --profile` is the END of the run (nothing follows it but the JSON line), so for every kernel
+name the last (dispatches per step) x steps dispatches are the timed ones; dispatches per step = (dispatches of that name
+in the run) // (passes of the step function in the run: setup + warm-up + timed, read from the bench line's own fields
+or given).  Columns:
+  calls/step, avg us per launch, us per step, share of the kernel time of a step        (stats pass)
+  HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE doubled per the gfx950 note of
+     MI355X_MICROARCH.md (HBM section), each counter from its own pass -- and the GB/s / fraction of 8 TB/s they imply
+  wait = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES, mfma = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 4 SIMDs) (x the CU count
+     the counter aggregates over: reported raw), LDS bank conflict cycles, instruction mix per launch
+usage: tools/profile_config_summary.py gpurun_out/prof_<tag> <timed steps> [passes]"""
+import glob
+import json
+import os
+import re
+import sqlite3
+import sys
+
+src = sys.argv[1]
+STEPS = int(sys.argv[2])
+bench = None
+try:
+    bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+except Exception as e:  # noqa: BLE001
+    print("no bench line:", e)
+SETUP = {"cfg2": 25}.get((bench or {}).get("config", {}).get("workload", "cfg4")[:4], 5)
+PASSES = int(sys.argv[3]) if len(sys.argv) > 3 else SETUP + (bench["warmup"] if bench else 3) + STEPS
+
+
+def short(n):
+    n = re.sub(r"^void ", "", n)
+    n = n.replace("(anonymous namespace)::", "").replace("kgcn::", "").replace("at::native::", "at::")
+    n = re.sub(r"\(.*$", "", n)
+    return n[:64]
+
+
+def timed(rows):
+    """rows: list in start order -> the dispatches of the timed steps."""
+    per_step = max(1, round(len(rows) / PASSES))
+    return per_step, rows[-per_step * STEPS:]
+
+
+dur, meta, pmc = {}, {}, {}
+for db in sorted(glob.glob(os.path.join(src, "*", "*.db"))):
+    sub = os.path.basename(os.path.dirname(db))
+    cur = sqlite3.connect(db).cursor()
+    per = {}
+    for name, start, d, vg, ag, lds in cur.execute("select name, start, duration, vgpr_count, accum_vgpr_count, lds_size "
+                                                    "from kernels order by start"):
+        per.setdefault(short(name), []).append(d / 1e3)
+        meta[short(name)] = (vg, ag, lds)
+    dur[sub] = {k: timed(v) for k, v in per.items()}
+    if sub != "stats":
+        rows = {}
+        for k, c, start, v in cur.execute("select kernel_name, counter_name, start, value from counters_collection order by start"):
+            rows.setdefault((short(k), c), []).append(v)
+        for (k, c), vs in rows.items():
+            _, t = timed(vs)
+            pmc.setdefault(k, {})[c] = sum(t) / len(t)
+
+avg = lambda xs: sum(xs) / len(xs)
+st = dur.get("stats", {})
+tot = sum(ps * avg(v) for ps, v in st.values()) or 1.0
+print("== %s" % (bench["config"]["workload"] if bench else src))
+if bench:
+    print("== un-profiled bench line: %.4g %s, %.4f ms/step (%d steps)" % (bench["value"], bench["unit"], bench["ms_per_step"],
+                                                                         bench["steps"]))
+print("== rocprofv3 --kernel-trace --stats: kernels of one TIMED step (averages over %d steps); kernel time per step %.1f us"
+      % (STEPS, tot))
+print("%-64s %5s %9s %9s %6s | %10s %8s %6s | %6s %6s %9s | %9s %8s %8s %8s %8s" % (
+    "kernel", "n/stp", "avg us", "us/step", "share", "HBM MB", "GB/s", "frac", "wait", "mfma", "ldsconf", "valu", "mfma_i",
+    "lds_i", "vmem_rd", "vmem_wr"))
+for k, (ps, v) in sorted(st.items(), key=lambda kv: -kv[1][0] * avg(kv[1][1])):
+    a = avg(v)
+    if ps * a < 0.002 * tot:
+        continue
+    c = pmc.get(k, {})
+    line = "%-64s %5d %9.1f %9.1f %5.1f%% |" % (k, ps, a, ps * a, 100 * ps * a / tot)
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        b = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+        line += " %10.2f %8.0f %6.3f |" % (b / 1e6, b / a / 1e3, b / a / 1e3 / 8000.0)
+    else:
+        line += " %10s %8s %6s |" % ("-", "-", "-")
+    if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"]:
+        line += " %6.3f %6.3f %9.3g |" % (c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"],
+                                          c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(c.get("SQ_BUSY_CYCLES", 1), 1) / 4,
+                                          c.get("SQ_LDS_BANK_CONFLICT", 0))
+    else:
+        line += " %6s %6s %9s |" % ("-", "-", "-")
+    line += " %9.3g %8.3g %8.3g %8.3g %8.3g" % tuple(c.get(n, float("nan")) for n in (
+        "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
+    print(line)
+print("== registers / LDS of those kernels")
+for k, (ps, v) in sorted(st.items(), key=lambda kv: -kv[1][0] * avg(kv[1][1])):
+    if ps * avg(v) >= 0.01 * tot:
+        print("%-64s vgpr %s agpr %s lds %s" % ((k,) + meta[k]))
+if "pmc_grbm" in dur:
+    print("== effective clock in the GRBM pass: GRBM_GUI_ACTIVE / 8 XCDs / duration")
+    for k, (ps, v) in sorted(dur["pmc_grbm"].items(), key=lambda kv: -kv[1][0] * avg(kv[1][1]))[:8]:
+        c = pmc.get(k, {})
+        if "GRBM_GUI_ACTIVE" in c:
+            print("%-64s %.3f GHz (%.1f us in that pass, %.1f us in the stats pass)" % (
+                k, c["GRBM_GUI_ACTIVE"] / 8 / avg(v) / 1e3, avg(v), avg(st[k][1]) if k in st else float("nan")))
