@@ -81,12 +81,14 @@ __device__ __forceinline__ void static_for(Fn&& f) {
 #define KGCN_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 
 // ---- activations fused into producer epilogues (KGCN_ACT_* of include/kgcn_hip.h) ----------------------------
+// reciprocals through v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence: an activation epilogue is
+// 1-2 instructions per element next to the exponential, not a dozen (the row-chunk SpMM is VALU-bound otherwise)
 __device__ __forceinline__ float act_fwd(float v, int act) {
-  if (act == KGCN_ACT_SIGMOID) return 1.0f / (1.0f + __expf(-v));
+  if (act == KGCN_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
   if (act == KGCN_ACT_RELU) return v > 0.f ? v : 0.f;
   if (act == KGCN_ACT_TANH) {
     const float e = __expf(-2.0f * fabsf(v));
-    const float t = (1.0f - e) / (1.0f + e);
+    const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
     return v < 0.f ? -t : t;
   }
   return v;

@@ -200,14 +200,28 @@ __global__ __launch_bounds__(64 * NW) void spmm_tile_kernel(
 // three per entry.  Neighbour rows of a block-diagonal matrix lie within one graph (<= N rows away): consecutive row
 // chunks are mapped to the SAME XCD (blockIdx -> chunk remap below), so those re-reads hit that XCD's L2.
 // ------------------------------------------------------------------------------------------------
-template <int VEC, int LPR>
+// (graph, local row) of global row `row` without a 64-bit division per row: one 32-bit division per 8-row chunk
+struct RowWalk {
+  int t, r;
+  __device__ __forceinline__ RowWalk(long row0, int M, bool one_graph) {
+    if (one_graph) { t = 0; r = (int)row0; }
+    else { t = (int)(row0 / M); r = (int)(row0 - (long)t * M); }
+  }
+  __device__ __forceinline__ void step(int M) { if (++r >= M) { r = 0; ++t; } }
+};
+
+// LPR == 64: a WAVE owns the 8-row chunk, so row offsets, entry indices, columns and values are wave-uniform: they are
+// pulled into SGPRs with v_readlane (no ds_bpermute), loop control and address bases run on the scalar unit, and entries
+// past the end of a row are skipped by scalar branches.
+template <int VEC, int LPR, bool DACT>
 __global__ __launch_bounds__(256) void spmm_rows_kernel(
-    SpmmChannels ch, const float* __restrict__ rhs, long rhs_ld, long rhs_gs, float* __restrict__ out, long out_ld,
+    SpmmChannels ch, const float* __restrict__ rhs, int rhs_ld, long rhs_gs, float* __restrict__ out, int out_ld,
     long out_gs, int M, long total_rows, int d, float beta, const float* __restrict__ self_scale, int act,
     const float* __restrict__ aout, int dact, int blocks_per_xcd) {
   using V = typename SpVec<VEC>::T;
   constexpr int ROWS = 8;
   constexpr int GPB = 256 / LPR;
+  constexpr bool WAVE = LPR == 64;
   auto ldv = [](const float* p) { return *reinterpret_cast<const V*>(p); };
   auto stv = [](float* p, V v) { *reinterpret_cast<V*>(p) = v; };
   // XCD-aware: workgroups are dealt round-robin to the 8 XCDs; logical chunk = (xcd, position inside the xcd)
@@ -215,7 +229,12 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
   const int gl = threadIdx.x % LPR, grp = threadIdx.x / LPR;
   const long r0 = (lb * GPB + grp) * ROWS;
   if (r0 >= total_rows) return;                      // whole lane group leaves together
+  const bool one_graph = (long)M == total_rows;
   const float sscale = self_scale ? self_scale[0] : 0.f;
+  auto bcast = [](int v, int src) __attribute__((always_inline)) {
+    if constexpr (WAVE) return __builtin_amdgcn_readlane(v, src);
+    else return __shfl(v, src, LPR);
+  };
   for (int c0 = gl * VEC; c0 - gl * VEC < d; c0 += LPR * VEC) {     // one trip unless d > LPR * VEC; group-uniform count
     const bool ok = c0 < d;
     V acc[ROWS];
@@ -228,17 +247,17 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
       const int2* cv = ch.cv[c];
       const long ri = r0 + (gl <= ROWS ? gl : ROWS);
       const int my = rp[ri < total_rows ? ri : total_rows];          // rows past the end: empty
-      const int e_all = __shfl(my, ROWS, LPR);
-      int wbase = __shfl(my, 0, LPR);
+      const int e_all = bcast(my, ROWS);
+      int wbase = bcast(my, 0);
       int2 w = (wbase + gl < e_all) ? cv[wbase + gl] : make_int2(0, 0);
-      const float* rc = rhs + c * ch.rhs_cs;
+      const float* rc = rhs + c * ch.rhs_cs + c0;
+      const float* ac = aout + c0;
+      RowWalk rw(r0, M, one_graph);
       static_for<ROWS>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        const int s = __shfl(my, i, LPR), e = __shfl(my, i + 1, LPR);
-        const long row = r0 + i;
-        const long t = row / M;
-        const float* rb = rc + t * rhs_gs + c0;
-        const float* ab = aout + t * rhs_gs + c0;
+        const int s = bcast(my, i), e = bcast(my, i + 1);
+        const float* rb = rc + rw.t * rhs_gs;
+        const float* ab = ac + rw.t * rhs_gs;
         for (int k = s; k < e; k += 4) {
           const int last = (k + 4 < e ? k + 4 : e);
           if (last > wbase + LPR) {                   // slide the window (group-uniform)
@@ -249,39 +268,48 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
           float v[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const bool valid = k + j < e;
-            const int idx = (k + j - wbase) & (LPR - 1);
-            const int col = __shfl(w.x, idx, LPR);
-            v[j] = valid ? __int_as_float(__shfl(w.y, idx, LPR)) : 0.f;
 #pragma unroll
             for (int q = 0; q < VEC; ++q) { x[j][q] = 0.f; a[j][q] = 0.f; }
-            if (valid && ok) {
-              x[j] = ldv(rb + (long)col * rhs_ld);
-              if (dact != KGCN_ACT_NONE) a[j] = ldv(ab + (long)col * rhs_ld);
+            v[j] = 0.f;
+            if constexpr (WAVE) {
+              if (k + j < e) {                        // scalar branch
+                const int col = __builtin_amdgcn_readlane(w.x, k + j - wbase);
+                v[j] = __int_as_float(__builtin_amdgcn_readlane(w.y, k + j - wbase));
+                if (ok) {
+                  x[j] = ldv(rb + (long)col * rhs_ld);
+                  if constexpr (DACT) a[j] = ldv(ab + (long)col * rhs_ld);
+                }
+              }
+            } else {
+              const bool valid = k + j < e;
+              const int idx = (k + j - wbase) & (LPR - 1);
+              const int col = __shfl(w.x, idx, LPR);
+              const float vv = __int_as_float(__shfl(w.y, idx, LPR));
+              if (valid) v[j] = vv;
+              if (valid && ok) {
+                x[j] = ldv(rb + (long)col * rhs_ld);
+                if constexpr (DACT) a[j] = ldv(ab + (long)col * rhs_ld);
+              }
             }
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            if (dact != KGCN_ACT_NONE) {
+            if constexpr (DACT) {
 #pragma unroll
               for (int q = 0; q < VEC; ++q) x[j][q] *= act_dout(a[j][q], dact);
             }
             acc[i] += v[j] * x[j];
           }
         }
-        if (self_scale && c == 0 && ok && row < total_rows) {
-          const int r = (int)(row - t * M);
-          acc[i] += sscale * ldv(rb + (long)r * rhs_ld);
-        }
+        if (self_scale && c == 0 && ok && r0 + i < total_rows) acc[i] += sscale * ldv(rb + (long)rw.r * rhs_ld);
+        rw.step(M);
       });
     }
+    RowWalk rw(r0, M, one_graph);
     static_for<ROWS>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      const long row = r0 + i;
-      if (ok && row < total_rows) {
-        const long t = row / M;
-        const int r = (int)(row - t * M);
-        float* o = out + t * out_gs + (long)r * out_ld + c0;
+      if (ok && r0 + i < total_rows) {
+        float* o = out + rw.t * out_gs + (long)rw.r * out_ld + c0;
         V y = acc[i];
         if (beta != 0.f) y += ldv(o);
         if (act != KGCN_ACT_NONE) {
@@ -290,6 +318,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
         }
         stv(o, y);
       }
+      rw.step(M);
     });
   }
 }
@@ -571,22 +600,28 @@ int launch_spmm_multi(const kgcn_csr_batch* a, int nch, const float* rhs, long r
     const uintptr_t ptrs = reinterpret_cast<uintptr_t>(rhs) | reinterpret_cast<uintptr_t>(out) |
                            (dact ? reinterpret_cast<uintptr_t>(aout) : 0);
     const int vec = (all % 4 == 0 && ptrs % 16 == 0) ? 4 : ((all % 2 == 0 && ptrs % 8 == 0) ? 2 : 0);
-    if (vec && total_rows < (1L << 31)) {
+    if (vec && total_rows < (1L << 31) && rhs_ld < (1L << 31) && out_ld < (1L << 31)) {
       const int lanes = d / vec;
       const int lpr = lanes <= 16 ? 16 : (lanes <= 32 ? 32 : 64);
       const long rows_per_block = (long)(256 / lpr) * 8;
       const long nblocks = (total_rows + rows_per_block - 1) / rows_per_block;
       const int per_xcd = (int)((nblocks + 7) / 8);
       const dim3 grid((unsigned)(per_xcd * 8));
+#define KGCN_ROWS2(VEC, LPR, DACT)                                                                                    \
+  hipLaunchKernelGGL((spmm_rows_kernel<VEC, LPR, DACT>), grid, dim3(256), 0, stream, ch, rhs, (int)rhs_ld, rhs_gs,    \
+                     out, (int)out_ld, out_gs, M, total_rows, d, beta, self_scale, act, aout, dact, per_xcd)
 #define KGCN_ROWS(VEC, LPR)                                                                                           \
-  hipLaunchKernelGGL((spmm_rows_kernel<VEC, LPR>), grid, dim3(256), 0, stream, ch, rhs, rhs_ld, rhs_gs, out, out_ld,  \
-                     out_gs, M, total_rows, d, beta, self_scale, act, aout, dact, per_xcd)
+  {                                                                                                                   \
+    if (dact != KGCN_ACT_NONE) KGCN_ROWS2(VEC, LPR, true);                                                            \
+    else KGCN_ROWS2(VEC, LPR, false);                                                                                 \
+  }
       if (vec == 4) {
-        if (lpr == 16) KGCN_ROWS(4, 16); else if (lpr == 32) KGCN_ROWS(4, 32); else KGCN_ROWS(4, 64);
+        if (lpr == 16) KGCN_ROWS(4, 16) else if (lpr == 32) KGCN_ROWS(4, 32) else KGCN_ROWS(4, 64)
       } else {
-        if (lpr == 16) KGCN_ROWS(2, 16); else if (lpr == 32) KGCN_ROWS(2, 32); else KGCN_ROWS(2, 64);
+        if (lpr == 16) KGCN_ROWS(2, 16) else if (lpr == 32) KGCN_ROWS(2, 32) else KGCN_ROWS(2, 64)
       }
 #undef KGCN_ROWS
+#undef KGCN_ROWS2
       return check_launch("spmm_rows_kernel");
     }
   }
