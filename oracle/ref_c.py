@@ -71,3 +71,39 @@ def bspmm(off, idx, val, rhs, m, k, adjoint_a=False, nthreads=0):
     load().kgcn_ref_bspmm(T, m, k, d, _p(off), _p(idx), _p(val), _p(rhs), _p(out), int(adjoint_a),
                           int(nthreads))
     return out
+
+
+def dense_fwd(x, w, bias=None, act=0, nthreads=0):
+    """y = act(x @ w + bias) on [m, din] rows (act: 0 none, 1 sigmoid, 2 relu, 3 tanh)."""
+    x, w = np.ascontiguousarray(x, np.float32), np.ascontiguousarray(w, np.float32)
+    m, din = x.shape
+    dout = w.shape[1]
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32).reshape(-1)
+    y = np.empty((m, dout), np.float32)
+    load().kgcn_ref_dense_fwd(ctypes.c_int64(m), din, dout, _p(x), _p(w), _p(b), int(act), _p(y), int(nthreads))
+    return y
+
+
+def dense_bwd(x, w, y, g, act=0, want_dx=True, nthreads=0):
+    """-> dx [m, din] f32 (or None), dw [din, dout] f64, db [dout] f64 (sums over the m rows accumulated in fp64)."""
+    x, w, y, g = (np.ascontiguousarray(a, np.float32) for a in (x, w, y, g))
+    m, din = x.shape
+    dout = w.shape[1]
+    dx = np.empty_like(x) if want_dx else None
+    dw = np.empty((din, dout), np.float64)
+    db = np.empty((dout,), np.float64)
+    load().kgcn_ref_dense_bwd(ctypes.c_int64(m), din, dout, _p(x), _p(w), _p(y), _p(g), int(act), _p(dx), _p(dw), _p(db),
+                              int(nthreads))
+    return dx, dw, db
+
+
+def gin_aggregate(off, idx, val, x, eps, adjoint=False, dot_with=None, nthreads=0):
+    """out[t] = eps x[t] + op(A[t]) x[t]; with dot_with=g also returns <x, g> in fp64 (d eps)."""
+    x = np.ascontiguousarray(x, np.float32)
+    T, n, d = x.shape
+    out = np.empty_like(x)
+    g2 = None if dot_with is None else np.ascontiguousarray(dot_with, np.float32)
+    dot = ctypes.c_double(0.0)
+    load().kgcn_ref_gin_aggregate(T, n, d, _p(off), _p(idx), _p(val), _p(x), ctypes.c_float(eps), int(adjoint), _p(out),
+                                  _p(g2), ctypes.byref(dot) if g2 is not None else None, int(nthreads))
+    return (out, dot.value) if g2 is not None else out

@@ -1,0 +1,282 @@
+"""Closable parity holes of round 2:
+
+(a) the exact 3-way bf16 split under stress in EVERY kernel that uses it, not only the fused 32x64 layer: the wide-layer
+    GEMMs gemm3 forward / dX / weight gradient (256 -> 256, 81 -> 256, with and without the W fragment table: the table is
+    only used from 1,024 rows), gemmn (256 -> 50), wgradn (256 x 50), dense_dx_dact (sigmoid / relu / tanh riding in the dX
+    GEMM, also with a layer input wider than 256: several column blocks, ONE of them writes d pre-activation).
+    Inputs: per-row exponents 1e-18 .. 1e18, all-ones significands, fp32 denormals, +-inf / NaN.  References: the fp64
+    oracle (numpy) and, as a second independent fp32 implementation, rocBLAS / hipBLASLt through torch.matmul.
+(b) BASELINE configs 4 and 5 at their FULL benchmark sizes (204,800 / 200,000 node rows): forward, dX and the weight /
+    bias gradients -- sums over 2e5 rows through up to 256 row-range partials -- against the C restatement
+    (oracle/kgcn_ref.c, fp32 products, fp64 row sums), in the padded AND the ragged-compact layout.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kgcn_oracle as K
+from test_gpu_parity import _row_close, close, dev, t32
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(4100, 256, 256), (300, 256, 256), (4101, 81, 256), (4100, 256, 50), (1500, 300, 256), (4100, 512, 96)]
+ACTS = {None: 0, "sigmoid": 1, "relu": 2, "tanh": 3}
+
+
+def _act64(v, act):
+    if act == "sigmoid":
+        return 1.0 / (1.0 + np.exp(-v))
+    if act == "relu":
+        return np.maximum(v, 0)
+    if act == "tanh":
+        return np.tanh(v)
+    return v
+
+
+def _dact64(a, act):
+    if act == "sigmoid":
+        return a * (1 - a)
+    if act == "relu":
+        return (a > 0).astype(np.float64)
+    if act == "tanh":
+        return 1 - a * a
+    return np.ones_like(a)
+
+
+def _inputs(case, M, din, dout, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((M, din)).astype(np.float32)
+    g = rng.standard_normal((M, dout)).astype(np.float32)
+    w = K.glorot_uniform(rng, din, dout)
+    b = (rng.standard_normal(dout) * 0.1).astype(np.float32)
+    if case == "exponents":
+        x *= (10.0 ** rng.uniform(-18, 18, size=(M, 1))).astype(np.float32)
+        g *= (10.0 ** rng.uniform(-9, 9, size=(M, 1))).astype(np.float32)
+        b[:] = 0                                   # a bias of 0.1 would swamp rows of scale 1e-18: the row test needs a scale
+    elif case == "full_significands":
+        ones = lambda a: (a.view(np.uint32) | np.uint32(0x007fffff)).view(np.float32)
+        x, g, w = ones(x), ones(g), ones(w)
+    elif case == "denormals":
+        tiny = np.float32(2.0 ** -140)
+        x[::2] = (x[::2] * tiny).astype(np.float32)
+        assert (np.abs(x[::2]) < 2.0 ** -126).all() and (x[::2] != 0).any()
+        b[:] = 0
+    return x, g, w, b
+
+
+@pytest.mark.parametrize("case", ["normal", "exponents", "full_significands", "denormals"])
+@pytest.mark.parametrize("M,din,dout", SHAPES)
+def test_bf16_split_dense_kernels_edge_values(case, M, din, dout):
+    from kgcn_amd import ops
+    x, g, w, b = _inputs(case, M, din, dout, seed=M + din + dout)
+    tx, tw, tb = t32(x).requires_grad_(True), t32(w).requires_grad_(True), t32(b).requires_grad_(True)
+    y = ops.dense(tx, tw, tb)
+    y.backward(t32(g))
+    x64, w64, g64 = x.astype(np.float64), w.astype(np.float64), g.astype(np.float64)
+    ref_y, ref_dx, ref_dw, ref_db = x64 @ w64 + b, g64 @ w64.T, x64.T @ g64, g64.sum(0)
+    assert np.isfinite(ref_y).all() and np.isfinite(ref_dw).all()
+    _row_close(y, ref_y, 2e-6, "%s dense fwd %d->%d" % (case, din, dout))
+    _row_close(tx.grad, ref_dx, 2e-6, "%s dense dX" % case)
+    if case == "exponents":            # dW rows mix row scales of 36 decades: meaningful against the row's own maximum only
+        _row_close(tw.grad, ref_dw, 1e-5, "%s dense dW" % case)
+    else:
+        close(tw.grad, ref_dw, atol=0, rel=3e-6, what="%s dense dW" % case)
+        close(tb.grad, ref_db, atol=0, rel=3e-6, what="%s dense dbias" % case)
+    # second fp32 implementation (rocBLAS / hipBLASLt through torch): same inputs, agreement to a few fp32 roundings
+    if case != "denormals":            # the BLAS kernels flush fp32 denormals; ours keep them (checked against fp64 above)
+        ty = torch.matmul(t32(x), t32(w)) + t32(b)
+        _row_close(y, ty.cpu().numpy(), 4e-6, "%s dense fwd vs torch.matmul" % case)
+        _row_close(tx.grad, torch.matmul(t32(g), t32(w).t()).cpu().numpy(), 4e-6, "%s dense dX vs torch.matmul" % case)
+
+
+@pytest.mark.parametrize("act", ["sigmoid", "relu", "tanh"])
+@pytest.mark.parametrize("M,din,dout", [(4100, 256, 256), (4101, 300, 256), (333, 256, 256), (4100, 256, 50), (2050, 81, 256)])
+def test_dense_dx_dact_all_routes(act, M, din, dout):
+    """act(x W + b) with the activation in the GEMM epilogue and its derivative riding in the dX GEMM (kgcn_dense_dx_dact_f32);
+    din = 300 > 256: two column blocks stage the same gradient rows, only blockIdx.y == 0 stores d pre-activation
+    (gemm3.hip) -- dW / dbias below are computed FROM that stored tensor."""
+    from kgcn_amd import ops
+    rng = np.random.default_rng(M + din)
+    x = rng.standard_normal((M, din)).astype(np.float32)
+    g = rng.standard_normal((M, dout)).astype(np.float32)
+    w = K.glorot_uniform(rng, din, dout)
+    b = (rng.standard_normal(dout) * 0.1).astype(np.float32)
+    tx, tw, tb = t32(x).requires_grad_(True), t32(w).requires_grad_(True), t32(b).requires_grad_(True)
+    y = ops.dense(tx, tw, tb, activation=act)
+    y.backward(t32(g))
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    a = _act64(x64 @ w64 + b, act)
+    if act == "relu":                   # the mask comes from the GPU activations (a pre-activation of 1e-9 may flip its sign)
+        dpre = g.astype(np.float64) * (y.detach().cpu().numpy() > 0)
+    else:
+        dpre = g.astype(np.float64) * _dact64(a, act)
+    close(y, a, atol=1e-6, rel=1e-6, what="act(dense) fwd")
+    close(tx.grad, dpre @ w64.T, atol=0, rel=3e-6, what="dX with d activation")
+    close(tw.grad, x64.T @ dpre, atol=0, rel=3e-6, what="dW from the stored d pre-activation")
+    close(tb.grad, dpre.sum(0), atol=0, rel=3e-6, what="dbias from the stored d pre-activation")
+    # the stored d pre-activation against the stand-alone activation backward kernel
+    ref_dpre = ops.activation_backward(y.detach(), t32(g), ACTS[act])
+    close(ref_dpre, dpre, atol=0, rel=2e-6, what="kgcn_act_bwd_f32")
+
+
+@pytest.mark.parametrize("M,din,dout", [(4100, 256, 256), (300, 256, 256), (4100, 81, 256), (4100, 256, 50)])
+def test_bf16_split_dense_kernels_non_finite(M, din, dout):
+    """+-inf splits into (inf, NaN, NaN), NaN into three NaNs: every output element that depends on a non-finite input is
+    non-finite, every other element is untouched (include/kgcn_hip.h)."""
+    from kgcn_amd import ops
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((M, din)).astype(np.float32)
+    g = rng.standard_normal((M, dout)).astype(np.float32)
+    w = K.glorot_uniform(rng, din, dout)
+    bad = [(5, 3, np.inf), (77, din - 1, -np.inf), (M - 1, 0, np.nan)]
+    xb = x.copy()
+    for r, k, v in bad:
+        xb[r, k] = v
+    tx, tw = t32(xb).requires_grad_(True), t32(w).requires_grad_(True)
+    y = ops.dense(tx, tw, None)
+    y.backward(t32(g))
+    yo = y.detach().cpu().numpy()
+    rows = [r for r, _, _ in bad]
+    assert not np.isfinite(yo[rows]).any()
+    clean = np.ones(M, bool); clean[rows] = False
+    np.testing.assert_allclose(yo[clean], (x.astype(np.float64) @ w)[clean], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(tx.grad.cpu().numpy(), g.astype(np.float64) @ w.T.astype(np.float64), rtol=0, atol=2e-5)
+    dw = tw.grad.cpu().numpy()
+    ks = sorted({k for _, k, _ in bad})
+    assert not np.isfinite(dw[ks]).any() and np.isfinite(np.delete(dw, ks, axis=0)).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (b) BASELINE configs 4 / 5 at full benchmark size vs the C restatement
+# ---------------------------------------------------------------------------------------------------------------------
+def _cfg4_batch(B=4096, N=50, F=81):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    sizes, g, r, c, rng = bench.gen_tox21_like(B, N, seed=4)
+    val = bench.kipf_values(g, r, c, B, N)
+    valid = np.arange(N)[None, :] < sizes[:, None]
+    x = rng.standard_normal((B, N, F)).astype(np.float32) * valid[:, :, None]
+    off = np.zeros(B + 1, np.int64)
+    np.cumsum(np.bincount(g, minlength=B), out=off[1:])
+    idx = np.ascontiguousarray(np.stack([r, c], 1).astype(np.int32))
+    return sizes, g, r, c, val, x, off, idx, rng
+
+
+def test_cfg4_full_size_layers_vs_c_oracle():
+    """4,096 Tox21-shaped molecules x 50 padded nodes = 204,800 rows: GraphConv 81 -> 256 (sigmoid), GraphDense 256 -> 256
+    (sigmoid), GraphConv 256 -> 50, GraphDense 50 -> 50 (sigmoid), each forward + backward on the padded layout AND on the
+    ragged-compact layout, against oracle/kgcn_ref.c."""
+    from kgcn_amd import BatchedAdjacency, BatchedCSR, layers, ragged
+    from oracle import ref_c
+    B, N, F = 4096, 50, 81
+    sizes, g, r, c, val, x, off, idx, rng = _cfg4_batch(B, N, F)
+    csr = BatchedCSR.from_arrays(g, r, c, val, B, N, N, device=dev())
+    adj = BatchedAdjacency([csr])
+    rb = ragged.compact(t32(x), adj, sizes)
+    valid = (np.arange(N)[None, :] < sizes[:, None])
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+
+    def run(layer, inp, upstream, ragged_mode, **kw):
+        """-> (out, d input, parameter grads), everything brought back to the padded layout."""
+        if ragged_mode:
+            ti = rb.compact_rows(t32(inp)).requires_grad_(True)
+            out = layer(ti, adj=rb) if kw.get("conv") else layer(ti)
+            out.backward(rb.compact_rows(t32(upstream)))
+            return rb.expand(out.detach(), fill="zero").cpu().numpy(), rb.expand(ti.grad, fill="zero").cpu().numpy()
+        ti = t32(inp).requires_grad_(True)
+        out = layer(ti, adj=adj) if kw.get("conv") else layer(ti)
+        out.backward(t32(upstream))
+        return out.detach().cpu().numpy(), ti.grad.cpu().numpy()
+
+    # ---- GraphConv din -> dout with sigmoid ----
+    for din, dout, act in ((F, 256, "sigmoid"), (256, 50, None)):
+        inp = x if din == F else (rng.standard_normal((B, N, din)).astype(np.float32) * valid[:, :, None])
+        up = rng.standard_normal((B, N, dout)).astype(np.float32) * valid[:, :, None]
+        for mode in (False, True):
+            torch.manual_seed(1)
+            layer = layers.GraphConv(dout, 1, activation=act)
+            layer.build((B, N, din), dev())
+            with torch.no_grad():
+                layer.bias[0].copy_(t32(rng.standard_normal((1, dout)) * 0.1))
+            wn, bn = layer.w[0].detach().cpu().numpy(), layer.bias[0].detach().cpu().numpy()
+            out, dinp = run(layer, inp, up, mode, conv=True)
+            pre = ref_c.graphconv_fwd(off, idx, val, inp, wn, bn)
+            ref_out = sig(pre.astype(np.float64)) if act else pre
+            if mode:                                   # ragged: padded rows are not stored (they are act(0) constants)
+                ref_cmp, out_cmp = ref_out * valid[:, :, None], out * valid[:, :, None]
+            else:
+                ref_cmp, out_cmp = ref_out, out
+            close(out_cmp, ref_cmp, atol=1e-6, rel=2e-6, what="cfg4 full GraphConv %d->%d fwd (ragged=%s)" % (din, dout, mode))
+            gpre = (up * (ref_out * (1 - ref_out) if act else 1.0)).astype(np.float32)
+            rdx, rdw, rdb = ref_c.graphconv_bwd(off, idx, val, inp, wn, gpre)
+            close(dinp, rdx, atol=0, rel=5e-6, what="cfg4 full GraphConv %d->%d dX (ragged=%s)" % (din, dout, mode))
+            close(layer.w[0].grad, rdw, atol=0, rel=2e-5, what="cfg4 full GraphConv %d->%d dW (ragged=%s)" % (din, dout, mode))
+            close(layer.bias[0].grad, rdb, atol=0, rel=2e-5, what="cfg4 full GraphConv %d->%d dbias (ragged=%s)" % (din, dout, mode))
+    # ---- GraphDense din -> dout with sigmoid (all 204,800 rows; ragged: the valid rows + the padding representative) ----
+    for din, dout in ((256, 256), (50, 50)):
+        inp = rng.standard_normal((B, N, din)).astype(np.float32)
+        up = rng.standard_normal((B, N, dout)).astype(np.float32)
+        torch.manual_seed(2)
+        layer = layers.GraphDense(dout, activation="sigmoid")
+        layer.build((B, N, din), dev())
+        with torch.no_grad():
+            layer.bias.copy_(t32(rng.standard_normal(dout) * 0.1))
+        kn, bn = layer.kernel.detach().cpu().numpy(), layer.bias.detach().cpu().numpy()
+        out, dinp = run(layer, inp, up, False)
+        x2, u2 = inp.reshape(B * N, din), up.reshape(B * N, dout)
+        ry = ref_c.dense_fwd(x2, kn, bn, act=1)
+        close(out.reshape(B * N, dout), ry, atol=1e-6, rel=2e-6, what="cfg4 full GraphDense %d->%d fwd" % (din, dout))
+        rdx, rdw, rdb = ref_c.dense_bwd(x2, kn, ry, u2, act=1)
+        close(dinp.reshape(B * N, din), rdx, atol=0, rel=5e-6, what="cfg4 full GraphDense dX")
+        close(layer.kernel.grad, rdw, atol=0, rel=5e-6, what="cfg4 full GraphDense %d->%d dK over 204,800 rows" % (din, dout))
+        close(layer.bias.grad, rdb, atol=0, rel=5e-6, what="cfg4 full GraphDense %d->%d dbias over 204,800 rows" % (din, dout))
+
+
+def test_cfg5_full_size_layers_vs_c_oracle():
+    """20,000 ring graphs x 10 nodes x 256 features = 200,000 rows: GINAggregate (epsilon = 0.25) forward, d x, d epsilon and
+    GraphDense 256 -> 256 (relu) forward, dX, dK, dbias against oracle/kgcn_ref.c."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from kgcn_amd import BatchedAdjacency, BatchedCSR, layers
+    from oracle import ref_c
+    B, N, D = 20000, 10, 256
+    g, r, c, _, rng = bench.gen_ring_graphs(B, N, seed=5)
+    val = np.ones(g.shape[0], np.float32)
+    off = np.zeros(B + 1, np.int64)
+    np.cumsum(np.bincount(g, minlength=B), out=off[1:])
+    idx = np.ascontiguousarray(np.stack([r, c], 1).astype(np.int32))
+    adj = BatchedAdjacency([BatchedCSR.from_arrays(g, r, c, val, B, N, N, device=dev())])
+    x = rng.standard_normal((B, N, D)).astype(np.float32)
+    up = rng.standard_normal((B, N, D)).astype(np.float32)
+    gin = layers.GINAggregate(1)
+    tx = t32(x).requires_grad_(True)
+    gin(tx, adj=adj)
+    with torch.no_grad():
+        gin.epsilon[0].fill_(0.25)
+    out = gin(tx, adj=adj)
+    out.backward(t32(up))
+    ro = ref_c.gin_aggregate(off, idx, val, x, 0.25)
+    close(out, ro, atol=0, rel=2e-6, what="cfg5 full GINAggregate fwd")
+    rdx, deps = ref_c.gin_aggregate(off, idx, val, up, 0.25, adjoint=True, dot_with=x)
+    close(tx.grad, rdx, atol=0, rel=2e-6, what="cfg5 full GINAggregate dX")
+    scale = float(np.abs(up.astype(np.float64) * x).sum())
+    assert abs(float(gin.epsilon[0].grad) - deps) <= 2e-6 * scale, (float(gin.epsilon[0].grad), deps, scale)
+    layer = layers.GraphDense(D, activation="relu")
+    layer.build((B, N, D), dev())
+    with torch.no_grad():
+        layer.bias.copy_(t32(rng.standard_normal(D) * 0.1))
+    kn, bn = layer.kernel.detach().cpu().numpy(), layer.bias.detach().cpu().numpy()
+    ti = t32(x).requires_grad_(True)
+    y = layer(ti)
+    y.backward(t32(up))
+    x2, u2 = x.reshape(B * N, D), up.reshape(B * N, D)
+    yo = y.detach().cpu().numpy().reshape(B * N, D)
+    ry = ref_c.dense_fwd(x2, kn, bn, act=2)
+    close(yo, ry, atol=1e-6, rel=2e-6, what="cfg5 full GraphDense fwd")
+    # relu mask from the GPU activations (a pre-activation of 1e-8 may flip its sign between two fp32 summation orders)
+    rdx, rdw, rdb = ref_c.dense_bwd(x2, kn, yo, u2, act=2)
+    close(ti.grad.reshape(B * N, D), rdx, atol=0, rel=5e-6, what="cfg5 full GraphDense dX")
+    close(layer.kernel.grad, rdw, atol=0, rel=5e-6, what="cfg5 full GraphDense dK over 200,000 rows")
+    close(layer.bias.grad, rdb, atol=0, rel=5e-6, what="cfg5 full GraphDense dbias over 200,000 rows")
