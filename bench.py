@@ -634,6 +634,7 @@ class Cfg4(_ModelStep):
         self.lab_s, self.ml_s = torch.zeros((B, TASKS), device=dev), torch.zeros((B, TASKS), device=dev)
         self.en_s = torch.zeros(B, device=dev, dtype=self.sizes_d.dtype)
         self.en_s.copy_(self.sizes_d[:B])
+        self.it_s = torch.zeros(B, device=dev, dtype=torch.int64)
         model(sb.features, sb.adjacency, enabled_node_nums=self.en_s)           # Keras-style build
         mask = torch.ones(B, device=dev)
         self.units_local, self.units_global = B, B * ctx.world
@@ -653,11 +654,11 @@ class Cfg4(_ModelStep):
             lo = self.cursor = 0
         self.cursor += B
         idx = self.perm[lo:lo + B]
-        it = torch.from_numpy(idx).to(self.ctx.device)
+        self.it_s.copy_(torch.from_numpy(idx), non_blocking=True)
         self.sb.load(idx)
-        self.lab_s.copy_(self.lab_d[it])
-        self.ml_s.copy_(self.ml_d[it])
-        self.en_s.copy_(self.sizes_d[it])
+        torch.index_select(self.lab_d, 0, self.it_s, out=self.lab_s)       # one gather kernel each, straight into the static
+        torch.index_select(self.ml_d, 0, self.it_s, out=self.ml_s)         # buffers the captured step reads
+        torch.index_select(self.sizes_d, 0, self.it_s, out=self.en_s)
 
     def report(self, evs):
         args = self.args
@@ -797,6 +798,8 @@ def build_parser():
     ap.add_argument("--unfused", action="store_true", help="cfg2: dense GEMM + Bspmm kernels instead of the fused layer")
     ap.add_argument("--eager", action="store_true", help="cfg4 / cfg5: plain launches instead of one hipGraph per step")
     ap.add_argument("--padded", action="store_true", help="cfg4: compute all padded rows (round-2 behaviour)")
+    ap.add_argument("--contract-first", action="store_true",
+                    help="A/B switch: GraphConv always contracts before it aggregates (kgcn_amd.layers.aggregate_first = False)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --graphs per GPU; strong (cfg2): --graphs in total, sharded over the GPUs")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="nccl = RCCL on ROCm")
@@ -827,6 +830,9 @@ def main(argv=None):
 
     ctx = Ctx(args)
     torch, dist = ctx.torch, ctx.dist
+    if args.contract_first:
+        from kgcn_amd import layers as _layers
+        _layers.aggregate_first = False
     wl = Dry(args, ctx) if args.dry else {"cfg2": Cfg2, "cfg4": Cfg4, "cfg5": Cfg5}[args.config](args, ctx)
 
     ev = [[ctx.event() for _ in range(wl.n_events)] for _ in range(args.steps)] if ctx.on_gpu else None

@@ -404,6 +404,17 @@ int kgcn_masked_softmax_ce_f32(const float* logits, const float* labels, const f
 int kgcn_adam_tf_f32(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, int64_t* step_counter, void* stream);
 
+/* -- aggregate-FIRST GraphConv: A (X W + 1 b) = (A [X | 1]) [W ; b] --------------------------------------------------- */
+/* kgcn/layers.py:112-113 computes fw = X W + b and then A fw: a [rows, dout] aggregation.  When din + 1 < dout the other
+ * association is cheaper (an aggregation of din + 1 columns, the same contraction, and in the backward no dout-wide adjoint
+ * aggregation at all: dW', db = (A [X | 1])^T d pre-activation).  The bias term rowsum(A) (x) b -- NOT b: rows of A sum to
+ * anything, empty rows to 0 -- is carried by a column of ones:
+ *   out[r, 0:din] = x[r, 0:din], out[r, din] = 1, out[r, din+1 : out_ld] = 0          (out_ld >= din + 1)
+ * backward: dx[r, 0:din] = dout[r, 0:din]. */
+int kgcn_augment_ones_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, float* out, int64_t out_ld, void* stream);
+int kgcn_augment_ones_bwd_f32(const float* dout_grad, int64_t m, int32_t din, int64_t g_ld, float* dx, int64_t dx_ld,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

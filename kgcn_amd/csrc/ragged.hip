@@ -169,7 +169,14 @@ __global__ __launch_bounds__(256) void ragged_rows_kernel(const float* __restric
     const long len = (long)(graph_ptr[t + 1] - r0) * d;
     const float* s = src + (long)g * M * d;
     float* o = dst + (long)r0 * d;
-    for (long i = lane; i < len; i += kWave) o[i] = s[i];
+    // the run starts at an arbitrary 4-byte offset (d = 81: 324-byte rows): dword accesses, four independent loads in
+    // flight per lane
+    long i = lane;
+    for (; i + 3 * kWave < len; i += 4 * kWave) {
+      const float a0 = s[i], a1 = s[i + kWave], a2 = s[i + 2 * kWave], a3 = s[i + 3 * kWave];
+      o[i] = a0; o[i + kWave] = a1; o[i + 2 * kWave] = a2; o[i + 3 * kWave] = a3;
+    }
+    for (; i < len; i += kWave) o[i] = s[i];
   }
 }
 
@@ -265,6 +272,23 @@ __global__ __launch_bounds__(256) void ragged_gather_pad_bwd_kernel(const float*
 }
 
 int launch_reduce_partials(const float* part, int nparts, long n, float* out, hipStream_t s);
+
+// out[r, 0:din] = x[r, 0:din], out[r, din] = 1, out[r, din+1:out_ld] = 0: the operand of an aggregate-FIRST GraphConv,
+//   A (X W + 1 b) = (A [X | 1]) [W ; b]        (kgcn/layers.py:112-113 evaluated in the cheaper order when din + 1 < dout)
+// -- the column of ones turns the bias term rowsum(A) (x) b into one more row of the contraction.
+// BWD: dx[r, 0:din] = g[r, 0:din] (the gradient of the ones / padding columns is dropped).
+template <bool BWD>
+__global__ __launch_bounds__(256) void augment_ones_kernel(const float* __restrict__ src, long m, int din, long src_ld,
+                                                           float* __restrict__ dst, long dst_ld) {
+  const int w = BWD ? din : (int)dst_ld;
+  const long total = m * w;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / w;
+    const int c = (int)(i - r * w);
+    if (BWD) dst[r * dst_ld + c] = src[r * src_ld + c];
+    else dst[r * dst_ld + c] = c < din ? src[r * src_ld + c] : (c == din ? 1.f : 0.f);
+  }
+}
 
 static unsigned grid_cap(long work_items, long cap = (long)kNumCU * 16) {
   long b = (work_items + 255) / 256;
@@ -399,4 +423,26 @@ extern "C" int kgcn_ragged_gather_bwd_f32(const float* dout_grad, const int32_t*
                      (int)batch, n_nodes, d, part);
   if (int rc = check_launch("ragged_gather_pad_bwd_kernel")) return rc;
   return launch_reduce_partials(part, nparts, d, dx + (long)pad_row * d, s);
+}
+
+extern "C" int kgcn_augment_ones_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, float* out, int64_t out_ld,
+                                     void* stream) {
+  if (m < 0 || din <= 0) return fail("kgcn_augment_ones_f32: bad shape m=%lld din=%d", (long long)m, din);
+  if (m == 0) return 0;
+  if (!x || !out) return fail("kgcn_augment_ones_f32: NULL operand");
+  if (x_ld < din || out_ld < din + 1) return fail("kgcn_augment_ones_f32: leading dimension too small (out_ld >= din + 1)");
+  hipLaunchKernelGGL(augment_ones_kernel<false>, dim3(grid_cap(m * out_ld, (long)kNumCU * 32)), dim3(256), 0,
+                     as_stream(stream), x, (long)m, din, (long)x_ld, out, (long)out_ld);
+  return check_launch("augment_ones_kernel");
+}
+
+extern "C" int kgcn_augment_ones_bwd_f32(const float* dout_grad, int64_t m, int32_t din, int64_t g_ld, float* dx,
+                                         int64_t dx_ld, void* stream) {
+  if (m < 0 || din <= 0) return fail("kgcn_augment_ones_bwd_f32: bad shape m=%lld din=%d", (long long)m, din);
+  if (m == 0) return 0;
+  if (!dout_grad || !dx) return fail("kgcn_augment_ones_bwd_f32: NULL operand");
+  if (g_ld < din + 1 || dx_ld < din) return fail("kgcn_augment_ones_bwd_f32: leading dimension too small");
+  hipLaunchKernelGGL(augment_ones_kernel<true>, dim3(grid_cap(m * din, (long)kNumCU * 32)), dim3(256), 0, as_stream(stream),
+                     dout_grad, (long)m, din, (long)g_ld, dx, (long)dx_ld);
+  return check_launch("augment_ones_kernel<bwd>");
 }

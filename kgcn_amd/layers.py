@@ -21,6 +21,9 @@ from .batched_csr import BatchedAdjacency, BatchedCSR, as_batched_adjacency
 enabled_batched = False
 enabled_bspmm = False
 enabled_bconv = False
+# default branch only: evaluate A (X W + b) as (A [X | 1]) [W ; b] when the input is narrower than the output (same function,
+# fewer bytes: kgcn/layers.py:112-113 aggregates dout columns, this din + 1).  False = always contract first.
+aggregate_first = True
 
 
 def load_bspmm(args):
@@ -134,6 +137,18 @@ class GraphConv(nn.Module):
         # multi-channel aggregation (one launch for all channels, activation in its epilogue).
         if C == 1 and ops.graphconv_fused_supported(a.channels[0], din, dout):
             return ops.activation(ops.graphconv_fused(inputs, self.w[0], self.bias[0], a.channels[0]), act)
+        dp = (din + 1 + 3) // 4 * 4
+        if aggregate_first and dp < dout and B * N >= 1024:
+            # A (X W + 1 b) = (A [X | 1]) [W ; b]: the aggregation runs over din + 1 (padded to a multiple of 4) columns
+            # instead of dout, the activation rides in the GEMM epilogue, and the backward needs NO dout-wide adjoint
+            # aggregation (dW, db come out of ONE weight-gradient GEMM over [A X | rowsum(A)]; d inputs -- when asked for --
+            # is a dp-wide adjoint).  Per channel the operand is aggregated with that channel's adjacency; the channels are
+            # concatenated along the contraction axis.
+            xa = ops.augment_ones(x2d, dp)
+            z = [ops.bspmm(a.channels[c], xa) for c in range(C)]
+            pad = self.w[0].new_zeros((dp - din - 1, dout))
+            wa = torch.cat([t for c in range(C) for t in (self.w[c], self.bias[c], pad)], dim=0)
+            return ops.dense(z[0] if C == 1 else torch.cat(z, dim=1), wa, None, activation=act).reshape(B, N, dout)
         if C == 1:
             fw = ops.dense(x2d, self.w[0], self.bias[0])
         else:

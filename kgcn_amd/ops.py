@@ -583,6 +583,34 @@ def ragged_compact_rows(padded, rb):
 
 
 # -------------------------------------------------------------------------------------------------
+# aggregate-first GraphConv operand: [X | 1 | 0..]
+# -------------------------------------------------------------------------------------------------
+class _AugmentOnes(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2d, width):
+        x2d = _f32c(x2d, "inputs")
+        m, din = x2d.shape
+        out = torch.empty((m, width), device=x2d.device, dtype=torch.float32)
+        check(lib.kgcn_augment_ones_f32(ptr(x2d), m, din, din, ptr(out), width, current_stream()), "kgcn_augment_ones_f32")
+        ctx.shape = (m, din)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32c(g, "grad")
+        m, din = ctx.shape
+        dx = torch.empty((m, din), device=g.device, dtype=torch.float32)
+        check(lib.kgcn_augment_ones_bwd_f32(ptr(g), m, din, g.shape[1], ptr(dx), din, current_stream()),
+              "kgcn_augment_ones_bwd_f32")
+        return dx, None
+
+
+def augment_ones(x2d, width):
+    """[m, din] -> [m, width] = [x | 1 | 0 ...] (width >= din + 1)."""
+    return _AugmentOnes.apply(x2d, width)
+
+
+# -------------------------------------------------------------------------------------------------
 # losses of the model files: one HIP pass (cost per graph, d cost_sum / d logits, partial sums) + one finishing block
 # -------------------------------------------------------------------------------------------------
 class _MaskedCE(torch.autograd.Function):
@@ -636,7 +664,7 @@ def masked_softmax_ce(logits, labels, mask):
 __all__ = ["BatchedCSR", "BatchedAdjacency", "bspmm", "bspmm_raw", "bconv", "dense", "activation", "act_code",
            "graphconv_fused", "graphconv_fused_supported", "gin_aggregate", "graph_gather",
            "graph_maxpool", "gat", "gram", "ragged_gather", "ragged_compact_rows",
-           "masked_sigmoid_ce", "masked_softmax_ce"]
+           "masked_sigmoid_ce", "masked_softmax_ce", "augment_ones"]
 
 
 # -------------------------------------------------------------------------------------------------

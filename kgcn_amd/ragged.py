@@ -98,11 +98,11 @@ def _container(rowptr, cv, capacity):
 
 def default_capacity(sizes, batch_size, n_nodes):
     """A row capacity that a batch of `batch_size` graphs drawn from a dataset with these sizes exceeds with negligible
-    probability (mean + 8 sigma of the sum), rounded up to a multiple of 64, never above the padded row count + 1."""
+    probability (mean + 6 sigma of the sum: 1e-9 per batch; load() raises if it ever happens), rounded up to a multiple of 64, never above the padded row count + 1."""
     sizes = np.asarray(sizes, np.float64)
     if sizes.size == 0:
         return 64
-    cap = batch_size * sizes.mean() + 8.0 * np.sqrt(batch_size) * sizes.std() + 1
+    cap = batch_size * sizes.mean() + 6.0 * np.sqrt(batch_size) * sizes.std() + 1
     cap = int(-(-cap // 64) * 64)
     return int(min(cap, -(-(batch_size * n_nodes + 1) // 64) * 64))
 

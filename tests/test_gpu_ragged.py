@@ -201,3 +201,58 @@ def test_static_ragged_batch_equals_compact_and_replays():
     torch.cuda.synchronize()
     for pe, pg in zip(m_e.parameters(), m_g.parameters()):
         close(pg, pe.detach().cpu().numpy(), atol=2e-5, rel=1e-4, what="parameters after 4 steps: captured ragged vs eager")
+
+
+@pytest.mark.parametrize("B,N,din,dout,C,act", [(40, 50, 81, 256, 1, "sigmoid"), (64, 20, 6, 40, 2, None), (30, 40, 30, 50, 1, "relu"),
+                                                (64, 20, 7, 64, 6, "tanh")])
+def test_graphconv_aggregate_first_equals_contract_first(B, N, din, dout, C, act):
+    """A (X W + 1 b) evaluated as (A [X | 1]) [W ; b] (layers.aggregate_first, taken when din + 1 < dout): forward, d inputs,
+    dW and dbias against the oracle's contract-first formulation (kgcn/layers.py:105-116) with NON-ZERO biases, graphs with
+    empty adjacency rows (padded nodes: rowsum(A) = 0, so the bias must NOT reach them) and several channels; and against
+    the product's own contract-first route."""
+    from kgcn_amd import layers
+    rng = np.random.default_rng(B + din)
+    x, adjs, _, _, _, sizes = tox21_like_batch(rng, B=B, N=N, F=din, T=2)
+    if C > 1:
+        adjs = [[(a[0][0], (np.asarray(a[0][1]) * (0.5 + c)).astype(np.float32), a[0][2]) if c % 2 == 0 else
+                 (np.asarray(a[0][0])[:, ::-1].copy(), (np.asarray(a[0][1]) * (0.5 + c)).astype(np.float32), a[0][2])
+                 for c in range(C)] for a in adjs]
+    g = rng.standard_normal((B, N, dout)).astype(np.float32)
+    res = {}
+    for first in (True, False):
+        layers.aggregate_first = first
+        try:
+            torch.manual_seed(0)
+            layer = layers.GraphConv(dout, C, activation=act)
+            tx = t32(x).requires_grad_(True)
+            layer.build(tx.shape, dev())
+            with torch.no_grad():
+                for c in range(C):
+                    layer.bias[c].copy_(t32(np.random.default_rng(c).standard_normal((1, dout)) * 0.3))
+            out = layer(tx, adj=adjs)
+            out.backward(t32(g))
+            res[first] = (out.detach().cpu().numpy(), tx.grad.cpu().numpy(), [p.grad.cpu().numpy() for p in layer.w],
+                          [p.grad.cpu().numpy() for p in layer.bias], [p.detach().cpu().numpy() for p in layer.w],
+                          [p.detach().cpu().numpy() for p in layer.bias])
+        finally:
+            layers.aggregate_first = True
+    out, dx, dw, db, w, b = res[True]
+    pre = K.graphconv_fwd(x, adjs, w, b)
+    if act == "sigmoid":
+        ref, dpre = 1 / (1 + np.exp(-pre)), None
+        dpre = g * ref * (1 - ref)
+    elif act == "relu":
+        ref = np.maximum(pre, 0); dpre = g * (out > 0)
+    elif act == "tanh":
+        ref = np.tanh(pre); dpre = g * (1 - ref * ref)
+    else:
+        ref, dpre = pre, g
+    close(out, ref, atol=2e-6, rel=1e-6, what="aggregate-first fwd")
+    assert np.all(out[-1] == (0.5 if act == "sigmoid" else 0.0)), "rows of an empty graph must not see the bias"
+    rdx, rdw, rdb = K.graphconv_bwd(x, adjs, w, b, dpre)
+    close(dx, rdx, atol=1e-6, rel=3e-6, what="aggregate-first d inputs")
+    for c in range(C):
+        close(dw[c], rdw[c], atol=1e-6, rel=3e-6, what="aggregate-first dW channel %d" % c)
+        close(db[c], rdb[c], atol=1e-6, rel=3e-6, what="aggregate-first dbias channel %d" % c)
+    close(out, res[False][0], atol=3e-6, rel=1e-6, what="aggregate-first vs contract-first fwd")
+    close(dx, res[False][1], atol=2e-6, rel=5e-6, what="aggregate-first vs contract-first d inputs")
