@@ -415,6 +415,40 @@ int kgcn_augment_ones_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, 
 int kgcn_augment_ones_bwd_f32(const float* dout_grad, int64_t m, int32_t din, int64_t g_ld, float* dx, int64_t dx_ld,
                               void* stream);
 
+/* -- cross-layer kernels for small graphs: the node-level body of example_model/model.py:42-54 in ONE launch ------------ */
+/* For N <= 32 nodes per graph and layer widths <= 64 a graph's activations and all weights fit LDS: one forward and one
+ * backward launch run   [GraphConv -> act] x k -> [BatchNormalization (moving statistics) -> act] -> [GraphDense -> act]
+ * -> GraphGather   for every graph, instead of one launch and one HBM round trip per layer (at the reference's batch sizes
+ * -- 30 graphs in example_config/synth.json -- a step is bound by launch latency).  Plain fp32 FMAs.
+ *   kind 0  H <- act(A (H W + b))   one adjacency channel (kgcn/layers.py:105-116);  w [din, dout], b [dout] or NULL
+ *   kind 1  H <- act(H W + b)       GraphDense (:255-262)
+ *   kind 2  H <- act(gamma (H - mean) / sqrt(var + eps) + beta) on rows < enabled[t], act(0) on the others
+ *                                   GraphBatchNormalization with its moving statistics (:196-216); w = gamma, b = beta
+ * layer_out: HOST array of num_layers device pointers, layer l's output [T, N, dout_l] (written by the forward, read by
+ * the backward).  pooled (forward) non-NULL: GraphGather over all N rows (:163-164) -> [T, dout_last].
+ * backward: dlast = d pooled [T, dout_last] (gather != 0) or d (last layer output) [T, N, dout_last]; dx [T, N, din_0] or
+ * NULL; dparams: flat, per layer dW [din, dout] | db [dout] (kind 2: dgamma [d] | dbeta [d]), kgcn_gcn_stack_param_floats()
+ * floats in total; deterministic (one partial per workgroup, fixed-order second stage);
+ * workspace >= kgcn_gcn_stack_bwd_workspace_bytes(). */
+#define KGCN_STACK_MAX_LAYERS 8
+typedef struct kgcn_stack_layer {
+  int32_t kind, act, din, dout;
+  const float* w;
+  const float* b;
+  const float* mean; /* kind 2 only */
+  const float* var;  /* kind 2 only */
+  float eps;         /* kind 2 only */
+  int32_t reserved_;
+} kgcn_stack_layer;
+int kgcn_gcn_stack_supported(int32_t n_nodes, int32_t max_nnz_per_graph, const kgcn_stack_layer* layers, int32_t num_layers);
+int64_t kgcn_gcn_stack_param_floats(const kgcn_stack_layer* layers, int32_t num_layers);
+int kgcn_gcn_stack_fwd_f32(const kgcn_csr_batch* a, const float* x, const int32_t* enabled, const kgcn_stack_layer* layers,
+                           int32_t num_layers, float* const* layer_out, float* pooled, void* stream);
+int64_t kgcn_gcn_stack_bwd_workspace_bytes(int32_t num_graphs, const kgcn_stack_layer* layers, int32_t num_layers);
+int kgcn_gcn_stack_bwd_f32(const kgcn_csr_batch* at, const float* x, const int32_t* enabled, const kgcn_stack_layer* layers,
+                           int32_t num_layers, float* const* layer_out, const float* dlast, int32_t gather, float* dx,
+                           float* dparams, void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,17 @@ class CsrBatch(ctypes.Structure):
 
 _CSRP = ctypes.POINTER(CsrBatch)
 
+
+class StackLayer(ctypes.Structure):
+    """struct kgcn_stack_layer (include/kgcn_hip.h)."""
+    _fields_ = [("kind", c_i32), ("act", c_i32), ("din", c_i32), ("dout", c_i32), ("w", ctypes.c_void_p),
+                ("b", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("var", ctypes.c_void_p), ("eps", ctypes.c_float),
+                ("reserved_", c_i32)]
+
+
+_STKP = ctypes.POINTER(StackLayer)
+_PTRP = ctypes.POINTER(ctypes.c_void_p)
+
 # name -> (restype, argtypes); must list EVERY function include/kgcn_hip.h declares
 # (tests/test_abi.py parses the header and compares).
 SIGNATURES = {
@@ -153,6 +164,12 @@ SIGNATURES = {
                                         ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "kgcn_augment_ones_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i64, c_f32p, c_i64, ctypes.c_void_p]),
     "kgcn_augment_ones_bwd_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i64, c_f32p, c_i64, ctypes.c_void_p]),
+    "kgcn_gcn_stack_supported": (ctypes.c_int, [c_i32, c_i32, _STKP, c_i32]),
+    "kgcn_gcn_stack_param_floats": (c_i64, [_STKP, c_i32]),
+    "kgcn_gcn_stack_fwd_f32": (ctypes.c_int, [_CSRP, c_f32p, c_i32p, _STKP, c_i32, _PTRP, c_f32p, ctypes.c_void_p]),
+    "kgcn_gcn_stack_bwd_workspace_bytes": (c_i64, [c_i32, _STKP, c_i32]),
+    "kgcn_gcn_stack_bwd_f32": (ctypes.c_int, [_CSRP, c_f32p, c_i32p, _STKP, c_i32, _PTRP, c_f32p, c_i32, c_f32p, c_f32p,
+                                              ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_dot_workspace_bytes": (c_i64, [c_i64]),
     "kgcn_dot_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i64, c_f32p, ctypes.c_void_p, c_i64,
                                     ctypes.c_void_p]),

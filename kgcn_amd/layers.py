@@ -513,7 +513,68 @@ class GraphGather(nn.Module):
         return ops.graph_gather(inputs)
 
 
+# default on: models run eligible layer sequences through the cross-layer kernels (see fused_stack) for batches of at most
+# stack_fusion_max_rows node rows (graphs x nodes): the cross-layer kernels use plain fp32 FMAs and win where a step is bound
+# by launch latency; above that the per-layer MFMA kernels are faster (tools/stack_sweep.py)
+stack_fusion = True
+stack_fusion_max_rows = 6144
+
+
+def fused_stack(seq, features, adj, enabled_node_nums=None, gather=True):
+    """Run the layer sequence `seq` -- GraphConv (one channel) / GraphBatchNormalization (learning phase 0) / GraphDense
+    modules, each with its fused `activation` -- followed by GraphGather (gather=True) through the cross-layer kernels of
+    csrc/stack.hip: ONE forward and ONE backward launch for the whole node-level body of example_model/model.py:42-54.
+    Returns None when the sequence is not eligible (graphs of more than 32 nodes, widths above 64, several adjacency
+    channels, differentiable adjacency values, a reference dispatch flag, BatchNormalization in its training phase, ragged
+    GraphDense); the caller then runs the layers one by one.  Same function either way (tests/test_gpu_model.py)."""
+    if not stack_fusion or enabled_batched or enabled_bspmm or enabled_bconv or features.dim() != 3:
+        return None
+    if features.shape[0] * features.shape[1] > stack_fusion_max_rows:
+        return None
+    if hasattr(adj, "graph_ptr") and hasattr(adj, "adjacency"):
+        return None                                          # ragged-compact batches have their own route
+    for m in seq:                                            # Keras build semantics: parameters exist after the first call
+        if isinstance(m, (GraphConv, GraphDense)) and not m.built:
+            return None
+        if isinstance(m, GraphBatchNormalization) and m.gamma is None:
+            return None
+    a = _pack(adj, features)
+    if a.num_channels != 1 or a.values is not None:
+        return None
+    csr = a.channels[0]
+    spec, params, buffers = [], [], []
+    d = int(features.shape[2])
+    for m in seq:
+        act = ops.act_code(m.activation)
+        if isinstance(m, GraphConv):
+            if m.adj_channel_num != 1 or m.w[0].shape[0] != d:
+                return None
+            spec.append((0, act, d, m.output_dim, 0.0)); params += [m.w[0], m.bias[0]]; buffers.append(None)
+            d = m.output_dim
+        elif isinstance(m, GraphDense):
+            if m.kernel.shape[0] != d:
+                return None
+            spec.append((1, act, d, m.output_dim, 0.0)); params += [m.kernel, m.bias]; buffers.append(None)
+            d = m.output_dim
+        elif isinstance(m, GraphBatchNormalization):
+            phase = _learning_phase if m.learning_phase is None else int(m.learning_phase)
+            if phase or m.gamma.shape[0] != d:
+                return None
+            spec.append((2, act, d, d, float(m.eps))); params += [m.gamma, m.beta]
+            buffers.append((m.moving_mean, m.moving_variance))
+        else:
+            return None
+    if not ops.gcn_stack_supported(csr, spec):
+        return None
+    en = None
+    if enabled_node_nums is not None and any(s[0] == 2 for s in spec):
+        en = torch.as_tensor(enabled_node_nums, device=features.device).to(torch.int32).reshape(-1).contiguous()
+        if en.numel() != features.shape[0]:
+            raise ValueError("enabled_node_nums has %d entries for a batch of %d graphs" % (en.numel(), features.shape[0]))
+    return ops.gcn_stack(features, csr, en, spec, buffers, gather, params)
+
+
 __all__ = ["GraphConv", "GraphDense", "GINAggregate", "GraphGather", "GraphMaxPooling",
            "GraphBatchNormalization", "set_learning_phase", "learning_phase", "GAT", "GraphDecoderInnerProd",
            "GraphDecoderDistMult", "DistMult", "BatchGraphConv", "load_bspmm",
-           "BatchedAdjacency"]
+           "BatchedAdjacency", "fused_stack"]

@@ -72,6 +72,11 @@ class GCN(nn.Module):
         features, adjs, enabled_node_nums, rb = _ragged.enter(self.ragged, features, adjs, enabled_node_nums)
         if rb is None:
             adjs = layers._pack(adjs, features)         # list-of-lists feed: packed ONCE per forward, not per layer
+            # small graphs (N <= 32, widths <= 64, one channel): the whole node-level body in one launch per direction
+            pooled = layers.fused_stack([self.conv1, self.conv2, self.conv3, self.bn, self.dense], features, adjs,
+                                        enabled_node_nums=enabled_node_nums, gather=True)
+            if pooled is not None:
+                return self.out(pooled)
         layer = self.conv1(features, adj=adjs)
         layer = self.conv2(layer, adj=adjs)
         layer = self.conv3(layer, adj=adjs)

@@ -583,6 +583,99 @@ def ragged_compact_rows(padded, rb):
 
 
 # -------------------------------------------------------------------------------------------------
+# cross-layer stack for small graphs (csrc/stack.hip): [GraphConv | GraphDense | BatchNormalization(moving stats)] x k
+# (+ GraphGather) in one forward and one backward launch
+# -------------------------------------------------------------------------------------------------
+def _stack_descriptors(spec, params, buffers):
+    """spec: list of (kind, act_code, din, dout, eps); params: flat list, two tensors (or None) per layer (w, b | gamma,
+    beta); buffers: per layer (mean, var) or None.  -> (ctypes array of kgcn_stack_layer, keep-alive list)."""
+    import ctypes
+    arr = (_lib.StackLayer * len(spec))()
+    keep = []
+    for l, (kind, act, din, dout, eps) in enumerate(spec):
+        w, b = params[2 * l], params[2 * l + 1]
+        w = _f32c(w.reshape(-1), "stack parameter")
+        b = None if b is None else _f32c(b.reshape(-1), "stack parameter")
+        mean = var = None
+        if kind == 2:
+            mean, var = (_f32c(t.reshape(-1), "moving statistics") for t in buffers[l])
+        keep += [w, b, mean, var]
+        arr[l] = _lib.StackLayer(kind, act, din, dout, w.data_ptr(), 0 if b is None else b.data_ptr(),
+                                 0 if mean is None else mean.data_ptr(), 0 if var is None else var.data_ptr(), float(eps), 0)
+    return arr, keep
+
+
+def gcn_stack_supported(csr, spec):
+    import ctypes
+    if csr.row_pad or csr.rows != csr.cols or csr.rows > 32 or len(spec) > 8:
+        return False
+    arr = (_lib.StackLayer * len(spec))()
+    for l, (kind, act, din, dout, eps) in enumerate(spec):
+        arr[l] = _lib.StackLayer(kind, act, din, dout, 1, 1, 1, 1, float(eps), 0)       # pointers only checked for NULL
+    return bool(lib.kgcn_gcn_stack_supported(csr.rows, csr.max_nnz, arr, len(spec)))
+
+
+class _GcnStack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, csr, enabled, spec, buffers, gather, *params):
+        import ctypes
+        x = _f32c(x, "inputs")
+        T, N, d0 = x.shape
+        if (T, N) != (csr.num_graphs, csr.rows) or d0 != spec[0][2]:
+            raise _lib.KgcnHipError("inputs %s do not match the adjacency batch / the first layer" % (tuple(x.shape),))
+        arr, keep = _stack_descriptors(spec, params, buffers)
+        outs = [torch.empty((T, N, s[3]), device=x.device, dtype=torch.float32) for s in spec]
+        optr = (ctypes.c_void_p * len(spec))(*[o.data_ptr() for o in outs])
+        pooled = torch.empty((T, spec[-1][3]), device=x.device, dtype=torch.float32) if gather else None
+        check(lib.kgcn_gcn_stack_fwd_f32(csr.desc(), ptr(x), ptr(enabled), arr, len(spec), optr, ptr(pooled), current_stream()),
+              "kgcn_gcn_stack_fwd_f32")
+        ctx.csr, ctx.enabled, ctx.spec, ctx.buffers, ctx.gather = csr, enabled, spec, buffers, gather
+        ctx.nparams = len(params)
+        ctx.save_for_backward(x, *outs, *[p for p in params if p is not None])
+        ctx.param_none = [p is None for p in params]
+        ctx.param_shapes = [None if p is None else tuple(p.shape) for p in params]
+        return pooled if gather else outs[-1]
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        spec = ctx.spec
+        saved = list(ctx.saved_tensors)
+        x, outs, rest = saved[0], saved[1:1 + len(spec)], saved[1 + len(spec):]
+        params, it = [], iter(rest)
+        for is_none in ctx.param_none:
+            params.append(None if is_none else next(it))
+        g = _f32c(g, "grad")
+        arr, keep = _stack_descriptors(spec, params, ctx.buffers)
+        optr = (ctypes.c_void_p * len(spec))(*[o.data_ptr() for o in outs])
+        n = int(lib.kgcn_gcn_stack_param_floats(arr, len(spec)))
+        dparams = torch.empty((n,), device=g.device, dtype=torch.float32)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        wsb = lib.kgcn_gcn_stack_bwd_workspace_bytes(x.shape[0], arr, len(spec))
+        ws = torch.empty((max(wsb, 4) // 4,), device=g.device, dtype=torch.float32)
+        check(lib.kgcn_gcn_stack_bwd_f32(ctx.csr.transpose().desc(), ptr(x), ptr(ctx.enabled), arr, len(spec), optr, ptr(g),
+                                         1 if ctx.gather else 0, ptr(dx), ptr(dparams), ptr(ws), wsb, current_stream()),
+              "kgcn_gcn_stack_bwd_f32")
+        grads, off = [], 0
+        for l, (kind, act, din, dout, eps) in enumerate(spec):
+            nw = dout if kind == 2 else din * dout
+            for which, cnt in ((0, nw), (1, dout)):
+                i = 2 * l + which
+                if ctx.param_none[i]:
+                    grads.append(None)
+                else:
+                    grads.append(dparams[off:off + cnt].reshape(ctx.param_shapes[i]))
+                off += cnt
+        return (dx, None, None, None, None, None) + tuple(grads)
+
+
+def gcn_stack(x, csr, enabled, spec, buffers, gather, params):
+    """x [T, N, d0]; spec / buffers / params as in _stack_descriptors.  Returns pooled [T, d_last] (gather) or the last
+    layer's output [T, N, d_last]."""
+    return _GcnStack.apply(x, csr, enabled, tuple(spec), tuple(buffers), bool(gather), *params)
+
+
+# -------------------------------------------------------------------------------------------------
 # aggregate-first GraphConv operand: [X | 1 | 0..]
 # -------------------------------------------------------------------------------------------------
 class _AugmentOnes(torch.autograd.Function):
@@ -664,7 +757,8 @@ def masked_softmax_ce(logits, labels, mask):
 __all__ = ["BatchedCSR", "BatchedAdjacency", "bspmm", "bspmm_raw", "bconv", "dense", "activation", "act_code",
            "graphconv_fused", "graphconv_fused_supported", "gin_aggregate", "graph_gather",
            "graph_maxpool", "gat", "gram", "ragged_gather", "ragged_compact_rows",
-           "masked_sigmoid_ce", "masked_softmax_ce", "augment_ones"]
+           "masked_sigmoid_ce", "masked_softmax_ce", "augment_ones",
+           "gcn_stack", "gcn_stack_supported"]
 
 
 # -------------------------------------------------------------------------------------------------

@@ -372,3 +372,62 @@ def test_graphed_step_with_captured_rccl_allreduce(tmp_path):
         assert abs(ce - cg) < 2e-4 * max(1.0, abs(ce)), res
     assert res["costs"][-1][1] < res["costs"][0][1]
     assert res["param_diff"] < 2e-5, res
+
+
+@pytest.mark.parametrize("B,N,F,W,with_en", [(30, 10, 3, 50, False), (64, 32, 40, 48, True), (1, 5, 7, 13, True), (200, 16, 5, 50, True),
+                                             (37, 17, 64, 50, True)])
+def test_cross_layer_stack_equals_layer_by_layer(B, N, F, W, with_en):
+    """example_model/model.py's node-level body (3 x GraphConv, BatchNormalization with its moving statistics, GraphDense,
+    GraphGather) through the cross-layer kernels (csrc/stack.hip: one forward, one backward launch) against the same
+    modules run one by one: logits, d features and every parameter gradient; non-trivial moving statistics / gamma / beta /
+    biases, true sizes (padded rows -> act(0) behind the normalisation), a dummy graph, 32 nodes / odd node counts / 64 input features.  The layer-by-layer route is itself checked against the fp64 model oracle above."""
+    from kgcn_amd import layers, models
+    from test_oracle_model import tox21_like_batch
+    rng = np.random.default_rng(B + N)
+    x, adjs, _, mask, _, sizes = tox21_like_batch(rng, B=B, N=N, F=F, T=2)
+    if B == 1:
+        sizes = np.array([N - 1]); mask = np.ones(1)
+        a = K.synth_mol_graphs(rng, 1, N - 1, 1)[0][0]
+        adjs = [[(a[0], a[1], [N, N])]]
+        x = np.zeros((1, N, F)); x[0, :N - 1] = rng.standard_normal((N - 1, F))
+    lab = np.eye(2)[rng.integers(0, 2, B)]
+    res = {}
+    for fused in (True, False):
+        layers.stack_fusion = fused
+        try:
+            torch.manual_seed(0)
+            model = models.GCN(1, 2).to(dev())
+            for m, w in ((model.conv1, W), (model.conv2, W), (model.conv3, W), (model.dense, W)):
+                m.output_dim = w
+            tx = t32(x).requires_grad_(True)
+            en = torch.as_tensor(sizes) if with_en else None
+            model(tx, adjs, enabled_node_nums=en)                      # Keras-style build (layer by layer)
+            with torch.no_grad():
+                gen = torch.Generator(device="cpu").manual_seed(1)
+                for p_ in model.parameters():
+                    if p_.dim() == 1 or p_.shape[0] == 1:
+                        p_.copy_(torch.randn(p_.shape, generator=gen).to(p_.device) * 0.2 + (1.0 if p_ is model.bn.gamma else 0.0))
+                model.bn.moving_mean.copy_(torch.randn(W, generator=gen).to(dev()) * 0.1)
+                model.bn.moving_variance.copy_(torch.rand(W, generator=gen).to(dev()) + 0.5)
+            logits = model(tx, adjs, enabled_node_nums=en)
+            used = logits.grad_fn.next_functions[0][0].__class__.__name__ if fused else ""
+            cost, _ = models.masked_softmax_ce(logits, t32(lab), t32(mask))
+            cost.backward()
+            res[fused] = (logits.detach().cpu().numpy(), tx.grad.cpu().numpy(),
+                          [(n_, p_.grad.cpu().numpy()) for n_, p_ in model.named_parameters()])
+            if fused:                                                  # the fused route really ran
+                names = set()
+                fn, stack_ = logits.grad_fn, [logits.grad_fn]
+                while stack_:
+                    f = stack_.pop()
+                    if f is None:
+                        continue
+                    names.add(f.__class__.__name__)
+                    stack_ += [nf[0] for nf in f.next_functions]
+                assert any("GcnStack" in n_ for n_ in names), names
+        finally:
+            layers.stack_fusion = True
+    close(res[True][0], res[False][0], atol=2e-5, what="stack vs layers: logits")
+    close(res[True][1], res[False][1], atol=1e-7, rel=2e-5, what="stack vs layers: d features")
+    for (n_, a), (_, b) in zip(res[True][2], res[False][2]):
+        close(a, b, atol=2e-7, rel=2e-5, what="stack vs layers: grad %s" % n_)
