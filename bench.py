@@ -15,6 +15,9 @@ already set RANK / WORLD_SIZE it just runs as the rank it is.  Rank 0 prints ONE
     graphs per GPU (random spanning tree + 3 extra edges, symmetrised, + self loops => nnz = 100 exactly), 64-dim
     features, one adjacency channel, kernel [64,64].  One step = kgcn_amd.layers.GraphConv forward, then backward
     producing dX, dW, dbias (+ for N > 1 one RCCL all-reduce of the flat [dW, dbias] bucket).
+--config cfg3 (BASELINE config 3): example_model/sparse.py on the kgcn-sparse path: --graphs (128) molecules per GPU as ONE
+    block-diagonal adjacency, 128-dim features, widths 256; one step = forward, summed sparse softmax CE, backward,
+    all-reduce, TF-Adam on the resident batch.
 --config cfg4 (BASELINE config 4): Tox21-shaped multitask training, example_model/model_multitask.py network, N = 50
     padded nodes with true sizes 5..50, F = 81, 12 masked tasks; --graphs molecules resident in HBM per GPU (default
     125,000 = 1 M / 8), one step = one mini-batch of --batch (4,096) molecules per GPU assembled on the device,
@@ -715,11 +718,86 @@ class Cfg5(_ModelStep):
         return config, self.model_roofline(), {}
 
 
+class Cfg3(_ModelStep):
+    """BASELINE config 3 (example_config/sparse.json, example_model/sparse.py): the kgcn-sparse path -- ONE block-diagonal
+    [sum N x sum N] adjacency per batch of 128 molecules (20..50 atoms), 128-dim features, 3 x GraphConv(256) relu,
+    GraphDense(256), BN, per-molecule sum, tanh, Dense(10); summed sparse softmax CE; TF-Adam.  The batch is resident."""
+    name = "cfg3"
+
+    def __init__(self, args, ctx):
+        import types
+        import torch
+        from kgcn_amd import data_util as D, models
+        self.args, self.ctx = args, ctx
+        nmol, F = args.graphs or 128, 128
+        rng = np.random.default_rng(3 + ctx.rank)
+        size = rng.integers(20, 51, size=nmol)
+        rows, cols, elem, deg = [], [], [], []
+        for n in size:                                       # random tree + 3 extra edges + self loops per molecule
+            a = np.zeros((n, n), np.bool_)
+            for i in range(1, n):
+                j = rng.integers(0, i)
+                a[i, j] = a[j, i] = True
+            for _ in range(3):
+                i, j = rng.integers(0, n, size=2)
+                a[i, j] = a[j, i] = True
+            a[np.arange(n), np.arange(n)] = True
+            r, c = np.nonzero(a)
+            d = a.sum(axis=0)
+            rows.append(r); cols.append(c); elem.append(len(r)); deg.append(np.where(r == c, 0, d[r]))
+        total = int(size.sum())
+        feats = rng.standard_normal((total, F)).astype(np.float32)
+        fr = np.concatenate([np.repeat(np.arange(n), F) for n in size])
+        fc = np.tile(np.arange(F), total)
+        adj_row, adj_col = np.concatenate(rows), np.concatenate(cols)
+        batch = D.block_diagonal_batch(size, adj_row, adj_col, np.ones(adj_row.shape[0], np.float32), np.asarray(elem),
+                                       np.concatenate(deg), fr, fc, feats.reshape(-1), size * F, F, max_degree=0,
+                                       normalize=True, device=ctx.device)
+        self.nmol, self.total, self.nnz = nmol, total, int(adj_row.shape[0])
+        labels = torch.from_numpy(rng.integers(0, 10, size=nmol)).to(ctx.device)
+        torch.manual_seed(0)
+        model = models.SparseGCN(10).to(ctx.device)
+        model(batch)
+        self.units_local, self.units_global = nmol, nmol * ctx.world
+        sbn = types.SimpleNamespace(features=batch, adjacency=None)
+        self._finish(_SparseAdapter(model), lambda lg, lb, mk: (models.sparse_softmax_ce_sum(lg, lb),) * 2, sbn, labels,
+                     torch.ones(nmol, device=ctx.device))
+
+    def next_batch(self):
+        pass
+
+    def report(self, evs):
+        config = {"workload": "cfg3: example_model/sparse.py training step on the kgcn-sparse path: %d molecules (20..50 atoms) "
+                              "as ONE block-diagonal [%d x %d] adjacency (%d stored entries, Kipf-normalised), 128-dim "
+                              "features, 3 x GraphConv(256) relu, GraphDense(256), BN, per-molecule sum, tanh, Dense(10); "
+                              "summed sparse softmax CE; TF-Adam; %s" % (self.nmol, self.total, self.total, self.nnz,
+                                                                        "eager launches" if self.args.eager else
+                                                                        "one hipGraph per step"),
+                  "molecules_per_gpu": self.nmol, "rows": self.total, "features": 128}
+        return config, self.model_roofline(), {}
+
+
+class _SparseAdapter:
+    """models.SparseGCN takes the BlockDiagonalBatch as its only argument; the train-step helpers call
+    model(features, adjacency, **kw)."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def parameters(self):
+        return self.model.parameters()
+
+    def __call__(self, batch, _adjacency=None, **kw):
+        return self.model(batch)
+
+
 # ---------------------------------------------------------------------------------------------
 # --dry: the multi-rank path without the kernels (launcher + bucket exchange), any device / backend
 # ---------------------------------------------------------------------------------------------
 PARAM_SHAPES = {
     "cfg2": [(64, 64), (1, 64)],
+    "cfg3": [(128, 256), (1, 256), (256, 256), (1, 256), (256, 256), (1, 256), (256, 256), (256,), (256,), (256,), (256, 10),
+             (10,)],
     "cfg4": [(81, 256), (1, 256), (256, 256), (1, 256), (256, 256), (256,), (256, 50), (1, 50), (50,), (50,), (50, 50),
              (50,), (50, 12), (12,)],
     "cfg5": [(), (), (256, 256), (256,), (256, 256), (256,), (256, 256), (256,), (256, 256), (256,), (512, 2), (2,)],
@@ -789,7 +867,7 @@ def build_parser():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", choices=("cfg2", "cfg4", "cfg5"), default="cfg2")
+    ap.add_argument("--config", choices=("cfg2", "cfg3", "cfg4", "cfg5"), default="cfg2")
     ap.add_argument("--graphs", type=int, default=0,
                     help="cfg2 / cfg5: graphs per GPU per step (100,000 / 20,000); cfg4: molecules resident per GPU (125,000)")
     ap.add_argument("--batch", type=int, default=0, help="cfg4: molecules per GPU per step (4,096)")
@@ -833,7 +911,7 @@ def main(argv=None):
     if args.contract_first:
         from kgcn_amd import layers as _layers
         _layers.aggregate_first = False
-    wl = Dry(args, ctx) if args.dry else {"cfg2": Cfg2, "cfg4": Cfg4, "cfg5": Cfg5}[args.config](args, ctx)
+    wl = Dry(args, ctx) if args.dry else {"cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4, "cfg5": Cfg5}[args.config](args, ctx)
 
     ev = [[ctx.event() for _ in range(wl.n_events)] for _ in range(args.steps)] if ctx.on_gpu else None
     # setup: prime the caching allocator, the lazily built A^T / row-padded containers, the LDS attributes
