@@ -876,6 +876,8 @@ def build_parser():
     ap.add_argument("--unfused", action="store_true", help="cfg2: dense GEMM + Bspmm kernels instead of the fused layer")
     ap.add_argument("--eager", action="store_true", help="cfg4 / cfg5: plain launches instead of one hipGraph per step")
     ap.add_argument("--padded", action="store_true", help="cfg4: compute all padded rows (round-2 behaviour)")
+    ap.add_argument("--no-wgrad-dact", action="store_true",
+                    help="A/B switch: a stand-alone activation-backward pass in front of the first layer's weight gradient")
     ap.add_argument("--contract-first", action="store_true",
                     help="A/B switch: GraphConv always contracts before it aggregates (kgcn_amd.layers.aggregate_first = False)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
@@ -911,6 +913,9 @@ def main(argv=None):
     if args.contract_first:
         from kgcn_amd import layers as _layers
         _layers.aggregate_first = False
+    if args.no_wgrad_dact:
+        from kgcn_amd import ops as _ops
+        _ops.wgrad_dact_fusion = False
     wl = Dry(args, ctx) if args.dry else {"cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4, "cfg5": Cfg5}[args.config](args, ctx)
 
     ev = [[ctx.event() for _ in range(wl.n_events)] for _ in range(args.steps)] if ctx.on_gpu else None

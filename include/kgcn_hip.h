@@ -449,6 +449,15 @@ int kgcn_gcn_stack_bwd_f32(const kgcn_csr_batch* at, const float* x, const int32
                            int32_t num_layers, float* const* layer_out, const float* dlast, int32_t gather, float* dx,
                            float* dparams, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* dW, dbias of act(x W + b) when the layer INPUT needs no gradient (first layer of a model): d pre-activation = dy * act'(act_out)
+ * is formed while the weight-gradient GEMM stages the gradient rows, so it never exists in HBM.  Wide layers only
+ * (kgcn_dense_wgrad_dact_supported(din, dout) != 0); otherwise run kgcn_act_bwd_f32 + kgcn_dense_wgrad_f32.  dy and act_out
+ * share the leading dimension dy_ld; workspace as for kgcn_dense_wgrad_f32. */
+int kgcn_dense_wgrad_dact_supported(int32_t din, int32_t dout);
+int kgcn_dense_wgrad_dact_f32(const float* x, int64_t x_ld, const float* dy, const float* act_out, int64_t dy_ld, int32_t act,
+                              int64_t m, int32_t din, int32_t dout, float* dw, float* dbias, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -170,6 +170,9 @@ SIGNATURES = {
     "kgcn_gcn_stack_bwd_workspace_bytes": (c_i64, [c_i32, _STKP, c_i32]),
     "kgcn_gcn_stack_bwd_f32": (ctypes.c_int, [_CSRP, c_f32p, c_i32p, _STKP, c_i32, _PTRP, c_f32p, c_i32, c_f32p, c_f32p,
                                               ctypes.c_void_p, c_i64, ctypes.c_void_p]),
+    "kgcn_dense_wgrad_dact_supported": (ctypes.c_int, [c_i32, c_i32]),
+    "kgcn_dense_wgrad_dact_f32": (ctypes.c_int, [c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_i32, c_i64, c_i32, c_i32, c_f32p,
+                                                 c_f32p, ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_dot_workspace_bytes": (c_i64, [c_i64]),
     "kgcn_dot_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i64, c_f32p, ctypes.c_void_p, c_i64,
                                     ctypes.c_void_p]),

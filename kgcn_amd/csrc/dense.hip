@@ -41,7 +41,8 @@ int launch_wgradn(const float* x, long x_ld, const float* dy, long dy_ld, long m
 int64_t wtable_bytes(int din, int dout);
 void launch_wtable_split(const float* w, long w_ld, int trans_w, int din, int dout, void* workspace, hipStream_t s);
 int launch_gemm3_wgrad(const float* x, long x_ld, const float* dy, long dy_ld, long m, int din, int dout,
-                       float* part_dw, float* part_db, int nblocks, hipStream_t s);
+                       float* part_dw, float* part_db, int nblocks, hipStream_t s, const float* yact = nullptr,
+                       int act = KGCN_ACT_NONE);
 
 constexpr int BM = 128;      // rows per workgroup (32 per wave)
 constexpr int BN = 64;       // output columns per workgroup
@@ -649,9 +650,35 @@ extern "C" int64_t kgcn_dense_wgrad_workspace_bytes(int64_t m, int32_t din, int3
   return (int64_t)nchunks * ((int64_t)din * dout + dout) * 4;
 }
 
+static int dense_wgrad_impl(const float* x, int64_t x_ld, const float* dy, int64_t dy_ld, int64_t m, int32_t din,
+                            int32_t dout, float* dw, float* dbias, void* workspace, int64_t workspace_bytes, void* stream,
+                            const float* yact, int act);
+
 extern "C" int kgcn_dense_wgrad_f32(const float* x, int64_t x_ld, const float* dy, int64_t dy_ld,
                                     int64_t m, int32_t din, int32_t dout, float* dw, float* dbias,
                                     void* workspace, int64_t workspace_bytes, void* stream) {
+  return dense_wgrad_impl(x, x_ld, dy, dy_ld, m, din, dout, dw, dbias, workspace, workspace_bytes, stream, nullptr,
+                          KGCN_ACT_NONE);
+}
+
+// 1 when kgcn_dense_wgrad_dact_f32 forms d pre-activation inside the weight-gradient GEMM for this shape (else the caller
+// runs kgcn_act_bwd_f32 first)
+extern "C" int kgcn_dense_wgrad_dact_supported(int32_t din, int32_t dout) { return din > 64 && dout > 128 ? 1 : 0; }
+
+extern "C" int kgcn_dense_wgrad_dact_f32(const float* x, int64_t x_ld, const float* dy, const float* act_out, int64_t dy_ld,
+                                         int32_t act, int64_t m, int32_t din, int32_t dout, float* dw, float* dbias,
+                                         void* workspace, int64_t workspace_bytes, void* stream) {
+  if (act <= KGCN_ACT_NONE || act > KGCN_ACT_TANH) return fail("kgcn_dense_wgrad_dact_f32: activation code %d", act);
+  if (!kgcn_dense_wgrad_dact_supported(din, dout))
+    return fail("kgcn_dense_wgrad_dact_f32: shape %d x %d is not a wide layer (run kgcn_act_bwd_f32 + kgcn_dense_wgrad_f32)",
+                din, dout);
+  if (m > 0 && !act_out) return fail("kgcn_dense_wgrad_dact_f32: act_out is NULL");
+  return dense_wgrad_impl(x, x_ld, dy, dy_ld, m, din, dout, dw, dbias, workspace, workspace_bytes, stream, act_out, act);
+}
+
+static int dense_wgrad_impl(const float* x, int64_t x_ld, const float* dy, int64_t dy_ld, int64_t m, int32_t din,
+                            int32_t dout, float* dw, float* dbias, void* workspace, int64_t workspace_bytes, void* stream,
+                            const float* yact, int act) {
   if (m < 0 || din <= 0 || dout <= 0)
     return fail("kgcn_dense_wgrad_f32: bad shape m=%lld din=%d dout=%d", (long long)m, din, dout);
   if (!dw && !dbias) return 0;
@@ -677,7 +704,8 @@ extern "C" int kgcn_dense_wgrad_f32(const float* x, int64_t x_ld, const float* d
     if (nb > chunks) nb = chunks;
     float* part_dw = static_cast<float*>(workspace);
     float* part_db = part_dw + nb * din * dout;
-    if (int rc = launch_gemm3_wgrad(x, (long)x_ld, dy, (long)dy_ld, (long)m, din, dout, part_dw, part_db, (int)nb, s))
+    if (int rc = launch_gemm3_wgrad(x, (long)x_ld, dy, (long)dy_ld, (long)m, din, dout, part_dw, part_db, (int)nb, s, yact,
+                                    act))
       return rc;
     return launch_reduce_pair(part_dw, (long)din * dout, dw, part_db, dout, dbias, (int)nb, s);
   }

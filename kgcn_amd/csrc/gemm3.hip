@@ -507,11 +507,18 @@ int launch_gemm3_dx_dact(const float* grad, const float* act_out, float* dpre, l
 // workspace; reduce_partials_kernel adds the partials in a fixed order.
 // ------------------------------------------------------------------------------------------------
 constexpr int G3W_BM = 128;   // din columns per workgroup
-struct G3RawT { float a[8], b0[8], b1[8]; };
+template <bool DACT> struct G3RawTT { float a[8], b0[8], b1[8]; };
+template <> struct G3RawTT<true> { float a[8], b0[8], b1[8], y0[8], y1[8]; };
 
+// DACT: dy is the gradient of an ACTIVATED layer output; the saved output `yact` (same layout as dy) is staged next to it and
+// d pre-activation = dy * act'(yact) is formed when the chunk is split -- it never exists in HBM (used when the layer's
+// input needs no gradient, so no dX GEMM produces it on the way: the first layer of a model).
+template <bool DACT>
 __global__ __launch_bounds__(512, 2) void gemm3_wgrad_kernel(
     const float* __restrict__ x, long x_ld, const float* __restrict__ dy, long dy_ld, long m, int din, int dout,
-    float* __restrict__ part_dw, float* __restrict__ part_db, long chunks_per_block) {
+    float* __restrict__ part_dw, float* __restrict__ part_db, long chunks_per_block,
+    const float* __restrict__ yact, int act) {
+  using G3RawT = G3RawTT<DACT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   u32x4* lds = reinterpret_cast<u32x4*>(dsm);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -537,6 +544,10 @@ __global__ __launch_bounds__(512, 2) void gemm3_wgrad_kernel(
       r.a[j] = x[(ra < m ? ra : m - 1) * x_ld + ca];
       r.b0[j] = dy[(rb0 < m ? rb0 : m - 1) * dy_ld + cb];
       r.b1[j] = dy[(rb1 < m ? rb1 : m - 1) * dy_ld + cb];
+      if constexpr (DACT) {
+        r.y0[j] = yact[(rb0 < m ? rb0 : m - 1) * dy_ld + cb];
+        r.y1[j] = yact[(rb1 < m ? rb1 : m - 1) * dy_ld + cb];
+      }
     }
   };
   float colsum = 0.f;               // of dy column bc over this thread's row groups
@@ -551,13 +562,15 @@ __global__ __launch_bounds__(512, 2) void gemm3_wgrad_kernel(
       fa.p1[J] = q1; fa.p2[J] = q2; fa.p3[J] = q3;
     } else if constexpr (STEP < 8) {
       const long row = row0 + 8 * bq + 2 * J;
-      const float v0 = (bok && row < m) ? r.b0[2 * J] : 0.f, v1 = (bok && row + 1 < m) ? r.b0[2 * J + 1] : 0.f;
+      float v0 = (bok && row < m) ? r.b0[2 * J] : 0.f, v1 = (bok && row + 1 < m) ? r.b0[2 * J + 1] : 0.f;
+      if constexpr (DACT) { v0 *= act_dout(r.y0[2 * J], act); v1 *= act_dout(r.y0[2 * J + 1], act); }
       colsum += v0 + v1;
       split_pair(v0, v1, q1, q2, q3);
       f0.p1[J] = q1; f0.p2[J] = q2; f0.p3[J] = q3;
     } else {
       const long row = row0 + 8 * (bq + 2) + 2 * J;
-      const float v0 = (bok && row < m) ? r.b1[2 * J] : 0.f, v1 = (bok && row + 1 < m) ? r.b1[2 * J + 1] : 0.f;
+      float v0 = (bok && row < m) ? r.b1[2 * J] : 0.f, v1 = (bok && row + 1 < m) ? r.b1[2 * J + 1] : 0.f;
+      if constexpr (DACT) { v0 *= act_dout(r.y1[2 * J], act); v1 *= act_dout(r.y1[2 * J + 1], act); }
       colsum += v0 + v1;
       split_pair(v0, v1, q1, q2, q3);
       f1.p1[J] = q1; f1.p2[J] = q2; f1.p3[J] = q3;
@@ -653,18 +666,24 @@ __global__ __launch_bounds__(512, 2) void gemm3_wgrad_kernel(
 }
 
 int launch_gemm3_wgrad(const float* x, long x_ld, const float* dy, long dy_ld, long m, int din, int dout,
-                       float* part_dw, float* part_db, int nblocks, hipStream_t s) {
+                       float* part_dw, float* part_db, int nblocks, hipStream_t s, const float* yact, int act) {
   static thread_local bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_wgrad_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_wgrad_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_wgrad_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     attr_set = true;
   }
   const long nchunks = (m + G3_BK - 1) / G3_BK;
   const long cpb = (nchunks + nblocks - 1) / nblocks;
   const dim3 grid((unsigned)nblocks, (unsigned)((din + G3W_BM - 1) / G3W_BM), (unsigned)((dout + G3_BN - 1) / G3_BN));
-  hipLaunchKernelGGL(gemm3_wgrad_kernel, grid, dim3(512), G3_LDS, s, x, x_ld, dy, dy_ld, m, din, dout, part_dw, part_db,
-                     cpb);
+  if (yact && act != KGCN_ACT_NONE)
+    hipLaunchKernelGGL(gemm3_wgrad_kernel<true>, grid, dim3(512), G3_LDS, s, x, x_ld, dy, dy_ld, m, din, dout, part_dw,
+                       part_db, cpb, yact, act);
+  else
+    hipLaunchKernelGGL(gemm3_wgrad_kernel<false>, grid, dim3(512), G3_LDS, s, x, x_ld, dy, dy_ld, m, din, dout, part_dw,
+                       part_db, cpb, nullptr, KGCN_ACT_NONE);
   return check_launch("gemm3_wgrad_kernel");
 }
 

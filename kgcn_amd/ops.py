@@ -16,6 +16,8 @@ from .batched_csr import BatchedAdjacency, BatchedCSR
 
 
 ACT_CODES = {None: 0, "none": 0, "linear": 0, "sigmoid": 1, "relu": 2, "tanh": 3}
+# A/B switch: d pre-activation inside the wide weight-gradient GEMM when the layer input needs no gradient
+wgrad_dact_fusion = True
 
 
 def act_code(activation):
@@ -248,6 +250,10 @@ class _Dense(torch.autograd.Function):
         m, din = x2d.shape
         dout = w.shape[1]
         dx = dw = db = None
+        # first layer of a model (no d inputs), wide layer: d pre-activation is formed while the weight-gradient GEMM stages
+        # the gradient rows -- no elementwise pass over the [m, dout] tensor
+        fuse_dact = bool(ctx.act) and not ctx.needs_input_grad[0] and wgrad_dact_fusion and \
+            bool(lib.kgcn_dense_wgrad_dact_supported(din, dout))
         if ctx.act and ctx.needs_input_grad[0]:
             # d pre-activation is produced by the dX GEMM itself while it stages the gradient rows (wide layers); the
             # weight-gradient GEMM reads it afterwards
@@ -258,7 +264,7 @@ class _Dense(torch.autograd.Function):
                                              ptr(dpre), ptr(wsp), wsb, current_stream()), "kgcn_dense_dx_dact_f32")
             gy = dpre
         else:
-            if ctx.act:
+            if ctx.act and not fuse_dact:
                 gy = activation_backward(yact, gy, ctx.act)
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x2d)
@@ -273,9 +279,13 @@ class _Dense(torch.autograd.Function):
             wsp = torch.empty((max(wsb, 4) // 4,), device=gy.device, dtype=torch.float32)
             dw = torch.empty_like(w) if need_w else None
             db = torch.empty((dout,), device=gy.device, dtype=torch.float32) if need_b else None
-            check(lib.kgcn_dense_wgrad_f32(ptr(x2d), din, ptr(gy), dout, m, din, dout, ptr(dw),
-                                           ptr(db), ptr(wsp), wsb, current_stream()),
-                  "kgcn_dense_wgrad_f32")
+            if fuse_dact:
+                check(lib.kgcn_dense_wgrad_dact_f32(ptr(x2d), din, ptr(gy), ptr(yact), dout, ctx.act, m, din, dout, ptr(dw),
+                                                    ptr(db), ptr(wsp), wsb, current_stream()), "kgcn_dense_wgrad_dact_f32")
+            else:
+                check(lib.kgcn_dense_wgrad_f32(ptr(x2d), din, ptr(gy), dout, m, din, dout, ptr(dw),
+                                               ptr(db), ptr(wsp), wsb, current_stream()),
+                      "kgcn_dense_wgrad_f32")
             if db is not None:
                 db = db.reshape(ctx.bias_shape)
         return dx, dw, db, None

@@ -119,6 +119,37 @@ def test_dense_dx_dact_all_routes(act, M, din, dout):
     close(ref_dpre, dpre, atol=0, rel=2e-6, what="kgcn_act_bwd_f32")
 
 
+@pytest.mark.parametrize("act", ["sigmoid", "relu", "tanh"])
+@pytest.mark.parametrize("M,din,dout", [(4100, 256, 256), (4101, 84, 256), (333, 100, 300), (2050, 300, 256)])
+def test_dense_wgrad_with_fused_activation_derivative(act, M, din, dout):
+    """act(x W + b) whose INPUT needs no gradient (the first layer of a model): d pre-activation is formed inside the wide
+    weight-gradient GEMM's staging (kgcn_dense_wgrad_dact_f32) -- dW / dbias vs fp64 and vs the unfused route (activation backward
+    pass + plain weight gradient)."""
+    from kgcn_amd import ops
+    rng = np.random.default_rng(M + dout)
+    x = rng.standard_normal((M, din)).astype(np.float32)
+    g = rng.standard_normal((M, dout)).astype(np.float32)
+    w = K.glorot_uniform(rng, din, dout)
+    b = (rng.standard_normal(dout) * 0.1).astype(np.float32)
+    res = {}
+    for fused in (True, False):
+        ops.wgrad_dact_fusion = fused
+        try:
+            tw, tb = t32(w).requires_grad_(True), t32(b).requires_grad_(True)
+            y = ops.dense(t32(x), tw, tb, activation=act)
+            y.backward(t32(g))
+            res[fused] = (y.detach().cpu().numpy(), tw.grad.cpu().numpy(), tb.grad.cpu().numpy())
+        finally:
+            ops.wgrad_dact_fusion = True
+    yo = res[True][0]
+    a = _act64(x.astype(np.float64) @ w.astype(np.float64) + b, act)
+    dpre = g.astype(np.float64) * ((yo > 0) if act == "relu" else _dact64(a, act))
+    close(res[True][1], x.astype(np.float64).T @ dpre, atol=0, rel=3e-6, what="dW, d activation inside the weight-gradient GEMM")
+    close(res[True][2], dpre.sum(0), atol=0, rel=3e-6, what="dbias, d activation inside the weight-gradient GEMM")
+    close(res[True][1], res[False][1], atol=0, rel=3e-6, what="fused vs unfused dW")
+    close(res[True][2], res[False][2], atol=0, rel=3e-6, what="fused vs unfused dbias")
+
+
 @pytest.mark.parametrize("M,din,dout", [(4100, 256, 256), (300, 256, 256), (4100, 81, 256), (4100, 256, 50)])
 def test_bf16_split_dense_kernels_non_finite(M, din, dout):
     """+-inf splits into (inf, NaN, NaN), NaN into three NaNs: every output element that depends on a non-finite input is
