@@ -230,6 +230,11 @@ int kgcn_graph_gather_fwd_f32(const float* x, int64_t batch, int32_t n_nodes, in
 int kgcn_graph_gather_bwd_f32(const float* dout_grad, int64_t batch, int32_t n_nodes, int32_t d,
                               float* dx, void* stream);
 
+/* dx[b, n, :] = dx_in[b, n, :] + dout[b, :] -- the gradient of a tensor that feeds a GraphGather read-out AND the next layer
+ * (example_model/model_gin.py:45-60) in one pass; d % 4 == 0, 16-byte aligned tensors; dx may alias dx_in. */
+int kgcn_graph_gather_bwd_add_f32(const float* dout_grad, const float* dx_in, int64_t batch, int32_t n_nodes, int32_t d,
+                                  float* dx, void* stream);
+
 /* -- small reductions used by the layer gradients ------------------------------------------- */
 /* out[0] = sum_i a[i]*b[i]  (d eps of GINAggregate).  workspace >= kgcn_dot_workspace_bytes(). */
 int64_t kgcn_dot_workspace_bytes(int64_t n);
@@ -457,6 +462,15 @@ int kgcn_dense_wgrad_dact_supported(int32_t din, int32_t dout);
 int kgcn_dense_wgrad_dact_f32(const float* x, int64_t x_ld, const float* dy, const float* act_out, int64_t dy_ld, int32_t act,
                               int64_t m, int32_t din, int32_t dout, float* dw, float* dbias, void* workspace,
                               int64_t workspace_bytes, void* stream);
+
+/* Backward of GINAggregate (kgcn/layers.py:461-472) in one call: dx = sum_c (eps_c g + A_c^T g) -- at_ch = the TRANSPOSED
+ * channel containers -- and d eps = <g, x> (one scalar: the same for every channel, :469), accumulated while the gradient
+ * tiles are staged for the aggregation (no pass of its own over g and x); deterministic (one partial per graph, fixed-order
+ * sum).  dx or deps may be NULL.  workspace >= kgcn_gin_aggregate_bwd_workspace_bytes(T, N, d). */
+int64_t kgcn_gin_aggregate_bwd_workspace_bytes(int32_t num_graphs, int32_t n_nodes, int32_t d);
+int kgcn_gin_aggregate_bwd_f32(const kgcn_csr_batch* at_ch, int32_t num_channels, const float* grad, int32_t d,
+                               const float* eps, const float* x, float* dx, float* deps, void* workspace,
+                               int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -173,6 +173,10 @@ SIGNATURES = {
     "kgcn_dense_wgrad_dact_supported": (ctypes.c_int, [c_i32, c_i32]),
     "kgcn_dense_wgrad_dact_f32": (ctypes.c_int, [c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_i32, c_i64, c_i32, c_i32, c_f32p,
                                                  c_f32p, ctypes.c_void_p, c_i64, ctypes.c_void_p]),
+    "kgcn_gin_aggregate_bwd_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
+    "kgcn_gin_aggregate_bwd_f32": (ctypes.c_int, [_CSRP, c_i32, c_f32p, c_i32, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p,
+                                                  c_i64, ctypes.c_void_p]),
+    "kgcn_graph_gather_bwd_add_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i64, c_i32, c_i32, c_f32p, ctypes.c_void_p]),
     "kgcn_dot_workspace_bytes": (c_i64, [c_i64]),
     "kgcn_dot_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i64, c_f32p, ctypes.c_void_p, c_i64,
                                     ctypes.c_void_p]),

@@ -509,6 +509,18 @@ static bool wide_layer(int din, int dout) { return dout > 128 && din >= 32; }
 // 204,800 rows: 256 -> 256 +15% forward / +5% dX, 512 -> 256 +5% / -3%, 256 -> 512 +2%; 128 -> 256 -14%: few k-steps)
 static bool table_pays(int din, int dout) { return wide_layer(din, dout) && din >= 32; }
 
+namespace kgcn {
+bool skinny_n_ok(int din, int dout, int trans_w);
+bool skinny_k_ok(int din, int dout);
+int launch_skinny_n_fwd(const float* x, long m, int din, long x_ld, const float* w, long w_ld, const float* bias, float* y,
+                        int dout, long y_ld, int act, hipStream_t s);
+int launch_skinny_k_fwd(const float* x, long m, int din, long x_ld, const float* w, long w_ld, int trans_w, const float* bias,
+                        float* y, int dout, long y_ld, int act, hipStream_t s);
+int skinny_wgrad_parts(long m);
+int launch_skinny_n_wgrad(const float* x, long m, int din, long x_ld, const float* g, long g_ld, int dout, float* part_dw,
+                          float* part_db, int nparts, hipStream_t s);
+}  // namespace kgcn
+
 static int dense_fwd_impl(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w, int64_t w_ld,
                           int32_t trans_w, const float* bias, float* y, int32_t dout, int64_t y_ld, int act,
                           void* workspace, int64_t workspace_bytes, void* stream) {
@@ -519,6 +531,12 @@ static int dense_fwd_impl(const float* x, int64_t m, int32_t din, int64_t x_ld, 
   if (!x || !w || !y) return fail("kgcn_dense_fwd_f32: NULL operand");
   if (x_ld < din || y_ld < dout) return fail("kgcn_dense_fwd_f32: leading dimension too small");
   if (w_ld < (trans_w ? din : dout)) return fail("kgcn_dense_fwd_f32: w_ld too small");
+  // read-out layers (2..16 columns on one side): a row per wave, no panels (skinny.hip)
+  if (skinny_n_ok(din, dout, trans_w))
+    return launch_skinny_n_fwd(x, (long)m, din, (long)x_ld, w, (long)w_ld, bias, y, dout, (long)y_ld, act, as_stream(stream));
+  if (skinny_k_ok(din, dout))
+    return launch_skinny_k_fwd(x, (long)m, din, (long)x_ld, w, (long)w_ld, trans_w, bias, y, dout, (long)y_ld, act,
+                               as_stream(stream));
   // wide layers: f32-MFMA bound -> the bf16-split GEMM (gemm3.hip).  With a workspace W is split ONCE into a fragment
   // table (wtable.hip) that the waves read from L2, and the kernel's staging only splits x.
   if (wide_layer(din, dout)) {
@@ -647,6 +665,7 @@ extern "C" int64_t kgcn_dense_wgrad_workspace_bytes(int64_t m, int32_t din, int3
   int nchunks;
   wgrad_plan(m, &rpc, &nchunks);
   if (nchunks < kNumCU) nchunks = kNumCU;   // the persistent kernel writes one partial per workgroup
+  if (skinny_n_ok(din, dout, 0) && nchunks < 4 * kNumCU) nchunks = 4 * kNumCU;     // skinny.hip: up to 1,024 partials
   return (int64_t)nchunks * ((int64_t)din * dout + dout) * 4;
 }
 
@@ -695,6 +714,15 @@ static int dense_wgrad_impl(const float* x, int64_t x_ld, const float* dy, int64
                 (long long)need);
   long rpc;
   int nchunks;
+  if (!yact && skinny_n_ok(din, dout, 0)) {
+    // read-out layers: lanes own k, the 2..16 gradient columns of a row are wave-uniform (skinny.hip)
+    nchunks = skinny_wgrad_parts(m);
+    float* part_dw = static_cast<float*>(workspace);
+    float* part_db = part_dw + (long)nchunks * din * dout;
+    if (int rc = launch_skinny_n_wgrad(x, (long)m, din, (long)x_ld, dy, (long)dy_ld, dout, part_dw, part_db, nchunks, s))
+      return rc;
+    return launch_reduce_pair(part_dw, (long)din * dout, dw, part_db, dout, dbias, nchunks, s);
+  }
   if (din > 64 && dout > 128) {
     // wide layers: bf16-split GEMM (gemm3.hip); one partial per row-range workgroup, <= kNumCU of them
     const int tiles = ((din + 127) / 128) * ((dout + 255) / 256);

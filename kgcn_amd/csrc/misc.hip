@@ -72,6 +72,23 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
   }
 }
 
+// dx[b, n, :] = dx_in[b, n, :] + g[b, :]: the gradient of a tensor that feeds BOTH a GraphGather read-out and the next layer
+// (example_model/model_gin.py:45-60: every block's output is gathered and passed on) in one pass instead of a broadcast
+// pass plus autograd's accumulation pass
+__global__ __launch_bounds__(256) void gather_bwd_add_kernel(const float* __restrict__ g, const float* __restrict__ dx_in,
+                                                             long batch, int n_nodes, int d, float* __restrict__ dx) {
+  const int dv = d >> 2;
+  const long total = batch * n_nodes * dv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long bn = i / dv;
+    const int c = (int)(i - bn * dv) * 4;
+    const long b = bn / n_nodes;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(dx_in + bn * d + c);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + b * d + c);
+    *reinterpret_cast<f32x4*>(dx + bn * d + c) = a + gv;
+  }
+}
+
 constexpr int kDotBlocks = 1024;
 
 // 16-byte loads, four independent accumulators per thread and four loads of each operand in flight (the scalar form
@@ -173,6 +190,18 @@ extern "C" int kgcn_graph_gather_bwd_f32(const float* dout_grad, int64_t batch, 
     hipLaunchKernelGGL((gather_bwd_kernel<1>), dim3(grid_for(batch * n_nodes * d)), dim3(256), 0,
                        as_stream(stream), dout_grad, (long)batch, n_nodes, d, dx);
   return check_launch("gather_bwd_kernel");
+}
+
+extern "C" int kgcn_graph_gather_bwd_add_f32(const float* dout_grad, const float* dx_in, int64_t batch, int32_t n_nodes,
+                                             int32_t d, float* dx, void* stream) {
+  if (batch < 0 || n_nodes < 0 || d < 0) return fail("kgcn_graph_gather_bwd_add_f32: negative shape");
+  if (batch == 0 || d == 0 || n_nodes == 0) return 0;
+  if (!dout_grad || !dx_in || !dx) return fail("kgcn_graph_gather_bwd_add_f32: NULL operand");
+  if (d % 4 != 0 || !aligned16(dout_grad) || !aligned16(dx_in) || !aligned16(dx))
+    return fail("kgcn_graph_gather_bwd_add_f32: d must be a multiple of 4 and the tensors 16-byte aligned");
+  hipLaunchKernelGGL(gather_bwd_add_kernel, dim3(grid_for(batch * n_nodes * (d / 4))), dim3(256), 0, as_stream(stream),
+                     dout_grad, dx_in, (long)batch, n_nodes, d, dx);
+  return check_launch("gather_bwd_add_kernel");
 }
 
 extern "C" int64_t kgcn_dot_workspace_bytes(int64_t n) {

@@ -59,11 +59,14 @@ template <int VEC> struct SpVec;
 template <> struct SpVec<4> { using T = f32x4; };
 template <> struct SpVec<2> { using T = f32x2; };
 
-template <int LPR, int VEC, int NW>
+// DOT (GINAggregate backward, kgcn/layers.py:469): while the gradient tile of channel 0 is staged, the matching tile of `dotx`
+// (the layer input) is read next to it and <grad, x> of this graph is accumulated: d epsilon without a pass of its own
+// (one partial per workgroup in dot_part, fixed-order second stage).  Contiguous operands only (rhs_ld == ds).
+template <int LPR, int VEC, int NW, bool DOT = false>
 __global__ __launch_bounds__(64 * NW) void spmm_tile_kernel(
     SpmmChannels ch, const float* __restrict__ rhs, long rhs_ld, long rhs_gs, float* __restrict__ out, long out_ld,
     long out_gs, int M, int K, int ds, int nslices, float beta, const float* __restrict__ self_scale, int act,
-    const float* __restrict__ aout, int dact) {
+    const float* __restrict__ aout, int dact, const float* __restrict__ dotx = nullptr, float* __restrict__ dot_part = nullptr) {
   using V = typename SpVec<VEC>::T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // slices of one graph are neighbours in the grid: they run at the same time and share the DRAM pages of its rows
@@ -79,6 +82,7 @@ __global__ __launch_bounds__(64 * NW) void spmm_tile_kernel(
 
   // ---- stage: per channel the rhs block (vector loads, fully coalesced; times act'(aout) in a backward launch) and
   // the CSR slice -----------------------------------------------------------------------------
+  float dot_acc = 0.f;
   size_t off = 0;
   for (int c = 0; c < ch.n; ++c) {
     float* tile = reinterpret_cast<float*>(smem + off);
@@ -92,8 +96,24 @@ __global__ __launch_bounds__(64 * NW) void spmm_tile_kernel(
       if (rhs_ld == ds) {
         const V* src = reinterpret_cast<const V*>(rb);
         V* dst = reinterpret_cast<V*>(tile);
+        if constexpr (DOT) {
+          if (c == 0) {
+            const V* xs = reinterpret_cast<const V*>(dotx + (long)t * rhs_gs + col0);
 #pragma unroll 4
-        for (int i = lane; i < nv; i += NT) dst[i] = src[i];
+            for (int i = lane; i < nv; i += NT) {
+              const V v = src[i], xv = xs[i];
+              dst[i] = v;
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) dot_acc = __builtin_fmaf(v[j], xv[j], dot_acc);
+            }
+          } else {
+#pragma unroll 4
+            for (int i = lane; i < nv; i += NT) dst[i] = src[i];
+          }
+        } else {
+#pragma unroll 4
+          for (int i = lane; i < nv; i += NT) dst[i] = src[i];
+        }
       } else {
         int r = lane / dv, cc = lane - r * dv;             // (row, vector) of element i, walked without dividing
         int i = lane;
@@ -185,6 +205,24 @@ __global__ __launch_bounds__(64 * NW) void spmm_tile_kernel(
         for (int j = 0; j < VEC; ++j) acc[j] = act_fwd(acc[j], act);
       }
       stv(o, acc);
+    }
+  }
+  if constexpr (DOT) {
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) dot_acc += __shfl_xor(dot_acc, o2, 64);
+    if constexpr (NW == 1) {
+      if (lane == 0) dot_part[blockIdx.x] = dot_acc;
+    } else {
+      __syncthreads();                                  // every wave is done with the tiles: reuse the first floats
+      float* red = reinterpret_cast<float*>(smem);
+      if ((lane & 63) == 0) red[lane >> 6] = dot_acc;
+      __syncthreads();
+      if (lane == 0) {
+        float s2 = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) s2 += red[w2];
+        dot_part[blockIdx.x] = s2;
+      }
     }
   }
 }
@@ -533,7 +571,8 @@ static TilePlan tile_plan(const kgcn_csr_batch* a, int nch, const float* rhs, lo
 // out[t] = act(beta*out[t] + sum_c A_c[t] @ (rhs_c[t] (.) act'(aout[t])));  a: nch channel descriptors of one batch shape
 int launch_spmm_multi(const kgcn_csr_batch* a, int nch, const float* rhs, long rhs_ld, long rhs_gs, long rhs_cs, int d,
                       float* out, long out_ld, long out_gs, float beta, const float* self_scale, int act,
-                      const float* aout, int dact, hipStream_t stream) {
+                      const float* aout, int dact, hipStream_t stream, const float* dotx = nullptr,
+                      float* dot_part = nullptr, bool* dot_done = nullptr) {
   const int T = a->num_graphs, M = a->rows, K = a->cols;
   if (T == 0 || M == 0 || d == 0) return 0;
   if (nch > MAX_CH) {                       // more channels than one launch takes: groups of MAX_CH, accumulate
@@ -562,6 +601,33 @@ int launch_spmm_multi(const kgcn_csr_batch* a, int nch, const float* rhs, long r
     for (int c = 0; c < nch; ++c) lds += tile_chan_bytes(M, K, ds, a[c].max_nnz_per_graph);
     const int lanes = ds / plan.vec;
     const dim3 grid((unsigned)(T * plan.slices));
+    if (dotx && dot_part && dot_done && plan.vec == 4 && plan.slices == 1 && rhs_ld == ds && dact == KGCN_ACT_NONE) {
+      // <rhs, dotx> of every graph rides in the staging of channel 0 (one partial per workgroup = per graph)
+#define KGCN_TILE_DOT2(LPR, NW)                                                                                       \
+  hipLaunchKernelGGL((spmm_tile_kernel<LPR, 4, NW, true>), grid, dim3(64 * NW), lds, stream, ch, rhs, rhs_ld, rhs_gs, \
+                     out, out_ld, out_gs, M, K, ds, plan.slices, beta, self_scale, act, aout, dact, dotx, dot_part)
+#define KGCN_TILE_DOT(LPR)                                                                                            \
+  {                                                                                                                   \
+    if (plan.nw == 1) KGCN_TILE_DOT2(LPR, 1);                                                                         \
+    else {                                                                                                            \
+      static thread_local bool big = false;                                                                           \
+      if (!big) {                                                                                                     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_tile_kernel<LPR, 4, 4, true>),                   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);                            \
+        big = true;                                                                                                   \
+      }                                                                                                               \
+      KGCN_TILE_DOT2(LPR, 4);                                                                                         \
+    }                                                                                                                 \
+  }
+      if (lanes <= 8) KGCN_TILE_DOT(8)
+      else if (lanes <= 16) KGCN_TILE_DOT(16)
+      else if (lanes <= 32) KGCN_TILE_DOT(32)
+      else KGCN_TILE_DOT(64)
+#undef KGCN_TILE_DOT
+#undef KGCN_TILE_DOT2
+      *dot_done = true;
+      return check_launch("spmm_tile_kernel<dot>");
+    }
 #define KGCN_TILE2(LPR, VEC, NW)                                                                                      \
   hipLaunchKernelGGL((spmm_tile_kernel<LPR, VEC, NW>), grid, dim3(64 * NW), lds, stream, ch, rhs, rhs_ld, rhs_gs, out,   \
                      out_ld, out_gs, M, K, ds, plan.slices, beta, self_scale, act, aout, dact)
@@ -747,6 +813,57 @@ extern "C" int kgcn_gin_aggregate_f32(const kgcn_csr_batch* a_ch, int32_t num_ch
     if (rc) return rc;
   }
   return 0;
+}
+
+namespace kgcn {
+__global__ void dot_final_kernel(const float* __restrict__ part, int nparts, float* __restrict__ out);
+}
+
+extern "C" int64_t kgcn_gin_aggregate_bwd_workspace_bytes(int32_t num_graphs, int32_t n_nodes, int32_t d) {
+  const int64_t a = (int64_t)(num_graphs > 0 ? num_graphs : 1) * 4;
+  const int64_t b = kgcn_dot_workspace_bytes((int64_t)num_graphs * n_nodes * d);
+  return a > b ? a : b;
+}
+
+// Backward of GINAggregate (kgcn/layers.py:461-472) in one go: dx = sum_c (eps_c g + A_c^T g) and d eps = <g, x>.
+extern "C" int kgcn_gin_aggregate_bwd_f32(const kgcn_csr_batch* at_ch, int32_t num_channels, const float* grad, int32_t d,
+                                          const float* eps, const float* x, float* dx, float* deps, void* workspace,
+                                          int64_t workspace_bytes, void* stream) {
+  if (num_channels <= 0) return fail("kgcn_gin_aggregate_bwd_f32: num_channels=%d", num_channels);
+  if (!at_ch) return fail("kgcn_gin_aggregate_bwd_f32: at_ch is NULL");
+  for (int c = 0; c < num_channels; ++c) {
+    if (int rc = validate_csr(at_ch + c, "kgcn_gin_aggregate_bwd_f32")) return rc;
+    if (at_ch[c].rows != at_ch[c].cols) return fail("kgcn_gin_aggregate_bwd_f32: adjacency must be square");
+    if (at_ch[c].num_graphs != at_ch[0].num_graphs || at_ch[c].rows != at_ch[0].rows)
+      return fail("kgcn_gin_aggregate_bwd_f32: channel %d has a different batch shape", c);
+  }
+  hipStream_t s = as_stream(stream);
+  const int T = at_ch[0].num_graphs, N = at_ch[0].rows;
+  if (T == 0 || N == 0 || d == 0) {
+    if (deps) (void)hipMemsetAsync(deps, 0, 4, s);
+    return 0;
+  }
+  if (!grad || (!dx && !deps)) return fail("kgcn_gin_aggregate_bwd_f32: NULL operand");
+  if (deps && (!x || !workspace || workspace_bytes < kgcn_gin_aggregate_bwd_workspace_bytes(T, N, d)))
+    return fail("kgcn_gin_aggregate_bwd_f32: d eps needs x and a workspace of %lld bytes",
+                (long long)kgcn_gin_aggregate_bwd_workspace_bytes(T, N, d));
+  const long gs = (long)N * d;
+  bool dot_done = false;
+  if (dx) {
+    for (int c = 0; c < num_channels; ++c) {
+      const bool try_dot = deps && c == 0;
+      int rc = launch_spmm_multi(at_ch + c, 1, grad, d, gs, 0, d, dx, d, gs, c == 0 ? 0.f : 1.f, eps ? eps + c : nullptr,
+                                 KGCN_ACT_NONE, nullptr, KGCN_ACT_NONE, s, try_dot ? x : nullptr,
+                                 try_dot ? static_cast<float*>(workspace) : nullptr, try_dot ? &dot_done : nullptr);
+      if (rc) return rc;
+    }
+  }
+  if (!deps) return 0;
+  if (dot_done) {
+    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, s, static_cast<const float*>(workspace), T, deps);
+    return check_launch("dot_final_kernel");
+  }
+  return kgcn_dot_f32(grad, x, (int64_t)T * N * d, deps, workspace, workspace_bytes, stream);
 }
 
 extern "C" int kgcn_spmm_values_grad_f32(const kgcn_csr_batch* a, const float* grad,

@@ -106,9 +106,12 @@ class GIN(nn.Module):
             layer = self.agg[blk](layer, adj=adjs)
             layer = self.dense[2 * blk](layer)
             layer = self.dense[2 * blk + 1](layer)
-            outs.append(layer)
-        read_out = [self.gather(o) for o in outs]
-        return self.out(torch.cat(read_out, dim=1))
+            if blk == 0:                                 # read out AND passed on: one backward pass for both gradients
+                layer, pooled = ops.graph_gather_tee(layer)
+            else:
+                pooled = self.gather(layer)
+            outs.append(pooled)
+        return self.out(torch.cat(outs, dim=1))
 
 
 def masked_sigmoid_ce(logits, labels, mask, mask_label, pos_weight=None):

@@ -372,20 +372,19 @@ class _GinAggregate(torch.autograd.Function):
         g = _f32c(g, "grad")
         T, N, d = x.shape
         dx = deps = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            check(lib.kgcn_gin_aggregate_f32(adj.desc_array(True), adj.num_channels, ptr(g), d,
-                                             ptr(e) if ctx.has_eps else None, ptr(dx),
-                                             current_stream()), "kgcn_gin_aggregate_f32(bwd)")
-        if ctx.has_eps and ctx.needs_input_grad[1]:
-            # d eps_c = <g, x> for every channel (same inner product, kgcn/layers.py:469)
-            n = x.numel()
-            wsb = lib.kgcn_dot_workspace_bytes(n)
-            wsp = torch.empty((wsb // 4,), device=x.device, dtype=torch.float32)
-            one = torch.empty((1,), device=x.device, dtype=torch.float32)
-            check(lib.kgcn_dot_f32(ptr(g), ptr(x), n, ptr(one), ptr(wsp), wsb, current_stream()),
-                  "kgcn_dot_f32")
-            deps = one.expand(adj.num_channels).reshape(ctx.eps_shape).clone()
+        want_eps = ctx.has_eps and ctx.needs_input_grad[1]
+        if ctx.needs_input_grad[0] or want_eps:
+            # one call: dx = sum_c (eps_c g + A_c^T g) and d eps_c = <g, x> (the same inner product for every channel,
+            # kgcn/layers.py:469), the inner product accumulated while the gradient tiles are staged for the aggregation
+            dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+            one = torch.empty((1,), device=x.device, dtype=torch.float32) if want_eps else None
+            wsb = lib.kgcn_gin_aggregate_bwd_workspace_bytes(T, N, d)
+            wsp = torch.empty((max(wsb, 4) // 4,), device=x.device, dtype=torch.float32)
+            check(lib.kgcn_gin_aggregate_bwd_f32(adj.desc_array(True), adj.num_channels, ptr(g), d,
+                                                 ptr(e) if ctx.has_eps else None, ptr(x), ptr(dx), ptr(one), ptr(wsp), wsb,
+                                                 current_stream()), "kgcn_gin_aggregate_bwd_f32")
+            if want_eps:
+                deps = one.expand(adj.num_channels).reshape(ctx.eps_shape).clone()
         return dx, deps, None
 
 
@@ -539,6 +538,41 @@ class _Gather(torch.autograd.Function):
 
 def graph_gather(x):
     return _Gather.apply(x)
+
+
+class _GatherTee(torch.autograd.Function):
+    """(x, sum over nodes of x): for a tensor that is read out AND handed to the next layer (model_gin.py:45-60).  Backward:
+    d x = d(passed-on x) + broadcast(d pooled) in ONE pass (kgcn_graph_gather_bwd_add_f32) -- separate ops cost a broadcast
+    pass plus autograd's accumulation pass over the [B, N, D] tensor."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x, "inputs")
+        B, N, d = x.shape
+        out = torch.empty((B, d), device=x.device, dtype=torch.float32)
+        check(lib.kgcn_graph_gather_fwd_f32(ptr(x), B, N, d, ptr(out), current_stream()), "kgcn_graph_gather_fwd_f32")
+        ctx.shape = (B, N, d)
+        return x.view_as(x), out
+
+    @staticmethod
+    def backward(ctx, gx, gp):
+        B, N, d = ctx.shape
+        if gp is None:
+            return gx
+        gp = _f32c(gp, "grad")
+        dx = torch.empty((B, N, d), device=gp.device, dtype=torch.float32)
+        if gx is None or d % 4 != 0:
+            check(lib.kgcn_graph_gather_bwd_f32(ptr(gp), B, N, d, ptr(dx), current_stream()), "kgcn_graph_gather_bwd_f32")
+            return dx if gx is None else dx + gx
+        gx = _f32c(gx, "grad")
+        check(lib.kgcn_graph_gather_bwd_add_f32(ptr(gp), ptr(gx), B, N, d, ptr(dx), current_stream()),
+              "kgcn_graph_gather_bwd_add_f32")
+        return dx
+
+
+def graph_gather_tee(x):
+    """-> (x, pooled [B, D]); use the returned x downstream."""
+    return _GatherTee.apply(x)
 
 
 class _RaggedGather(torch.autograd.Function):
@@ -768,7 +802,7 @@ __all__ = ["BatchedCSR", "BatchedAdjacency", "bspmm", "bspmm_raw", "bconv", "den
            "graphconv_fused", "graphconv_fused_supported", "gin_aggregate", "graph_gather",
            "graph_maxpool", "gat", "gram", "ragged_gather", "ragged_compact_rows",
            "masked_sigmoid_ce", "masked_softmax_ce", "augment_ones",
-           "gcn_stack", "gcn_stack_supported"]
+           "gcn_stack", "gcn_stack_supported", "graph_gather_tee"]
 
 
 # -------------------------------------------------------------------------------------------------
