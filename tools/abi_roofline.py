@@ -113,6 +113,41 @@ def _cost(name, a):
     if name in ("kgcn_graph_maxpool_fwd_f32",):
         c = _csr(a[0]); b, f = _spmm(c, a[2])
         return b, f // 2, "T=%d N=%d d=%d" % (c.num_graphs, c.rows, a[2])
+    if name == "kgcn_gin_aggregate_bwd_f32":
+        c = _csr(a[0]); d = a[3]
+        b, f = _spmm(c, d, extra_reads=0)
+        extra = 4 * d * c.num_graphs * c.rows if a[7] is not None else 0          # x read once more for d eps
+        return b + extra, f * a[1] + (2 * d * c.num_graphs * c.rows if a[7] is not None else 0), \
+            "C=%d T=%d N=%d d=%d%s" % (a[1], c.num_graphs, c.rows, d, " +deps" if a[7] is not None else "")
+    if name == "kgcn_dense_wgrad_dact_f32":
+        m, din, dout = a[6], a[7], a[8]
+        return 4 * (m * din + 2 * m * dout + din * dout), 2 * m * din * dout, "m=%d %dx%d dact=%d" % (m, din, dout, a[5])
+    if name == "kgcn_graph_gather_bwd_add_f32":
+        B, N, d = a[2], a[3], a[4]
+        return 4 * (2 * B * N * d + B * d), B * N * d, "B=%d N=%d d=%d" % (B, N, d)
+    if name == "kgcn_ragged_gather_fwd_f32":
+        B, N, d = a[2], a[3], a[4]
+        return 4 * B * d, 0, "B=%d N=%d d=%d (+ valid rows)" % (B, N, d)
+    if name == "kgcn_ragged_gather_bwd_f32":
+        B, N, d, cap = a[2], a[3], a[4], a[6]
+        return 4 * (cap * d + B * d), 0, "B=%d d=%d capacity=%d" % (B, d, cap)
+    if name == "kgcn_augment_ones_f32":
+        return 4 * a[1] * (a[2] + a[5]), 0, "m=%d %d->%d" % (a[1], a[2], a[5])
+    if name == "kgcn_augment_ones_bwd_f32":
+        return 4 * a[1] * 2 * a[2], 0, "m=%d din=%d" % (a[1], a[2])
+    if name == "kgcn_masked_sigmoid_ce_f32":
+        return 4 * 4 * a[4] * a[5], 20 * a[4] * a[5], "B=%d tasks=%d" % (a[4], a[5])
+    if name == "kgcn_masked_softmax_ce_f32":
+        return 4 * 3 * a[3] * a[4], 20 * a[3] * a[4], "B=%d classes=%d" % (a[3], a[4])
+    if name == "kgcn_adam_tf_f32":
+        return 4 * 7 * a[4], 10 * a[4], "n=%d" % a[4]
+    if name == "kgcn_ragged_compact_rows_f32":
+        return 8 * a[6] * a[4], 0, "capacity=%d d=%d" % (a[6], a[4])
+    if name == "kgcn_ragged_compact_csr":
+        c = _csr(a[0])
+        return 16 * a[8] // 4 + 8 * a[5], 0, "sel=%d capacity=%d" % (a[2], a[5])
+    if name == "kgcn_ragged_plan":
+        return 16 * a[3], 0, "sel=%d" % a[3]
     if name == "kgcn_csr_gather_graphs":
         c = _csr(a[0])
         return 16 * c.max_nnz_per_graph * a[2], 0, "sel=%d" % a[2]
