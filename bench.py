@@ -876,6 +876,8 @@ def build_parser():
     ap.add_argument("--unfused", action="store_true", help="cfg2: dense GEMM + Bspmm kernels instead of the fused layer")
     ap.add_argument("--eager", action="store_true", help="cfg4 / cfg5: plain launches instead of one hipGraph per step")
     ap.add_argument("--padded", action="store_true", help="cfg4: compute all padded rows (round-2 behaviour)")
+    ap.add_argument("--side-wgrad", action="store_true",
+                    help="A/B switch: weight gradients of the big dense layers on a side stream (measured: no gain, see ops.py)")
     ap.add_argument("--no-wgrad-dact", action="store_true",
                     help="A/B switch: a stand-alone activation-backward pass in front of the first layer's weight gradient")
     ap.add_argument("--contract-first", action="store_true",
@@ -913,6 +915,9 @@ def main(argv=None):
     if args.contract_first:
         from kgcn_amd import layers as _layers
         _layers.aggregate_first = False
+    if args.side_wgrad:
+        from kgcn_amd import ops as _ops2
+        _ops2.side_stream_wgrad = True
     if args.no_wgrad_dact:
         from kgcn_amd import ops as _ops
         _ops.wgrad_dact_fusion = False

@@ -8,6 +8,8 @@ Gradients follow the reference's registered gradients:
   Bspmdt kgcn/batched_call.py:33-75 d rhs is the stacked [T*K, D] tensor
 and TF's MatMul / BiasAdd gradients for the dense part.
 """
+import contextlib
+
 import torch
 
 from . import _lib
@@ -18,6 +20,45 @@ from .batched_csr import BatchedAdjacency, BatchedCSR
 ACT_CODES = {None: 0, "none": 0, "linear": 0, "sigmoid": 1, "relu": 2, "tanh": 3}
 # A/B switch: d pre-activation inside the wide weight-gradient GEMM when the layer input needs no gradient
 wgrad_dact_fusion = True
+# OPTION (off): weight gradients of the big dense layers on a SIDE HIP stream.  In a backward pass dW / dbias hang off the
+# critical chain (d pre-activation -> d inputs -> adjoint aggregation -> the layer below); the chain's aggregation kernels are
+# bound by HBM, the weight-gradient GEMMs by the matrix pipe, so overlapping them looked free.  Measured (tools/gpu_round3_i.sh,
+# same box, two rounds): cfg4 1.756 / 1.773 ms with the side stream vs 1.747 / 1.751 without, cfg5 3.03 / 3.04 vs 2.98 / 2.99 --
+# the step runs at the package power limit (DESIGN.md lesson 4c), so concurrency buys nothing and costs the fork / join.
+# The mechanism stays for experiments: the side stream forks from the calling stream when d pre-activation is ready and is
+# joined by an autograd end-of-backward callback (inside a hipGraph capture fork and join become graph edges).
+side_stream_wgrad = False
+side_wgrad_min_rows = 16384
+_side_streams = {}
+_side_pending = set()
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+def join_side_streams():
+    """Make the current stream wait for every weight gradient still running on a side stream."""
+    for key in list(_side_pending):
+        torch.cuda.current_stream(torch.device(*key)).wait_stream(_side_streams[key])
+    _side_pending.clear()
+
+
+def _fork_side(device):
+    """-> the side stream, forked from the current one; the join is queued for the end of this backward pass."""
+    side = _side_stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    key = (device.type, device.index)
+    if key not in _side_pending:
+        _side_pending.add(key)
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+        except RuntimeError:                     # not inside a backward pass (a direct call of .backward of the Function)
+            pass
+    return side
 
 
 def act_code(activation):
@@ -275,6 +316,19 @@ class _Dense(torch.autograd.Function):
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.bias_shape is not None and ctx.needs_input_grad[2]
         if need_w or need_b:
+            side = None
+            if side_stream_wgrad and m >= side_wgrad_min_rows:
+                side = _fork_side(gy.device)
+                for t in (gy, x2d, yact):
+                    t.record_stream(side)        # the caching allocator must not hand their memory out while `side` reads it
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                dw, db = _Dense._wgrad(ctx, x2d, w, gy, yact, m, din, dout, need_w, need_b, fuse_dact)
+        return dx, dw, db, None
+
+    @staticmethod
+    def _wgrad(ctx, x2d, w, gy, yact, m, din, dout, need_w, need_b, fuse_dact):
+        db = None
+        if True:
             wsb = lib.kgcn_dense_wgrad_workspace_bytes(m, din, dout)
             wsp = torch.empty((max(wsb, 4) // 4,), device=gy.device, dtype=torch.float32)
             dw = torch.empty_like(w) if need_w else None
@@ -288,7 +342,7 @@ class _Dense(torch.autograd.Function):
                       "kgcn_dense_wgrad_f32")
             if db is not None:
                 db = db.reshape(ctx.bias_shape)
-        return dx, dw, db, None
+        return dw, db
 
 
 def dense(x2d, w, bias=None, activation=None):

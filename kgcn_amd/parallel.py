@@ -70,6 +70,9 @@ class GradBucket:
         Four launches per step whatever the number of parameters: one multi-tensor pack, one scale, the collective,
         one multi-tensor unpack -- the payload is latency-bound, so launches are what it costs.  Capturable: inside
         a hipGraph capture the collective is recorded on the capturing stream like any kernel."""
+        if torch.cuda.is_available():
+            from . import ops
+            ops.join_side_streams()
         grads = [p.grad for p in self.params]
         if any(g is None for g in grads):
             raise RuntimeError("GradBucket: a parameter has no gradient")

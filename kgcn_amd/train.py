@@ -40,6 +40,8 @@ class FlatParameters:
 
     def pack_grads(self):
         """flat gradient buffer <- the parameters' .grad tensors (ONE multi-tensor copy launch)."""
+        from . import ops
+        ops.join_side_streams()                 # weight gradients of the big layers may still run on the side stream
         grads = [p.grad for p in self.params]
         if any(g is None for g in grads):
             raise RuntimeError("FlatParameters: a parameter has no gradient")
