@@ -1,0 +1,47 @@
+"""bench.py on the GPU box at small sizes: every configuration prints ONE JSON line with the contract's fields, a roofline
+object and (cfg2, N = 1) the CPU baseline -- so that a change in the product cannot silently break the line the driver parses."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIELDS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+          "dtype", "data", "config", "roofline")
+
+
+def _bench(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    for f in FIELDS:
+        assert f in res, f
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["ms_per_step"] > 0 and res["unit"] == "graphs/sec"
+    assert "workload" in res["config"] and res["config"]["library"]["dev_overrides"] == {}
+    return res
+
+
+def test_bench_cfg2_line_small():
+    res = _bench("--graphs", "4096", "--steps", "3", "--warmup", "1")
+    rf = res["roofline"]
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and rf["peak"] == 8000.0
+    assert rf["spmm_kernel"]["forward"]["frac"] > 0
+    cb = res["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+
+
+@pytest.mark.parametrize("cfg,extra", [("cfg4", ["--graphs", "3000", "--batch", "256"]), ("cfg4", ["--graphs", "3000", "--batch", "256", "--padded"]),
+                                       ("cfg4", ["--graphs", "3000", "--batch", "256", "--eager"]), ("cfg5", ["--graphs", "2000"]),
+                                       ("cfg3", ["--graphs", "32"])])
+def test_bench_model_configs_small(cfg, extra):
+    res = _bench("--config", cfg, "--steps", "3", "--warmup", "1", *extra)
+    assert cfg in res["config"]["workload"]
+    rf = res["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["frac"] is not None and rf["per_call_table"]
+    assert rf["unpriced_calls"] == [], rf["unpriced_calls"]

@@ -187,8 +187,8 @@ def instrument():
     lib = _lib.lib
     for name in _lib.SIGNATURES:
         fn = getattr(lib, name)
-        if name.endswith("_bytes") or name in ("kgcn_abi_version", "kgcn_last_error", "kgcn_build_arch",
-                                               "kgcn_graphconv_fused_supported"):
+        if name.endswith(("_bytes", "_supported", "_floats")) or name in ("kgcn_abi_version", "kgcn_last_error",
+                                                                          "kgcn_build_arch"):
             continue
 
         def wrapper(*a, _fn=fn, _name=name):
