@@ -15,6 +15,9 @@ already set RANK / WORLD_SIZE it just runs as the rank it is.  Rank 0 prints ONE
     graphs per GPU (random spanning tree + 3 extra edges, symmetrised, + self loops => nnz = 100 exactly), 64-dim
     features, one adjacency channel, kernel [64,64].  One step = kgcn_amd.layers.GraphConv forward, then backward
     producing dX, dW, dbias (+ for N > 1 one RCCL all-reduce of the flat [dW, dbias] bucket).
+--config cfg1 (BASELINE config 1, the reference's own CPU-runnable case): example_model/model.py on example_jbl/synthetic.jbl
+    (tiled to --graphs (20,000) graphs resident), one step = one mini-batch of --batch (30, example_config/synth.json) graphs:
+    device-side assembly, forward, masked softmax CE, backward, all-reduce, TF-Adam as one hipGraph replay.
 --config cfg3 (BASELINE config 3): example_model/sparse.py on the kgcn-sparse path: --graphs (128) molecules per GPU as ONE
     block-diagonal adjacency, 128-dim features, widths 256; one step = forward, summed sparse softmax CE, backward,
     all-reduce, TF-Adam on the resident batch.
@@ -718,6 +721,59 @@ class Cfg5(_ModelStep):
         return config, self.model_roofline(), {}
 
 
+class Cfg1(_ModelStep):
+    """BASELINE config 1 (example_jbl/synthetic.jbl + example_model/model.py, example_config/synth.json: batch 30): the
+    reference's own CPU-runnable training case -- 3 x GraphConv(50), BN, GraphDense(50), gather, Dense(2), masked softmax CE,
+    TF-Adam -- on the shipped 200 graphs (tests/golden/g1_synthetic_raw.npz = the converted .jbl), tiled to --graphs graphs
+    resident in HBM; one step = one mini-batch of --batch (30) graphs assembled on the device."""
+    name = "cfg1"
+
+    def __init__(self, args, ctx):
+        import torch
+        from kgcn_amd import data_util as D, models
+        self.args, self.ctx = args, ctx
+        z = np.load(os.path.join(ROOT, "tests", "golden", "g1_synthetic_raw.npz"))
+        G = args.graphs or 20_000
+        rep = -(-G // z["dense_adj"].shape[0])
+        dense = np.tile(z["dense_adj"].astype(np.int64), (rep, 1, 1))[:G]
+        feats = np.tile(z["feature"], (rep, 1, 1)).astype(np.float32)[:G]
+        labels = np.tile(z["label"], (rep, 1)).astype(np.float32)[:G]
+        chans, _ = D.build_adjs({"dense_adj": dense, "max_node_num": 10})
+        self.ds = D.DeviceGraphDataset(chans, feats, device=ctx.device)
+        self.G, self.B = G, args.batch or 30
+        B = self.B
+        self.lab_d = torch.from_numpy(labels).to(ctx.device)
+        self.rng = np.random.default_rng(ctx.rank)
+        torch.manual_seed(0)
+        model = models.GCN(1, 2).to(ctx.device)
+        sb = self.ds.static_batch(B)
+        sb.load(np.arange(B))
+        model(sb.features, sb.adjacency)
+        self.lab_s = torch.zeros((B, 2), device=ctx.device)
+        self.it_s = torch.zeros(B, device=ctx.device, dtype=torch.int64)
+        self.units_local, self.units_global = B, B * ctx.world
+        self._finish(model, models.masked_softmax_ce, sb, self.lab_s, torch.ones(B, device=ctx.device))
+
+    def next_batch(self):
+        torch = self.ctx.torch
+        idx = self.rng.integers(0, self.G, size=self.B)
+        self.it_s.copy_(torch.from_numpy(idx), non_blocking=True)
+        self.sb.load(idx)
+        torch.index_select(self.lab_d, 0, self.it_s, out=self.lab_s)
+
+    def report(self, evs):
+        from kgcn_amd import layers
+        rows = self.B * 10
+        config = {"workload": "cfg1: example_model/model.py training step (3 x GraphConv(50) sigmoid, BN, GraphDense(50), gather, "
+                              "Dense(2); masked softmax CE; TF-Adam) on example_jbl/synthetic.jbl (200 graphs of 10 nodes, 3 "
+                              "features) tiled to %d graphs resident per GPU, batch %d per GPU assembled on the device, %s, %s"
+                              % (self.G, self.B, "cross-layer stack kernels" if layers.stack_fusion and rows <=
+                                 layers.stack_fusion_max_rows else "per-layer kernels",
+                                 "eager launches" if self.args.eager else "one hipGraph per step"),
+                  "graphs_resident_per_gpu": self.G, "batch_per_gpu": self.B, "n_nodes": 10, "features": 3}
+        return config, self.model_roofline(), {}
+
+
 class Cfg3(_ModelStep):
     """BASELINE config 3 (example_config/sparse.json, example_model/sparse.py): the kgcn-sparse path -- ONE block-diagonal
     [sum N x sum N] adjacency per batch of 128 molecules (20..50 atoms), 128-dim features, 3 x GraphConv(256) relu,
@@ -795,6 +851,7 @@ class _SparseAdapter:
 # --dry: the multi-rank path without the kernels (launcher + bucket exchange), any device / backend
 # ---------------------------------------------------------------------------------------------
 PARAM_SHAPES = {
+    "cfg1": [(3, 50), (1, 50), (50, 50), (1, 50), (50, 50), (1, 50), (50,), (50,), (50, 50), (50,), (50, 2), (2,)],
     "cfg2": [(64, 64), (1, 64)],
     "cfg3": [(128, 256), (1, 256), (256, 256), (1, 256), (256, 256), (1, 256), (256, 256), (256,), (256,), (256,), (256, 10),
              (10,)],
@@ -867,10 +924,10 @@ def build_parser():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", choices=("cfg2", "cfg3", "cfg4", "cfg5"), default="cfg2")
+    ap.add_argument("--config", choices=("cfg1", "cfg2", "cfg3", "cfg4", "cfg5"), default="cfg2")
     ap.add_argument("--graphs", type=int, default=0,
                     help="cfg2 / cfg5: graphs per GPU per step (100,000 / 20,000); cfg4: molecules resident per GPU (125,000)")
-    ap.add_argument("--batch", type=int, default=0, help="cfg4: molecules per GPU per step (4,096)")
+    ap.add_argument("--batch", type=int, default=0, help="cfg4: molecules per GPU per step (4,096); cfg1: graphs per step (30)")
     ap.add_argument("--normalize", action="store_true", help="cfg2: Kipf-normalised adjacency values")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="cfg2: dense GEMM + Bspmm kernels instead of the fused layer")
@@ -921,7 +978,7 @@ def main(argv=None):
     if args.no_wgrad_dact:
         from kgcn_amd import ops as _ops
         _ops.wgrad_dact_fusion = False
-    wl = Dry(args, ctx) if args.dry else {"cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4, "cfg5": Cfg5}[args.config](args, ctx)
+    wl = Dry(args, ctx) if args.dry else {"cfg1": Cfg1, "cfg2": Cfg2, "cfg3": Cfg3, "cfg4": Cfg4, "cfg5": Cfg5}[args.config](args, ctx)
 
     ev = [[ctx.event() for _ in range(wl.n_events)] for _ in range(args.steps)] if ctx.on_gpu else None
     # setup: prime the caching allocator, the lazily built A^T / row-padded containers, the LDS attributes

@@ -246,13 +246,29 @@ __global__ __launch_bounds__(256) void stack_bwd_kernel(StackArgs a, const int* 
     }
     sk_load_csr(rowptr_t, cv_t, t, N, a.max_nnz, rp, ent);
     const int nvalid = enabled ? enabled[t] : N;
+    // the saved output of the LAST layer; every other saved tensor is loaded once, as the input of the layer above it, and
+    // then serves as the output of the layer below (Yt / Ht swap roles)
+    sk_load_tile(a.out[a.nl - 1] + t * N * dl, N, dl, Yt);
     for (int l = a.nl - 1; l >= 0; --l) {
       const int din = a.din[l], dout = a.dout[l], act = a.act[l], kind = a.kind[l];
       const float* W = wl + a.woff[l];
       float* G = ga + a.goff[l];
-      __syncthreads();                                 // Dy of this layer complete; tiles of the previous iteration free
-      sk_load_tile(a.out[l] + t * N * dout, N, dout, Yt);
-      sk_load_tile(l == 0 ? x + t * N * a.din[0] : a.out[l - 1] + t * N * a.dout[l - 1], N, l == 0 ? a.din[0] : a.dout[l - 1], Ht);
+      // this layer's input tile: requested now (registers), landed in LDS behind the first barrier
+      const float* hsrc = l == 0 ? x + t * N * a.din[0] : a.out[l - 1] + t * N * a.dout[l - 1];
+      const int hd = l == 0 ? a.din[0] : a.dout[l - 1];
+      float hp[8];                                     // N <= 32: at most 8 tile elements per thread
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = threadIdx.x + 256 * q;
+        const int r = i >> 6, c = i & 63;
+        hp[q] = (i < N * 64 && c < hd) ? hsrc[(long)r * hd + c] : 0.f;
+      }
+      __syncthreads();                                 // Dy and Yt of this layer complete; tiles of the previous iteration free
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = threadIdx.x + 256 * q;
+        if (i < N * 64) Ht[i] = hp[q];
+      }
       __syncthreads();
       if (kind == 2) {
         // y = act(sc * x + sh) on valid rows; d sc x-term: dgamma = sum dpre * xhat, xhat = (x - mean) rstd = (sc x + sh - beta) / gamma
@@ -275,6 +291,7 @@ __global__ __launch_bounds__(256) void stack_bwd_kernel(StackArgs a, const int* 
         G[256 + w * 64 + j] += s0;
         __syncthreads();
         for (int i = threadIdx.x; i < N * 64; i += 256) Dy[i] = Tt[i];
+        { float* tmp = Yt; Yt = Ht; Ht = tmp; }        // this layer's input is the output of the layer below
         continue;
       }
       // d pre-activation into Yt (in place)
@@ -330,6 +347,7 @@ __global__ __launch_bounds__(256) void stack_bwd_kernel(StackArgs a, const int* 
           if (r < N) Dy[r * SK_LD + j] = di[q];
         }
       }
+      { float* tmp = Yt; Yt = Ht; Ht = tmp; }          // this layer's input is the output of the layer below
     }
     if (dx) {
       __syncthreads();

@@ -304,6 +304,17 @@ class StaticBatch:
         self._sel_dev = torch.zeros(T, dtype=torch.int32, device=dataset.channels[0].rowptr.device)
         self._idx_dev = torch.zeros(T, dtype=torch.int64, device=self._sel_dev.device)
 
+    def reset_usage(self):
+        """Forget which containers a kernel has received so far (their descriptors are rebuilt on demand): called before the
+        warm-up of a capture, so that prune_unused() keeps exactly the containers the CAPTURED step reads -- a model whose
+        first call took another route (Keras-style build, layer by layer) must not keep refilling that route's containers."""
+        for pairs in self._sources:
+            for _, st in pairs:
+                st._desc = None
+        self.adjacency._desc_arr = None
+        self.adjacency._desc_arr_t = None
+        self._pruned = False
+
     def prune_unused(self):
         """After the consumer (e.g. a captured hipGraph) has run once: refill only the containers whose
         descriptor a kernel actually received -- a fused-kernel model reads the two row-padded containers,

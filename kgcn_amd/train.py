@@ -141,6 +141,8 @@ class GraphedTrainStep:
         self.labels, self.mask, self.kw = labels, mask, fwd_kwargs
         self.cost_sum = self.logits = None
         # warm-up and capture must not train: model and optimiser state are restored afterwards
+        if hasattr(static_batch, "reset_usage"):
+            static_batch.reset_usage()
         saved = [t.detach().clone() for t in list(optimizer.params) + optimizer.m + optimizer.v]
         saved_t = optimizer.t
         side = torch.cuda.Stream()

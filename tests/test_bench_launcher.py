@@ -26,7 +26,7 @@ def _run(*args, timeout=240):
                           stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=ROOT)
 
 
-@pytest.mark.parametrize("config,scaling,graphs", [("cfg2", "weak", 1000), ("cfg4", "weak", 0), ("cfg2", "strong", 25)])
+@pytest.mark.parametrize("config,scaling,graphs", [("cfg2", "weak", 1000), ("cfg4", "weak", 0), ("cfg2", "strong", 25), ("cfg1", "weak", 0)])
 def test_bench_spawns_its_ranks_and_prints_one_line(config, scaling, graphs):
     args = ["--gpus", "2", "--dry", "--device", "cpu", "--backend", "gloo", "--steps", "3", "--warmup", "1",
             "--config", config, "--scaling", scaling]

@@ -38,7 +38,7 @@ def test_bench_cfg2_line_small():
 
 @pytest.mark.parametrize("cfg,extra", [("cfg4", ["--graphs", "3000", "--batch", "256"]), ("cfg4", ["--graphs", "3000", "--batch", "256", "--padded"]),
                                        ("cfg4", ["--graphs", "3000", "--batch", "256", "--eager"]), ("cfg5", ["--graphs", "2000"]),
-                                       ("cfg3", ["--graphs", "32"])])
+                                       ("cfg3", ["--graphs", "32"]), ("cfg1", ["--graphs", "400"]), ("cfg1", ["--graphs", "2000", "--batch", "1024"])])
 def test_bench_model_configs_small(cfg, extra):
     res = _bench("--config", cfg, "--steps", "3", "--warmup", "1", *extra)
     assert cfg in res["config"]["workload"]

@@ -37,8 +37,12 @@ def short(n):
 
 
 def timed(rows):
-    """rows: list in start order -> the dispatches of the timed steps."""
-    per_step = max(1, round(len(rows) / PASSES))
+    """rows: list in start order -> (dispatches per step, the dispatches of the timed steps).  A kernel that ran fewer
+    than PASSES / 2 times in the whole run belongs to set-up (model build, data generation, graph capture warm-up), not to
+    the steady-state step: per_step = 0."""
+    per_step = round(len(rows) / PASSES)
+    if per_step < 1:
+        return 0, []
     return per_step, rows[-per_step * STEPS:]
 
 
@@ -51,14 +55,15 @@ for db in sorted(glob.glob(os.path.join(src, "*", "*.db"))):
                                                     "from kernels order by start"):
         per.setdefault(short(name), []).append(d / 1e3)
         meta[short(name)] = (vg, ag, lds)
-    dur[sub] = {k: timed(v) for k, v in per.items()}
+    dur[sub] = {k: timed(v) for k, v in per.items() if timed(v)[0] > 0}
     if sub != "stats":
         rows = {}
         for k, c, start, v in cur.execute("select kernel_name, counter_name, start, value from counters_collection order by start"):
             rows.setdefault((short(k), c), []).append(v)
         for (k, c), vs in rows.items():
-            _, t = timed(vs)
-            pmc.setdefault(k, {})[c] = sum(t) / len(t)
+            ps, t = timed(vs)
+            if ps > 0:
+                pmc.setdefault(k, {})[c] = sum(t) / len(t)
 
 avg = lambda xs: sum(xs) / len(xs)
 st = dur.get("stats", {})
