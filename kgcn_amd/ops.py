@@ -358,6 +358,8 @@ def graphconv_fused_supported(csr, din, dout):
     whose per-graph entry count is bounded by max_nnz + 4 * rows."""
     if csr.rows != csr.cols or csr.rows > BatchedCSR.PAD_COL:
         return False
+    if csr.row_pad == 0 and csr._p4 is None and csr._make_p4 is None and csr._host is None:
+        return False                    # no way to the row-padded copy (ragged-compact / value-substituted containers)
     bound = csr._p4.max_nnz if csr._p4 is not None else csr.max_nnz + 4 * csr.rows
     return bool(lib.kgcn_graphconv_fused_supported(csr.rows, din, dout, bound))
 

@@ -256,3 +256,18 @@ def test_graphconv_aggregate_first_equals_contract_first(B, N, din, dout, C, act
         close(db[c], rdb[c], atol=1e-6, rel=3e-6, what="aggregate-first dbias channel %d" % c)
     close(out, res[False][0], atol=3e-6, rel=1e-6, what="aggregate-first vs contract-first fwd")
     close(dx, res[False][1], atol=2e-6, rel=5e-6, what="aggregate-first vs contract-first d inputs")
+
+
+def test_tiny_ragged_batch_takes_the_unfused_route():
+    """A ragged-compact batch of fewer than 32 rows is a one-graph batch whose shape would fit the fused GraphConv kernels, but
+    its container has no row-padded copy: it must go through the dense + row-chunk aggregation route (found by tools/fuzz_gpu.py)."""
+    from kgcn_amd import layers, ragged
+    rng = np.random.default_rng(0)
+    x, adjs, _, _, _, sizes = tox21_like_batch(rng, B=3, N=8, F=5, T=2)
+    rb = ragged.compact(t32(x), adjs, sizes)
+    assert rb.capacity <= 32
+    conv = layers.GraphConv(7, 1, activation="sigmoid")
+    out = conv(rb.features, adj=rb)
+    ref = 1 / (1 + np.exp(-K.graphconv_fwd_fast(x, adjs, [conv.w[0].detach().cpu().numpy()], [conv.bias[0].detach().cpu().numpy()])))
+    valid = (np.arange(8)[None, :] < sizes[:, None])[:, :, None]
+    close(rb.expand(out, fill="zero").cpu().numpy() * valid, ref * valid, atol=2e-6, what="tiny ragged GraphConv")

@@ -164,6 +164,66 @@ for case in range(CASES):
     ctx = ("dense+act", M3, di3, do3, act3)
     check("dense act fwd", y3, a3, ctx=ctx); check("dense act dx", tx3.grad, gz3 @ w3.astype(np.float64).T, ctx=ctx)
     check("dense act dw", tw3.grad, x3.astype(np.float64).T @ gz3, rel=5e-5, ctx=ctx); check("dense act db", tb3.grad, gz3.sum(0), rel=5e-5, ctx=ctx)
+    # ---- round 3: ragged-compact layer chain vs the oracle's PADDED formulation ---------------------------------------------
+    from kgcn_amd import ragged as RG
+    Br, Nr = int(rng.integers(1, 60)), int(rng.integers(2, 40))
+    Fr, W1, W2 = int(rng.integers(1, 90)), int(rng.choice([7, 50, 64, 130, 256])), int(rng.choice([5, 50, 64]))
+    szr = rng.integers(0, Nr + 1, size=Br)
+    adjr, xr = [], np.zeros((Br, Nr, Fr), np.float32)
+    for b_, n_ in enumerate(szr):
+        if n_ == 0:
+            adjr.append([(np.zeros((0, 2), np.int32), np.zeros(0, np.float32), [Nr, Nr])]); continue
+        a_ = (rng.random((n_, n_)) < 0.3) * rng.standard_normal((n_, n_))
+        ii = np.argwhere(a_ != 0).astype(np.int32)
+        adjr.append([(ii, a_[a_ != 0].astype(np.float32), [Nr, Nr])])
+        xr[b_, :n_] = rng.standard_normal((n_, Fr))
+    actr = [None, "sigmoid", "relu", "tanh"][int(rng.integers(0, 4))]
+    layers.aggregate_first = bool(rng.integers(0, 2))
+    c1, d1 = layers.GraphConv(W1, 1, activation=actr), layers.GraphDense(W2, activation="sigmoid")
+    rb = RG.compact(t32(xr), adjr, szr)
+    h_r = d1(c1(rb.features, adj=rb))
+    pooled_r = layers.GraphGather()(h_r, ragged=rb)
+    w1n, b1n = rng.standard_normal((1, W1)).astype(np.float32) * 0.2, None
+    with torch.no_grad():
+        c1.bias[0].copy_(t32(w1n)); d1.bias.copy_(t32(rng.standard_normal(W2) * 0.2))
+    txr = t32(xr).requires_grad_(True)
+    rb = RG.compact(txr, adjr, szr)
+    pooled_r = layers.GraphGather()(d1(c1(rb.features, adj=rb)), ragged=rb)
+    gr = rng.standard_normal((Br, W2)).astype(np.float32)
+    pooled_r.backward(t32(gr))
+    p_ = lambda t: t.detach().cpu().numpy()
+    f_a = {None: lambda z: z, "sigmoid": lambda z: 1 / (1 + np.exp(-z)), "relu": lambda z: np.maximum(z, 0), "tanh": np.tanh}[actr]
+    pre1 = K.graphconv_fwd_fast(xr, adjr, [p_(c1.w[0])], [p_(c1.bias[0])])
+    a1 = f_a(pre1)
+    z2 = K.graphdense_fwd(a1, p_(d1.kernel), p_(d1.bias)); a2 = 1 / (1 + np.exp(-z2))
+    ctx = ("ragged chain", Br, Nr, Fr, W1, W2, actr, layers.aggregate_first)
+    check("ragged pooled", pooled_r, K.gather_fwd(a2), ctx=ctx)
+    if actr != "relu":                       # relu masks of pre-activations near 0 may differ between fp32 and fp64
+        dz2 = K.gather_bwd(gr, Nr) * a2 * (1 - a2)
+        da1, dk2, dc2 = K.graphdense_bwd(a1, p_(d1.kernel), dz2)
+        dpre1 = da1 * {None: 1.0, "sigmoid": a1 * (1 - a1), "tanh": 1 - a1 ** 2}[actr]
+        dxr, dw1, db1 = K.graphconv_bwd_fast(xr, adjr, [p_(c1.w[0])], dpre1)
+        check("ragged dK2", d1.kernel.grad, dk2, rel=5e-5, ctx=ctx); check("ragged dc2", d1.bias.grad, dc2, rel=5e-5, ctx=ctx)
+        check("ragged dW1", c1.w[0].grad, dw1[0], rel=5e-5, ctx=ctx); check("ragged db1", c1.bias[0].grad, db1[0], rel=5e-5, ctx=ctx)
+        check("ragged dx", txr.grad, dxr, rel=5e-5, ctx=ctx)
+    layers.aggregate_first = True
+    # ---- round 3: GINAggregate with epsilon (d eps rides in the adjoint aggregation) -------------------------------------------
+    Dg = int(rng.choice([4, 8, 50, 64, 128, 256, int(rng.integers(1, 130))]))
+    xg = rng.standard_normal((T, N, Dg)).astype(np.float32)
+    gg = rng.standard_normal((T, N, Dg)).astype(np.float32)
+    gin = layers.GINAggregate(1)
+    txg2 = t32(xg).requires_grad_(True)
+    gin(txg2, adj=csr)
+    with torch.no_grad():
+        gin.epsilon[0].fill_(0.3)
+    og2 = gin(txg2, adj=csr)
+    og2.backward(t32(gg))
+    check("gin fwd", og2, K.gin_fwd(xg, adjs, [0.3]), ctx=("gin", N, Dg, T))
+    dxg2, deps2 = K.gin_bwd(xg, adjs, [0.3], gg)
+    check("gin dx", txg2.grad, dxg2, ctx=("gin", N, Dg, T))
+    sc_ = float(np.abs(gg.astype(np.float64) * xg).sum()) + 1e-30
+    if abs(float(gin.epsilon[0].grad) - float(deps2[0])) > 3e-6 * sc_:
+        fails.append(("gin deps", (N, Dg, T), float(gin.epsilon[0].grad), float(deps2[0])))
     # ---- device-side COO pack -----------------------------------------------------------------------------------------------
     Tp, Np, nz = int(rng.integers(1, 60)), int(rng.integers(1, 65)), int(rng.integers(0, 4000))
     gp, rp_, cp = rng.integers(0, Tp, nz), rng.integers(0, Np, nz), rng.integers(0, Np, nz)
