@@ -224,6 +224,42 @@ for case in range(CASES):
     sc_ = float(np.abs(gg.astype(np.float64) * xg).sum()) + 1e-30
     if abs(float(gin.epsilon[0].grad) - float(deps2[0])) > 3e-6 * sc_:
         fails.append(("gin deps", (N, Dg, T), float(gin.epsilon[0].grad), float(deps2[0])))
+    # ---- round 3: cross-layer stack (model.py network) vs the same modules layer by layer -------------------------------------
+    from kgcn_amd import models as MD
+    Bs, Ns = int(rng.integers(1, 50)), int(rng.integers(1, 33))
+    Fs, Ws = int(rng.integers(1, 65)), int(rng.integers(1, 57))
+    szs = rng.integers(0, Ns + 1, size=Bs)
+    adjs_s, xs = [], np.zeros((Bs, Ns, Fs), np.float32)
+    for b_, n_ in enumerate(szs):
+        if n_ == 0:
+            adjs_s.append([(np.zeros((0, 2), np.int32), np.zeros(0, np.float32), [Ns, Ns])]); continue
+        a_ = (rng.random((n_, n_)) < 0.3) * rng.standard_normal((n_, n_))
+        adjs_s.append([(np.argwhere(a_ != 0).astype(np.int32), a_[a_ != 0].astype(np.float32), [Ns, Ns])])
+        xs[b_, :n_] = rng.standard_normal((n_, Fs))
+    use_en = bool(rng.integers(0, 2))
+    outs_s = {}
+    for fused_s in (True, False):
+        layers.stack_fusion = fused_s
+        torch.manual_seed(case)
+        md = MD.GCN(1, 2).to(dev)
+        for m_ in (md.conv1, md.conv2, md.conv3, md.dense):
+            m_.output_dim = Ws
+        txs = t32(xs).requires_grad_(True)
+        en_s = torch.as_tensor(szs) if use_en else None
+        md(txs, adjs_s, enabled_node_nums=en_s)
+        with torch.no_grad():
+            gen_ = torch.Generator(device="cpu").manual_seed(case)
+            for p__ in md.parameters():
+                if p__.dim() == 1 or p__.shape[0] == 1:
+                    p__.copy_(torch.randn(p__.shape, generator=gen_).to(dev) * 0.2 + (1.0 if p__ is md.bn.gamma else 0.0))
+            md.bn.moving_mean.copy_(torch.randn(Ws, generator=gen_).to(dev) * 0.1)
+            md.bn.moving_variance.copy_(torch.rand(Ws, generator=gen_).to(dev) + 0.5)
+        lg = md(txs, adjs_s, enabled_node_nums=en_s)
+        lg.sum().backward()
+        outs_s[fused_s] = [lg.detach(), txs.grad] + [p__.grad for p__ in md.parameters()]
+    layers.stack_fusion = True
+    for i_, (a_, b_) in enumerate(zip(outs_s[True], outs_s[False])):
+        check("stack vs layers #%d" % i_, a_, b_.cpu().numpy(), rel=5e-5, atol=5e-6, ctx=("stack", Bs, Ns, Fs, Ws, use_en))
     # ---- device-side COO pack -----------------------------------------------------------------------------------------------
     Tp, Np, nz = int(rng.integers(1, 60)), int(rng.integers(1, 65)), int(rng.integers(0, 4000))
     gp, rp_, cp = rng.integers(0, Tp, nz), rng.integers(0, Np, nz), rng.integers(0, Np, nz)
