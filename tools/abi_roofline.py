@@ -148,6 +148,21 @@ def _cost(name, a):
         return 16 * a[8] // 4 + 8 * a[5], 0, "sel=%d capacity=%d" % (a[2], a[5])
     if name == "kgcn_ragged_plan":
         return 16 * a[3], 0, "sel=%d" % a[3]
+    if name in ("kgcn_gcn_stack_fwd_f32", "kgcn_gcn_stack_bwd_f32"):
+        bwd = name.endswith("bwd_f32")
+        c = _csr(a[0])
+        layers_arr, nl = a[3], a[4]
+        rows = c.num_graphs * c.rows
+        by = 4 * rows * layers_arr[0].din + _csr_bytes(c)
+        fl = 0
+        for l in range(nl):
+            L = layers_arr[l]
+            by += 4 * rows * L.dout * (2 if bwd else 1)              # saved outputs: written once, read once
+            if L.kind != 2:
+                fl += 2 * rows * L.din * L.dout * (3 if bwd else 1)
+            if L.kind == 0:
+                fl += 2 * c.nnz * L.dout
+        return by, fl, "T=%d N=%d layers=%d %s" % (c.num_graphs, c.rows, nl, "bwd" if bwd else "fwd")
     if name == "kgcn_csr_gather_graphs":
         c = _csr(a[0])
         return 16 * c.max_nnz_per_graph * a[2], 0, "sel=%d" % a[2]
