@@ -402,6 +402,11 @@ int kgcn_masked_sigmoid_ce_f32(const float* logits, const float* labels, const f
 int kgcn_masked_softmax_ce_f32(const float* logits, const float* labels, const float* mask, int64_t batch, int32_t classes,
                                float* cost, float* dlogits, float* sums, void* workspace, int64_t workspace_bytes,
                                void* stream);
+/* example_model/sparse.py:112-113: tf.nn.sparse_softmax_cross_entropy_with_logits -- label_idx [batch] int64 class indices
+ * instead of dense labels; mask may be NULL (all ones); outputs as above (sums[0] = the reduce_sum the model minimises). */
+int kgcn_sparse_softmax_ce_f32(const float* logits, const int64_t* label_idx, const float* mask, int64_t batch,
+                               int32_t classes, float* cost, float* dlogits, float* sums, void* workspace,
+                               int64_t workspace_bytes, void* stream);
 /* tf.train.AdamOptimizer(lr) (kgcn/core.py:124) over one flat buffer of n floats, with t = *step_counter + 1:
  *   lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t) (fp64);  m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g^2;
  *   params -= lr_t m / (sqrt(v) + eps)

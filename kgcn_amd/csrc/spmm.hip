@@ -251,13 +251,15 @@ struct RowWalk {
 // LPR == 64: a WAVE owns the 8-row chunk, so row offsets, entry indices, columns and values are wave-uniform: they are
 // pulled into SGPRs with v_readlane (no ds_bpermute), loop control and address bases run on the scalar unit, and entries
 // past the end of a row are skipped by scalar branches.
-template <int VEC, int LPR, bool DACT>
+// ROWS: consecutive rows per lane group: 8 for big matrices (amortises the two index loads), 2 for small ones (a matrix of a
+// few thousand rows -- the 128-molecule batch of the kgcn-sparse path -- is latency-bound: 8 sequential rows per wave on
+// 140 workgroups took 16 us for 4.5 MB; with 2 rows per group four times as many waves share the latency)
+template <int VEC, int LPR, bool DACT, int ROWS>
 __global__ __launch_bounds__(256) void spmm_rows_kernel(
     SpmmChannels ch, const float* __restrict__ rhs, int rhs_ld, long rhs_gs, float* __restrict__ out, int out_ld,
     long out_gs, int M, long total_rows, int d, float beta, const float* __restrict__ self_scale, int act,
     const float* __restrict__ aout, int dact, int blocks_per_xcd) {
   using V = typename SpVec<VEC>::T;
-  constexpr int ROWS = 8;
   constexpr int GPB = 256 / LPR;
   constexpr bool WAVE = LPR == 64;
   auto ldv = [](const float* p) { return *reinterpret_cast<const V*>(p); };
@@ -669,17 +671,23 @@ int launch_spmm_multi(const kgcn_csr_batch* a, int nch, const float* rhs, long r
     if (vec && total_rows < (1L << 31) && rhs_ld < (1L << 31) && out_ld < (1L << 31)) {
       const int lanes = d / vec;
       const int lpr = lanes <= 16 ? 16 : (lanes <= 32 ? 32 : 64);
-      const long rows_per_block = (long)(256 / lpr) * 8;
+      const int rows_per_group = total_rows >= 32768 ? 8 : 2;
+      const long rows_per_block = (long)(256 / lpr) * rows_per_group;
       const long nblocks = (total_rows + rows_per_block - 1) / rows_per_block;
       const int per_xcd = (int)((nblocks + 7) / 8);
       const dim3 grid((unsigned)(per_xcd * 8));
-#define KGCN_ROWS2(VEC, LPR, DACT)                                                                                    \
-  hipLaunchKernelGGL((spmm_rows_kernel<VEC, LPR, DACT>), grid, dim3(256), 0, stream, ch, rhs, (int)rhs_ld, rhs_gs,    \
+#define KGCN_ROWS3(VEC, LPR, DACT, R)                                                                                 \
+  hipLaunchKernelGGL((spmm_rows_kernel<VEC, LPR, DACT, R>), grid, dim3(256), 0, stream, ch, rhs, (int)rhs_ld, rhs_gs, \
                      out, (int)out_ld, out_gs, M, total_rows, d, beta, self_scale, act, aout, dact, per_xcd)
+#define KGCN_ROWS2(VEC, LPR, DACT)                                                                                    \
+  {                                                                                                                   \
+    if (rows_per_group == 8) KGCN_ROWS3(VEC, LPR, DACT, 8);                                                           \
+    else KGCN_ROWS3(VEC, LPR, DACT, 2);                                                                               \
+  }
 #define KGCN_ROWS(VEC, LPR)                                                                                           \
   {                                                                                                                   \
-    if (dact != KGCN_ACT_NONE) KGCN_ROWS2(VEC, LPR, true);                                                            \
-    else KGCN_ROWS2(VEC, LPR, false);                                                                                 \
+    if (dact != KGCN_ACT_NONE) KGCN_ROWS2(VEC, LPR, true)                                                             \
+    else KGCN_ROWS2(VEC, LPR, false)                                                                                  \
   }
       if (vec == 4) {
         if (lpr == 16) KGCN_ROWS(4, 16) else if (lpr == 32) KGCN_ROWS(4, 32) else KGCN_ROWS(4, 64)
@@ -688,6 +696,7 @@ int launch_spmm_multi(const kgcn_csr_batch* a, int nch, const float* rhs, long r
       }
 #undef KGCN_ROWS
 #undef KGCN_ROWS2
+#undef KGCN_ROWS3
       return check_launch("spmm_rows_kernel");
     }
   }

@@ -68,7 +68,10 @@ __global__ __launch_bounds__(kLossBlock) void sigmoid_ce_kernel(const float* __r
 }
 
 // example_model/model.py:56-61:  cost[b] = mask[b] * -(sum_c labels[b,c] log_softmax(logits[b])[c])
+// labels: dense [B, C] (model.py's one-hot / soft labels), or NULL with label_idx [B] = the class index per graph
+// (tf.nn.sparse_softmax_cross_entropy_with_logits, example_model/sparse.py:112): z[k] = (k == label_idx[b])
 __global__ __launch_bounds__(kLossBlock) void softmax_ce_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                               const long long* __restrict__ label_idx,
                                                                const float* __restrict__ mask, long B, int C,
                                                                float* __restrict__ cost, float* __restrict__ dlogits,
                                                                float* __restrict__ part) {
@@ -77,20 +80,23 @@ __global__ __launch_bounds__(kLossBlock) void softmax_ce_kernel(const float* __r
   float c = 0.f;
   if (b < B) {
     const float* x = logits + b * C;
-    const float* z = labels + b * C;
+    const float* z = labels ? labels + b * C : nullptr;
+    const int li = label_idx ? (int)label_idx[b] : -1;
     float mx = -INFINITY;
     for (int k = 0; k < C; ++k) mx = fmaxf(mx, x[k]);
     float se = 0.f, zs = 0.f, zx = 0.f;
     for (int k = 0; k < C; ++k) {
+      const float zk = z ? z[k] : (k == li ? 1.f : 0.f);
       se += __expf(x[k] - mx);
-      zs += z[k];
-      zx += z[k] * (x[k] - mx);
+      zs += zk;
+      zx += zk * (x[k] - mx);
     }
     const float lse = __logf(se);
-    const float mk = mask[b];
+    const float mk = mask ? mask[b] : 1.f;
     c = mk * (zs * lse - zx);                                   // -sum_c z_c (x_c - mx - lse)
     const float inv = 1.0f / se;
-    for (int k = 0; k < C; ++k) dlogits[b * C + k] = mk * (__expf(x[k] - mx) * inv * zs - z[k]);
+    for (int k = 0; k < C; ++k)
+      dlogits[b * C + k] = mk * (__expf(x[k] - mx) * inv * zs - (z ? z[k] : (k == li ? 1.f : 0.f)));
     if (cost) cost[b] = c;
   }
   const float s = block_sum_256(c, red);
@@ -196,8 +202,24 @@ extern "C" int kgcn_masked_softmax_ce_f32(const float* logits, const float* labe
   const int nb = (int)((batch + kLossBlock - 1) / kLossBlock);
   float* part = static_cast<float*>(workspace);
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(softmax_ce_kernel, dim3(nb), dim3(kLossBlock), 0, s, logits, labels, mask, (long)batch, classes, cost,
-                     dlogits, part);
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(nb), dim3(kLossBlock), 0, s, logits, labels, nullptr, mask, (long)batch, classes,
+                     cost, dlogits, part);
+  if (int rc = check_launch("softmax_ce_kernel")) return rc;
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kLossBlock), 0, s, part, nb, (long)batch, sums);
+  return check_launch("loss_finish_kernel");
+}
+
+extern "C" int kgcn_sparse_softmax_ce_f32(const float* logits, const int64_t* label_idx, const float* mask, int64_t batch,
+                                          int32_t classes, float* cost, float* dlogits, float* sums, void* workspace,
+                                          int64_t workspace_bytes, void* stream) {
+  if (batch <= 0 || classes <= 0) return fail("kgcn_sparse_softmax_ce_f32: bad shape batch=%lld classes=%d", (long long)batch, classes);
+  if (!logits || !label_idx || !dlogits || !sums) return fail("kgcn_sparse_softmax_ce_f32: NULL operand");
+  if (!workspace || workspace_bytes < kgcn_loss_workspace_bytes(batch)) return fail("kgcn_sparse_softmax_ce_f32: workspace too small");
+  const int nb = (int)((batch + kLossBlock - 1) / kLossBlock);
+  float* part = static_cast<float*>(workspace);
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(nb), dim3(kLossBlock), 0, s, logits, nullptr,
+                     reinterpret_cast<const long long*>(label_idx), mask, (long)batch, classes, cost, dlogits, part);
   if (int rc = check_launch("softmax_ce_kernel")) return rc;
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kLossBlock), 0, s, part, nb, (long)batch, sums);
   return check_launch("loss_finish_kernel");

@@ -146,7 +146,10 @@ class GraphConv(nn.Module):
             # concatenated along the contraction axis.
             xa = ops.augment_ones(x2d, dp)
             z = [ops.bspmm(a.channels[c], xa) for c in range(C)]
-            pad = self.w[0].new_zeros((dp - din - 1, dout))
+            if getattr(self, "_agg_pad", None) is None or tuple(self._agg_pad.shape) != (dp - din - 1, dout) or \
+                    self._agg_pad.device != inputs.device:
+                self._agg_pad = self.w[0].new_zeros((dp - din - 1, dout))          # constant: allocated and zeroed once
+            pad = self._agg_pad
             wa = torch.cat([t for c in range(C) for t in (self.w[c], self.bias[c], pad)], dim=0)
             return ops.dense(z[0] if C == 1 else torch.cat(z, dim=1), wa, None, activation=act).reshape(B, N, dout)
         if C == 1:

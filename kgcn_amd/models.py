@@ -123,8 +123,7 @@ def masked_sigmoid_ce(logits, labels, mask, mask_label, pos_weight=None):
 
 def sparse_softmax_ce_sum(logits, labels):
     """sparse.py:112-113: loss_to_minimize = reduce_sum(sparse_softmax_cross_entropy_with_logits)."""
-    onehot = torch.nn.functional.one_hot(labels.reshape(-1).long(), logits.shape[1]).to(torch.float32)
-    return ops.masked_softmax_ce(logits, onehot, torch.ones(logits.shape[0], device=logits.device))[1]
+    return ops.sparse_softmax_ce_sum(logits, labels)
 
 
 class MultitaskGCN(nn.Module):

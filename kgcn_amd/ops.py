@@ -844,6 +844,35 @@ class _MaskedCE(torch.autograd.Function):
         return (dlog * scale if scale is not None else None), None, None, None, None, None
 
 
+class _SparseCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, label_idx):
+        x = _f32c(logits, "logits")
+        B, W = x.shape
+        idx = label_idx.reshape(-1).to(torch.int64).contiguous()
+        require_gpu(idx, "labels")
+        if idx.numel() != B:
+            raise _lib.KgcnHipError("labels have %d entries for %d rows of logits" % (idx.numel(), B))
+        dlog = torch.empty_like(x)
+        sums = torch.empty((2,), device=x.device, dtype=torch.float32)
+        wsb = lib.kgcn_loss_workspace_bytes(B)
+        ws = torch.empty((max(wsb, 4) // 4,), device=x.device, dtype=torch.float32)
+        check(lib.kgcn_sparse_softmax_ce_f32(ptr(x), ptr(idx), None, B, W, None, ptr(dlog), ptr(sums), ptr(ws), wsb,
+                                             current_stream()), "kgcn_sparse_softmax_ce_f32")
+        ctx.save_for_backward(dlog)
+        return sums[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlog,) = ctx.saved_tensors
+        return dlog * g, None
+
+
+def sparse_softmax_ce_sum(logits, label_idx):
+    """example_model/sparse.py:112-113: reduce_sum(sparse_softmax_cross_entropy_with_logits(labels, logits))."""
+    return _SparseCE.apply(logits, label_idx)
+
+
 def masked_sigmoid_ce(logits, labels, mask, mask_label=None, pos_weight=None):
     """example_model/model_multitask.py:66-79 -> (cost_opt, cost_sum)."""
     return _MaskedCE.apply(logits, labels, mask, mask_label, "sigmoid", pos_weight)
@@ -857,7 +886,7 @@ def masked_softmax_ce(logits, labels, mask):
 __all__ = ["BatchedCSR", "BatchedAdjacency", "bspmm", "bspmm_raw", "bconv", "dense", "activation", "act_code",
            "graphconv_fused", "graphconv_fused_supported", "gin_aggregate", "graph_gather",
            "graph_maxpool", "gat", "gram", "ragged_gather", "ragged_compact_rows",
-           "masked_sigmoid_ce", "masked_softmax_ce", "augment_ones",
+           "masked_sigmoid_ce", "masked_softmax_ce", "sparse_softmax_ce_sum", "augment_ones",
            "gcn_stack", "gcn_stack_supported", "graph_gather_tee"]
 
 
