@@ -266,7 +266,10 @@ class Ctx:
         else:
             self.device = torch.device("cpu")
         self.backend = args.backend
-        if self.world > 1:
+        # the data-parallel path (process group, gradient bucket, all-reduce) also runs with ONE rank under a launcher when
+        # --force-dist is given: the only way to exercise RCCL inside the captured step on a 1-GPU box
+        self.dist_on = self.world > 1 or (args.force_dist and "RANK" in os.environ)
+        if self.dist_on:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             kw = {"device_id": self.device} if self.on_gpu else {}
             # the communication libraries print connection banners on fd 1 (gloo always, RCCL with NCCL_DEBUG): stdout
@@ -289,7 +292,7 @@ class Ctx:
     def barrier(self):
         """barrier + device synchronisation on both sides (the contract's bracket of the timed region)."""
         self.sync()
-        if self.world > 1:
+        if self.dist_on:
             self.dist.barrier()
         self.sync()
 
@@ -314,7 +317,7 @@ class Ctx:
     def collective_report(self, bucket, weight, in_step_us=None, reps=50):
         """The all-reduce of the gradient bucket alone, event-timed (HIP events on the stream the collective is
         enqueued on; host clock on CPU), after the timed region."""
-        if self.world == 1 or bucket is None:
+        if not self.dist_on or bucket is None:
             return None
         torch, dist = self.torch, self.dist
         for p in bucket.params:
@@ -398,7 +401,7 @@ class Cfg2:
             self.T, self.T_global = hi - lo, graphs
         else:
             self.T, self.T_global = graphs, graphs * ctx.world
-        self.weight = shard_weight(self.T, self.T_global) if ctx.world > 1 else None
+        self.weight = shard_weight(self.T, self.T_global) if ctx.dist_on else None
         self.wl = make_cfg2(self.T, ctx.device, seed=1234 + ctx.rank, normalize=args.normalize)
         self.csr = self.wl["csr"]
         self.layer = layers.GraphConv(FEAT, 1).to(ctx.device)
@@ -410,7 +413,7 @@ class Cfg2:
             layers.enabled_batched = True
         self.x = self.wl["x"].requires_grad_(True)
         self.g = self.wl["g"]
-        self.bucket = GradBucket(list(self.layer.parameters())) if ctx.world > 1 else None
+        self.bucket = GradBucket(list(self.layer.parameters())) if ctx.dist_on else None
         self.units_local = self.T
         self.units_global = self.T_global
 
@@ -568,7 +571,7 @@ class _ModelStep:
         ctx = self.ctx
         self.model, self.loss_fn, self.sb, self.labels, self.mask, self.kw = model, loss_fn, static_batch, labels, mask, \
             fwd_kwargs
-        dp = ctx.world > 1
+        dp = ctx.dist_on
         self.weight = parallel.shard_weight(self.units_local, self.units_local * ctx.world) if dp else None
         params = list(model.parameters())
         self.opt = train.TFAdam(params, lr=1e-3)
@@ -875,9 +878,9 @@ class Dry:
             self.units_local, self.units_global = hi - lo, graphs
         else:
             self.units_local, self.units_global = graphs, graphs * ctx.world
-        self.weight = shard_weight(self.units_local, self.units_global) if ctx.world > 1 else None
+        self.weight = shard_weight(self.units_local, self.units_global) if ctx.dist_on else None
         self.params = [torch.nn.Parameter(torch.zeros(s, device=ctx.device)) for s in PARAM_SHAPES[args.config]]
-        self.bucket = GradBucket(self.params) if ctx.world > 1 else None
+        self.bucket = GradBucket(self.params) if ctx.dist_on else None
         self.checked = 0
 
     def setup_passes(self):
@@ -946,6 +949,8 @@ def build_parser():
     ap.add_argument("--profile", action="store_true",
                     help="for rocprofv3 runs: nothing after the timed region (no per-call roofline pass, no SpMM probe, no "
                          "CPU baseline), so the trace ends with the timed steps")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="under a launcher with ONE rank: still build the process group and run the gradient exchange")
     ap.add_argument("--dry", action="store_true",
                     help="launcher + gradient exchange only (no kernels); the only mode that runs without a GPU")
     return ap
@@ -1006,7 +1011,7 @@ def main(argv=None):
     if ctx.rank == 0:
         config, roofline, extra = wl.report(ev)
         config["parallelism"] = "dp%d" % ctx.world
-        config["collective"] = None if ctx.world == 1 else \
+        config["collective"] = None if not ctx.dist_on else \
             "one %s all-reduce of the flat gradient bucket (%d floats) per step over %d ranks" \
             % ("RCCL" if ctx.backend == "nccl" else ctx.backend, wl.bucket.total, dist.get_world_size())
         from kgcn_amd import _lib
@@ -1031,7 +1036,7 @@ def main(argv=None):
             res["collective"] = collective
         res.update(extra)
         print(json.dumps(res), flush=True)
-    if ctx.world > 1:
+    if ctx.dist_on:
         dist.destroy_process_group()
 
 

@@ -80,11 +80,14 @@ class GradBucket:
         views = self._views(flat)
         torch._foreach_copy_(views, grads)
         world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if world == 1 and weight is not None and float(weight) != 1.0:
+            raise ValueError("a single rank owns the whole batch: its weight must be 1")
         if world > 1:
             flat.mul_(1.0 / world if weight is None else float(weight))
+        if dist.is_initialized():
+            # also with ONE rank: the collective is a no-op numerically but goes through RCCL (and, inside a hipGraph
+            # capture, into the graph) -- the only way a 1-GPU box exercises the data-parallel path end to end
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        elif weight is not None and float(weight) != 1.0:
-            raise ValueError("a single rank owns the whole batch: its weight must be 1")
         if unpack:
             torch._foreach_copy_(grads, views)
         return flat

@@ -45,3 +45,28 @@ def test_bench_model_configs_small(cfg, extra):
     rf = res["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["frac"] is not None and rf["per_call_table"]
     assert rf["unpriced_calls"] == [], rf["unpriced_calls"]
+
+
+@pytest.mark.parametrize("cfg,extra", [("cfg2", ["--graphs", "4096", "--no-cpu-baseline"]),
+                                       ("cfg4", ["--graphs", "3000", "--batch", "256"]), ("cfg5", ["--graphs", "2000"])])
+def test_bench_data_parallel_path_with_one_rcc_rank(cfg, extra):
+    """The data-parallel path of bench.py as the driver launches it (torch.distributed.run, one process per GPU, RCCL) with the
+    ONE rank a 1-GPU box has (--force-dist): process group, flat gradient bucket (= the fused optimiser's gradient buffer for
+    cfg4 / cfg5), the all-reduce inside the captured step, the `collective` report with the RCCL version."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--config", cfg, "--steps", "3",
+           "--warmup", "1"] + extra
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    col = res["collective"]
+    assert col["ranks"] == 1 and col["backend"] == "nccl" and col["bucket_floats"] > 0
+    assert "rccl_version" in col and col["allreduce_us_standalone"]["median"] > 0
+    assert res["value"] > 0 and res["config"]["collective"]
