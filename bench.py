@@ -562,6 +562,7 @@ def train_exchange(bucket, opt, weight):
 class _ModelStep:
     """Shared by cfg4 / cfg5: eager or hipGraph-captured train step + the per-call roofline of one eager step."""
     n_events = 2
+    assemble_in_step = False        # a new mini-batch per step: the device-side assembly is the head of the (captured) step
 
     def setup_passes(self):
         return 5
@@ -580,10 +581,13 @@ class _ModelStep:
         self.graph_step = None
         if not self.args.eager:
             self.graph_step = train.GraphedTrainStep(model, self.opt, loss_fn, static_batch, labels, mask,
-                                                     bucket=self.bucket, shard_weight=self.weight, **fwd_kwargs)
+                                                     bucket=self.bucket, shard_weight=self.weight,
+                                                     capture_assembly=self.assemble_in_step, **fwd_kwargs)
 
     def _eager_step(self):
         self.opt.zero_grad(set_to_none=False)
+        if self.assemble_in_step:
+            self.sb.assemble()
         logits = self.model(self.sb.features, self.sb.adjacency, **self.kw)
         cost_opt, _ = self.loss_fn(logits, self.labels, self.mask)
         cost_opt.backward()
@@ -612,6 +616,7 @@ class _ModelStep:
 
 class Cfg4(_ModelStep):
     name = "cfg4"
+    assemble_in_step = True
 
     def __init__(self, args, ctx):
         import torch
@@ -634,16 +639,14 @@ class Cfg4(_ModelStep):
         self.ds = D.DeviceGraphDataset([chan], feats, device=dev, sizes=sizes)
         self.dataset_bytes = int(feats.nbytes + 8 * g.shape[0] + 4 * (G * N + 1))
         self.lab_d, self.ml_d = torch.from_numpy(labels).to(dev), torch.from_numpy(mask_label).to(dev)
-        self.sizes_d = torch.from_numpy(sizes).to(dev)
+        self.sizes_d = torch.from_numpy(sizes.astype(np.int32)).to(dev)
         torch.manual_seed(0)                                                    # the same initial weights on every rank
         model = models.MultitaskGCN(1, TASKS, ragged=not args.padded).to(dev)
         sb = self.ds.static_batch(B) if args.padded else self.ds.static_ragged_batch(B)
+        # labels / label mask / true sizes of the batch come out of the same device-side assembly as its adjacency and features
+        self.lab_s, self.ml_s, self.en_s = sb.add_table(self.lab_d), sb.add_table(self.ml_d), sb.add_table(self.sizes_d)
         sb.load(np.arange(B))
         self.capacity = getattr(sb, "capacity", B * N)
-        self.lab_s, self.ml_s = torch.zeros((B, TASKS), device=dev), torch.zeros((B, TASKS), device=dev)
-        self.en_s = torch.zeros(B, device=dev, dtype=self.sizes_d.dtype)
-        self.en_s.copy_(self.sizes_d[:B])
-        self.it_s = torch.zeros(B, device=dev, dtype=torch.int64)
         model(sb.features, sb.adjacency, enabled_node_nums=self.en_s)           # Keras-style build
         mask = torch.ones(B, device=dev)
         self.units_local, self.units_global = B, B * ctx.world
@@ -654,20 +657,16 @@ class Cfg4(_ModelStep):
                      enabled_node_nums=self.en_s)
 
     def next_batch(self):
-        """Mini-batch assembly on the device (part of the step): adjacency by kgcn_csr_gather_graphs into the static
-        containers, features / labels / sizes by index_select."""
-        torch = self.ctx.torch
+        """Mini-batch selection (host: a slice of the epoch's permutation, one pinned upload); the assembly itself -- the
+        adjacency containers, feature rows, labels, label mask and sizes of the selected graphs -- runs on the device as the
+        head of the step."""
         G, B = self.G, self.B
         lo = self.cursor
         if lo + B > G:
             lo = self.cursor = 0
         self.cursor += B
         idx = self.perm[lo:lo + B]
-        self.it_s.copy_(torch.from_numpy(idx), non_blocking=True)
-        self.sb.load(idx)
-        torch.index_select(self.lab_d, 0, self.it_s, out=self.lab_s)       # one gather kernel each, straight into the static
-        torch.index_select(self.ml_d, 0, self.it_s, out=self.ml_s)         # buffers the captured step reads
-        torch.index_select(self.sizes_d, 0, self.it_s, out=self.en_s)
+        self.sb.stage(idx)                                # one pinned upload; the assembly kernels are the head of the step
 
     def report(self, evs):
         args = self.args
@@ -730,6 +729,7 @@ class Cfg1(_ModelStep):
     TF-Adam -- on the shipped 200 graphs (tests/golden/g1_synthetic_raw.npz = the converted .jbl), tiled to --graphs graphs
     resident in HBM; one step = one mini-batch of --batch (30) graphs assembled on the device."""
     name = "cfg1"
+    assemble_in_step = True
 
     def __init__(self, args, ctx):
         import torch
@@ -750,19 +750,15 @@ class Cfg1(_ModelStep):
         torch.manual_seed(0)
         model = models.GCN(1, 2).to(ctx.device)
         sb = self.ds.static_batch(B)
+        self.lab_s = sb.add_table(self.lab_d)
         sb.load(np.arange(B))
         model(sb.features, sb.adjacency)
-        self.lab_s = torch.zeros((B, 2), device=ctx.device)
-        self.it_s = torch.zeros(B, device=ctx.device, dtype=torch.int64)
         self.units_local, self.units_global = B, B * ctx.world
         self._finish(model, models.masked_softmax_ce, sb, self.lab_s, torch.ones(B, device=ctx.device))
 
     def next_batch(self):
-        torch = self.ctx.torch
         idx = self.rng.integers(0, self.G, size=self.B)
-        self.it_s.copy_(torch.from_numpy(idx), non_blocking=True)
-        self.sb.load(idx)
-        torch.index_select(self.lab_d, 0, self.it_s, out=self.lab_s)
+        self.sb.stage(idx)                                # the assembly kernels are part of the step (head of the hipGraph)
 
     def report(self, evs):
         from kgcn_amd import layers

@@ -179,6 +179,30 @@ int kgcn_csr_gather_graphs(const kgcn_csr_batch* src, const int32_t* sel, int32_
                            int32_t* dst_slots, int32_t* dst_graph_ptr, void* workspace,
                            int64_t workspace_bytes, void* stream);
 
+/* The whole mini-batch in TWO launches: up to KGCN_ASSEMBLE_MAX_CSR containers of the same dataset (A, A^T, their row-padded
+ * copies: each as in kgcn_csr_gather_graphs, dst_graph_ptr[num_sel + 1] included) and up to KGCN_ASSEMBLE_MAX_TABLES per-graph
+ * float tables (features [G, N * F], labels, masks ... -- what kgcn/feed.py:112-133 slices per batch on the host):
+ * table_out[k][t, :] = table[k][sel[t], :], a row of zeros for sel[t] = -1.  dst_cv_capacity must cover the worst case
+ * num_sel * max(max_nnz_per_graph, 4 * rows of a row-padded source): the selection is device data.
+ * workspace >= kgcn_batch_assemble_workspace_bytes(num_sel). */
+#define KGCN_ASSEMBLE_MAX_CSR 4
+#define KGCN_ASSEMBLE_MAX_TABLES 6
+typedef struct kgcn_assemble_plan {
+  int32_t num_csr, num_tables;
+  const kgcn_csr_batch* src[KGCN_ASSEMBLE_MAX_CSR];
+  int32_t* dst_rowptr[KGCN_ASSEMBLE_MAX_CSR];
+  int32_t* dst_cv[KGCN_ASSEMBLE_MAX_CSR];
+  int64_t dst_cv_capacity[KGCN_ASSEMBLE_MAX_CSR];
+  int32_t* dst_slots[KGCN_ASSEMBLE_MAX_CSR];
+  int32_t* dst_graph_ptr[KGCN_ASSEMBLE_MAX_CSR];
+  const float* table[KGCN_ASSEMBLE_MAX_TABLES];
+  float* table_out[KGCN_ASSEMBLE_MAX_TABLES];
+  int64_t row_floats[KGCN_ASSEMBLE_MAX_TABLES];
+} kgcn_assemble_plan;
+int64_t kgcn_batch_assemble_workspace_bytes(int32_t num_sel);
+int kgcn_batch_assemble(const kgcn_assemble_plan* plan, const int32_t* sel, int32_t num_sel, void* workspace,
+                        int64_t workspace_bytes, void* stream);
+
 /* -- GraphMaxPooling ------------------------------------------------------------------------ */
 /* kgcn/layers.py:122-150 (one adjacency channel per call; beta = 1 accumulates the channel add-n):
  *   out[t,i,k] = beta*out[t,i,k] + max_j dense(A[t] .* x[t][:,k])[i,j]
@@ -429,7 +453,9 @@ int kgcn_augment_ones_bwd_f32(const float* dout_grad, int64_t m, int32_t din, in
 /* For N <= 32 nodes per graph and layer widths <= 64 a graph's activations and all weights fit LDS: one forward and one
  * backward launch run   [GraphConv -> act] x k -> [BatchNormalization (moving statistics) -> act] -> [GraphDense -> act]
  * -> GraphGather   for every graph, instead of one launch and one HBM round trip per layer (at the reference's batch sizes
- * -- 30 graphs in example_config/synth.json -- a step is bound by launch latency).  Plain fp32 FMAs.
+ * -- 30 graphs in example_config/synth.json -- a step is bound by launch latency).  Two routes with the same results up to
+ * the summation order: one graph per workgroup trip on plain fp32 FMAs (a few hundred graphs: the latency of one graph), and
+ * 64-row tiles of floor(64 / N) whole graphs on v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate) for thousands.
  *   kind 0  H <- act(A (H W + b))   one adjacency channel (kgcn/layers.py:105-116);  w [din, dout], b [dout] or NULL
  *   kind 1  H <- act(H W + b)       GraphDense (:255-262)
  *   kind 2  H <- act(gamma (H - mean) / sqrt(var + eps) + beta) on rows < enabled[t], act(0) on the others
@@ -448,7 +474,8 @@ typedef struct kgcn_stack_layer {
   const float* mean; /* kind 2 only */
   const float* var;  /* kind 2 only */
   float eps;         /* kind 2 only */
-  int32_t reserved_;
+  int32_t route;     /* read from layers[0] only: 0 automatic, 1 one graph per workgroup trip (plain fp32 FMAs), 2 64-row tiles of
+                        whole graphs on the f32 MFMA (<= 5 layers); the others: 0 */
 } kgcn_stack_layer;
 int kgcn_gcn_stack_supported(int32_t n_nodes, int32_t max_nnz_per_graph, const kgcn_stack_layer* layers, int32_t num_layers);
 int64_t kgcn_gcn_stack_param_floats(const kgcn_stack_layer* layers, int32_t num_layers);

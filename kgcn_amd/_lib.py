@@ -57,10 +57,26 @@ class StackLayer(ctypes.Structure):
     """struct kgcn_stack_layer (include/kgcn_hip.h)."""
     _fields_ = [("kind", c_i32), ("act", c_i32), ("din", c_i32), ("dout", c_i32), ("w", ctypes.c_void_p),
                 ("b", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("var", ctypes.c_void_p), ("eps", ctypes.c_float),
-                ("reserved_", c_i32)]
+                ("route", c_i32)]
 
 
 _STKP = ctypes.POINTER(StackLayer)
+
+ASSEMBLE_MAX_CSR, ASSEMBLE_MAX_TABLES = 4, 6
+
+
+class AssemblePlan(ctypes.Structure):
+    """struct kgcn_assemble_plan (include/kgcn_hip.h)."""
+    _fields_ = [("num_csr", c_i32), ("num_tables", c_i32),
+                ("src", _CSRP * ASSEMBLE_MAX_CSR),
+                ("dst_rowptr", ctypes.c_void_p * ASSEMBLE_MAX_CSR), ("dst_cv", ctypes.c_void_p * ASSEMBLE_MAX_CSR),
+                ("dst_cv_capacity", c_i64 * ASSEMBLE_MAX_CSR), ("dst_slots", ctypes.c_void_p * ASSEMBLE_MAX_CSR),
+                ("dst_graph_ptr", ctypes.c_void_p * ASSEMBLE_MAX_CSR),
+                ("table", ctypes.c_void_p * ASSEMBLE_MAX_TABLES), ("table_out", ctypes.c_void_p * ASSEMBLE_MAX_TABLES),
+                ("row_floats", c_i64 * ASSEMBLE_MAX_TABLES)]
+
+
+_ASMP = ctypes.POINTER(AssemblePlan)
 _PTRP = ctypes.POINTER(ctypes.c_void_p)
 
 # name -> (restype, argtypes); must list EVERY function include/kgcn_hip.h declares
@@ -93,6 +109,8 @@ SIGNATURES = {
     "kgcn_csr_gather_workspace_bytes": (c_i64, [c_i32]),
     "kgcn_csr_gather_graphs": (ctypes.c_int, [_CSRP, c_i32p, c_i32, c_i32p, c_i32p, c_i64, c_i32p, c_i32p,
                                               ctypes.c_void_p, c_i64, ctypes.c_void_p]),
+    "kgcn_batch_assemble_workspace_bytes": (c_i64, [c_i32]),
+    "kgcn_batch_assemble": (ctypes.c_int, [_ASMP, c_i32p, c_i32, ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_graph_maxpool_fwd_f32": (ctypes.c_int, [_CSRP, c_f32p, c_i32, c_f32p, ctypes.c_float,
                                                   ctypes.c_void_p]),
     "kgcn_graph_maxpool_bwd_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),

@@ -22,31 +22,11 @@
 // Workgroup = 4 waves; thread (wave w, lane j) owns rows r = w, w+4, ... of column j.  Backward: dW / dbias / dgamma / dbeta
 // accumulate over the workgroup's graphs in LDS slots owned by exactly one thread (no atomics), one partial per workgroup,
 // reduce_partials adds the partials in a fixed order: deterministic.
-#include "kgcn_common.h"
+#include "stack_common.h"
 
 namespace kgcn {
 
 int launch_reduce_partials(const float* part, int nparts, long n, float* out, hipStream_t s);
-
-constexpr int SK_MAXL = KGCN_STACK_MAX_LAYERS;
-constexpr int SK_LD = 64;          // activation tile leading dimension (floats)
-constexpr int SK_WLD = 65;         // weight leading dimension: conflict-free along k AND along j
-
-struct StackArgs {
-  int nl, N, gather, max_nnz;
-  int kind[SK_MAXL], act[SK_MAXL], din[SK_MAXL], dout[SK_MAXL];
-  const float* w[SK_MAXL];
-  const float* b[SK_MAXL];
-  const float* mean[SK_MAXL];
-  const float* var[SK_MAXL];
-  float eps[SK_MAXL];
-  float* out[SK_MAXL];            // saved layer outputs [T, N, dout]
-  int woff[SK_MAXL];              // float offset of the layer's weight block in LDS (kind 2: scale | shift)
-  int poff[SK_MAXL];              // float offset of the layer's gradients in the flat parameter-gradient layout
-  int goff[SK_MAXL];              // float offset of the layer's accumulator block in LDS (backward)
-  int wtotal;                     // floats of all weight blocks
-  int ptotal;                     // floats of the flat parameter-gradient layout
-};
 
 // LDS floats of one weight block: kind 0/1: W [din x 65] + b [64]; kind 2: scale [64] + shift [64]
 __host__ __device__ inline int sk_wblock(int kind, int din) { return kind == 2 ? 128 : din * SK_WLD + 64; }
@@ -386,7 +366,16 @@ __global__ __launch_bounds__(256) void stack_bwd_kernel(StackArgs a, const int* 
   }
 }
 
-struct StackPlan { StackArgs a; int gtotal; size_t lds_fwd, lds_bwd; };
+struct StackPlan { StackArgs a; int gtotal; size_t lds_fwd, lds_bwd; Stack2Plan tile; int route; };
+
+// Route of a launch: layers[0].route 1 / 2 force the one-graph / the tile kernels (tests, measurements); 0: tiles once there are
+// more graphs than CUs (model.py step, 10-node graphs: 256 graphs 0.123 vs 0.132 ms, 512 graphs 0.169 vs 0.134 ms).
+static bool use_tiles(const StackPlan& p, long T) {
+  if (!p.tile.ok || p.route == 1) return false;
+  if (p.route == 2) return true;
+  if (p.lds_fwd > (size_t)kLdsBytes || p.lds_bwd > (size_t)kLdsBytes) return true;     // the one-graph kernels do not fit
+  return T > (long)kNumCU;
+}
 
 static int stack_plan(int n_nodes, int max_nnz, const kgcn_stack_layer* layers, int nl, StackPlan* p, const char* who) {
   if (nl <= 0 || nl > SK_MAXL) return fail("%s: %d layers (1..%d)", who, nl, SK_MAXL);
@@ -414,6 +403,10 @@ static int stack_plan(int n_nodes, int max_nnz, const kgcn_stack_layer* layers, 
   const size_t csr = (size_t)36 * 4 + (size_t)a.max_nnz * 8;
   p->lds_fwd = ((size_t)wo + 3 * (size_t)n_nodes * SK_LD + 4 * 64) * 4 + csr;
   p->lds_bwd = ((size_t)wo + (size_t)go + 4 * (size_t)n_nodes * SK_LD) * 4 + csr;
+  p->route = layers[0].route;
+  if (p->route < 0 || p->route > 2) return fail("%s: route %d of the first layer (0 automatic, 1 one graph per trip, 2 tiles)", who, p->route);
+  p->tile = stack2_plan(a);
+  if (p->route == 2 && !p->tile.ok) return fail("%s: the tile kernels do not take this layer list", who);
   return 0;
 }
 
@@ -425,6 +418,7 @@ extern "C" int kgcn_gcn_stack_supported(int32_t n_nodes, int32_t max_nnz_per_gra
                                         int32_t num_layers) {
   StackPlan p;
   if (!layers || stack_plan(n_nodes, max_nnz_per_graph, layers, num_layers, &p, "kgcn_gcn_stack_supported")) return 0;
+  if (p.route != 1 && p.tile.ok) return 1;
   return p.lds_fwd <= (size_t)kLdsBytes && p.lds_bwd <= (size_t)kLdsBytes ? 1 : 0;
 }
 
@@ -452,7 +446,8 @@ extern "C" int kgcn_gcn_stack_fwd_f32(const kgcn_csr_batch* a, const float* x, c
   if (!layers || !layer_out) return fail("kgcn_gcn_stack_fwd_f32: NULL layer list");
   StackPlan p;
   if (int rc = stack_plan(a->rows, a->max_nnz_per_graph, layers, num_layers, &p, "kgcn_gcn_stack_fwd_f32")) return rc;
-  if (p.lds_fwd > (size_t)kLdsBytes) return fail("kgcn_gcn_stack_fwd_f32: %zu bytes of LDS needed", p.lds_fwd);
+  const bool tiles = use_tiles(p, a->num_graphs);
+  if (!tiles && p.lds_fwd > (size_t)kLdsBytes) return fail("kgcn_gcn_stack_fwd_f32: %zu bytes of LDS needed", p.lds_fwd);
   if (a->num_graphs == 0) return 0;
   if (!x) return fail("kgcn_gcn_stack_fwd_f32: x is NULL");
   for (int l = 0; l < num_layers; ++l) {
@@ -460,6 +455,9 @@ extern "C" int kgcn_gcn_stack_fwd_f32(const kgcn_csr_batch* a, const float* x, c
     p.a.out[l] = layer_out[l];
   }
   p.a.gather = pooled ? 1 : 0;
+  if (tiles)
+    return launch_stack2_fwd(p.a, p.tile, a->rowptr, reinterpret_cast<const int2*>(a->cv), x, enabled, (long)a->num_graphs,
+                             pooled, as_stream(stream));
   const dim3 grid(stack_blocks(a->num_graphs, p.lds_fwd));
   const int2* cvp = reinterpret_cast<const int2*>(a->cv);
 #define KGCN_SK_FWD(NQ)                                                                                               \
@@ -503,7 +501,8 @@ extern "C" int kgcn_gcn_stack_bwd_f32(const kgcn_csr_batch* at, const float* x, 
   if (!layers || !layer_out) return fail("kgcn_gcn_stack_bwd_f32: NULL layer list");
   StackPlan p;
   if (int rc = stack_plan(at->rows, at->max_nnz_per_graph, layers, num_layers, &p, "kgcn_gcn_stack_bwd_f32")) return rc;
-  if (p.lds_bwd > (size_t)kLdsBytes) return fail("kgcn_gcn_stack_bwd_f32: %zu bytes of LDS needed", p.lds_bwd);
+  const bool tiles = use_tiles(p, at->num_graphs);
+  if (!tiles && p.lds_bwd > (size_t)kLdsBytes) return fail("kgcn_gcn_stack_bwd_f32: %zu bytes of LDS needed", p.lds_bwd);
   if (!dparams) return fail("kgcn_gcn_stack_bwd_f32: dparams is NULL");
   hipStream_t s = as_stream(stream);
   if (at->num_graphs == 0) {
@@ -516,12 +515,17 @@ extern "C" int kgcn_gcn_stack_bwd_f32(const kgcn_csr_batch* at, const float* x, 
     p.a.out[l] = layer_out[l];
   }
   p.a.gather = gather ? 1 : 0;
-  const int blocks = stack_blocks(at->num_graphs, p.lds_bwd);
+  const int blocks = tiles ? stack2_blocks(at->num_graphs, p.a.G) : stack_blocks(at->num_graphs, p.lds_bwd);
   const int64_t need = (int64_t)blocks * p.a.ptotal * 4;
   if (!workspace || workspace_bytes < need)
     return fail("kgcn_gcn_stack_bwd_f32: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
   float* part = static_cast<float*>(workspace);
   const int2* cvp = reinterpret_cast<const int2*>(at->cv);
+  if (tiles) {
+    if (int rc = launch_stack2_bwd(p.a, p.tile, at->rowptr, cvp, x, enabled, (long)at->num_graphs, dlast, dx, part, blocks, s))
+      return rc;
+    return launch_reduce_partials(part, blocks, p.a.ptotal, dparams, s);
+  }
 #define KGCN_SK_BWD(NQ)                                                                                               \
   {                                                                                                                   \
     static thread_local bool attr = false;                                                                            \

@@ -517,10 +517,11 @@ class GraphGather(nn.Module):
 
 
 # default on: models run eligible layer sequences through the cross-layer kernels (see fused_stack) for batches of at most
-# stack_fusion_max_rows node rows (graphs x nodes): the cross-layer kernels use plain fp32 FMAs and win where a step is bound
-# by launch latency; above that the per-layer MFMA kernels are faster (tools/stack_sweep.py)
+# stack_fusion_max_rows node rows (graphs x nodes): one launch per direction wins where a step is bound by launch latency (up
+# to a few hundred graphs: one graph per workgroup trip, plain fp32 FMAs; thousands: 64-row tiles on the f32 MFMA -- 4,096
+# graphs of 10 nodes still 5 % ahead); above that the per-layer bf16-split kernels are faster (tools/stack_sweep.py)
 stack_fusion = True
-stack_fusion_max_rows = 6144
+stack_fusion_max_rows = 49152
 
 
 def fused_stack(seq, features, adj, enabled_node_nums=None, gather=True):

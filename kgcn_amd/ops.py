@@ -686,6 +686,10 @@ def ragged_compact_rows(padded, rb):
 # cross-layer stack for small graphs (csrc/stack.hip): [GraphConv | GraphDense | BatchNormalization(moving stats)] x k
 # (+ GraphGather) in one forward and one backward launch
 # -------------------------------------------------------------------------------------------------
+# kernels of the cross-layer stack (kgcn_stack_layer.route): 0 automatic, 1 one graph per workgroup trip, 2 64-row tiles (f32 MFMA)
+stack_route = 0
+
+
 def _stack_descriptors(spec, params, buffers):
     """spec: list of (kind, act_code, din, dout, eps); params: flat list, two tensors (or None) per layer (w, b | gamma,
     beta); buffers: per layer (mean, var) or None.  -> (ctypes array of kgcn_stack_layer, keep-alive list)."""
@@ -701,7 +705,8 @@ def _stack_descriptors(spec, params, buffers):
             mean, var = (_f32c(t.reshape(-1), "moving statistics") for t in buffers[l])
         keep += [w, b, mean, var]
         arr[l] = _lib.StackLayer(kind, act, din, dout, w.data_ptr(), 0 if b is None else b.data_ptr(),
-                                 0 if mean is None else mean.data_ptr(), 0 if var is None else var.data_ptr(), float(eps), 0)
+                                 0 if mean is None else mean.data_ptr(), 0 if var is None else var.data_ptr(), float(eps),
+                                 stack_route if l == 0 else 0)
     return arr, keep
 
 
@@ -711,7 +716,7 @@ def gcn_stack_supported(csr, spec):
         return False
     arr = (_lib.StackLayer * len(spec))()
     for l, (kind, act, din, dout, eps) in enumerate(spec):
-        arr[l] = _lib.StackLayer(kind, act, din, dout, 1, 1, 1, 1, float(eps), 0)       # pointers only checked for NULL
+        arr[l] = _lib.StackLayer(kind, act, din, dout, 1, 1, 1, 1, float(eps), stack_route if l == 0 else 0)   # pointers: NULL checks only
     return bool(lib.kgcn_gcn_stack_supported(csr.rows, csr.max_nnz, arr, len(spec)))
 
 

@@ -204,6 +204,7 @@ class StaticRaggedBatch:
         dev = dataset.channels[0].rowptr.device
         i32 = dict(device=dev, dtype=torch.int32)
         self._sel_dev = torch.zeros(B, **i32)
+        self._tables, self._ring, self._asm_ws = [], None, None
         self._graph_ptr = torch.zeros(B + 1, **i32)
         self._ws = torch.empty(max(_lib.lib.kgcn_ragged_workspace_bytes(B), 8) // 4, **i32)
         self.status = torch.zeros(1, **i32)
@@ -224,8 +225,16 @@ class StaticRaggedBatch:
         self.features = feat
         self.adjacency = self.ragged
 
-    def load(self, batch_idx):
-        import torch
+    def add_table(self, table):
+        """Register a per-graph device table [G, ...] (labels, masks ...): returns the static [batch_size, ...] buffer that
+        assemble() fills with the selected graphs' rows (zeros for dummy graphs), one launch for all tables."""
+        from .data_util import _add_table
+        return _add_table(self, table)
+
+    def stage(self, batch_idx):
+        """Host half of load(): validate, check the row capacity, send the selection to the device (one asynchronous copy out
+        of a pinned staging ring)."""
+        from .data_util import _stage_selection
         ds = self.dataset
         batch_idx = np.asarray(batch_idx, np.int64).reshape(-1)
         B, nb = self.batch_size, batch_idx.shape[0]
@@ -234,9 +243,15 @@ class StaticRaggedBatch:
         R = int(ds.sizes[batch_idx].sum())
         if R + 1 > self.capacity:
             raise ValueError("batch holds %d valid rows: beyond the static capacity %d" % (R, self.capacity))
-        sel = np.full(B, -1, np.int32)
-        sel[:nb] = batch_idx
-        self._sel_dev.copy_(torch.from_numpy(sel), non_blocking=True)
+        _stage_selection(self, batch_idx, B)
+        self.ragged.rows = R
+        return self
+
+    def assemble(self):
+        """Device half of load(): the plan, the two container copies per channel, the feature rows and the registered tables
+        -- capturable (GraphedTrainStep(capture_assembly=True))."""
+        from .data_util import _fill_tables
+        ds, B = self.dataset, self.batch_size
         for src, src_t, entry_ptr, pair in self._chan:
             _plan(src, ds.sizes_dev, self._sel_dev, B, self._graph_ptr, entry_ptr, self._ws)
             for s, c in ((src, pair[0]), (src_t, pair[1])):
@@ -247,5 +262,17 @@ class StaticRaggedBatch:
                                                              _lib.ptr(self._graph_ptr), self.capacity,
                                                              _lib.ptr(self.features), _lib.current_stream()),
                        "kgcn_ragged_compact_rows_f32")
-        self.ragged.rows = R
+        if self._tables:
+            import torch
+            plan = _lib.AssemblePlan()
+            plan.num_csr, plan.num_tables = 0, _fill_tables(self, plan, with_features=False)
+            if self._asm_ws is None:
+                wsb = _lib.lib.kgcn_batch_assemble_workspace_bytes(B)
+                self._asm_ws = torch.empty(max(wsb, 4) // 4, dtype=torch.int32, device=self._sel_dev.device)
+            _lib.check(_lib.lib.kgcn_batch_assemble(plan, self._sel_dev.data_ptr(), B, self._asm_ws.data_ptr(),
+                                                    self._asm_ws.numel() * 4, _lib.current_stream()), "kgcn_batch_assemble")
         return self
+
+    def load(self, batch_idx):
+        """stage(batch_idx) + assemble()."""
+        return self.stage(batch_idx).assemble()

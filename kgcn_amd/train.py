@@ -131,15 +131,21 @@ class GraphedTrainStep:
     model(features, adjacency, **fwd_kwargs) -> logits;  loss_fn(logits, labels, mask) -> (cost_opt, cost_sum)."""
 
     def __init__(self, model, optimizer, loss_fn, static_batch, labels, mask, warmup=3, bucket=None,
-                 shard_weight=None, **fwd_kwargs):
+                 shard_weight=None, capture_assembly=False, **fwd_kwargs):
         """bucket / shard_weight: data parallel -- the ONE all-reduce of the flat gradient bucket (RCCL) is captured
-        in the graph between backward and the Adam update, so a replay is still a single host call per step."""
+        in the graph between backward and the Adam update, so a replay is still a single host call per step.
+        capture_assembly: static_batch.assemble() (mini-batch assembly on the device: adjacency containers, feature rows and
+        the tables registered with add_table -- labels, masks) becomes the head of the graph; a step is then
+        static_batch.stage(indices) -- one small asynchronous upload -- followed by replay()."""
         if not optimizer.capturable:
             raise ValueError("GraphedTrainStep needs TFAdam(capturable=True)")
         self.bucket, self.shard_weight = bucket, shard_weight
         self.model, self.opt, self.loss_fn, self.sb = model, optimizer, loss_fn, static_batch
         self.labels, self.mask, self.kw = labels, mask, fwd_kwargs
         self.cost_sum = self.logits = None
+        self.capture_assembly = bool(capture_assembly)
+        if self.capture_assembly and not hasattr(static_batch, "assemble"):
+            raise ValueError("capture_assembly needs a static batch with stage() / assemble()")
         # warm-up and capture must not train: model and optimiser state are restored afterwards
         if hasattr(static_batch, "reset_usage"):
             static_batch.reset_usage()
@@ -168,6 +174,8 @@ class GraphedTrainStep:
         # backward's own result tensors become the new .grad (static addresses inside the captured graph's memory pool) and
         # one multi-tensor copy packs them into the flat buffer the update kernel / the all-reduce read
         self.opt.zero_grad(set_to_none=True)
+        if self.capture_assembly:
+            self.sb.assemble()
         logits = self.model(self.sb.features, self.sb.adjacency, **self.kw)
         cost_opt, cost_sum = self.loss_fn(logits, self.labels, self.mask)
         cost_opt.backward()

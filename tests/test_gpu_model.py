@@ -374,12 +374,14 @@ def test_graphed_step_with_captured_rccl_allreduce(tmp_path):
     assert res["param_diff"] < 2e-5, res
 
 
+@pytest.mark.parametrize("route", [1, 2])
 @pytest.mark.parametrize("B,N,F,W,with_en", [(30, 10, 3, 50, False), (64, 32, 40, 48, True), (1, 5, 7, 13, True), (200, 16, 5, 50, True),
-                                             (37, 17, 64, 50, True)])
-def test_cross_layer_stack_equals_layer_by_layer(B, N, F, W, with_en):
+                                             (37, 17, 64, 50, True), (1500, 10, 3, 50, True), (301, 7, 9, 64, True)])
+def test_cross_layer_stack_equals_layer_by_layer(B, N, F, W, with_en, route):
     """example_model/model.py's node-level body (3 x GraphConv, BatchNormalization with its moving statistics, GraphDense,
-    GraphGather) through the cross-layer kernels (csrc/stack.hip: one forward, one backward launch) against the same
-    modules run one by one: logits, d features and every parameter gradient; non-trivial moving statistics / gamma / beta /
+    GraphGather) through the cross-layer kernels (one forward, one backward launch; route 1: csrc/stack.hip, one graph per
+    workgroup trip, plain FMAs; route 2: csrc/stack_tile.hip, 64-row tiles of whole graphs on the f32 MFMA -- more tiles than
+    CUs and a ragged last tile in the 1,500-graph case) against the same modules run one by one: logits, d features and every parameter gradient; non-trivial moving statistics / gamma / beta /
     biases, true sizes (padded rows -> act(0) behind the normalisation), a dummy graph, 32 nodes / odd node counts / 64 input features.  The layer-by-layer route is itself checked against the fp64 model oracle above."""
     from kgcn_amd import layers, models
     from test_oracle_model import tox21_like_batch
@@ -392,8 +394,11 @@ def test_cross_layer_stack_equals_layer_by_layer(B, N, F, W, with_en):
         x = np.zeros((1, N, F)); x[0, :N - 1] = rng.standard_normal((N - 1, F))
     lab = np.eye(2)[rng.integers(0, 2, B)]
     res = {}
+    from kgcn_amd import ops
     for fused in (True, False):
         layers.stack_fusion = fused
+        ops.stack_route = route
+        max_rows, layers.stack_fusion_max_rows = layers.stack_fusion_max_rows, 1 << 30
         try:
             torch.manual_seed(0)
             model = models.GCN(1, 2).to(dev())
@@ -427,7 +432,89 @@ def test_cross_layer_stack_equals_layer_by_layer(B, N, F, W, with_en):
                 assert any("GcnStack" in n_ for n_ in names), names
         finally:
             layers.stack_fusion = True
+            layers.stack_fusion_max_rows = max_rows
+            ops.stack_route = 0
     close(res[True][0], res[False][0], atol=2e-5, what="stack vs layers: logits")
     close(res[True][1], res[False][1], atol=1e-7, rel=2e-5, what="stack vs layers: d features")
     for (n_, a), (_, b) in zip(res[True][2], res[False][2]):
         close(a, b, atol=2e-7, rel=2e-5, what="stack vs layers: grad %s" % n_)
+
+
+@pytest.mark.parametrize("T,nsel", [(30, 30), (300, 257), (1000, 1000), (5, 0)])
+def test_batch_assemble_equals_per_container_gather(T, nsel):
+    """kgcn_batch_assemble (all containers of a mini-batch + feature rows + registered tables in two launches) against the
+    per-container kgcn_csr_gather_graphs and torch.index_select: bit-exact rowptr / entries / slot tables / graph_ptr of A,
+    A^T and both row-padded copies, feature rows, a float and an int32 table; dummy graphs (-1) pad a short batch; more than
+    256 graphs (several scan blocks) and an empty selection."""
+    from kgcn_amd import data_util as D
+    raw = load_golden("g1_synthetic_raw.npz")
+    rep = 6
+    dense = np.tile(raw["dense_adj"].astype(np.int64), (rep, 1, 1))
+    feats = np.tile(raw["feature"], (rep, 1, 1)).astype(np.float32)
+    G = dense.shape[0]
+    chans, _ = D.build_adjs({"dense_adj": dense, "max_node_num": 10})
+    ds = D.DeviceGraphDataset(chans, feats, device=dev())
+    rng = np.random.default_rng(T)
+    lab = torch.from_numpy(rng.standard_normal((G, 3)).astype(np.float32)).to(dev())
+    sizes = torch.from_numpy(rng.integers(0, 11, G).astype(np.int32)).to(dev())
+    sb = ds.static_batch(T)
+    lab_s, sz_s = sb.add_table(lab), sb.add_table(sizes)
+    idx = rng.integers(0, G, nsel)
+    sb.load(idx)
+    sel = np.full(T, -1, np.int64); sel[:nsel] = idx
+    for pairs in sb._sources:
+        for src, st in pairs:
+            ref = src.gather(sel)
+            n = int(ref.rowptr[-1])
+            assert torch.equal(st.rowptr, ref.rowptr), "rowptr (row_pad %d)" % src.row_pad
+            assert torch.equal(st.cv[:n], ref.cv[:n]), "entries (row_pad %d)" % src.row_pad
+            assert int(st._gptr_buf[-1]) == n
+            if src.row_pad:
+                assert torch.equal(st.slots, ref.slots) and torch.equal(st._gptr_buf, ref.graph_ptr)
+    seld = torch.from_numpy(np.maximum(sel, 0)).to(dev())
+    valid = torch.from_numpy(sel >= 0).to(dev())
+    assert torch.equal(sb.features, ds.features[seld] * valid[:, None, None])
+    assert torch.equal(lab_s, lab[seld] * valid[:, None])
+    assert torch.equal(sz_s, sizes[seld] * valid.to(torch.int32))
+
+
+def test_graphed_train_step_with_captured_assembly():
+    """GraphedTrainStep(capture_assembly=True): the device-side batch assembly (adjacency, features, label / mask tables) is the
+    head of the hipGraph and a step is stage(indices) + replay(); costs and parameters follow eager steps on batches assembled
+    the plain way, through two epochs with a padded last batch."""
+    from kgcn_amd import data_util as D, models, train
+    raw = load_golden("g1_synthetic_raw.npz")
+    chans, _ = D.build_adjs({"dense_adj": raw["dense_adj"].astype(np.int64), "max_node_num": 10})
+    feats, labels = raw["feature"], raw["label"]
+    G = feats.shape[0]
+    ds = D.DeviceGraphDataset(chans, feats, device=dev())
+    torch.manual_seed(0)
+    m_e, m_g = models.GCN(1).to(dev()), models.GCN(1).to(dev())
+    adj0, x0 = ds.batch(np.arange(30), 30)
+    m_e(x0, adj0); m_g(x0, adj0)
+    m_g.load_state_dict(m_e.state_dict())
+    o_e = train.TFAdam(m_e.parameters(), lr=0.01)
+    o_g = train.TFAdam(m_g.parameters(), lr=0.01)
+    sb = ds.static_batch(30)
+    lab_s = sb.add_table(t32(labels))
+    mask_s = sb.add_table(torch.ones(G, device=dev()))
+    sb.load(np.arange(30))
+    step = train.GraphedTrainStep(m_g, o_g, models.masked_softmax_ce, sb, lab_s, mask_s, capture_assembly=True)
+    rng = np.random.default_rng(2)
+    idx = np.arange(160)
+    lab, mask = torch.zeros((30, 2), device=dev()), torch.zeros(30, device=dev())
+    for epoch in range(2):
+        rng.shuffle(idx)
+        for it in range(6):
+            bidx = idx[it * 30:(it + 1) * 30]
+            nb = len(bidx)
+            lab.zero_(); lab[:nb] = t32(labels[bidx])
+            mask.zero_(); mask[:nb] = 1
+            adj, x = ds.batch(bidx, 30)
+            cs_e, lg_e = train.train_step(m_e, o_e, models.masked_softmax_ce, x, adj, lab, mask)
+            sb.stage(bidx)
+            cs_g, lg_g = step.replay()
+            assert abs(cs_e - float(cs_g)) < 1e-4 * max(1.0, abs(cs_e)), (epoch, it, cs_e, float(cs_g))
+            close(lg_g, lg_e.cpu().numpy(), atol=1e-4, what="logits")
+    for a, b in zip(m_e.parameters(), m_g.parameters()):
+        close(b, a.detach().cpu().numpy(), atol=2e-5, what="params after 12 steps")

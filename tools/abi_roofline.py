@@ -168,6 +168,16 @@ def _cost(name, a):
     if name == "kgcn_csr_gather_graphs":
         c = _csr(a[0])
         return 16 * c.max_nnz_per_graph * a[2], 0, "sel=%d" % a[2]
+    if name == "kgcn_batch_assemble":
+        plan = a[0].contents if hasattr(a[0], "contents") else a[0]
+        T = a[2]
+        by = 0
+        for i in range(plan.num_csr):
+            c = plan.src[i].contents
+            by += T * (16 * c.max_nnz_per_graph + 8 * c.rows)          # worst-case entries + row pointers, read and written
+        for k in range(plan.num_tables):
+            by += 8 * T * plan.row_floats[k]
+        return by, 0, "sel=%d containers=%d tables=%d" % (T, plan.num_csr, plan.num_tables)
     return None
 
 

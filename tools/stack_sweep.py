@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """model.py training step (hipGraph replay, batch resident) with and without the cross-layer kernels over batch sizes:
-where the one-launch-per-direction stack (plain fp32 FMAs, csrc/stack.hip) beats the per-layer MFMA kernels."""
+the one-launch-per-direction stack on its two routes (stack: one graph per workgroup trip, plain fp32 FMAs, csrc/stack.hip;
+tiles: 64-row tiles on the f32 MFMA, csrc/stack_tile.hip) against the per-layer kernels."""
 import json
 import os
 import sys
@@ -11,7 +12,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from kgcn_amd import data_util as D, layers, models, train  # noqa: E402
+from kgcn_amd import data_util as D, layers, models, ops, train  # noqa: E402
 
 dev = torch.device("cuda:0")
 z = np.load(os.path.join(ROOT, "tests", "golden", "g1_synthetic_raw.npz"))
@@ -23,8 +24,9 @@ ds = D.DeviceGraphDataset(chans, feats, device=dev)
 res = {}
 for batch in [int(a) for a in sys.argv[1:]] or [30, 128, 256, 512, 1024, 4096]:
     row = {}
-    for fused in (True, False):
+    for name, fused, route in (("stack", True, 1), ("tiles", True, 2), ("layers", False, 0)):
         layers.stack_fusion = fused
+        ops.stack_route = route
         layers.stack_fusion_max_rows = 1 << 30
         torch.manual_seed(0)
         model = models.GCN(1).to(dev)
@@ -42,6 +44,6 @@ for batch in [int(a) for a in sys.argv[1:]] or [30, 128, 256, 512, 1024, 4096]:
         for _ in range(200):
             step.replay()
         torch.cuda.synchronize()
-        row["stack" if fused else "layers"] = round((time.perf_counter() - t0) / 200 * 1e3, 4)
+        row[name] = round((time.perf_counter() - t0) / 200 * 1e3, 4)
     res["batch_%d" % batch] = row
 print(json.dumps(res, indent=1))
