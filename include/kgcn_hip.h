@@ -431,6 +431,10 @@ int kgcn_masked_softmax_ce_f32(const float* logits, const float* labels, const f
 int kgcn_sparse_softmax_ce_f32(const float* logits, const int64_t* label_idx, const float* mask, int64_t batch,
                                int32_t classes, float* cost, float* dlogits, float* sums, void* workspace,
                                int64_t workspace_bytes, void* stream);
+/* Backward of those heads: out = dlogits * (g_sum + g_opt / batch), g_opt / g_sum = the upstream gradients of sums[1] (cost_opt)
+ * and sums[0] (cost_sum) as DEVICE scalars, either may be NULL (no gradient through that output). */
+int kgcn_loss_grad_f32(const float* dlogits, const float* g_opt, const float* g_sum, int64_t batch, int64_t n, float* out,
+                       void* stream);
 /* tf.train.AdamOptimizer(lr) (kgcn/core.py:124) over one flat buffer of n floats, with t = *step_counter + 1:
  *   lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t) (fp64);  m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g^2;
  *   params -= lr_t m / (sqrt(v) + eps)
@@ -475,7 +479,7 @@ typedef struct kgcn_stack_layer {
   const float* var;  /* kind 2 only */
   float eps;         /* kind 2 only */
   int32_t route;     /* read from layers[0] only: 0 automatic, 1 one graph per workgroup trip (plain fp32 FMAs), 2 64-row tiles of
-                        whole graphs on the f32 MFMA (<= 5 layers); the others: 0 */
+                        whole graphs on the f32 MFMA (<= 4 weight matrices); the others: 0 */
 } kgcn_stack_layer;
 int kgcn_gcn_stack_supported(int32_t n_nodes, int32_t max_nnz_per_graph, const kgcn_stack_layer* layers, int32_t num_layers);
 int64_t kgcn_gcn_stack_param_floats(const kgcn_stack_layer* layers, int32_t num_layers);

@@ -180,6 +180,7 @@ SIGNATURES = {
                                                   ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_sparse_softmax_ce_f32": (ctypes.c_int, [c_f32p, ctypes.c_void_p, c_f32p, c_i64, c_i32, c_f32p, c_f32p, c_f32p,
                                                   ctypes.c_void_p, c_i64, ctypes.c_void_p]),
+    "kgcn_loss_grad_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_f32p, ctypes.c_void_p]),
     "kgcn_adam_tf_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "kgcn_augment_ones_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i64, c_f32p, c_i64, ctypes.c_void_p]),

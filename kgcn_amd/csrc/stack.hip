@@ -368,13 +368,14 @@ __global__ __launch_bounds__(256) void stack_bwd_kernel(StackArgs a, const int* 
 
 struct StackPlan { StackArgs a; int gtotal; size_t lds_fwd, lds_bwd; Stack2Plan tile; int route; };
 
-// Route of a launch: layers[0].route 1 / 2 force the one-graph / the tile kernels (tests, measurements); 0: tiles once there are
-// more graphs than CUs (model.py step, 10-node graphs: 256 graphs 0.123 vs 0.132 ms, 512 graphs 0.169 vs 0.134 ms).
+// Route of a launch: layers[0].route 1 / 2 force the one-graph / the tile kernels (tests, measurements); 0: the tile kernels
+// whenever they take the layer list (model.py step, 10-node graphs: 30 graphs 0.099 vs 0.118 ms, 512 graphs 0.103 vs 0.169 ms,
+// 4,096 graphs 0.208 vs 0.867 ms), the one-graph kernels for what they do not (more than four weight matrices, LDS).
 static bool use_tiles(const StackPlan& p, long T) {
   if (!p.tile.ok || p.route == 1) return false;
   if (p.route == 2) return true;
   if (p.lds_fwd > (size_t)kLdsBytes || p.lds_bwd > (size_t)kLdsBytes) return true;     // the one-graph kernels do not fit
-  return T > (long)kNumCU;
+  return true;
 }
 
 static int stack_plan(int n_nodes, int max_nnz, const kgcn_stack_layer* layers, int nl, StackPlan* p, const char* who) {

@@ -37,7 +37,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 __global__ __launch_bounds__(kLossBlock) void sigmoid_ce_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
                                                                const float* __restrict__ mask, const float* __restrict__ mask_label,
                                                                long B, int T, int weighted, float q, float* __restrict__ cost,
-                                                               float* __restrict__ dlogits, float* __restrict__ part) {
+                                                               float* __restrict__ dlogits, float* __restrict__ part,
+                                                               float* __restrict__ sums_direct) {
   __shared__ float red[kLossBlock];
   const long b = (long)blockIdx.x * kLossBlock + threadIdx.x;
   float c = 0.f;
@@ -64,7 +65,13 @@ __global__ __launch_bounds__(kLossBlock) void sigmoid_ce_kernel(const float* __r
     if (cost) cost[b] = c;
   }
   const float s = block_sum_256(c, red);
-  if (threadIdx.x == 0) part[blockIdx.x] = s;
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = s;
+    if (sums_direct) {                                 // the batch fits this one workgroup: no finishing launch
+      sums_direct[0] = s;
+      sums_direct[1] = s / (float)B;
+    }
+  }
 }
 
 // example_model/model.py:56-61:  cost[b] = mask[b] * -(sum_c labels[b,c] log_softmax(logits[b])[c])
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(kLossBlock) void softmax_ce_kernel(const float* __r
                                                                const long long* __restrict__ label_idx,
                                                                const float* __restrict__ mask, long B, int C,
                                                                float* __restrict__ cost, float* __restrict__ dlogits,
-                                                               float* __restrict__ part) {
+                                                               float* __restrict__ part, float* __restrict__ sums_direct) {
   __shared__ float red[kLossBlock];
   const long b = (long)blockIdx.x * kLossBlock + threadIdx.x;
   float c = 0.f;
@@ -100,7 +107,13 @@ __global__ __launch_bounds__(kLossBlock) void softmax_ce_kernel(const float* __r
     if (cost) cost[b] = c;
   }
   const float s = block_sum_256(c, red);
-  if (threadIdx.x == 0) part[blockIdx.x] = s;
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = s;
+    if (sums_direct) {                                 // the batch fits this one workgroup: no finishing launch
+      sums_direct[0] = s;
+      sums_direct[1] = s / (float)B;
+    }
+  }
 }
 
 // sums[0] = sum of the block partials (fixed order), sums[1] = sums[0] / B  (reduce_sum / reduce_mean over the PADDED batch)
@@ -114,6 +127,15 @@ __global__ __launch_bounds__(kLossBlock) void loss_finish_kernel(const float* __
     sums[0] = s;
     sums[1] = s / (float)B;
   }
+}
+
+// backward of the loss heads: d logits = dlogits (= d cost_sum / d logits) * (g_sum + g_opt / B), the two upstream gradients
+// read from device scalars -- one launch instead of autograd's scalar multiply, add and broadcast multiply
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ dlogits, const float* __restrict__ g_opt,
+                                                        const float* __restrict__ g_sum, float inv_batch, long n,
+                                                        float* __restrict__ out) {
+  const float sc = (g_opt ? *g_opt * inv_batch : 0.f) + (g_sum ? *g_sum : 0.f);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = dlogits[i] * sc;
 }
 
 template <bool VEC>
@@ -187,8 +209,9 @@ extern "C" int kgcn_masked_sigmoid_ce_f32(const float* logits, const float* labe
   float* part = static_cast<float*>(workspace);
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(sigmoid_ce_kernel, dim3(nb), dim3(kLossBlock), 0, s, logits, labels, mask, mask_label, (long)batch, tasks,
-                     weighted ? 1 : 0, pos_weight, cost, dlogits, part);
+                     weighted ? 1 : 0, pos_weight, cost, dlogits, part, nb == 1 ? sums : nullptr);
   if (int rc = check_launch("sigmoid_ce_kernel")) return rc;
+  if (nb == 1) return 0;
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kLossBlock), 0, s, part, nb, (long)batch, sums);
   return check_launch("loss_finish_kernel");
 }
@@ -203,8 +226,9 @@ extern "C" int kgcn_masked_softmax_ce_f32(const float* logits, const float* labe
   float* part = static_cast<float*>(workspace);
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(softmax_ce_kernel, dim3(nb), dim3(kLossBlock), 0, s, logits, labels, nullptr, mask, (long)batch, classes,
-                     cost, dlogits, part);
+                     cost, dlogits, part, nb == 1 ? sums : nullptr);
   if (int rc = check_launch("softmax_ce_kernel")) return rc;
+  if (nb == 1) return 0;
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kLossBlock), 0, s, part, nb, (long)batch, sums);
   return check_launch("loss_finish_kernel");
 }
@@ -219,10 +243,24 @@ extern "C" int kgcn_sparse_softmax_ce_f32(const float* logits, const int64_t* la
   float* part = static_cast<float*>(workspace);
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(softmax_ce_kernel, dim3(nb), dim3(kLossBlock), 0, s, logits, nullptr,
-                     reinterpret_cast<const long long*>(label_idx), mask, (long)batch, classes, cost, dlogits, part);
+                     reinterpret_cast<const long long*>(label_idx), mask, (long)batch, classes, cost, dlogits, part,
+                     nb == 1 ? sums : nullptr);
   if (int rc = check_launch("softmax_ce_kernel")) return rc;
+  if (nb == 1) return 0;
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kLossBlock), 0, s, part, nb, (long)batch, sums);
   return check_launch("loss_finish_kernel");
+}
+
+extern "C" int kgcn_loss_grad_f32(const float* dlogits, const float* g_opt, const float* g_sum, int64_t batch, int64_t n,
+                                  float* out, void* stream) {
+  if (n < 0 || batch <= 0) return fail("kgcn_loss_grad_f32: bad shape n=%lld batch=%lld", (long long)n, (long long)batch);
+  if (n == 0) return 0;
+  if (!dlogits || !out) return fail("kgcn_loss_grad_f32: NULL operand");
+  long blocks = (n + 255) / 256;
+  if (blocks > 4L * kNumCU) blocks = 4L * kNumCU;
+  hipLaunchKernelGGL(loss_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), dlogits, g_opt, g_sum,
+                     1.0f / (float)batch, (long)n, out);
+  return check_launch("loss_grad_kernel");
 }
 
 extern "C" int kgcn_adam_tf_f32(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1,

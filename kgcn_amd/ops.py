@@ -811,6 +811,17 @@ def augment_ones(x2d, width):
 # -------------------------------------------------------------------------------------------------
 # losses of the model files: one HIP pass (cost per graph, d cost_sum / d logits, partial sums) + one finishing block
 # -------------------------------------------------------------------------------------------------
+def _loss_grad(dlog, g_opt, g_sum, batch):
+    """d logits = dlog * (g_sum + g_opt / batch) in one launch (kgcn_loss_grad_f32)."""
+    if g_opt is None and g_sum is None:
+        return None
+    go = None if g_opt is None else _f32c(g_opt.reshape(1), "grad")
+    gs = None if g_sum is None else _f32c(g_sum.reshape(1), "grad")
+    out = torch.empty_like(dlog)
+    check(lib.kgcn_loss_grad_f32(ptr(dlog), ptr(go), ptr(gs), batch, dlog.numel(), ptr(out), current_stream()), "kgcn_loss_grad_f32")
+    return out
+
+
 class _MaskedCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, mask, mask_label, kind, pos_weight):
@@ -836,17 +847,13 @@ class _MaskedCE(torch.autograd.Function):
                                                  current_stream()), "kgcn_masked_softmax_ce_f32")
         ctx.save_for_backward(dlog)
         ctx.batch = B
+        ctx.set_materialize_grads(False)           # an output nobody differentiates must not become a zero-filled gradient
         return sums[1], sums[0]                    # cost_opt (mean over the padded batch, Q5), cost_sum
 
     @staticmethod
     def backward(ctx, g_opt, g_sum):
         (dlog,) = ctx.saved_tensors
-        scale = None
-        if g_opt is not None:
-            scale = g_opt * (1.0 / ctx.batch)
-        if g_sum is not None:
-            scale = g_sum if scale is None else scale + g_sum
-        return (dlog * scale if scale is not None else None), None, None, None, None, None
+        return _loss_grad(dlog, g_opt, g_sum, ctx.batch), None, None, None, None, None
 
 
 class _SparseCE(torch.autograd.Function):

@@ -142,7 +142,7 @@ class GraphedTrainStep:
         self.bucket, self.shard_weight = bucket, shard_weight
         self.model, self.opt, self.loss_fn, self.sb = model, optimizer, loss_fn, static_batch
         self.labels, self.mask, self.kw = labels, mask, fwd_kwargs
-        self.cost_sum = self.logits = None
+        self.cost_sum = self.logits = self._seed = None
         self.capture_assembly = bool(capture_assembly)
         if self.capture_assembly and not hasattr(static_batch, "assemble"):
             raise ValueError("capture_assembly needs a static batch with stage() / assemble()")
@@ -178,7 +178,9 @@ class GraphedTrainStep:
             self.sb.assemble()
         logits = self.model(self.sb.features, self.sb.adjacency, **self.kw)
         cost_opt, cost_sum = self.loss_fn(logits, self.labels, self.mask)
-        cost_opt.backward()
+        if self._seed is None or self._seed.shape != cost_opt.shape:
+            self._seed = torch.ones_like(cost_opt)     # persistent d cost / d cost = 1: no fill launch per step
+        cost_opt.backward(self._seed)
         self.opt.step(packed=_exchange(self.bucket, self.opt, self.shard_weight))
         self.cost_sum, self.logits = cost_sum.detach(), logits.detach()
 

@@ -168,6 +168,8 @@ def _cost(name, a):
     if name == "kgcn_csr_gather_graphs":
         c = _csr(a[0])
         return 16 * c.max_nnz_per_graph * a[2], 0, "sel=%d" % a[2]
+    if name == "kgcn_loss_grad_f32":
+        return 8 * a[4], a[4], "n=%d" % a[4]
     if name == "kgcn_batch_assemble":
         plan = a[0].contents if hasattr(a[0], "contents") else a[0]
         T = a[2]
