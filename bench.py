@@ -468,12 +468,17 @@ class Cfg2:
         """rank 0: config + roofline + cpu_baseline."""
         args, T, wl = self.args, self.T, self.wl
         spmm = None if (args.unfused or args.profile) else self.spmm_probe(args.steps)
-        traffic = {}
+        traffic, traffic_stale = {}, None
         tpath = os.path.join(ROOT, "profiles", "traffic_cfg2.json")
         if os.path.exists(tpath) and not args.unfused:
             tj = json.load(open(tpath))
             if tj.get("graphs_per_launch") == T:      # PMC-measured HBM bytes of the same launch shape
                 traffic = {k: v.get("bytes") for k, v in tj.items() if isinstance(v, dict)}
+                import hashlib
+                h = hashlib.sha256()
+                for f in ("fused.hip", "spmm.hip", "dense.hip", "kgcn_common.h"):
+                    h.update(open(os.path.join(ROOT, "kgcn_amd", "csrc", f), "rb").read())
+                traffic_stale = tj.get("kernel_sources_sha256") != h.hexdigest()
         fwd_st = stats([e[0].elapsed_time(e[1]) for e in evs])
         bwd_st = stats([e[1].elapsed_time(e[2]) for e in evs])
         fwd_ms, bwd_ms = fwd_st["mean_ms"], bwd_st["mean_ms"]
@@ -504,6 +509,8 @@ class Cfg2:
                     "launch_ms": bwd_st,
                     "traffic_note": "HBM bytes per launch, rocprofv3 PMC (profiles/traffic_cfg2.json); "
                                     "algorithmic bytes per launch = %d" % int(ab["bwd"] * T),
+                    "traffic_stale": traffic_stale,      # True: the kernel sources changed since that PMC run
+
                     "algorithmic_bytes_per_graph": ab["bwd"], "avg_launch_ms": bwd_ms,
                     "fwd_kernel": {"achieved": fwd_gbs, "frac": fwd_gbs / HBM_PEAK_GBS,
                                    "algorithmic_bytes_per_graph": ab["fwd"], "avg_launch_ms": fwd_ms,
