@@ -592,7 +592,9 @@ class _ModelStep:
                                                      capture_assembly=self.assemble_in_step, **fwd_kwargs)
 
     def _eager_step(self):
+        from kgcn_amd import ops
         self.opt.zero_grad(set_to_none=False)
+        ops.weight_tables.refresh()
         if self.assemble_in_step:
             self.sb.assemble()
         logits = self.model(self.sb.features, self.sb.adjacency, **self.kw)

@@ -297,6 +297,22 @@ int64_t kgcn_dense_fwd_workspace_bytes(int32_t din, int32_t dout);
 int kgcn_dense_fwd_ws_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w, int64_t w_ld,
                           int32_t trans_w, const float* bias, float* y, int32_t dout, int64_t y_ld, int32_t act,
                           void* workspace, int64_t workspace_bytes, void* stream);
+/* Fragment tables ahead of time: ONE launch splits every listed operand (a training step: W of each wide layer for the forward,
+ * W^T for d input -- 7-9 separate 5 us launches otherwise); job = the operand of a contraction over k with n output columns,
+ * i.e. w [k x n] (trans_w = 0) or [n x k] (trans_w = 1), table = kgcn_dense_fwd_workspace_bytes(k, n) bytes.  The *_tab entry
+ * points take such a READY table (valid as long as w is unchanged) instead of a workspace; table == NULL: no table. */
+#define KGCN_WTABLE_MAX_JOBS 16
+typedef struct kgcn_wtable_job {
+  const float* w;
+  int64_t w_ld;
+  int32_t trans_w, k, n;
+  int32_t reserved_;
+  void* table;
+} kgcn_wtable_job;
+int kgcn_wtable_split_multi(const kgcn_wtable_job* jobs, int32_t num_jobs, void* stream);
+int kgcn_dense_fwd_tab_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w, int64_t w_ld,
+                           int32_t trans_w, const float* bias, float* y, int32_t dout, int64_t y_ld, int32_t act,
+                           const void* table, int64_t table_bytes, void* stream);
 /* Backward of y = act(x @ w + bias) with respect to x (w: [din x dout], ld w_ld):
  *   dpre = grad (.) act'(act_out)   written to dpre (same layout as grad; must not alias it) -- the operand of
  *                                   kgcn_dense_wgrad_f32 for dw / dbias,
@@ -306,6 +322,9 @@ int kgcn_dense_fwd_ws_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, 
 int kgcn_dense_dx_dact_f32(const float* grad, const float* act_out, int64_t m, int32_t dout, int64_t ld, const float* w,
                            int64_t w_ld, int32_t din, float* dx, int64_t dx_ld, int32_t act, float* dpre,
                            void* workspace, int64_t workspace_bytes, void* stream);
+int kgcn_dense_dx_dact_tab_f32(const float* grad, const float* act_out, int64_t m, int32_t dout, int64_t ld, const float* w,
+                               int64_t w_ld, int32_t din, float* dx, int64_t dx_ld, int32_t act, float* dpre, const void* table,
+                               int64_t table_bytes, void* stream);
 /* stand-alone forms: y = act(x) over n floats; dpre = grad (.) act'(act_out) (dpre may alias grad) */
 int kgcn_act_fwd_f32(const float* x, int64_t n, int32_t act, float* y, void* stream);
 int kgcn_act_bwd_f32(const float* act_out, const float* grad, int64_t n, int32_t act, float* dpre, void* stream);

@@ -62,6 +62,12 @@ class StackLayer(ctypes.Structure):
 
 _STKP = ctypes.POINTER(StackLayer)
 
+class WtableJob(ctypes.Structure):
+    """struct kgcn_wtable_job (include/kgcn_hip.h)."""
+    _fields_ = [("w", ctypes.c_void_p), ("w_ld", c_i64), ("trans_w", c_i32), ("k", c_i32), ("n", c_i32), ("reserved_", c_i32),
+                ("table", ctypes.c_void_p)]
+
+
 ASSEMBLE_MAX_CSR, ASSEMBLE_MAX_TABLES = 4, 6
 
 
@@ -140,6 +146,11 @@ SIGNATURES = {
                                              c_i64, c_i32, ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_dense_dx_dact_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i64, c_i32, c_i64, c_f32p, c_i64, c_i32, c_f32p, c_i64, c_i32,
                                               c_f32p, ctypes.c_void_p, c_i64, ctypes.c_void_p]),
+    "kgcn_dense_dx_dact_tab_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i64, c_i32, c_i64, c_f32p, c_i64, c_i32, c_f32p, c_i64,
+                                                  c_i32, c_f32p, ctypes.c_void_p, c_i64, ctypes.c_void_p]),
+    "kgcn_dense_fwd_tab_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i64, c_f32p, c_i64, c_i32, c_f32p, c_f32p, c_i32,
+                                              c_i64, c_i32, ctypes.c_void_p, c_i64, ctypes.c_void_p]),
+    "kgcn_wtable_split_multi": (ctypes.c_int, [ctypes.c_void_p, c_i32, ctypes.c_void_p]),
     "kgcn_act_fwd_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_f32p, ctypes.c_void_p]),
     "kgcn_act_bwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i64, c_i32, c_f32p, ctypes.c_void_p]),
     "kgcn_graph_bn_workspace_bytes": (c_i64, [c_i32]),

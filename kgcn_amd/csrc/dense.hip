@@ -521,9 +521,10 @@ int launch_skinny_n_wgrad(const float* x, long m, int din, long x_ld, const floa
                           float* part_db, int nparts, hipStream_t s);
 }  // namespace kgcn
 
+// table_ready: `workspace` already holds the fragment table of (w, trans_w) (kgcn_wtable_split_multi at the start of the step)
 static int dense_fwd_impl(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w, int64_t w_ld,
                           int32_t trans_w, const float* bias, float* y, int32_t dout, int64_t y_ld, int act,
-                          void* workspace, int64_t workspace_bytes, void* stream) {
+                          void* workspace, int64_t workspace_bytes, void* stream, bool table_ready = false) {
   if (act < KGCN_ACT_NONE || act > KGCN_ACT_TANH) return fail("kgcn_dense_fwd_f32: unknown activation code %d", act);
   if (m < 0 || din <= 0 || dout <= 0)
     return fail("kgcn_dense_fwd_f32: bad shape m=%lld din=%d dout=%d", (long long)m, din, dout);
@@ -544,7 +545,7 @@ static int dense_fwd_impl(const float* x, int64_t m, int32_t din, int64_t x_ld, 
     const void* table = nullptr;
     if (!(route && !strcmp(route, "gemm3")) && table_pays(din, dout) && workspace &&
         workspace_bytes >= wtable_bytes(din, dout) && m >= 1024) {
-      launch_wtable_split(w, (long)w_ld, trans_w, din, dout, workspace, as_stream(stream));
+      if (!table_ready) launch_wtable_split(w, (long)w_ld, trans_w, din, dout, workspace, as_stream(stream));
       table = workspace;
     }
     return launch_gemm3_fwd(x, (long)m, din, (long)x_ld, w, (long)w_ld, trans_w, bias, y, dout, (long)y_ld, act, table,
@@ -554,7 +555,7 @@ static int dense_fwd_impl(const float* x, int64_t m, int32_t din, int64_t x_ld, 
   if (gemmn_pays(x, din, (long)x_ld, dout) && workspace && workspace_bytes >= wtable_bytes(din, dout) && m >= 1024) {
     static const char* route = dev_knob("KGCN_DENSE_ROUTE");
     if (!(route && !strcmp(route, "gemm3"))) {
-      launch_wtable_split(w, (long)w_ld, trans_w, din, dout, workspace, as_stream(stream));
+      if (!table_ready) launch_wtable_split(w, (long)w_ld, trans_w, din, dout, workspace, as_stream(stream));
       return launch_gemmn_fwd(x, (long)m, din, (long)x_ld, workspace, bias, y, dout, (long)y_ld, act, as_stream(stream));
     }
   }
@@ -602,9 +603,9 @@ extern "C" int kgcn_dense_fwd_f32(const float* x, int64_t m, int32_t din, int64_
   return dense_fwd_impl(x, m, din, x_ld, w, w_ld, trans_w, bias, y, dout, y_ld, KGCN_ACT_NONE, nullptr, 0, stream);
 }
 
-extern "C" int kgcn_dense_dx_dact_f32(const float* grad, const float* act_out, int64_t m, int32_t dout, int64_t ld,
-                                      const float* w, int64_t w_ld, int32_t din, float* dx, int64_t dx_ld, int32_t act,
-                                      float* dpre, void* workspace, int64_t workspace_bytes, void* stream) {
+static int dense_dx_dact_impl(const float* grad, const float* act_out, int64_t m, int32_t dout, int64_t ld,
+                             const float* w, int64_t w_ld, int32_t din, float* dx, int64_t dx_ld, int32_t act,
+                             float* dpre, void* workspace, int64_t workspace_bytes, void* stream, bool table_ready) {
   if (act <= KGCN_ACT_NONE || act > KGCN_ACT_TANH) return fail("kgcn_dense_dx_dact_f32: activation code %d", act);
   if (m < 0 || din <= 0 || dout <= 0)
     return fail("kgcn_dense_dx_dact_f32: bad shape m=%lld din=%d dout=%d", (long long)m, din, dout);
@@ -616,7 +617,7 @@ extern "C" int kgcn_dense_dx_dact_f32(const float* grad, const float* act_out, i
   static const char* route = dev_knob("KGCN_DENSE_ROUTE");
   if (!(route && !strcmp(route, "gemm3")) && table_pays(dout, din) && workspace && workspace_bytes >= wtable_bytes(dout, din) &&
       m >= 1024) {
-    launch_wtable_split(w, (long)w_ld, 1, dout, din, workspace, as_stream(stream));
+    if (!table_ready) launch_wtable_split(w, (long)w_ld, 1, dout, din, workspace, as_stream(stream));
     const int rc = launch_gemm3_dx_dact(grad, act_out, dpre, (long)m, dout, (long)ld, workspace, dx, din, (long)dx_ld, act,
                                         as_stream(stream));
     if (rc >= 0) return rc;
@@ -624,12 +625,33 @@ extern "C" int kgcn_dense_dx_dact_f32(const float* grad, const float* act_out, i
   if (ld != dout) return fail("kgcn_dense_dx_dact_f32: rows must be contiguous (ld == dout) outside the fused form");
   if (int rc = kgcn_act_bwd_f32(act_out, grad, m * dout, act, dpre, stream)) return rc;
   return dense_fwd_impl(dpre, m, dout, ld, w, w_ld, 1, nullptr, dx, din, dx_ld, KGCN_ACT_NONE, workspace, workspace_bytes,
-                        stream);
+                        stream, table_ready);
+}
+
+extern "C" int kgcn_dense_dx_dact_f32(const float* grad, const float* act_out, int64_t m, int32_t dout, int64_t ld,
+                                      const float* w, int64_t w_ld, int32_t din, float* dx, int64_t dx_ld, int32_t act,
+                                      float* dpre, void* workspace, int64_t workspace_bytes, void* stream) {
+  return dense_dx_dact_impl(grad, act_out, m, dout, ld, w, w_ld, din, dx, dx_ld, act, dpre, workspace, workspace_bytes, stream,
+                            false);
+}
+
+extern "C" int kgcn_dense_dx_dact_tab_f32(const float* grad, const float* act_out, int64_t m, int32_t dout, int64_t ld,
+                                          const float* w, int64_t w_ld, int32_t din, float* dx, int64_t dx_ld, int32_t act,
+                                          float* dpre, const void* table, int64_t table_bytes, void* stream) {
+  return dense_dx_dact_impl(grad, act_out, m, dout, ld, w, w_ld, din, dx, dx_ld, act, dpre, const_cast<void*>(table),
+                            table_bytes, stream, table != nullptr);
 }
 
 extern "C" int64_t kgcn_dense_fwd_workspace_bytes(int32_t din, int32_t dout) {
   if (din <= 0 || dout <= 0 || !(table_pays(din, dout) || (dout <= 64 && din >= 128 && din % 4 == 0))) return 0;
   return wtable_bytes(din, dout);
+}
+
+extern "C" int kgcn_dense_fwd_tab_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w, int64_t w_ld,
+                                      int32_t trans_w, const float* bias, float* y, int32_t dout, int64_t y_ld,
+                                      int32_t act, const void* table, int64_t table_bytes, void* stream) {
+  return dense_fwd_impl(x, m, din, x_ld, w, w_ld, trans_w, bias, y, dout, y_ld, act, const_cast<void*>(table), table_bytes,
+                        stream, table != nullptr);
 }
 
 extern "C" int kgcn_dense_fwd_ws_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w, int64_t w_ld,

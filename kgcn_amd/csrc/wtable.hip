@@ -44,6 +44,44 @@ __global__ __launch_bounds__(256) void wtable_split_kernel(const float* __restri
   }
 }
 
+// the same for up to KGCN_WTABLE_MAX_JOBS operands in one launch (grid.y = operand): a training step splits every weight
+// operand of its wide layers -- W for the forward, W^T for d input -- once, at its start, instead of 5 us launches in front
+// of every GEMM (7-9 per step of the BASELINE models)
+struct WtJobs {
+  const float* w[KGCN_WTABLE_MAX_JOBS];
+  u32x4* table[KGCN_WTABLE_MAX_JOBS];
+  long w_ld[KGCN_WTABLE_MAX_JOBS];
+  int trans[KGCN_WTABLE_MAX_JOBS], din[KGCN_WTABLE_MAX_JOBS], dout[KGCN_WTABLE_MAX_JOBS];
+};
+
+__global__ __launch_bounds__(256) void wtable_split_multi_kernel(WtJobs jb) {
+  const int q = blockIdx.y;
+  const float* __restrict__ w = jb.w[q];
+  const long w_ld = jb.w_ld[q];
+  const int trans_w = jb.trans[q], din = jb.din[q], dout = jb.dout[q];
+  u32x4* __restrict__ table = jb.table[q];
+  const int ntiles = ((dout + WT_BN - 1) / WT_BN) * (WT_BN / 32);
+  const long total = (long)((din + 15) / 16) * ntiles * 64;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int lane = (int)(i & 63);
+    const long blk = i >> 6;
+    const int nt = (int)(blk % ntiles), ks = (int)(blk / ntiles);
+    const int n = 32 * nt + (lane & 31), k0 = 16 * ks + 8 * (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      float x = 0.f;
+      if (n < dout && k < din) x = trans_w ? w[(long)n * w_ld + k] : w[(long)k * w_ld + n];
+      v[j] = x;
+    }
+    Frag3 f;
+    split8(v, f);
+    u32x4* d = table + ((long)(ks * ntiles + nt) * 3) * 64 + lane;
+    d[0] = f.p1; d[64] = f.p2; d[128] = f.p3;
+  }
+}
+
 int64_t wtable_bytes(int din, int dout) { return wtable_entries(din, dout) * 16; }
 
 void launch_wtable_split(const float* w, long w_ld, int trans_w, int din, int dout, void* workspace, hipStream_t s) {
@@ -53,3 +91,26 @@ void launch_wtable_split(const float* w, long w_ld, int trans_w, int din, int do
 }
 
 }  // namespace kgcn
+
+using namespace kgcn;
+
+extern "C" int kgcn_wtable_split_multi(const kgcn_wtable_job* jobs, int32_t num_jobs, void* stream) {
+  if (num_jobs < 0 || (num_jobs > 0 && !jobs)) return fail("kgcn_wtable_split_multi: bad job list");
+  for (int base = 0; base < num_jobs; base += KGCN_WTABLE_MAX_JOBS) {
+    const int n = num_jobs - base < KGCN_WTABLE_MAX_JOBS ? num_jobs - base : KGCN_WTABLE_MAX_JOBS;
+    WtJobs jb{};
+    long most = 0;
+    for (int q = 0; q < n; ++q) {
+      const kgcn_wtable_job& j = jobs[base + q];
+      if (!j.w || !j.table || j.k <= 0 || j.n <= 0) return fail("kgcn_wtable_split_multi: job %d: bad operand", base + q);
+      if (j.w_ld < (j.trans_w ? j.k : j.n)) return fail("kgcn_wtable_split_multi: job %d: w_ld too small", base + q);
+      jb.w[q] = j.w; jb.table[q] = static_cast<u32x4*>(j.table); jb.w_ld[q] = (long)j.w_ld;
+      jb.trans[q] = j.trans_w; jb.din[q] = j.k; jb.dout[q] = j.n;
+      const long threads = wtable_entries(j.k, j.n) / 3;
+      if (threads > most) most = threads;
+    }
+    hipLaunchKernelGGL(wtable_split_multi_kernel, dim3((unsigned)((most + 255) / 256), n), dim3(256), 0, as_stream(stream), jb);
+    if (int rc = check_launch("wtable_split_multi_kernel")) return rc;
+  }
+  return 0;
+}

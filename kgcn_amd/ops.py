@@ -264,6 +264,90 @@ def _dense_ws(din, dout, device):
     return wsb, torch.empty((wsb // 4,), device=device, dtype=torch.float32)
 
 
+class WeightTables:
+    """bf16 fragment tables of the weight operands of wide dense layers (csrc/wtable.hip), split ONCE per training step.
+
+    dense() registers every weight it sees that has a table route (both orientations: W for the forward, W^T for d input).
+    refresh() -- called at the start of a step by kgcn_amd.train (train_step / GraphedTrainStep) -- splits all registered
+    operands with one launch and stamps them with the current epoch; invalidate() -- called by TFAdam.step, which rewrites the
+    weights through raw pointers -- starts a new epoch.  A lookup returns a table only if it was refreshed in this epoch AND
+    the weight's torch version counter is the one seen at the refresh (copy_ / load_state_dict bump it); otherwise dense()
+    splits on its own as before.  Inside a captured hipGraph the refresh is part of the graph, so every replay rebuilds the
+    tables from the weights it is about to use."""
+
+    def __init__(self):
+        self.epoch = 0
+        self.entries = {}          # (data_ptr, shape) -> entry
+
+    class _Entry:
+        __slots__ = ("ref", "tables", "epoch", "version")
+
+    def _entry(self, w, create):
+        import weakref
+        key = (w.data_ptr(), tuple(w.shape))
+        e = self.entries.get(key)
+        if e is not None and e.ref() is None:
+            del self.entries[key]
+            e = None
+        if e is None and create and isinstance(w, torch.nn.Parameter):
+            din, dout = w.shape
+            sizes = [int(lib.kgcn_dense_fwd_workspace_bytes(din, dout)), int(lib.kgcn_dense_fwd_workspace_bytes(dout, din))]
+            if max(sizes) <= 0:
+                return None
+            e = WeightTables._Entry()
+            e.ref = weakref.ref(w)
+            e.tables = [None if b <= 0 else torch.empty((b // 4,), device=w.device, dtype=torch.float32) for b in sizes]
+            e.epoch, e.version = -1, -1
+            self.entries[key] = e
+        return e
+
+    def register(self, w):
+        if enabled_weight_tables and w.dim() == 2 and w.is_cuda and w.is_contiguous():
+            self._entry(w, True)
+
+    def lookup(self, w, trans):
+        """-> (table tensor, bytes) ready for (w, trans) or (None, 0)."""
+        if not enabled_weight_tables:
+            return None, 0
+        e = self._entry(w, False)
+        if e is None or e.epoch != self.epoch or e.tables[trans] is None:
+            return None, 0
+        p = e.ref()
+        if p is None or p._version != e.version:
+            return None, 0
+        return e.tables[trans], e.tables[trans].numel() * 4
+
+    def invalidate(self):
+        self.epoch += 1
+
+    def refresh(self):
+        import ctypes
+        live = []
+        for key, e in list(self.entries.items()):
+            p = e.ref()
+            if p is None or p.data_ptr() != key[0]:
+                del self.entries[key]
+                continue
+            live.append((p, e))
+        if not live or not enabled_weight_tables:
+            return
+        jobs = (_lib.WtableJob * (2 * len(live)))()
+        n = 0
+        for p, e in live:
+            din, dout = p.shape
+            for trans, (k, nn) in enumerate(((din, dout), (dout, din))):
+                if e.tables[trans] is not None:
+                    jobs[n] = _lib.WtableJob(p.data_ptr(), dout, trans, k, nn, 0, e.tables[trans].data_ptr())
+                    n += 1
+        check(lib.kgcn_wtable_split_multi(ctypes.cast(jobs, ctypes.c_void_p), n, current_stream()), "kgcn_wtable_split_multi")
+        for p, e in live:
+            e.epoch, e.version = self.epoch, p._version
+
+
+enabled_weight_tables = True
+weight_tables = WeightTables()
+
+
 class _Dense(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2d, w, bias, act=0):
@@ -276,9 +360,15 @@ class _Dense(torch.autograd.Function):
         if b is not None and b.numel() != dout:
             raise _lib.KgcnHipError("bias has %d elements, expected %d" % (b.numel(), dout))
         y = torch.empty((m, dout), device=x2d.device, dtype=torch.float32)
-        wsb, wsp = _dense_ws(din, dout, x2d.device)
-        check(lib.kgcn_dense_fwd_ws_f32(ptr(x2d), m, din, din, ptr(w), dout, 0, ptr(b), ptr(y), dout,
-                                        dout, int(act), ptr(wsp), wsb, current_stream()), "kgcn_dense_fwd_ws_f32")
+        tab, tb = weight_tables.lookup(w, 0)
+        if tab is not None:
+            check(lib.kgcn_dense_fwd_tab_f32(ptr(x2d), m, din, din, ptr(w), dout, 0, ptr(b), ptr(y), dout,
+                                             dout, int(act), ptr(tab), tb, current_stream()), "kgcn_dense_fwd_tab_f32")
+        else:
+            weight_tables.register(w)
+            wsb, wsp = _dense_ws(din, dout, x2d.device)
+            check(lib.kgcn_dense_fwd_ws_f32(ptr(x2d), m, din, din, ptr(w), dout, 0, ptr(b), ptr(y), dout,
+                                            dout, int(act), ptr(wsp), wsb, current_stream()), "kgcn_dense_fwd_ws_f32")
         ctx.act = int(act)
         ctx.save_for_backward(x2d, w, y if act else x2d)
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
@@ -300,9 +390,14 @@ class _Dense(torch.autograd.Function):
             # weight-gradient GEMM reads it afterwards
             dx = torch.empty_like(x2d)
             dpre = torch.empty_like(gy)
-            wsb, wsp = _dense_ws(dout, din, gy.device)
-            check(lib.kgcn_dense_dx_dact_f32(ptr(gy), ptr(yact), m, dout, dout, ptr(w), dout, din, ptr(dx), din, ctx.act,
-                                             ptr(dpre), ptr(wsp), wsb, current_stream()), "kgcn_dense_dx_dact_f32")
+            tab, tb = weight_tables.lookup(w, 1)
+            if tab is not None:
+                check(lib.kgcn_dense_dx_dact_tab_f32(ptr(gy), ptr(yact), m, dout, dout, ptr(w), dout, din, ptr(dx), din, ctx.act,
+                                                     ptr(dpre), ptr(tab), tb, current_stream()), "kgcn_dense_dx_dact_tab_f32")
+            else:
+                wsb, wsp = _dense_ws(dout, din, gy.device)
+                check(lib.kgcn_dense_dx_dact_f32(ptr(gy), ptr(yact), m, dout, dout, ptr(w), dout, din, ptr(dx), din, ctx.act,
+                                                 ptr(dpre), ptr(wsp), wsb, current_stream()), "kgcn_dense_dx_dact_f32")
             gy = dpre
         else:
             if ctx.act and not fuse_dact:
@@ -310,9 +405,14 @@ class _Dense(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x2d)
                 # dx = gy @ w^T : w [din, dout] used transposed
-                wsb, wsp = _dense_ws(dout, din, gy.device)
-                check(lib.kgcn_dense_fwd_ws_f32(ptr(gy), m, dout, dout, ptr(w), dout, 1, None, ptr(dx),
-                                                din, din, 0, ptr(wsp), wsb, current_stream()), "kgcn_dense_fwd_ws_f32(dx)")
+                tab, tb = weight_tables.lookup(w, 1)
+                if tab is not None:
+                    check(lib.kgcn_dense_fwd_tab_f32(ptr(gy), m, dout, dout, ptr(w), dout, 1, None, ptr(dx),
+                                                     din, din, 0, ptr(tab), tb, current_stream()), "kgcn_dense_fwd_tab_f32(dx)")
+                else:
+                    wsb, wsp = _dense_ws(dout, din, gy.device)
+                    check(lib.kgcn_dense_fwd_ws_f32(ptr(gy), m, dout, dout, ptr(w), dout, 1, None, ptr(dx),
+                                                    din, din, 0, ptr(wsp), wsb, current_stream()), "kgcn_dense_fwd_ws_f32(dx)")
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.bias_shape is not None and ctx.needs_input_grad[2]
         if need_w or need_b:

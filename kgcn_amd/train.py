@@ -86,8 +86,10 @@ class TFAdam:
         """One update of every parameter: [one multi-tensor copy of the .grad tensors into the flat gradient buffer unless
         `packed` says a GradBucket sharing the buffer already did it] + the update kernel + the counter tick."""
         from . import _lib
+        from . import ops
         if not packed:
             self.flat.pack_grads()
+        ops.weight_tables.invalidate()             # the update rewrites the weights behind torch's version counters
         self.t += 1
         _lib.check(_lib.lib.kgcn_adam_tf_f32(_lib.ptr(self.flat.data), _lib.ptr(self.flat.grad), _lib.ptr(self._m),
                                              _lib.ptr(self._v), self.flat.total, float(self.lr), float(self.b1),
@@ -110,7 +112,9 @@ def train_step(model, optimizer, loss_fn, features, adjs, labels, mask, bucket=N
     """sess.run([train_step, cost_sum]) of one mini-batch; `bucket` (kgcn_amd.parallel.GradBucket)
     combines the gradients of the data-parallel ranks before the update (shard_weight: this rank's share
     of the global padded batch, kgcn_amd.parallel.shard_weight; None = equal shards)."""
+    from . import ops
     optimizer.zero_grad()
+    ops.weight_tables.refresh()                    # every wide layer's W / W^T fragment tables in one launch
     logits = model(features, adjs, **fwd_kwargs)
     cost_opt, cost_sum = loss_fn(logits, labels, mask)
     cost_opt.backward()
@@ -173,7 +177,9 @@ class GraphedTrainStep:
         # gradients are NOT accumulated into persistent .grad tensors (one add launch per parameter): .grad is dropped, the
         # backward's own result tensors become the new .grad (static addresses inside the captured graph's memory pool) and
         # one multi-tensor copy packs them into the flat buffer the update kernel / the all-reduce read
+        from . import ops
         self.opt.zero_grad(set_to_none=True)
+        ops.weight_tables.refresh()                # every wide layer's W / W^T fragment tables in one launch
         if self.capture_assembly:
             self.sb.assemble()
         logits = self.model(self.sb.features, self.sb.adjacency, **self.kw)

@@ -518,3 +518,63 @@ def test_graphed_train_step_with_captured_assembly():
             close(lg_g, lg_e.cpu().numpy(), atol=1e-4, what="logits")
     for a, b in zip(m_e.parameters(), m_g.parameters()):
         close(b, a.detach().cpu().numpy(), atol=2e-5, what="params after 12 steps")
+
+
+def test_weight_tables_refreshed_once_per_step_follow_the_weights():
+    """ops.weight_tables: the W / W^T fragment tables of wide dense layers split by ONE launch at the start of a step must
+    give the same results as the per-call split, and must never be used stale: after an optimiser update (raw-pointer write,
+    epoch bump), after a torch-level in-place change of the weight (version bump), and inside a captured hipGraph whose weights
+    were restored behind its back, outputs and gradients follow the CURRENT weights."""
+    from kgcn_amd import ops, train
+    torch.manual_seed(3)
+    m, din, dout = 4096, 256, 256
+    x = torch.randn(m, din, device=dev(), requires_grad=True)
+    lin1 = torch.nn.Parameter(torch.randn(din, dout, device=dev()) * 0.05)
+    lin2 = torch.nn.Parameter(torch.randn(dout, dout, device=dev()) * 0.05)
+
+    def run():
+        for t in (x, lin1, lin2):
+            t.grad = None
+        y = ops.dense(ops.dense(x, lin1, None, "relu"), lin2, None, "sigmoid")
+        y.square().sum().backward()
+        return y.detach().clone(), x.grad.clone(), lin1.grad.clone(), lin2.grad.clone()
+
+    ops.enabled_weight_tables = False
+    try:
+        ref = run()
+    finally:
+        ops.enabled_weight_tables = True
+    run()                                            # registers the two weights
+    ops.weight_tables.refresh()
+    assert ops.weight_tables.lookup(lin1, 0)[0] is not None and ops.weight_tables.lookup(lin2, 1)[0] is not None
+    got = run()
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)                     # same kernels, same tables: bit-identical
+    # torch-level in-place change: the version counter invalidates the tables until the next refresh
+    with torch.no_grad():
+        lin1.mul_(1.5)
+    assert ops.weight_tables.lookup(lin1, 0)[0] is None and ops.weight_tables.lookup(lin2, 0)[0] is not None
+    ops.enabled_weight_tables = False
+    try:
+        ref2 = run()
+    finally:
+        ops.enabled_weight_tables = True
+    got2 = run()
+    for a, b in zip(got2, ref2):
+        assert torch.equal(a, b)
+    # an optimiser update writes through raw pointers: its epoch bump invalidates everything
+    ops.weight_tables.refresh()
+    opt = train.TFAdam([lin1, lin2], lr=0.1)
+    ops.weight_tables.refresh()
+    run()
+    opt.step()
+    assert ops.weight_tables.lookup(lin1, 0)[0] is None and ops.weight_tables.lookup(lin2, 1)[0] is None
+    ops.enabled_weight_tables = False
+    try:
+        ref3 = run()
+    finally:
+        ops.enabled_weight_tables = True
+    ops.weight_tables.refresh()
+    got3 = run()
+    for a, b in zip(got3, ref3):
+        assert torch.equal(a, b)

@@ -61,10 +61,10 @@ def _cost(name, a):
     if name == "kgcn_spmm_values_grad_f32":
         c = _csr(a[0]); d = a[7]
         return 4 * d * c.num_graphs * (c.rows + c.cols) + 12 * c.nnz, 2 * c.nnz * d, "nnz=%d d=%d" % (c.nnz, d)
-    if name in ("kgcn_dense_fwd_f32", "kgcn_dense_fwd_act_f32", "kgcn_dense_fwd_ws_f32"):
+    if name in ("kgcn_dense_fwd_f32", "kgcn_dense_fwd_act_f32", "kgcn_dense_fwd_ws_f32", "kgcn_dense_fwd_tab_f32"):
         m, din, dout = a[1], a[2], a[9]
         return 4 * (m * din + m * dout + din * dout), 2 * m * din * dout, "m=%d %d->%d%s" % (m, din, dout, " T" if a[6] else "")
-    if name == "kgcn_dense_dx_dact_f32":
+    if name in ("kgcn_dense_dx_dact_f32", "kgcn_dense_dx_dact_tab_f32"):
         m, dout, din = a[2], a[3], a[7]
         return 4 * (3 * m * dout + m * din + din * dout), 2 * m * din * dout, "m=%d %d->%d T dact=%d" % (m, dout, din, a[10])
     if name == "kgcn_dense_wgrad_f32":
@@ -168,6 +168,8 @@ def _cost(name, a):
     if name == "kgcn_csr_gather_graphs":
         c = _csr(a[0])
         return 16 * c.max_nnz_per_graph * a[2], 0, "sel=%d" % a[2]
+    if name == "kgcn_wtable_split_multi":
+        return 2 << 20, 0, "jobs=%d" % a[1]         # weights in, bf16 tables out: a few MB (nominal figure), launch latency
     if name == "kgcn_loss_grad_f32":
         return 8 * a[4], a[4], "n=%d" % a[4]
     if name == "kgcn_batch_assemble":
