@@ -519,6 +519,9 @@ int launch_skinny_k_fwd(const float* x, long m, int din, long x_ld, const float*
 int skinny_wgrad_parts(long m);
 int launch_skinny_n_wgrad(const float* x, long m, int din, long x_ld, const float* g, long g_ld, int dout, float* part_dw,
                           float* part_db, int nparts, hipStream_t s);
+bool wgradx_ok(int din, int dout, long x_ld, long dy_ld);
+int launch_wgradx(const float* x, long x_ld, const float* dy, long dy_ld, long m, int din, int dout, float* part_dw, float* part_db,
+                  int nparts, hipStream_t s, const float* yact, int act);
 }  // namespace kgcn
 
 // table_ready: `workspace` already holds the fragment table of (w, trans_w) (kgcn_wtable_split_multi at the start of the step)
@@ -742,6 +745,16 @@ static int dense_wgrad_impl(const float* x, int64_t x_ld, const float* dy, int64
     float* part_dw = static_cast<float*>(workspace);
     float* part_db = part_dw + (long)nchunks * din * dout;
     if (int rc = launch_skinny_n_wgrad(x, (long)m, din, (long)x_ld, dy, (long)dy_ld, dout, part_dw, part_db, nchunks, s))
+      return rc;
+    return launch_reduce_pair(part_dw, (long)din * dout, dw, part_db, dout, dbias, nchunks, s);
+  }
+  if (wgradx_ok(din, dout, (long)x_ld, (long)dy_ld) && m >= 4096) {
+    // narrow input, wide output (81 -> 256): operands straight from memory into the f32 MFMA (wgradx.hip); one workgroup per
+    // CU (four per CU: 101 instead of 94 us and a four times larger second stage)
+    nchunks = kNumCU;
+    float* part_dw = static_cast<float*>(workspace);
+    float* part_db = part_dw + (long)nchunks * din * dout;
+    if (int rc = launch_wgradx(x, (long)x_ld, dy, (long)dy_ld, (long)m, din, dout, part_dw, part_db, nchunks, s, yact, act))
       return rc;
     return launch_reduce_pair(part_dw, (long)din * dout, dw, part_db, dout, dbias, nchunks, s);
   }
