@@ -4,7 +4,7 @@
 #include <stdio.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int CHAINS, bool GLOBAL, bool RANDOM = false>
+template <int CHAINS, bool GLOBAL, bool RANDOM = false, int WINDOW = 60 * 1024>
 __global__ void probe(const float* __restrict__ src, float* out, unsigned long long* cyc, int iters) {
   f32x16 acc[CHAINS];
   for (int c = 0; c < CHAINS; ++c) for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
@@ -16,8 +16,8 @@ __global__ void probe(const float* __restrict__ src, float* out, unsigned long l
     float av[8], bv[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      av[u] = GLOBAL ? p[(it * 16 + 2 * u) * 64 % (60 * 1024)] : a + u;
-      bv[u] = GLOBAL ? p[(it * 16 + 2 * u + 1) * 64 % (60 * 1024)] : b + u;
+      av[u] = GLOBAL ? p[(it * 16 + 2 * u) * 64 % WINDOW] : a + u;
+      bv[u] = GLOBAL ? p[(it * 16 + 2 * u + 1) * 64 % WINDOW] : b + u;
       if (!GLOBAL && !RANDOM && CHAINS == 4) {         // variant: every operand freshly written by ONE cheap VALU op
         av[u] = a = a * 1.0001f; bv[u] = b = b * 0.9999f;
       }
@@ -38,15 +38,15 @@ __global__ void probe(const float* __restrict__ src, float* out, unsigned long l
   if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
-template <int CHAINS, bool GLOBAL, bool RANDOM = false>
+template <int CHAINS, bool GLOBAL, bool RANDOM = false, int WINDOW = 60 * 1024>
 void run(const char* name, int threads, int blocks, const float* src) {
   float* out; unsigned long long* cyc;
   hipMalloc(&out, 4 * threads * blocks); hipMalloc(&cyc, 8);
   const int iters = 1000;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  probe<CHAINS, GLOBAL, RANDOM><<<blocks, threads>>>(src, out, cyc, iters);
+  probe<CHAINS, GLOBAL, RANDOM, WINDOW><<<blocks, threads>>>(src, out, cyc, iters);
   hipEventRecord(e0);
-  for (int r = 0; r < 20; ++r) probe<CHAINS, GLOBAL, RANDOM><<<blocks, threads>>>(src, out, cyc, iters);
+  for (int r = 0; r < 20; ++r) probe<CHAINS, GLOBAL, RANDOM, WINDOW><<<blocks, threads>>>(src, out, cyc, iters);
   hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -66,6 +66,9 @@ int main() {
   run<3, false, true>("3 chains, registers, RANDOM, 2 waves/SIMD", 512, 256, src);
   run<4, false>("4 chains, operands rewritten by 1 VALU op", 256, 256, src);
   run<4, false>("4 chains, rewritten, 2 waves/SIMD", 512, 256, src);
+  run<3, true, false, 2048>("3 chains, global operands, 8 KB window (L1)", 256, 256, src);
+  run<3, true, false, 2048>("3 chains, global, 8 KB window, 2 waves/SIMD", 512, 256, src);
+  run<3, true, false, 2048>("3 chains, global, 8 KB window, 4 waves/SIMD", 1024, 256, src);
   run<3, true>("3 chains, global operands", 256, 256, src);
   run<3, true>("3 chains, global operands, 2 waves/SIMD", 512, 256, src);
   run<1, true>("1 chain, global operands, 2 waves/SIMD", 512, 256, src);
