@@ -226,20 +226,30 @@ for case in range(CASES):
         fails.append(("gin deps", (N, Dg, T), float(gin.epsilon[0].grad), float(deps2[0])))
     # ---- round 3: cross-layer stack (model.py network) vs the same modules layer by layer -------------------------------------
     from kgcn_amd import models as MD
-    Bs, Ns = int(rng.integers(1, 50)), int(rng.integers(1, 33))
+    Bs, Ns = int(rng.integers(1, 50)) if case % 4 else int(rng.integers(300, 900)), int(rng.integers(1, 33))
     Fs, Ws = int(rng.integers(1, 65)), int(rng.integers(1, 57))
     szs = rng.integers(0, Ns + 1, size=Bs)
+    dup_s = case % 3 == 0                            # duplicate entries: rows longer than N take the tile kernels' CSR walk
+    ops.stack_route = (0, 1, 2)[case % 3]
     adjs_s, xs = [], np.zeros((Bs, Ns, Fs), np.float32)
     for b_, n_ in enumerate(szs):
         if n_ == 0:
             adjs_s.append([(np.zeros((0, 2), np.int32), np.zeros(0, np.float32), [Ns, Ns])]); continue
         a_ = (rng.random((n_, n_)) < 0.3) * rng.standard_normal((n_, n_))
-        adjs_s.append([(np.argwhere(a_ != 0).astype(np.int32), a_[a_ != 0].astype(np.float32), [Ns, Ns])])
+        ix_, vl_ = np.argwhere(a_ != 0).astype(np.int32), a_[a_ != 0].astype(np.float32)
+        if dup_s and len(ix_):
+            k_ = rng.integers(0, len(ix_), size=2 * len(ix_))
+            ix_, vl_ = np.concatenate([ix_, ix_[k_]]), np.concatenate([vl_, vl_[k_]])
+        adjs_s.append([(ix_, vl_, [Ns, Ns])])
         xs[b_, :n_] = rng.standard_normal((n_, Fs))
     use_en = bool(rng.integers(0, 2))
     outs_s = {}
-    for fused_s in (True, False):
-        layers.stack_fusion = fused_s
+    for fused_s in (True, False, "route1"):
+        if fused_s == "route1":
+            if not os.environ.get("FUZZ_DEBUG"):
+                continue
+            ops.stack_route = 1
+        layers.stack_fusion = bool(fused_s)
         torch.manual_seed(case)
         md = MD.GCN(1, 2).to(dev)
         for m_ in (md.conv1, md.conv2, md.conv3, md.dense):
@@ -258,8 +268,46 @@ for case in range(CASES):
         lg.sum().backward()
         outs_s[fused_s] = [lg.detach(), txs.grad] + [p__.grad for p__ in md.parameters()]
     layers.stack_fusion = True
+    ops.stack_route = 0
+    nf_ = len(fails)
     for i_, (a_, b_) in enumerate(zip(outs_s[True], outs_s[False])):
-        check("stack vs layers #%d" % i_, a_, b_.cpu().numpy(), rel=5e-5, atol=5e-6, ctx=("stack", Bs, Ns, Fs, Ws, use_en))
+        # duplicate entries triple some adjacency values: saturated sigmoids make y (1 - y) ill-conditioned in fp32 and the three
+        # implementations (layers, one-graph stack, tile stack) then differ by ~1e-4 from EACH OTHER on such a graph (FUZZ_DEBUG=1)
+        check("stack vs layers #%d" % i_, a_, b_.cpu().numpy(), rel=1e-3 if dup_s else 5e-5, atol=5e-6,
+              ctx=("stack", Bs, Ns, Fs, Ws, use_en, dup_s, case % 3))
+    if len(fails) > nf_ and os.environ.get("FUZZ_DEBUG"):
+        d_ = (outs_s[True][1] - outs_s[False][1]).abs()
+        bi_ = int(d_.reshape(Bs, -1).max(dim=1).values.argmax())
+        print("DEBUG stack case", case, "worst graph", bi_, "size", int(szs[bi_]), "nnz", len(adjs_s[bi_][0][1]),
+              "max|dfeat| of that graph", float(outs_s[False][1][bi_].abs().max()), "err", float(d_[bi_].max()),
+              "route 1 vs layers on that graph:", float((outs_s["route1"][1] - outs_s[False][1]).abs()[bi_].max()),
+              "route 1 vs tiles:", float((outs_s["route1"][1] - outs_s[True][1]).abs()[bi_].max()),
+              "graphs with err > 1e-5:", int((d_.reshape(Bs, -1).max(dim=1).values > 1e-5).sum()),
+              "max |adj val|", max((float(np.abs(a__[0][1]).max()) if len(a__[0][1]) else 0.0) for a__ in adjs_s))
+    # ---- mini-batch assembly in two launches vs the per-container gather ----------------------------------------------------------
+    from kgcn_amd import data_util as DU
+    Ga, Na, Ta = int(rng.integers(1, 40)), int(rng.integers(1, 40)), int(rng.integers(1, 700))
+    mats_a = [a[0] for a in rand_graphs(Ga, Na, rng.uniform(0.0, 0.5), empty_every=int(rng.integers(0, 5)), dup=bool(rng.integers(0, 2)))]
+    fa = rng.standard_normal((Ga, Na, 3)).astype(np.float32)
+    dsa = DU.DeviceGraphDataset([DU.FlatAdjacency.from_coo_list(mats_a, n_nodes=Na)], fa, device=dev)
+    sba = dsa.static_batch(Ta)
+    taba = t32(rng.standard_normal((Ga, 5)).astype(np.float32))
+    tab_s = sba.add_table(taba)
+    nsel = int(rng.integers(0, Ta + 1))
+    ia = rng.integers(0, Ga, nsel)
+    sba.load(ia)
+    sela = np.full(Ta, -1, np.int64); sela[:nsel] = ia
+    for pairs_ in sba._sources:
+        for src_, st_ in pairs_:
+            ref_ = src_.gather(sela)
+            n_ = int(ref_.rowptr[-1])
+            if not (torch.equal(st_.rowptr, ref_.rowptr) and torch.equal(st_.cv[:n_], ref_.cv[:n_]) and
+                    (not src_.row_pad or torch.equal(st_.slots, ref_.slots))):
+                fails.append(("batch_assemble container", (Ga, Na, Ta, nsel, src_.row_pad), 0.0, 0.0))
+    sd_ = torch.from_numpy(np.maximum(sela, 0)).to(dev)
+    vd_ = torch.from_numpy(sela >= 0).to(dev)
+    if not (torch.equal(sba.features, dsa.features[sd_] * vd_[:, None, None]) and torch.equal(tab_s, taba[sd_] * vd_[:, None])):
+        fails.append(("batch_assemble tables", (Ga, Na, Ta, nsel), 0.0, 0.0))
     # ---- device-side COO pack -----------------------------------------------------------------------------------------------
     Tp, Np, nz = int(rng.integers(1, 60)), int(rng.integers(1, 65)), int(rng.integers(0, 4000))
     gp, rp_, cp = rng.integers(0, Tp, nz), rng.integers(0, Np, nz), rng.integers(0, Np, nz)
