@@ -578,3 +578,39 @@ def test_weight_tables_refreshed_once_per_step_follow_the_weights():
     got3 = run()
     for a, b in zip(got3, ref3):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("route", [1, 2])
+def test_cross_layer_stack_rows_with_duplicate_entries(route):
+    """Rows that store a column several times (more entries than nodes: the tile kernels leave their ELL copy for a lockstep
+    walk over the CSR) accumulate like the layer-by-layer route; small adjacency values keep the sigmoids out of saturation so
+    the comparison stays well conditioned."""
+    from kgcn_amd import layers, models, ops
+    rng = np.random.default_rng(11)
+    B, N, F, W = 70, 6, 9, 24
+    adjs, x = [], rng.standard_normal((B, N, F)).astype(np.float32)
+    for b in range(B):
+        a = (rng.random((N, N)) < 0.6) * rng.standard_normal((N, N)) * 0.2
+        ix, vl = np.argwhere(a != 0).astype(np.int32), a[a != 0].astype(np.float32)
+        k = rng.integers(0, len(ix), size=3 * len(ix))
+        ix, vl = np.concatenate([ix, ix[k]]), np.concatenate([vl, vl[k]])
+        p = rng.permutation(len(ix))
+        adjs.append([(ix[p], vl[p], [N, N])])
+    assert max(np.bincount(a[0][0][:, 0], minlength=N).max() for a in adjs) > N
+    res = {}
+    for fused in (True, False):
+        layers.stack_fusion, ops.stack_route = fused, route
+        try:
+            torch.manual_seed(0)
+            model = models.GCN(1, 2).to(dev())
+            for m in (model.conv1, model.conv2, model.conv3, model.dense):
+                m.output_dim = W
+            tx = t32(x).requires_grad_(True)
+            model(tx, adjs)
+            logits = model(tx, adjs)
+            logits.square().sum().backward()
+            res[fused] = [logits.detach().cpu().numpy(), tx.grad.cpu().numpy()] + [p_.grad.cpu().numpy() for p_ in model.parameters()]
+        finally:
+            layers.stack_fusion, ops.stack_route = True, 0
+    for a, b in zip(res[True], res[False]):
+        close(a, b, atol=2e-6, rel=5e-5, what="stack with duplicate entries vs layers")
