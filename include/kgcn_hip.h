@@ -460,6 +460,15 @@ int kgcn_loss_grad_f32(const float* dlogits, const float* g_opt, const float* g_
  * then *step_counter += 1 (device int64: a captured hipGraph advances it on every replay). */
 int kgcn_adam_tf_f32(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, int64_t* step_counter, void* stream);
+/* The same update without a packed gradient buffer: segment q covers `numel` floats at `offset` of params / m / v and reads its
+ * gradient from `grad` (the tensor the backward pass produced for that parameter); floats outside the segments are untouched. */
+#define KGCN_ADAM_MAX_SEGMENTS 32
+typedef struct kgcn_adam_segment {
+  const float* grad;
+  int64_t offset, numel;
+} kgcn_adam_segment;
+int kgcn_adam_tf_multi_f32(float* params, float* m, float* v, int64_t n, const kgcn_adam_segment* segments, int32_t num_segments,
+                           float lr, float beta1, float beta2, float eps, int64_t* step_counter, void* stream);
 
 /* -- aggregate-FIRST GraphConv: A (X W + 1 b) = (A [X | 1]) [W ; b] --------------------------------------------------- */
 /* kgcn/layers.py:112-113 computes fw = X W + b and then A fw: a [rows, dout] aggregation.  When din + 1 < dout the other

@@ -62,6 +62,11 @@ class StackLayer(ctypes.Structure):
 
 _STKP = ctypes.POINTER(StackLayer)
 
+class AdamSegment(ctypes.Structure):
+    """struct kgcn_adam_segment (include/kgcn_hip.h)."""
+    _fields_ = [("grad", ctypes.c_void_p), ("offset", c_i64), ("numel", c_i64)]
+
+
 class WtableJob(ctypes.Structure):
     """struct kgcn_wtable_job (include/kgcn_hip.h)."""
     _fields_ = [("w", ctypes.c_void_p), ("w_ld", c_i64), ("trans_w", c_i32), ("k", c_i32), ("n", c_i32), ("reserved_", c_i32),
@@ -191,6 +196,8 @@ SIGNATURES = {
                                                   ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_sparse_softmax_ce_f32": (ctypes.c_int, [c_f32p, ctypes.c_void_p, c_f32p, c_i64, c_i32, c_f32p, c_f32p, c_f32p,
                                                   ctypes.c_void_p, c_i64, ctypes.c_void_p]),
+    "kgcn_adam_tf_multi_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_i64, ctypes.c_void_p, c_i32, ctypes.c_float,
+                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "kgcn_loss_grad_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_f32p, ctypes.c_void_p]),
     "kgcn_adam_tf_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),

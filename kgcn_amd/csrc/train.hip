@@ -263,6 +263,66 @@ extern "C" int kgcn_loss_grad_f32(const float* dlogits, const float* g_opt, cons
   return check_launch("loss_grad_kernel");
 }
 
+// The same update with the gradients read where the backward pass left them (one tensor per parameter) instead of a packed
+// copy: segment q = `numel[q]` floats at `offset[q]` of the flat parameter / moment buffers, its gradient at grad[q].
+struct AdamSegs {
+  const float* grad[KGCN_ADAM_MAX_SEGMENTS];
+  long offset[KGCN_ADAM_MAX_SEGMENTS], numel[KGCN_ADAM_MAX_SEGMENTS];
+};
+
+__global__ __launch_bounds__(256) void adam_tf_multi_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                            AdamSegs sg, float lr, float b1, float b2, float eps,
+                                                            const long long* __restrict__ counter) {
+  __shared__ float lr_s;
+  if (threadIdx.x == 0) {
+    const double t = (double)(*counter + 1);
+    lr_s = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+  }
+  __syncthreads();
+  const float lr_t = lr_s;
+  const float c1 = 1.0f - b1, c2 = 1.0f - b2;
+  const int q = blockIdx.y;
+  const float* __restrict__ g = sg.grad[q];
+  const long off = sg.offset[q], n = sg.numel[q];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gv = g[i];
+    const float mv = m[off + i] * b1 + gv * c1;
+    const float vv = v[off + i] * b2 + (gv * gv) * c2;
+    m[off + i] = mv;
+    v[off + i] = vv;
+    p[off + i] -= lr_t * (mv / (__builtin_sqrtf(vv) + eps));
+  }
+}
+
+extern "C" int kgcn_adam_tf_multi_f32(float* params, float* m, float* v, int64_t n, const kgcn_adam_segment* segments,
+                                      int32_t num_segments, float lr, float beta1, float beta2, float eps, int64_t* step_counter,
+                                      void* stream) {
+  if (n < 0 || num_segments < 0) return fail("kgcn_adam_tf_multi_f32: negative size");
+  if (!step_counter) return fail("kgcn_adam_tf_multi_f32: step_counter is NULL");
+  if (num_segments > 0 && (!params || !m || !v || !segments)) return fail("kgcn_adam_tf_multi_f32: NULL operand");
+  hipStream_t s = as_stream(stream);
+  for (int base = 0; base < num_segments; base += KGCN_ADAM_MAX_SEGMENTS) {
+    const int cnt = num_segments - base < KGCN_ADAM_MAX_SEGMENTS ? num_segments - base : KGCN_ADAM_MAX_SEGMENTS;
+    AdamSegs sg{};
+    long most = 1;
+    for (int q = 0; q < cnt; ++q) {
+      const kgcn_adam_segment& e = segments[base + q];
+      if (e.offset < 0 || e.numel < 0 || e.offset + e.numel > n || (e.numel > 0 && !e.grad))
+        return fail("kgcn_adam_tf_multi_f32: segment %d: offset %lld + %lld floats of %lld", base + q, (long long)e.offset,
+                    (long long)e.numel, (long long)n);
+      sg.grad[q] = e.grad; sg.offset[q] = (long)e.offset; sg.numel[q] = (long)e.numel;
+      if (e.numel > most) most = (long)e.numel;
+    }
+    long blocks = (most + 255) / 256;
+    if (blocks > 2L * kNumCU) blocks = 2L * kNumCU;
+    hipLaunchKernelGGL(adam_tf_multi_kernel, dim3((unsigned)blocks, cnt), dim3(256), 0, s, params, m, v, sg, lr, beta1, beta2, eps,
+                       reinterpret_cast<const long long*>(step_counter));
+    if (int rc = check_launch("adam_tf_multi_kernel")) return rc;
+  }
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<long long*>(step_counter));
+  return check_launch("adam_tick_kernel");
+}
+
 extern "C" int kgcn_adam_tf_f32(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1,
                                 float beta2, float eps, int64_t* step_counter, void* stream) {
   if (n < 0) return fail("kgcn_adam_tf_f32: n < 0");

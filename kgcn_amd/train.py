@@ -83,14 +83,32 @@ class TFAdam:
 
     @torch.no_grad()
     def step(self, packed=False):
-        """One update of every parameter: [one multi-tensor copy of the .grad tensors into the flat gradient buffer unless
-        `packed` says a GradBucket sharing the buffer already did it] + the update kernel + the counter tick."""
+        """One update of every parameter: the update kernel + the counter tick.  packed: the flat gradient buffer already holds the
+        (exchanged) gradients -- a GradBucket sharing it did the pack; otherwise the kernel reads each parameter's .grad tensor in
+        place (kgcn_adam_tf_multi_f32), no packed copy."""
         from . import _lib
         from . import ops
-        if not packed:
-            self.flat.pack_grads()
         ops.weight_tables.invalidate()             # the update rewrites the weights behind torch's version counters
         self.t += 1
+        if not packed:
+            # no exchange in front of the update: the kernel reads every gradient where the backward pass left it -- no packed copy
+            import ctypes
+            ops.join_side_streams()
+            segs = (_lib.AdamSegment * len(self.params))()
+            keep = []
+            for i, (p, o) in enumerate(zip(self.params, self.flat.offsets)):
+                g = p.grad
+                if g is None:
+                    raise RuntimeError("TFAdam: a parameter has no gradient")
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    g = g.to(torch.float32).contiguous()
+                    keep.append(g)
+                segs[i] = _lib.AdamSegment(g.data_ptr(), o, p.numel())
+            _lib.check(_lib.lib.kgcn_adam_tf_multi_f32(_lib.ptr(self.flat.data), _lib.ptr(self._m), _lib.ptr(self._v),
+                                                       self.flat.total, ctypes.cast(segs, ctypes.c_void_p), len(self.params),
+                                                       float(self.lr), float(self.b1), float(self.b2), float(self.eps),
+                                                       _lib.ptr(self._t_dev), _lib.current_stream()), "kgcn_adam_tf_multi_f32")
+            return
         _lib.check(_lib.lib.kgcn_adam_tf_f32(_lib.ptr(self.flat.data), _lib.ptr(self.flat.grad), _lib.ptr(self._m),
                                              _lib.ptr(self._v), self.flat.total, float(self.lr), float(self.b1),
                                              float(self.b2), float(self.eps), _lib.ptr(self._t_dev), _lib.current_stream()),

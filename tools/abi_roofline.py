@@ -141,6 +141,8 @@ def _cost(name, a):
         return 4 * 3 * a[3] * a[4], 20 * a[3] * a[4], "B=%d classes=%d" % (a[3], a[4])
     if name == "kgcn_sparse_softmax_ce_f32":
         return 4 * 2 * a[3] * a[4] + 8 * a[3], 20 * a[3] * a[4], "B=%d classes=%d" % (a[3], a[4])
+    if name == "kgcn_adam_tf_multi_f32":
+        return 4 * 7 * a[3], 10 * a[3], "n=%d segments=%d" % (a[3], a[5])
     if name == "kgcn_adam_tf_f32":
         return 4 * 7 * a[4], 10 * a[4], "n=%d" % a[4]
     if name == "kgcn_ragged_compact_rows_f32":
