@@ -272,7 +272,8 @@ class WeightTables:
     operands with one launch and stamps them with the current epoch; invalidate() -- called by TFAdam.step, which rewrites the
     weights through raw pointers -- starts a new epoch.  A lookup returns a table only if it was refreshed in this epoch AND
     the weight's torch version counter is the one seen at the refresh (copy_ / load_state_dict bump it); otherwise dense()
-    splits on its own as before.  Inside a captured hipGraph the refresh is part of the graph, so every replay rebuilds the
+    splits on its own as before.  Only weights a dense() call touched since the previous refresh are split again (a second live
+    model costs nothing).  Inside a captured hipGraph the refresh is part of the graph, so every replay rebuilds the
     tables from the weights it is about to use."""
 
     def __init__(self):
@@ -280,7 +281,7 @@ class WeightTables:
         self.entries = {}          # (data_ptr, shape) -> entry
 
     class _Entry:
-        __slots__ = ("ref", "tables", "epoch", "version")
+        __slots__ = ("ref", "tables", "epoch", "version", "used")
 
     def _entry(self, w, create):
         import weakref
@@ -297,8 +298,10 @@ class WeightTables:
             e = WeightTables._Entry()
             e.ref = weakref.ref(w)
             e.tables = [None if b <= 0 else torch.empty((b // 4,), device=w.device, dtype=torch.float32) for b in sizes]
-            e.epoch, e.version = -1, -1
+            e.epoch, e.version, e.used = -1, -1, False
             self.entries[key] = e
+        if e is not None:
+            e.used = True
         return e
 
     def register(self, w):
@@ -328,6 +331,9 @@ class WeightTables:
             if p is None or p.data_ptr() != key[0]:
                 del self.entries[key]
                 continue
+            if not e.used:
+                continue                          # no dense() call touched this weight since the last refresh (another model's)
+            e.used = False
             live.append((p, e))
         if not live or not enabled_weight_tables:
             return
