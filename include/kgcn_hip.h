@@ -325,6 +325,16 @@ int kgcn_dense_dx_dact_f32(const float* grad, const float* act_out, int64_t m, i
 int kgcn_dense_dx_dact_tab_f32(const float* grad, const float* act_out, int64_t m, int32_t dout, int64_t ld, const float* w,
                                int64_t w_ld, int32_t din, float* dx, int64_t dx_ld, int32_t act, float* dpre, const void* table,
                                int64_t table_bytes, void* stream);
+/* The same for a layer whose output was read out by GraphGather (kgcn/layers.py:163-164) and possibly handed on as well
+ * (example_model/model_gin.py:45-60): the incoming gradient of node row r is  grad[r] + pooled_grad[r / n_nodes]  (grad == NULL: the
+ * read-out alone).  The broadcast of d pooled over the node rows is formed while the GEMM stages its rows -- it never exists in
+ * HBM (a [rows x dout] tensor written by kgcn_graph_gather_bwd(_add)_f32 and read back otherwise).  Wide layers only:
+ * kgcn_dense_dx_dact_gather_supported(m, din, dout); table: kgcn_dense_fwd_workspace_bytes(dout, din) bytes, already split
+ * (table_ready != 0, kgcn_wtable_split_multi) or a workspace the call splits into. */
+int kgcn_dense_dx_dact_gather_supported(int64_t m, int32_t din, int32_t dout);
+int kgcn_dense_dx_dact_gather_f32(const float* grad, const float* pooled_grad, int32_t n_nodes, const float* act_out, int64_t m,
+                                  int32_t dout, int64_t ld, const float* w, int64_t w_ld, int32_t din, float* dx, int64_t dx_ld,
+                                  int32_t act, float* dpre, void* table, int64_t table_bytes, int32_t table_ready, void* stream);
 /* stand-alone forms: y = act(x) over n floats; dpre = grad (.) act'(act_out) (dpre may alias grad) */
 int kgcn_act_fwd_f32(const float* x, int64_t n, int32_t act, float* y, void* stream);
 int kgcn_act_bwd_f32(const float* act_out, const float* grad, int64_t n, int32_t act, float* dpre, void* stream);

@@ -153,6 +153,9 @@ SIGNATURES = {
                                               c_f32p, ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_dense_dx_dact_tab_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i64, c_i32, c_i64, c_f32p, c_i64, c_i32, c_f32p, c_i64,
                                                   c_i32, c_f32p, ctypes.c_void_p, c_i64, ctypes.c_void_p]),
+    "kgcn_dense_dx_dact_gather_supported": (ctypes.c_int, [c_i64, c_i32, c_i32]),
+    "kgcn_dense_dx_dact_gather_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i32, c_f32p, c_i64, c_i32, c_i64, c_f32p, c_i64, c_i32,
+                                                     c_f32p, c_i64, c_i32, c_f32p, ctypes.c_void_p, c_i64, c_i32, ctypes.c_void_p]),
     "kgcn_dense_fwd_tab_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i64, c_f32p, c_i64, c_i32, c_f32p, c_f32p, c_i32,
                                               c_i64, c_i32, ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_wtable_split_multi": (ctypes.c_int, [ctypes.c_void_p, c_i32, ctypes.c_void_p]),

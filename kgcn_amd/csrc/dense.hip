@@ -31,7 +31,8 @@ bool narrow_wgrad_ok(const float* x, int din, long x_ld, const float* dy, int do
 int launch_narrow_wgrad(const float* x, const float* dy, long m, int din, int dout, float* part_dw, float* part_db,
                         int nblocks, hipStream_t s);
 int launch_gemm3_dx_dact(const float* grad, const float* act_out, float* dpre, long m, int k, long ld, const void* table,
-                         float* dx, int n, long dx_ld, int dact, hipStream_t s);
+                         float* dx, int n, long dx_ld, int dact, hipStream_t s, const float* pooled_grad = nullptr,
+                         int n_nodes = 0);
 bool gemmn_pays(const float* x, int din, long x_ld, int dout);
 int launch_gemmn_fwd(const float* x, long m, int din, long x_ld, const void* table, const float* bias, float* y, int dout,
                      long y_ld, int act, hipStream_t s);
@@ -629,6 +630,32 @@ static int dense_dx_dact_impl(const float* grad, const float* act_out, int64_t m
   if (int rc = kgcn_act_bwd_f32(act_out, grad, m * dout, act, dpre, stream)) return rc;
   return dense_fwd_impl(dpre, m, dout, ld, w, w_ld, 1, nullptr, dx, din, dx_ld, KGCN_ACT_NONE, workspace, workspace_bytes,
                         stream, table_ready);
+}
+
+// 1 when kgcn_dense_dx_dact_gather_f32 takes this shape (the fused table form of the wide layers)
+extern "C" int kgcn_dense_dx_dact_gather_supported(int64_t m, int32_t din, int32_t dout) {
+  return (m >= 1024 && din > 0 && dout > 0 && dout % 4 == 0 && table_pays(dout, din)) ? 1 : 0;
+}
+
+extern "C" int kgcn_dense_dx_dact_gather_f32(const float* grad, const float* pooled_grad, int32_t n_nodes, const float* act_out,
+                                             int64_t m, int32_t dout, int64_t ld, const float* w, int64_t w_ld, int32_t din,
+                                             float* dx, int64_t dx_ld, int32_t act, float* dpre, void* table, int64_t table_bytes,
+                                             int32_t table_ready, void* stream) {
+  if (act <= KGCN_ACT_NONE || act > KGCN_ACT_TANH) return fail("kgcn_dense_dx_dact_gather_f32: activation code %d", act);
+  if (!kgcn_dense_dx_dact_gather_supported(m, din, dout))
+    return fail("kgcn_dense_dx_dact_gather_f32: shape m=%lld %d -> %d has no fused form (kgcn_graph_gather_bwd_f32 + "
+                "kgcn_dense_dx_dact_f32)", (long long)m, din, dout);
+  if (!pooled_grad || n_nodes <= 0 || m % n_nodes != 0)
+    return fail("kgcn_dense_dx_dact_gather_f32: pooled gradient / %d nodes per graph do not match %lld rows", n_nodes, (long long)m);
+  if (!act_out || !w || !dx || !dpre) return fail("kgcn_dense_dx_dact_gather_f32: NULL operand");
+  if (dpre == grad) return fail("kgcn_dense_dx_dact_gather_f32: dpre must not alias grad");
+  if (ld < dout || dx_ld < din || w_ld < dout) return fail("kgcn_dense_dx_dact_gather_f32: leading dimension too small");
+  if (!table || table_bytes < wtable_bytes(dout, din)) return fail("kgcn_dense_dx_dact_gather_f32: table / workspace too small");
+  if (!table_ready) launch_wtable_split(w, (long)w_ld, 1, dout, din, table, as_stream(stream));
+  const int rc = launch_gemm3_dx_dact(grad, act_out, dpre, (long)m, dout, (long)ld, table, dx, din, (long)dx_ld, act,
+                                      as_stream(stream), pooled_grad, n_nodes);
+  if (rc < 0) return fail("kgcn_dense_dx_dact_gather_f32: operands must be 16-byte aligned with ld %% 4 == 0");
+  return rc;
 }
 
 extern "C" int kgcn_dense_dx_dact_f32(const float* grad, const float* act_out, int64_t m, int32_t dout, int64_t ld,

@@ -60,12 +60,15 @@ constexpr size_t G3_LDS = 2 * (size_t)(G3_XP + G3_WP) * 16;
 struct G3Raw {
   f32x4 xa, xb;        // x[row][k0 + 8 qx .. +7]
   f32x4 ya, yb;        // DK != 0: the saved layer output at the same positions (x is then the incoming gradient)
+  f32x4 ba, bb;        // DK != 0 with a gathered gradient: d pooled of the row's graph at the same columns
   float w0[8], w1[8];  // W^(T)[k0 + 8 q + j][n] for the thread's two (n, q) tasks
 };
 
 // per-thread staging coordinates (fixed for the whole launch / for one row tile)
 struct G3Coord {
   const float* xrow;   // clamped row of the current tile
+  const float* brow;   // gathered gradient: d pooled row of the row's graph (else nullptr)
+  bool bc_only;        // ... and no per-row gradient besides it
   bool rowok;
   int qx;              // x task: 8-k group 0..3
   unsigned wbase[2];   // W tasks: clamped column offset (elements)
@@ -82,8 +85,13 @@ __device__ __forceinline__ void g3_issue(G3Raw& r, const G3Coord& c, const float
   // select sits between a load and its first real use
   const int k = k0 + 8 * c.qx;
   if constexpr (XVEC) {
-    r.xa = *reinterpret_cast<const f32x4*>(c.xrow + (k < din ? k : 0));
-    r.xb = *reinterpret_cast<const f32x4*>(c.xrow + (k + 4 < din ? k + 4 : 0));
+    if (DK != 0 && c.bc_only) {                          // uniform: the gradient is the broadcast alone
+      r.xa = f32x4{0.f, 0.f, 0.f, 0.f};
+      r.xb = r.xa;
+    } else {
+      r.xa = *reinterpret_cast<const f32x4*>(c.xrow + (k < din ? k : 0));
+      r.xb = *reinterpret_cast<const f32x4*>(c.xrow + (k + 4 < din ? k + 4 : 0));
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -94,6 +102,10 @@ __device__ __forceinline__ void g3_issue(G3Raw& r, const G3Coord& c, const float
   if constexpr (DK != 0) {         // XVEC only
     r.ya = *reinterpret_cast<const f32x4*>(c.xrow + ydiff + (k < din ? k : 0));
     r.yb = *reinterpret_cast<const f32x4*>(c.xrow + ydiff + (k + 4 < din ? k + 4 : 0));
+    if (c.brow) {                                        // uniform
+      r.ba = *reinterpret_cast<const f32x4*>(c.brow + (k < din ? k : 0));
+      r.bb = *reinterpret_cast<const f32x4*>(c.brow + (k + 4 < din ? k + 4 : 0));
+    }
   }
   if constexpr (WTAB) return;      // W arrives pre-split from the fragment table
   if (c.wvec) {          // transposed source, rows 16-byte aligned: 8 k-values = 2 x 16 bytes
@@ -154,7 +166,10 @@ __device__ __forceinline__ void g3_write(u32x4* table, int tile, int q, int li, 
 // the stand-alone activation-backward pass (3 x 4 bytes per element) disappears.  DK = 1: act' = c0 + c1 a + c2 a^2
 // (sigmoid 0, 1, -1; tanh 1, 0, -1), DK = 2: relu (a > 0).  Every store goes to the clamped address its load came from:
 // threads whose row or k is out of range re-store values another thread stores too.
-struct G3Dact { long ydiff, pdiff; float c0, c1, c2; };
+// Gathered gradient (bc != nullptr): the incoming gradient of row r is g[r] + bc[(r / bc_n) * bc_ld + .] -- the layer's output was
+// read out by GraphGather (kgcn/layers.py:163-164: d pooled reaches every node row of its graph) and, unless bc_only, also handed
+// on (g): the broadcast never exists in HBM.
+struct G3Dact { long ydiff, pdiff; float c0, c1, c2; const float* bc; long bc_ld; int bc_n, bc_only; };
 
 template <bool XVEC, bool WTAB, int MW, int DK = 0>
 __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
@@ -174,6 +189,7 @@ __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
       for (int e = 0; e < 2; ++e) {
         const float a = (J < 2) ? R.ya[2 * J + e] : R.yb[2 * J - 4 + e];
         float g = (J < 2) ? R.xa[2 * J + e] : R.xb[2 * J - 4 + e];
+        if (da.bc) g += (J < 2) ? R.ba[2 * J + e] : R.bb[2 * J - 4 + e];
         if constexpr (DK == 1) g *= __builtin_fmaf(__builtin_fmaf(da.c2, a, da.c1), a, da.c0);
         else g = a > 0.f ? g : 0.f;
         if constexpr (J < 2) R.xa[2 * J + e] = g;
@@ -209,6 +225,8 @@ __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
   const int xr = tid >> 2;
   G3Coord co;
   co.qx = tid & 3;
+  co.brow = nullptr;
+  co.bc_only = DK != 0 && da.bc_only != 0;
   co.sk = trans_w ? 1u : (unsigned)w_ld;
   co.wvec = trans_w && (w_ld % 4 == 0) && (din % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15u) == 0);
 #pragma unroll
@@ -222,6 +240,7 @@ __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
     const long row = tile * BMT + xr;
     co.rowok = row < m;
     co.xrow = x + (row < m ? row : m - 1) * x_ld;
+    if constexpr (DK != 0) co.brow = da.bc ? da.bc + ((row < m ? row : m - 1) / da.bc_n) * da.bc_ld : nullptr;
   };
 
   // flattened (tile, k chunk) sequence: coordinates of the chunks being multiplied (0), split (1), loaded (2)
@@ -473,14 +492,21 @@ int launch_gemm3_fwd(const float* x, long m, int din, long x_ld, const float* w,
 
 // dx = (grad (.) act'(act_out)) @ W^T through the table variant, dpre written on the way (see G3Dact).  Returns -1 when the
 // shape / alignment is not one the fused form takes (the caller then runs the activation backward on its own).
+// pooled_grad != nullptr: gathered gradient (see G3Dact), `grad` may then be nullptr (nothing handed on besides the read-out)
 int launch_gemm3_dx_dact(const float* grad, const float* act_out, float* dpre, long m, int k, long ld, const void* table,
-                         float* dx, int n, long dx_ld, int dact, hipStream_t s) {
-  const bool ok = (k % 4 == 0) && (ld % 4 == 0) && aligned16(grad) && aligned16(act_out) && aligned16(dpre) && table &&
-                  dact != KGCN_ACT_NONE && dpre != grad;
+                         float* dx, int n, long dx_ld, int dact, hipStream_t s, const float* pooled_grad, int n_nodes) {
+  const bool ok = (k % 4 == 0) && (ld % 4 == 0) && (!grad || aligned16(grad)) && aligned16(act_out) && aligned16(dpre) && table &&
+                  dact != KGCN_ACT_NONE && dpre != grad && (grad || pooled_grad) &&
+                  (!pooled_grad || (aligned16(pooled_grad) && n_nodes > 0));
   if (!ok) return -1;
   G3Dact da;
-  da.ydiff = act_out - grad;
-  da.pdiff = dpre - grad;
+  const float* base = grad ? grad : act_out;             // the staging threads address everything relative to their x row
+  da.ydiff = act_out - base;
+  da.pdiff = dpre - base;
+  da.bc = pooled_grad;
+  da.bc_ld = k;
+  da.bc_n = n_nodes > 0 ? n_nodes : 1;
+  da.bc_only = grad ? 0 : 1;
   da.c0 = dact == KGCN_ACT_TANH ? 1.f : 0.f;
   da.c1 = dact == KGCN_ACT_SIGMOID ? 1.f : 0.f;
   da.c2 = -1.f;
@@ -490,10 +516,10 @@ int launch_gemm3_dx_dact(const float* grad, const float* act_out, float* dpre, l
   const size_t lds = 2 * (size_t)G3_XP * 16;
   const float* tw = static_cast<const float*>(table);
   if (dact == KGCN_ACT_RELU)
-    hipLaunchKernelGGL((gemm3_fwd_kernel<true, true, 1, 2>), grid, dim3(256), lds, s, grad, m, k, ld, tw, 0L, 1, nullptr, dx, n,
+    hipLaunchKernelGGL((gemm3_fwd_kernel<true, true, 1, 2>), grid, dim3(256), lds, s, base, m, k, ld, tw, 0L, 1, nullptr, dx, n,
                        dx_ld, KGCN_ACT_NONE, da);
   else
-    hipLaunchKernelGGL((gemm3_fwd_kernel<true, true, 1, 1>), grid, dim3(256), lds, s, grad, m, k, ld, tw, 0L, 1, nullptr, dx, n,
+    hipLaunchKernelGGL((gemm3_fwd_kernel<true, true, 1, 1>), grid, dim3(256), lds, s, base, m, k, ld, tw, 0L, 1, nullptr, dx, n,
                        dx_ld, KGCN_ACT_NONE, da);
   return check_launch("gemm3_fwd_kernel(dact)");
 }

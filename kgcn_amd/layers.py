@@ -229,6 +229,15 @@ class GraphDense(nn.Module):
         return ops.activation(y, self.activation)          # the model's activation follows the zero padding
 
 
+def graph_dense_gather(dense_layer, inputs):
+    """GraphDense (with its fused activation) + GraphGather as one op (ops.dense_gather): -> (layer output [B, N, D], pooled
+    [B, D]).  The backward of a wide layer forms d pooled's broadcast inside its dX GEMM.  `dense_layer`: a GraphDense applied
+    without enabled_node_nums."""
+    if not dense_layer.built:
+        dense_layer.build(inputs.shape, inputs.device)
+    return ops.dense_gather(inputs, dense_layer.kernel, dense_layer.bias, activation=dense_layer.activation)
+
+
 class GINAggregate(nn.Module):
     """kgcn/layers.py:400-475: Out[b] = sum_c (epsilon_c X[b] + A[b][c] @ X[b]).
 

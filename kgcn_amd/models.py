@@ -105,11 +105,8 @@ class GIN(nn.Module):
         for blk in range(2):
             layer = self.agg[blk](layer, adj=adjs)
             layer = self.dense[2 * blk](layer)
-            layer = self.dense[2 * blk + 1](layer)
-            if blk == 0:                                 # read out AND passed on: one backward pass for both gradients
-                layer, pooled = ops.graph_gather_tee(layer)
-            else:
-                pooled = self.gather(layer)
+            # the block output is read out (and, for block 0, passed on): d pooled joins the gradient inside the layer's dX GEMM
+            layer, pooled = layers.graph_dense_gather(self.dense[2 * blk + 1], layer)
             outs.append(pooled)
         return self.out(torch.cat(outs, dim=1))
 

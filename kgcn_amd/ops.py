@@ -456,6 +456,101 @@ def dense(x2d, w, bias=None, activation=None):
     return _Dense.apply(x2d, w, bias, act_code(activation))
 
 
+class _DenseGather(torch.autograd.Function):
+    """y = act(x W + b) of a layer whose output is read out by GraphGather -- and also handed on to the next layer when the
+    caller uses y (example_model/model_gin.py:45-60): returns (y [T, N, dout], pooled [T, dout]).  Backward: the incoming
+    gradient of node row r is d y[r] + d pooled[r / N]; for wide activated layers the broadcast is formed inside the dX GEMM
+    (kgcn_dense_dx_dact_gather_f32) instead of being written out by kgcn_graph_gather_bwd(_add)_f32 and read back."""
+
+    @staticmethod
+    def forward(ctx, x2d, w, bias, act, T, N):
+        x2d, w = _f32c(x2d, "x"), _f32c(w, "w")
+        m, din = x2d.shape
+        dout = w.shape[1]
+        if w.shape[0] != din or m != T * N:
+            raise _lib.KgcnHipError("kernel %s / %d graphs of %d nodes do not match inputs %s" % (tuple(w.shape), T, N, tuple(x2d.shape)))
+        b = None if bias is None else _f32c(bias, "bias").reshape(-1)
+        y = torch.empty((m, dout), device=x2d.device, dtype=torch.float32)
+        tab, tb = weight_tables.lookup(w, 0)
+        if tab is not None:
+            check(lib.kgcn_dense_fwd_tab_f32(ptr(x2d), m, din, din, ptr(w), dout, 0, ptr(b), ptr(y), dout,
+                                             dout, int(act), ptr(tab), tb, current_stream()), "kgcn_dense_fwd_tab_f32")
+        else:
+            weight_tables.register(w)
+            wsb, wsp = _dense_ws(din, dout, x2d.device)
+            check(lib.kgcn_dense_fwd_ws_f32(ptr(x2d), m, din, din, ptr(w), dout, 0, ptr(b), ptr(y), dout,
+                                            dout, int(act), ptr(wsp), wsb, current_stream()), "kgcn_dense_fwd_ws_f32")
+        pooled = torch.empty((T, dout), device=x2d.device, dtype=torch.float32)
+        check(lib.kgcn_graph_gather_fwd_f32(ptr(y), T, N, dout, ptr(pooled), current_stream()), "kgcn_graph_gather_fwd_f32")
+        ctx.act, ctx.T, ctx.N = int(act), int(T), int(N)
+        ctx.save_for_backward(x2d, w, y)
+        ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        ctx.set_materialize_grads(False)
+        return y.view(T, N, dout), pooled
+
+    @staticmethod
+    def backward(ctx, gy, gp):
+        x2d, w, y = ctx.saved_tensors
+        m, din = x2d.shape
+        dout = w.shape[1]
+        T, N = ctx.T, ctx.N
+        if gy is None and gp is None:
+            return None, None, None, None, None, None
+        gy = None if gy is None else _f32c(gy.reshape(m, dout), "grad")
+        gp = None if gp is None else _f32c(gp, "grad")
+        dx = dw = db = None
+        need_x = ctx.needs_input_grad[0]
+        if gp is not None and ctx.act and need_x and lib.kgcn_dense_dx_dact_gather_supported(m, din, dout):
+            dx = torch.empty_like(x2d)
+            dpre = torch.empty((m, dout), device=x2d.device, dtype=torch.float32)
+            tab, tb = weight_tables.lookup(w, 1)
+            ready = 1
+            if tab is None:
+                tb, tab = _dense_ws(dout, din, x2d.device)
+                ready = 0
+            check(lib.kgcn_dense_dx_dact_gather_f32(ptr(gy), ptr(gp), N, ptr(y), m, dout, dout, ptr(w), dout, din, ptr(dx), din,
+                                                    ctx.act, ptr(dpre), ptr(tab), tb, ready, current_stream()),
+                  "kgcn_dense_dx_dact_gather_f32")
+            g = dpre
+        else:
+            # incoming gradient as a tensor, then the plain dense backward
+            if gp is not None:
+                g = torch.empty((m, dout), device=x2d.device, dtype=torch.float32)
+                if gy is not None and dout % 4 == 0:
+                    check(lib.kgcn_graph_gather_bwd_add_f32(ptr(gp), ptr(gy), T, N, dout, ptr(g), current_stream()),
+                          "kgcn_graph_gather_bwd_add_f32")
+                else:
+                    check(lib.kgcn_graph_gather_bwd_f32(ptr(gp), T, N, dout, ptr(g), current_stream()), "kgcn_graph_gather_bwd_f32")
+                    if gy is not None:
+                        g = g + gy
+            else:
+                g = gy
+            if ctx.act:
+                g = activation_backward(y, g, ctx.act)
+            if need_x:
+                dx = torch.empty_like(x2d)
+                tab, tb = weight_tables.lookup(w, 1)
+                if tab is not None:
+                    check(lib.kgcn_dense_fwd_tab_f32(ptr(g), m, dout, dout, ptr(w), dout, 1, None, ptr(dx), din, din, 0, ptr(tab), tb,
+                                                     current_stream()), "kgcn_dense_fwd_tab_f32(dx)")
+                else:
+                    wsb, wsp = _dense_ws(dout, din, g.device)
+                    check(lib.kgcn_dense_fwd_ws_f32(ptr(g), m, dout, dout, ptr(w), dout, 1, None, ptr(dx), din, din, 0, ptr(wsp), wsb,
+                                                    current_stream()), "kgcn_dense_fwd_ws_f32(dx)")
+        need_w = ctx.needs_input_grad[1]
+        need_b = ctx.bias_shape is not None and ctx.needs_input_grad[2]
+        if need_w or need_b:
+            dw, db = _Dense._wgrad(ctx, x2d, w, g, y, m, din, dout, need_w, need_b, False)
+        return dx, dw, db, None, None, None
+
+
+def dense_gather(x3d, w, bias=None, activation=None):
+    """GraphDense followed by GraphGather on [T, N, din] inputs: -> (y [T, N, dout], pooled [T, dout]); use y only if the layer
+    output is also handed on."""
+    T, N, din = x3d.shape
+    return _DenseGather.apply(x3d.reshape(T * N, din), w, bias, act_code(activation), T, N)
+
+
 # -------------------------------------------------------------------------------------------------
 # fused GraphConv (one channel)
 # -------------------------------------------------------------------------------------------------

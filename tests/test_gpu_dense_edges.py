@@ -311,3 +311,37 @@ def test_cfg5_full_size_layers_vs_c_oracle():
     close(ti.grad.reshape(B * N, D), rdx, atol=0, rel=5e-6, what="cfg5 full GraphDense dX")
     close(layer.kernel.grad, rdw, atol=0, rel=5e-6, what="cfg5 full GraphDense dK over 200,000 rows")
     close(layer.bias.grad, rdb, atol=0, rel=5e-6, what="cfg5 full GraphDense dbias over 200,000 rows")
+
+
+@pytest.mark.parametrize("tee", [True, False])
+@pytest.mark.parametrize("act,T,N,din,dout", [("relu", 500, 10, 256, 256), ("sigmoid", 130, 32, 300, 256), ("relu", 60, 10, 50, 50),
+                                               (None, 200, 7, 256, 256), ("tanh", 512, 4, 256, 512)])
+def test_dense_gather_gradient_joins_inside_the_dx_gemm(act, T, N, din, dout, tee):
+    """ops.dense_gather = GraphDense (+ activation) followed by GraphGather, the layer output optionally handed on as well
+    (model_gin.py:45-60).  Backward of the wide activated cases goes through kgcn_dense_dx_dact_gather_f32 (d pooled's broadcast
+    formed inside the dX GEMM's staging; `tee`: added to the passed-on gradient there), the others through the fallback; all
+    against an fp64 evaluation: outputs, d inputs, dW, dbias."""
+    from kgcn_amd import ops
+    rng = np.random.default_rng(T + N + dout)
+    x = rng.standard_normal((T, N, din)).astype(np.float32)
+    w = (rng.standard_normal((din, dout)) / np.sqrt(din)).astype(np.float32)
+    b = rng.standard_normal(dout).astype(np.float32)
+    gp = rng.standard_normal((T, dout)).astype(np.float32)
+    gy = rng.standard_normal((T, N, dout)).astype(np.float32)
+    tx, tw, tb = (t32(a).requires_grad_(True) for a in (x, w, b))
+    y, pooled = ops.dense_gather(tx, tw, tb, activation=act)
+    loss = (pooled * t32(gp)).sum() + ((y * t32(gy)).sum() if tee else 0.0)
+    loss.backward()
+    pre = x.astype(np.float64).reshape(T * N, din) @ w.astype(np.float64) + b
+    f = {"relu": lambda v: np.maximum(v, 0), "sigmoid": lambda v: 1 / (1 + np.exp(-v)), "tanh": np.tanh, None: lambda v: v}[act]
+    df = {"relu": lambda a: (a > 0).astype(np.float64), "sigmoid": lambda a: a * (1 - a), "tanh": lambda a: 1 - a * a,
+          None: lambda a: np.ones_like(a)}[act]
+    yr = f(pre)
+    g = np.repeat(gp.astype(np.float64), N, axis=0) + (gy.reshape(T * N, dout) if tee else 0.0)
+    dpre = g * df(yr)
+    scale = float(np.abs(yr).max())
+    close(y, yr.reshape(T, N, dout), atol=2e-6 * max(1.0, scale), rel=2e-6, what="dense_gather y")
+    close(pooled, yr.reshape(T, N, dout).sum(1), atol=2e-5 * max(1.0, scale), rel=2e-6, what="dense_gather pooled")
+    close(tx.grad, (dpre @ w.astype(np.float64).T).reshape(T, N, din), atol=1e-5, rel=2e-5, what="dense_gather d inputs")
+    close(tw.grad, x.astype(np.float64).reshape(T * N, din).T @ dpre, atol=1e-4, rel=2e-5, what="dense_gather dW")
+    close(tb.grad, dpre.sum(0), atol=1e-4, rel=2e-5, what="dense_gather dbias")

@@ -64,6 +64,9 @@ def _cost(name, a):
     if name in ("kgcn_dense_fwd_f32", "kgcn_dense_fwd_act_f32", "kgcn_dense_fwd_ws_f32", "kgcn_dense_fwd_tab_f32"):
         m, din, dout = a[1], a[2], a[9]
         return 4 * (m * din + m * dout + din * dout), 2 * m * din * dout, "m=%d %d->%d%s" % (m, din, dout, " T" if a[6] else "")
+    if name == "kgcn_dense_dx_dact_gather_f32":
+        m, dout, din = a[4], a[5], a[9]
+        return 4 * m * (dout * (3 if a[0] else 2) + din), 2 * m * din * dout, "m=%d %d<-%d gathered%s" % (m, din, dout, "+g" if a[0] else "")
     if name in ("kgcn_dense_dx_dact_f32", "kgcn_dense_dx_dact_tab_f32"):
         m, dout, din = a[2], a[3], a[7]
         return 4 * (3 * m * dout + m * din + din * dout), 2 * m * din * dout, "m=%d %d->%d T dact=%d" % (m, dout, din, a[10])
