@@ -9,6 +9,8 @@ constexpr int SK_MAXL = KGCN_STACK_MAX_LAYERS;
 constexpr int SK_LD = 64;          // activation tile leading dimension (floats)
 constexpr int SK_WLD = 65;         // weight leading dimension: conflict-free along k AND along j
 
+constexpr int S2_MAXM = 4;         // matrix layers the tile backward keeps dW accumulators for (16 VGPRs each; five spill)
+
 struct StackArgs {
   int nl, N, gather, max_nnz;
   int kind[SK_MAXL], act[SK_MAXL], din[SK_MAXL], dout[SK_MAXL];
@@ -29,6 +31,7 @@ struct StackArgs {
   int G;                          // whole graphs per 64-row tile
   int max_ent;                    // stored entries one tile can hold
   int mslot[SK_MAXL];             // index of the layer's dW accumulator among the matrix layers (kind 2: -1)
+  int mlayer[S2_MAXM];            // ... and back: the layer of matrix slot i (-1: unused)
   int abl;                        // development (KGCN_DEV_KNOBS builds, KGCN_S2_ABL): phases to skip when measuring; else 0
 };
 
@@ -37,7 +40,6 @@ constexpr int S2_LD = 66;          // tile leading dimension: ds_read_b64 of 32 
 constexpr int S2_R = 64;           // rows of a tile
 constexpr int S2_TILE = (S2_R + 1) * S2_LD;   // + one row of zeros (target of the ELL padding)
 constexpr int S2_MAXL = SK_MAXL;   // layers (one dbias / dgamma / dbeta register pair per thread each)
-constexpr int S2_MAXM = 4;         // matrix layers the backward keeps dW accumulators for (16 VGPRs each; five spill)
 constexpr int S2_AUX = 68 + 3 * 64 + 4;   // ints: row pointers | first tile row of the row's graph | its valid rows | its index | misc
 
 struct Stack2Plan { bool ok; size_t lds_fwd, lds_bwd; };

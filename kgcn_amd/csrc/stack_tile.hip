@@ -31,7 +31,9 @@ Stack2Plan stack2_plan(StackArgs& a) {
     a.woff2[l] = wo;
     wo += s2_wblock(a.kind[l]);
     a.mslot[l] = a.kind[l] == 2 ? -1 : nmat++;
+    if (a.kind[l] != 2 && a.mslot[l] < S2_MAXM) a.mlayer[a.mslot[l]] = l;
   }
+  for (int i = nmat; i < S2_MAXM; ++i) a.mlayer[i] = -1;
   a.wtotal2 = wo;
   a.G = S2_R / a.N;
   const long ent = (long)a.G * a.max_nnz;
@@ -96,19 +98,33 @@ __device__ __forceinline__ S2Lds s2_carve(float* after_tiles, float* wl, int max
   return s;
 }
 
-// [din x dout] row-major matrix -> [64][66] block, zero padded: transposed (W^T, forward) or as is (backward); the sixteen
-// loads of a thread are in flight together
-__device__ __forceinline__ void s2_stage_matrix(const float* __restrict__ wsrc, int din, int dout, float* blk, bool transposed) {
-  float v[16];
+// Every weight matrix [din x dout] (row-major) -> its [64][66] block, zero padded: transposed (W^T, forward) or as is (backward).
+// The loads of ALL matrices are in flight together (sixteen per thread and matrix): one global round trip for the staging
+// instead of one per matrix (no measurable difference in the release build: 0.0895 / 0.1985 ms per step either way).
+__device__ __forceinline__ void s2_stage_matrices(const StackArgs& a, float* wl, bool transposed) {
+  float v[S2_MAXM][16];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int k = (threadIdx.x >> 6) + 4 * q, c = threadIdx.x & 63;
-    v[q] = (k < din && c < dout) ? wsrc[(long)k * dout + c] : 0.f;
+  for (int mi = 0; mi < S2_MAXM; ++mi) {
+    const int l = a.mlayer[mi];
+    if (l < 0) continue;
+    const int din = a.din[l], dout = a.dout[l];
+    const float* __restrict__ wsrc = a.w[l];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int k = (threadIdx.x >> 6) + 4 * q, c = threadIdx.x & 63;
+      v[mi][q] = (k < din && c < dout) ? wsrc[(long)k * dout + c] : 0.f;
+    }
   }
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int k = (threadIdx.x >> 6) + 4 * q, c = threadIdx.x & 63;
-    blk[transposed ? c * S2_LD + k : k * S2_LD + c] = v[q];
+  for (int mi = 0; mi < S2_MAXM; ++mi) {
+    const int l = a.mlayer[mi];
+    if (l < 0) continue;
+    float* blk = wl + a.woff2[l];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int k = (threadIdx.x >> 6) + 4 * q, c = threadIdx.x & 63;
+      blk[transposed ? c * S2_LD + k : k * S2_LD + c] = v[mi][q];
+    }
   }
 }
 
@@ -302,10 +318,10 @@ __global__ __launch_bounds__(256) void stack2_fwd_kernel(StackArgs a, const int*
         blk[64 + tid] = sh;
       }
     } else {
-      s2_stage_matrix(a.w[l], a.din[l], a.dout[l], blk, true);
       if (tid < 64) blk[64 * S2_LD + tid] = (tid < a.dout[l] && a.b[l]) ? a.b[l][tid] : 0.f;
     }
   }
+  s2_stage_matrices(a, s.wl, true);
   if (tid < S2_R) { s.gidx[tid] = tid / N; s.rowbase[tid] = (tid / N) * N; }
   if (tid < S2_LD) Tt[S2_R * S2_LD + tid] = 0.f;      // the row of zeros the ELL padding points at
   const long ntiles = (T + G - 1) / G;
@@ -446,10 +462,9 @@ __global__ __launch_bounds__(256) void stack2_bwd_kernel(StackArgs a, const int*
     float* blk = s.wl + a.woff2[l];
     if (a.kind[l] == 2) {
       if (tid < 64) blk[tid] = tid < a.dout[l] ? a.w[l][tid] * (1.0f / __builtin_sqrtf(a.var[l][tid] + a.eps[l])) : 0.f;
-    } else {
-      s2_stage_matrix(a.w[l], a.din[l], a.dout[l], blk, false);
     }
   }
+  s2_stage_matrices(a, s.wl, false);
   if (tid < S2_R) { s.gidx[tid] = tid / N; s.rowbase[tid] = (tid / N) * N; }
   if (tid < S2_LD) { P[S2_R * S2_LD + tid] = 0.f; Pn[S2_R * S2_LD + tid] = 0.f; }   // the aggregation reads P or Pn
   f32x16 dW[S2_MAXM];
