@@ -32,18 +32,16 @@ adj0, x0 = dataset.batch(train_idx[:BATCH], BATCH)
 model(x0, adj0)                                                   # creates the parameters (Keras-style lazy build)
 opt = train.TFAdam(model.parameters(), lr=1e-3, capturable=True)
 batch = dataset.static_batch(BATCH)
-labels = torch.zeros((BATCH, 2), device=dev)
-mask = torch.zeros(BATCH, device=dev)
+labels = batch.add_table(labels_all)                              # the selected graphs' label rows ...
+mask = batch.add_table(torch.ones(len(labels_all), device=dev))   # ... and 1 per real graph, 0 per dummy: same assembly launch
 batch.load(train_idx[:BATCH])
-step = train.GraphedTrainStep(model, opt, models.masked_softmax_ce, batch, labels, mask)
+# the device-side assembly (adjacency, features, labels, mask) is the head of the captured step: one step = stage() + replay()
+step = train.GraphedTrainStep(model, opt, models.masked_softmax_ce, batch, labels, mask, capture_assembly=True)
 
 
 def fill(idx):
-    n = len(idx)
-    batch.load(idx)                                               # kgcn_csr_gather_graphs + one index_select
-    labels.zero_(); labels[:n] = labels_all[torch.as_tensor(idx, device=dev)]
-    mask.zero_(); mask[:n] = 1
-    return n
+    batch.stage(idx)                                              # one small pinned upload of the selected graph indices
+    return len(idx)
 
 
 rng = np.random.default_rng(1234)
