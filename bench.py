@@ -464,6 +464,36 @@ class Cfg2:
             return None
         return [e[2].elapsed_time(e[3]) * 1e3 for e in evs]
 
+    def hipgraph_replay(self, steps, warmup):
+        """--graph: the same step (forward, backward [, gradient exchange]) captured ONCE in a hipGraph and replayed: at small
+        batches (4,096 graphs: example_config batch sizes) the eager step is bound by the host's launch calls, the replay by
+        the kernels' own launch latency.  After the timed region of the contract; reported next to `value`, never as it."""
+        import torch
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        self.x.grad = None
+        for p in self.layer.parameters():
+            p.grad = None
+        with torch.cuda.graph(graph):
+            self.step()
+        for _ in range(max(warmup, 3)):
+            graph.replay()
+        self.ctx.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            graph.replay()
+        self.ctx.barrier()
+        dt = self.ctx.max_over_ranks(time.perf_counter() - t0)
+        return {"ms_per_step": dt / steps * 1e3, "value": self.units_global * steps / dt, "steps": steps,
+                "note": "one hipGraph replay per step (forward + backward%s), same batch" %
+                        (" + gradient all-reduce" if self.bucket is not None else "")}
+
     def report(self, evs):
         """rank 0: config + roofline + cpu_baseline."""
         args, T, wl = self.args, self.T, self.wl
@@ -940,6 +970,9 @@ def build_parser():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="cfg2: dense GEMM + Bspmm kernels instead of the fused layer")
     ap.add_argument("--eager", action="store_true", help="cfg4 / cfg5: plain launches instead of one hipGraph per step")
+    ap.add_argument("--graph", action="store_true",
+                    help="cfg2: additionally capture the step in a hipGraph and report its replay rate as `hipgraph_replay` "
+                         "(small batches, e.g. --graphs 4096, are launch-bound in the eager step)")
     ap.add_argument("--padded", action="store_true", help="cfg4: compute all padded rows (round-2 behaviour)")
     ap.add_argument("--side-wgrad", action="store_true",
                     help="A/B switch: weight gradients of the big dense layers on a side stream (measured: no gain, see ops.py)")
@@ -1009,6 +1042,9 @@ def main(argv=None):
     elapsed = ctx.max_over_ranks(local_elapsed)
     per_rank = ctx.gather_over_ranks(local_elapsed / args.steps * 1e3)
 
+    hipgraph = None
+    if args.graph and ctx.on_gpu and args.config == "cfg2" and not args.dry:
+        hipgraph = wl.hipgraph_replay(args.steps, args.warmup)
     in_step = wl.in_step_allreduce_us(ev) if ev else None
     collective = ctx.collective_report(getattr(wl, "bucket", None), getattr(wl, "weight", None), in_step)
     if collective is not None:
@@ -1039,6 +1075,8 @@ def main(argv=None):
         }
         if collective is not None:
             res["collective"] = collective
+        if hipgraph is not None:
+            res["hipgraph_replay"] = hipgraph
         res.update(extra)
         print(json.dumps(res), flush=True)
     if ctx.dist_on:
