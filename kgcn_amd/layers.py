@@ -267,7 +267,8 @@ class GINAggregate(nn.Module):
             raise ValueError("layer has %d adjacency channels, adj has %d"
                              % (self.adj_channel_num, a.num_channels))
         drop_eps = enabled_bconv or enabled_bspmm or enabled_batched
-        eps = None if drop_eps else torch.stack(list(self.epsilon))
+        # one channel: a view of the parameter (torch.stack is a copy launch forward and a slice launch backward)
+        eps = None if drop_eps else (self.epsilon[0].reshape(1) if len(self.epsilon) == 1 else torch.stack(list(self.epsilon)))
         return ops.gin_aggregate(inputs, eps, a)
 
 
