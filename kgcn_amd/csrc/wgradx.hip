@@ -11,7 +11,8 @@
 // matrix work would be 37 us, under the memory time.  Measured (profiles/r03_g_cfg4_rocprof.txt): 94 us = 3.2 TB/s -- 5 % under
 // the split kernel, not the 40 % the arithmetic promises: more workgroups per CU, operand prefetch (ping-pong registers),
 // scalar address arithmetic and wide loads (one dwordx3 + one dwordx2 per operand for six MFMAs: 105 us) all left the time
-// where it is or worse; the instruction count that stays constant is the 1.41 M MFMAs -- ~150 cycles each; what holds the f32 MFMA at ~150 cycles per instruction here, while
+// where it is or worse; the instruction count that stays constant is the 1.41 M MFMAs -- ~150 cycles each (and
+// tools/probes/mfma_f32_probe3.hip: 16 L1-resident loads per 24 MFMAs cost the MFMAs 15 % at most); what holds the f32 MFMA at ~150 cycles per instruction here, while
 // tools/probes/mfma_f32_probe2.hip issues one per 64 cycles from registers, is not understood.  Kept for the exact products.
 // Eight row pairs of operands are requested before their MFMAs (two to four waves per SIMD; requesting the next chunk before
 // the current chunk's MFMAs -- ping-pong registers -- was slower: 102 vs 94 us).  One partial per workgroup, reduce_partials adds them in a fixed order: deterministic.
