@@ -11,8 +11,10 @@
 // matrix work would be 37 us, under the memory time.  Measured (profiles/r03_g_cfg4_rocprof.txt): 94 us = 3.2 TB/s -- 5 % under
 // the split kernel, not the 40 % the arithmetic promises: more workgroups per CU, operand prefetch (ping-pong registers),
 // scalar address arithmetic and wide loads (one dwordx3 + one dwordx2 per operand for six MFMAs: 105 us) all left the time
-// where it is or worse; the instruction count that stays constant is the 1.41 M MFMAs -- ~150 cycles each (and
-// tools/probes/mfma_f32_probe3.hip: 16 L1-resident loads per 24 MFMAs cost the MFMAs 15 % at most); what holds the f32 MFMA at ~150 cycles per instruction here, while
+// where it is or worse.  What the measurements say: the loads alone (MFMAs replaced by plain FMAs) take 58 us = 5.2 TB/s, the
+// 1.41 M MFMAs alone 38 us (27.5 ns each, tools/probes), together 96 us -- the sum, not the maximum -- with two or eight waves
+// per SIMD and also with the next chunk's loads issued in front of the current chunk's MFMAs (verified in the ISA: partial
+// vmcnt waits): while the f32 MFMA occupies the vector datapath, loads in flight do not seem to land; what holds the f32 MFMA at ~150 cycles per instruction here, while
 // tools/probes/mfma_f32_probe2.hip issues one per 64 cycles from registers, is not understood.  Kept for the exact products.
 // Eight row pairs of operands are requested before their MFMAs (two to four waves per SIMD; requesting the next chunk before
 // the current chunk's MFMAs -- ping-pong registers -- was slower: 102 vs 94 us).  One partial per workgroup, reduce_partials adds them in a fixed order: deterministic.
@@ -20,7 +22,8 @@
 
 namespace kgcn {
 
-constexpr int WX_U = 8;            // row pairs in flight per wave
+
+constexpr int WX_U = 8;            // row pairs in flight per wave (2: 134 us, 4: 113 us, 8: 103 us, 16: 102 us with the second stage)
 
 template <int MB, bool DACT>
 __global__ __launch_bounds__(512) void wgradx_kernel(const float* __restrict__ x, long x_ld, const float* __restrict__ dy,
@@ -58,21 +61,37 @@ __global__ __launch_bounds__(512) void wgradx_kernel(const float* __restrict__ x
   };
   const long step = 2 * WX_U;
   long r = r0;
-  for (; r + step <= r1; r += step) {
-    const float* xr = x + r * x_ld;                    // wave-uniform
-    const float* gr = dy + r * dy_ld;
-    const float* yr = DACT ? yact + r * dy_ld : nullptr;
-    Ops o;
+  const long rfull = r1 < m - 1 ? r1 : m - 1;          // full (unmasked) chunks end below the tensors' last row
+  auto load_full = [&](long rr, Ops& o) __attribute__((always_inline)) {
+    const float* xr = x + rr * x_ld;
+    const float* gr = dy + rr * dy_ld;
+    const float* yr = DACT ? yact + rr * dy_ld : nullptr;
+    // UNCONDITIONAL loads (a lane beyond the matrix edge reads into the next row -- the caller keeps full chunks away from the
+    // last row of the tensors -- and is zeroed by a select afterwards): a masked load is a branch around the load, every branch a
+    // basic block, and the counters are drained to zero at every join -- nothing stays in flight across the MFMAs
 #pragma unroll
     for (int u = 0; u < WX_U; ++u) {
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) o.a[u][mb] = kok[mb] ? xr[2 * u * x_ld + lane_x + 32 * mb] : 0.f;
-      o.b[u] = nok ? gr[2 * u * dy_ld + lane_y] : 0.f;
-      if constexpr (DACT) o.ya[u] = nok ? yr[2 * u * dy_ld + lane_y] : 0.f;
+      for (int mb = 0; mb < MB; ++mb) o.a[u][mb] = xr[2 * u * x_ld + lane_x + 32 * mb];
+      o.b[u] = gr[2 * u * dy_ld + lane_y];
+      if constexpr (DACT) o.ya[u] = yr[2 * u * dy_ld + lane_y];
     }
+  };
+  auto mask_full = [&](Ops& o) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < WX_U; ++u) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) o.a[u][mb] = kok[mb] ? o.a[u][mb] : 0.f;
+      o.b[u] = nok ? o.b[u] : 0.f;
+    }
+  };
+  for (; r + step <= rfull; r += step) {
+    Ops o;
+    load_full(r, o);
+    mask_full(o);
     mma(o);
   }
-  if (r < r1) {
+  for (; r < r1; r += step) {
     Ops o;
 #pragma unroll
     for (int u = 0; u < WX_U; ++u) {
@@ -105,12 +124,13 @@ int launch_wgradx(const float* x, long x_ld, const float* dy, long dy_ld, long m
   long rpb = (m + nparts - 1) / nparts;
   rpb = (rpb + 1) & ~1L;                               // row pairs never straddle two workgroups
   const int mb = (din + 31) / 32;
-#define KGCN_WX(MBV, DA)                                                                                              \
-  hipLaunchKernelGGL((wgradx_kernel<MBV, DA>), dim3(nparts), dim3(512), 0, s, x, x_ld, dy, yact, dy_ld, m, din, dout, act, rpb, \
-                     part_dw, part_db)
   if (mb != 3) return fail("wgradx: %d input columns", din);     // 65..96: three 32-row blocks of dW
-  if (yact && act != KGCN_ACT_NONE) KGCN_WX(3, true); else KGCN_WX(3, false);
-#undef KGCN_WX
+  if (yact && act != KGCN_ACT_NONE)
+    hipLaunchKernelGGL((wgradx_kernel<3, true>), dim3(nparts), dim3(512), 0, s, x, x_ld, dy, yact, dy_ld, m, din, dout, act, rpb,
+                       part_dw, part_db);
+  else
+    hipLaunchKernelGGL((wgradx_kernel<3, false>), dim3(nparts), dim3(512), 0, s, x, x_ld, dy, yact, dy_ld, m, din, dout, act, rpb,
+                       part_dw, part_db);
   return check_launch("wgradx_kernel");
 }
 
