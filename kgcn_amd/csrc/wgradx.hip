@@ -14,7 +14,8 @@
 // where it is or worse.  What the measurements say: the loads alone (MFMAs replaced by plain FMAs) take 58 us = 5.2 TB/s, the
 // 1.41 M MFMAs alone 38 us (27.5 ns each, tools/probes), together 96 us -- the sum, not the maximum -- with two or eight waves
 // per SIMD and also with the next chunk's loads issued in front of the current chunk's MFMAs (verified in the ISA: partial
-// vmcnt waits): while the f32 MFMA occupies the vector datapath, loads in flight do not seem to land; what holds the f32 MFMA at ~150 cycles per instruction here, while
+// vmcnt waits), and with the operands travelling global -> LDS directly (global_load_lds, no VGPR write on arrival: 110 us):
+// while the f32 MFMA works, the memory stream does not; what holds the f32 MFMA at ~150 cycles per instruction here, while
 // tools/probes/mfma_f32_probe2.hip issues one per 64 cycles from registers, is not understood.  Kept for the exact products.
 // Eight row pairs of operands are requested before their MFMAs (two to four waves per SIMD; requesting the next chunk before
 // the current chunk's MFMAs -- ping-pong registers -- was slower: 102 vs 94 us).  One partial per workgroup, reduce_partials adds them in a fixed order: deterministic.
