@@ -138,6 +138,15 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = dlogits[i] * sc;
 }
 
+// the update of ONE element, the same instruction sequence in every kernel below (explicit fmas: -ffp-contract must not give the
+// vector, scalar and per-segment paths different roundings)
+__device__ __forceinline__ void adam_tf_update(float& p, float& m, float& v, float g, float lr_t, float b1, float b2, float c1,
+                                               float c2, float eps) {
+  m = __builtin_fmaf(m, b1, g * c1);
+  v = __builtin_fmaf(v, b2, (g * g) * c2);
+  p = __builtin_fmaf(-lr_t, m / (__builtin_sqrtf(v) + eps), p);
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                       float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
@@ -157,9 +166,9 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, con
       const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        mv[j] = mv[j] * b1 + gv[j] * c1;
-        vv[j] = vv[j] * b2 + (gv[j] * gv[j]) * c2;
-        pv[j] -= lr_t * (mv[j] / (__builtin_sqrtf(vv[j]) + eps));
+        float pj = pv[j], mj = mv[j], vj = vv[j];
+        adam_tf_update(pj, mj, vj, gv[j], lr_t, b1, b2, c1, c2, eps);
+        pv[j] = pj; mv[j] = mj; vv[j] = vj;
       }
       reinterpret_cast<f32x4*>(p)[i] = pv;
       reinterpret_cast<f32x4*>(m)[i] = mv;
@@ -167,12 +176,9 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, con
     }
   } else {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-      const float gv = g[i];
-      const float mv = m[i] * b1 + gv * c1;
-      const float vv = v[i] * b2 + (gv * gv) * c2;
-      m[i] = mv;
-      v[i] = vv;
-      p[i] -= lr_t * (mv / (__builtin_sqrtf(vv) + eps));
+      float pj = p[i], mj = m[i], vj = v[i];
+      adam_tf_update(pj, mj, vj, g[i], lr_t, b1, b2, c1, c2, eps);
+      p[i] = pj; m[i] = mj; v[i] = vj;
     }
   }
 }
@@ -285,12 +291,9 @@ __global__ __launch_bounds__(256) void adam_tf_multi_kernel(float* __restrict__ 
   const float* __restrict__ g = sg.grad[q];
   const long off = sg.offset[q], n = sg.numel[q];
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const float gv = g[i];
-    const float mv = m[off + i] * b1 + gv * c1;
-    const float vv = v[off + i] * b2 + (gv * gv) * c2;
-    m[off + i] = mv;
-    v[off + i] = vv;
-    p[off + i] -= lr_t * (mv / (__builtin_sqrtf(vv) + eps));
+    float pj = p[off + i], mj = m[off + i], vj = v[off + i];
+    adam_tf_update(pj, mj, vj, g[i], lr_t, b1, b2, c1, c2, eps);
+    p[off + i] = pj; m[off + i] = mj; v[off + i] = vj;
   }
 }
 
