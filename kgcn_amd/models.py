@@ -187,6 +187,30 @@ class SparseGCN(nn.Module):
         return self.out(net)                                    # probabilities = softmax(logits)
 
 
+class DeepChemGCN(nn.Module):
+    """example_model/model_deepchem.py:31-81: 4 x [GraphConv(64 / 128 / 128 / 64) -> relu -> GraphMaxPooling ->
+    GraphBatchNormalization (valid rows) -> Dropout], GraphDense(64) -> sigmoid, GraphGather, Dense(num_classes).
+    dropout_rate: the `dropout_rate` placeholder (0 = the evaluation feed; torch's dropout mask otherwise)."""
+
+    def __init__(self, adj_channel_num=1, num_classes=2, widths=(64, 128, 128, 64)):
+        super().__init__()
+        self.conv = nn.ModuleList([layers.GraphConv(w, adj_channel_num, activation="relu") for w in widths])   # :44-45 tf.nn.relu(conv)
+        self.pool = nn.ModuleList([layers.GraphMaxPooling(adj_channel_num) for _ in widths])
+        self.bn = nn.ModuleList([GraphBatchNormalization() for _ in widths])
+        self.dense = layers.GraphDense(64, activation="sigmoid")                                              # :75-76
+        self.gather = layers.GraphGather()
+        self.out = KerasDense(num_classes)
+
+    def forward(self, features, adjs, enabled_node_nums=None, dropout_rate=0.0):
+        adjs = layers._pack(adjs, features)
+        layer = features
+        for conv, pool, bn in zip(self.conv, self.pool, self.bn):
+            layer = bn(pool(conv(layer, adj=adjs), adj=adjs), enabled_node_nums=enabled_node_nums)
+            if dropout_rate:
+                layer = torch.nn.functional.dropout(layer, p=float(dropout_rate), training=True)
+        return self.out(self.gather(self.dense(layer)))
+
+
 class GATNet(nn.Module):
     """example_model/model_gat.py:30-80."""
 

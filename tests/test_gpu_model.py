@@ -618,3 +618,43 @@ def test_cross_layer_stack_rows_with_duplicate_entries(route):
             layers.stack_fusion, ops.stack_route = True, 0
     for a, b in zip(res[True], res[False]):
         close(a, b, atol=2e-6, rel=5e-5, what="stack with duplicate entries vs layers")
+
+
+@pytest.mark.parametrize("phase", [0, 1])
+def test_deepchem_model_against_the_oracle_ops(phase):
+    """example_model/model_deepchem.py (GraphConv -> relu -> GraphMaxPooling -> GraphBatchNormalization over the valid rows, four
+    times; GraphDense -> sigmoid -> GraphGather -> Dense) on Tox21-shaped molecules with true sizes, in both Keras learning
+    phases: logits against the same chain of oracle ops in fp64; gradients flow to every parameter."""
+    from kgcn_amd import layers, models
+    from test_oracle_model import tox21_like_batch
+    rng = np.random.default_rng(3 + phase)
+    x, adjs, _, mask, _, sizes = tox21_like_batch(rng, B=24, N=20, F=17, T=2)
+    layers.set_learning_phase(phase)
+    try:
+        torch.manual_seed(0)
+        model = models.DeepChemGCN(1, 2).to(dev())
+        tx = t32(x)
+        model(tx, adjs, enabled_node_nums=torch.as_tensor(sizes))                      # Keras-style build
+        with torch.no_grad():
+            gen = torch.Generator(device="cpu").manual_seed(5)
+            for bn in model.bn:
+                bn.gamma.copy_(torch.rand(bn.gamma.shape, generator=gen).to(dev()) + 0.5)
+                bn.beta.copy_(torch.randn(bn.beta.shape, generator=gen).to(dev()) * 0.2)
+                bn.moving_mean.copy_(torch.randn(bn.moving_mean.shape, generator=gen).to(dev()) * 0.1)
+                bn.moving_variance.copy_(torch.rand(bn.moving_variance.shape, generator=gen).to(dev()) + 0.5)
+            stats = [(bn.moving_mean.cpu().numpy().astype(np.float64), bn.moving_variance.cpu().numpy().astype(np.float64)) for bn in model.bn]
+        logits = model(tx, adjs, enabled_node_nums=torch.as_tensor(sizes))
+        logits.square().sum().backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    finally:
+        layers.set_learning_phase(0)
+    f64 = lambda t: t.detach().cpu().numpy().astype(np.float64)
+    h = x.astype(np.float64)
+    for conv, bn, (mm, mv) in zip(model.conv, model.bn, stats):
+        h = np.maximum(K.graphconv_fwd(h, adjs, [f64(conv.w[0])], [f64(conv.bias[0])]), 0.0)
+        h = K.graph_maxpool_fwd(h, adjs)
+        h = K.graph_bn_fwd(h, f64(bn.gamma), f64(bn.beta), mm, mv, enabled_node_nums=sizes, training=bool(phase))[0]
+    B, N, D = h.shape
+    h = 1.0 / (1.0 + np.exp(-(h.reshape(B * N, D) @ f64(model.dense.kernel) + f64(model.dense.bias)))).reshape(B, N, -1)
+    ref = h.sum(1) @ f64(model.out.kernel) + f64(model.out.bias)
+    close(logits, ref, atol=3e-5, rel=2e-5, what="model_deepchem logits (phase %d)" % phase)
