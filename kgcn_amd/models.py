@@ -211,6 +211,33 @@ class DeepChemGCN(nn.Module):
         return self.out(self.gather(self.dense(layer)))
 
 
+class NodeLabelGCN(nn.Module):
+    """example_model/model_node_label.py:48-62 (features given): GraphConv(64) -> GraphBatchNormalization -> relu, twice, then
+    GraphConv(num_classes): per-NODE logits [B, N, num_classes]."""
+
+    def __init__(self, adj_channel_num=1, num_classes=2):
+        super().__init__()
+        self.conv = nn.ModuleList([layers.GraphConv(64, adj_channel_num), layers.GraphConv(64, adj_channel_num),
+                                   layers.GraphConv(num_classes, adj_channel_num)])
+        self.bn = nn.ModuleList([GraphBatchNormalization(activation="relu") for _ in range(2)])       # :52-55 tf.nn.relu(bn(...))
+
+    def forward(self, features, adjs, enabled_node_nums=None):
+        adjs = layers._pack(adjs, features)
+        layer = features
+        for conv, bn in zip(self.conv[:2], self.bn):
+            layer = bn(conv(layer, adj=adjs), enabled_node_nums=enabled_node_nums)
+        return self.conv[2](layer, adj=adjs)
+
+
+def node_softmax_ce(logits, node_labels, mask):
+    """model_node_label.py:64-70: cost[b] = mask[b] * mean over ALL N node rows of softmax_cross_entropy(node_label[b, n],
+    logits[b, n]) (the mask_node_label placeholder is read but not used there); cost_opt = reduce_mean over the padded batch,
+    cost_sum = reduce_sum.  -> (cost_opt, cost_sum)"""
+    ce = -(node_labels * torch.log_softmax(logits, dim=2)).sum(dim=2)
+    cost = mask * ce.mean(dim=1)
+    return cost.mean(), cost.sum()
+
+
 class GATNet(nn.Module):
     """example_model/model_gat.py:30-80."""
 

@@ -658,3 +658,43 @@ def test_deepchem_model_against_the_oracle_ops(phase):
     h = 1.0 / (1.0 + np.exp(-(h.reshape(B * N, D) @ f64(model.dense.kernel) + f64(model.dense.bias)))).reshape(B, N, -1)
     ref = h.sum(1) @ f64(model.out.kernel) + f64(model.out.bias)
     close(logits, ref, atol=3e-5, rel=2e-5, what="model_deepchem logits (phase %d)" % phase)
+
+
+def test_node_label_model_against_the_oracle_ops():
+    """example_model/model_node_label.py: two GraphConv(64) -> GraphBatchNormalization (valid rows) -> relu blocks and a
+    GraphConv(2) read per NODE; softmax cross entropy averaged over the node rows of a graph, masked per graph: logits and both
+    cost values against the same chain of oracle ops in fp64; the 2-wide last GraphConv goes through the narrow kernels."""
+    from kgcn_amd import models
+    from test_oracle_model import tox21_like_batch
+    rng = np.random.default_rng(9)
+    x, adjs, _, mask, _, sizes = tox21_like_batch(rng, B=20, N=15, F=12, T=2)
+    node_lab = np.eye(2)[rng.integers(0, 2, (20, 15))]
+    torch.manual_seed(0)
+    model = models.NodeLabelGCN(1, 2).to(dev())
+    tx = t32(x)
+    model(tx, adjs, enabled_node_nums=torch.as_tensor(sizes))
+    with torch.no_grad():
+        gen = torch.Generator(device="cpu").manual_seed(2)
+        for bn in model.bn:
+            bn.gamma.copy_(torch.rand(bn.gamma.shape, generator=gen).to(dev()) + 0.5)
+            bn.beta.copy_(torch.randn(bn.beta.shape, generator=gen).to(dev()) * 0.2)
+            bn.moving_mean.copy_(torch.randn(bn.moving_mean.shape, generator=gen).to(dev()) * 0.1)
+            bn.moving_variance.copy_(torch.rand(bn.moving_variance.shape, generator=gen).to(dev()) + 0.5)
+        for conv in model.conv:
+            conv.bias[0].copy_(torch.randn(conv.bias[0].shape, generator=gen).to(dev()) * 0.1)
+    logits = model(tx, adjs, enabled_node_nums=torch.as_tensor(sizes))
+    cost_opt, cost_sum = models.node_softmax_ce(logits, t32(node_lab), t32(mask))
+    cost_opt.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    f64 = lambda t: t.detach().cpu().numpy().astype(np.float64)
+    h = x.astype(np.float64)
+    for conv, bn in zip(model.conv[:2], model.bn):
+        h = K.graphconv_fwd(h, adjs, [f64(conv.w[0])], [f64(conv.bias[0])])
+        h = np.maximum(K.graph_bn_fwd(h, f64(bn.gamma), f64(bn.beta), f64(bn.moving_mean), f64(bn.moving_variance),
+                                      enabled_node_nums=sizes)[0], 0.0)
+    ref = K.graphconv_fwd(h, adjs, [f64(model.conv[2].w[0])], [f64(model.conv[2].bias[0])])
+    close(logits, ref, atol=3e-5, rel=2e-5, what="model_node_label logits")
+    lse = np.log(np.exp(ref - ref.max(2, keepdims=True)).sum(2)) + ref.max(2)
+    ce = -(node_lab * (ref - lse[..., None])).sum(2)
+    cost = mask * ce.mean(1)
+    assert abs(float(cost_opt) - cost.mean()) < 2e-5 and abs(float(cost_sum) - cost.sum()) < 2e-4
