@@ -171,7 +171,12 @@ __device__ __forceinline__ void g3_write(u32x4* table, int tile, int q, int li, 
 // on (g): the broadcast never exists in HBM.
 struct G3Dact { long ydiff, pdiff; float c0, c1, c2; const float* bc; long bc_ld; int bc_n, bc_only; };
 
-template <bool XVEC, bool WTAB, int MW, int DK = 0>
+// MT x NT (table variant, 4-wave workgroups): 32 x 32 tiles per wave.  2 x 2: the workgroup covers 64 rows x 256 columns
+// (waves side by side).  When a launch has fewer such tiles than a quarter of the chip's workgroup slots (2 per CU) --
+// sparse.py's 4,457 node rows are 70 tiles -- the columns are cut instead: 1 x 1 = 64 rows x 64 columns (waves 2 x 2),
+// blockIdx.y = the column block.  Every column block stages the x pieces of its rows again (latency-bound launches: the
+// staging is not what they wait for); d pre-activation is written by column block 0 only.
+template <bool XVEC, bool WTAB, int MW, int DK = 0, int MT = 2, int NT = 2>
 __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
     const float* __restrict__ x, long m, int din, long x_ld, const float* __restrict__ w, long w_ld, int trans_w,
     const float* __restrict__ bias, float* __restrict__ y, int dout, long y_ld, int act, G3Dact da) {
@@ -180,6 +185,9 @@ __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, hi = lane >> 5;
   static_assert(MW == 2 || WTAB, "the 4-wave workgroup stages x only");
+  static_assert((MT == 2 && NT == 2) || (MW == 1 && WTAB && (MT == 2 || NT == 1)), "narrow column blocks: table variant, 4 waves");
+  constexpr int WC = (MT == 1) ? 2 : 4;                    // waves side by side
+  constexpr int BN = WC * NT * 32;                         // columns per workgroup
   static_assert(DK == 0 || (WTAB && XVEC), "the activation-derivative prologue lives in the table variant");
   // g (.) act'(a) for the pair J of a raw set, in place (before the pair is split)
   auto dact_pair = [&](G3Raw& R, auto jc) __attribute__((always_inline)) {
@@ -207,16 +215,16 @@ __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
     }
   };
   constexpr int BMT = 64 * MW;                             // rows per workgroup tile
-  const int wr = wave >> 2, wc = wave & 3;
-  const int n0 = blockIdx.y * G3_BN;
+  const int wr = wave / WC, wc = wave % WC;
+  const int n0 = blockIdx.y * BN;
   const long ntiles = (m + BMT - 1) / BMT;
   const int nkc = (din + G3_BK - 1) / G3_BK;
   if ((long)blockIdx.x >= ntiles) return;      // uniform for the whole workgroup
 
-  float bcol[2];
+  float bcol[NT];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int c = n0 + 64 * wc + 32 * nt + li;
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c = n0 + 32 * NT * wc + 32 * nt + li;
     bcol[nt] = (bias && c < dout) ? bias[c] : 0.f;
   }
 
@@ -261,12 +269,12 @@ __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
   constexpr int LBUF = WTAB ? G3_XP : G3_XP + G3_WP;     // u32x4 entries of one LDS buffer
   const u32x4* wtab = reinterpret_cast<const u32x4*>(w);
   const int tab_nt = ((dout + 63) / 64) * 2, tab_ks = (din + 15) / 16;
-  u32x4 B0[2][3], B1[2][3];
-  auto load_b = [&](u32x4 (&Bd)[2][3], int g) __attribute__((always_inline)) {
+  u32x4 B0[NT][3], B1[NT][3];
+  auto load_b = [&](u32x4 (&Bd)[NT][3], int g) __attribute__((always_inline)) {
     const int gg = g < tab_ks ? g : tab_ks - 1;
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) {
-      int nt = (n0 + 64 * wc) / 32 + t2;
+    for (int t2 = 0; t2 < NT; ++t2) {
+      int nt = (n0 + 32 * NT * wc) / 32 + t2;
       nt = nt < tab_nt ? nt : tab_nt - 1;
       const u32x4* e = wtab + ((long)(gg * tab_nt + nt) * 3) * 64 + lane;
 #pragma unroll
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
   g3_issue<XVEC, WTAB, DK>(rb, co, w, din, (t1 < ntiles ? k1c : k0c) * G3_BK, da.ydiff);
   __syncthreads();
 
-  f32x16 acc[2][2];
+  f32x16 acc[MT][NT];
   int buf = 0;
   bool done = false;
   float touch = 0.f, sink = 0.f;
@@ -310,11 +318,15 @@ __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
     const long rowl = tl * BMT + xr;
     const float* xrow_l = x + (rowl < m ? rowl : m - 1) * x_ld;
     const bool rowok_l = rowl < m;
+    const float* brow_l = co.brow;                       // gathered gradient: the row's graph changes with the tile
+    if constexpr (DK != 0) {
+      if (kl == 0 && da.bc) brow_l = da.bc + ((rowl < m ? rowl : m - 1) / da.bc_n) * da.bc_ld;      // uniform
+    }
     if (k0c == 0) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[mt][nt][r] = bcol[nt];
     }
@@ -329,21 +341,26 @@ __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
     G3P(0)
     static_for<2>([&](auto ksc) __attribute__((always_inline)) {
       constexpr int ks = decltype(ksc)::value;
-      u32x4 A[2][3], B[2][3];
+      u32x4 A[MT][3], B[NT][3];
 #pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2)
+      for (int p = 0; p < 3; ++p) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          A[t2][p] = xp[g3_slot(2 * wr + t2, ks, p, li, hi)];
+        for (int t2 = 0; t2 < MT; ++t2) A[t2][p] = xp[g3_slot(MT * wr + t2, ks, p, li, hi)];
+#pragma unroll
+        for (int t2 = 0; t2 < NT; ++t2) {
           if constexpr (!WTAB) B[t2][p] = wp[g3_slot(2 * wc + t2, ks, p, li, hi)];
           else B[t2][p] = ks == 0 ? B0[t2][p] : B1[t2][p];
         }
-      static_for<24>([&](auto mc) __attribute__((always_inline)) {
-        constexpr int mm = decltype(mc)::value, pr = mm >> 2, tl4 = mm & 3, slot = 24 * ks + mm;
+      }
+      constexpr int NMF = 6 * MT * NT;                     // MFMAs per k-step
+      constexpr int SL = 24 / NMF;                         // staging slices behind each of them (the slice plan has 48 slots)
+      static_for<NMF * SL>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int mm = decltype(mc)::value / SL, pr = mm / (MT * NT), tl4 = mm % (MT * NT), slot = 24 * ks + decltype(mc)::value;
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
-        acc[tl4 >> 1][tl4 & 1] = mfma_bf16(A[tl4 >> 1][PA[pr]], B[tl4 & 1][PB[pr]], acc[tl4 >> 1][tl4 & 1]);
+        if constexpr (decltype(mc)::value % SL == 0)
+          acc[tl4 / NT][tl4 % NT] = mfma_bf16(A[tl4 / NT][PA[pr]], B[tl4 % NT][PB[pr]], acc[tl4 / NT][tl4 % NT]);
         // ---- one slice of the staging work behind every MFMA (the matrix pipe runs beside the VALU) ----
-        if constexpr (WTAB && mm == 1) {
+        if constexpr (WTAB && decltype(mc)::value == SL) {
           // the other fragment set <- the k-step after this one (its previous contents were consumed one k-step ago)
           if constexpr (ks == 0) load_b(B1, 2 * k0c + 1);
           else load_b(B0, gnext);
@@ -364,6 +381,7 @@ __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
         } else if constexpr (slot == 16) {
           co.xrow = xrow_l;
           co.rowok = rowok_l;
+          co.brow = brow_l;
           g3_issue<XVEC, WTAB, DK>(RL, co, w, din, kl * G3_BK, da.ydiff);
         } else if constexpr (slot == 18) {
           // one more chunk of x on its way from HBM: a single k chunk per workgroup in flight (16 KB) caps the
@@ -384,32 +402,32 @@ __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
     if (k0c + 1 == nkc) {                                // last chunk of the tile: y <- act(acc)
       if (act != KGCN_ACT_NONE) {                        // ONE uniform branch: the plain epilogue stays what it was
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
+          for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = act_fwd(acc[mt][nt][r], act);
       }
-      const long row0 = t0 * BMT + 64 * wr;
-      const int cb = n0 + 64 * wc;
-      if (row0 + 64 <= m && cb + 64 <= dout) {
+      const long row0 = t0 * BMT + 32 * MT * wr;
+      const int cb = n0 + 32 * NT * wc;
+      if (row0 + 32 * MT <= m && cb + 32 * NT <= dout) {
         // interior block (wave-uniform test): no masks, one running row pointer (the masked form below costs
         // ~12k cycles per tile in compares, branches and 64-bit multiplies)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
           float* p = y + (row0 + 32 * mt + 4 * hi) * y_ld + cb + li;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            p[0] = acc[mt][0][r];
-            p[32] = acc[mt][1][r];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) p[32 * nt] = acc[mt][nt][r];
             p += ((r & 3) == 3) ? 5 * y_ld : y_ld;          // rows 0-3, 8-11, 16-19, 24-27 (+ 4 hi)
           }
         }
       } else {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
+          for (int nt = 0; nt < NT; ++nt) {
             const int c = cb + 32 * nt + li;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -438,6 +456,36 @@ __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
   G3P_FLUSH
 }
 
+// Table variant, 4-wave workgroups: how a launch is cut into workgroup jobs.  Fewer 64-row tiles than a quarter of the
+// workgroups the chip runs at once (two per CU): 64-column blocks (sparse.py's 4,457 node rows: 70 tiles -> 280 workgroups;
+// 20.3 against 23.8 us per 256 x 256 layer, its training step 0.335 against 0.362 ms).  Measured and NOT kept
+// (tools/gemm_cut_bench.py, profiles/r03_i_gemm_cut.txt): 128-column blocks up to half of the slots (equal or slower), and
+// a second, narrow-block launch over the rows of a last, partial round (200,000 rows = 6 rounds + 53 tiles: 190.7 against
+// 186.6 us -- the lone workgroups of the seventh round run faster than the launch gap + a latency-bound launch cost).
+template <int DK, int MT, int NT>
+static void g3_table_launch_shape(const float* x, long m, int din, long x_ld, const float* tw, long w_ld, int trans_w,
+                                  const float* bias, float* y, int dout, long y_ld, int act, const G3Dact& da, hipStream_t s) {
+  constexpr int BN = (MT == 1 ? 2 : 4) * NT * 32;
+  const long nt64 = (m + 63) / 64;
+  const long cap = 2L * kNumCU;
+  const dim3 grid((unsigned)(nt64 < cap ? nt64 : cap), (unsigned)((dout + BN - 1) / BN));
+  const size_t lds = 2 * (size_t)G3_XP * 16;
+  hipLaunchKernelGGL((gemm3_fwd_kernel<true, true, 1, DK, MT, NT>), grid, dim3(256), lds, s, x, m, din, x_ld, tw, w_ld, trans_w,
+                     bias, y, dout, y_ld, act, da);
+}
+
+template <int DK>
+static void g3_table_launch(const float* x, long m, int din, long x_ld, const float* tw, long w_ld, int trans_w, const float* bias,
+                            float* y, int dout, long y_ld, int act, const G3Dact& da, hipStream_t s) {
+  const long jobs = ((m + 63) / 64) * ((dout + G3_BN - 1) / G3_BN), slots = 2L * kNumCU;
+  static const char* knob = dev_knob("KGCN_GEMM3_CUT");       // development: "0" = whole column blocks only
+  // the backward form carries more staging per row (two or three operands, the d pre-activation store): it pays up to 96 tiles
+  const long limit = DK == 0 ? slots : slots * 3 / 4;
+  if (!(knob && knob[0] == '0') && jobs * 4 <= limit)
+    return g3_table_launch_shape<DK, 1, 1>(x, m, din, x_ld, tw, w_ld, trans_w, bias, y, dout, y_ld, act, da, s);
+  g3_table_launch_shape<DK, 2, 2>(x, m, din, x_ld, tw, w_ld, trans_w, bias, y, dout, y_ld, act, da, s);
+}
+
 // table == nullptr: W is split inside the kernel; else `table` is the fragment table of wtable.hip for (w, trans_w)
 int launch_gemm3_fwd(const float* x, long m, int din, long x_ld, const float* w, long w_ld, int trans_w,
                      const float* bias, float* y, int dout, long y_ld, int act, const void* table, hipStream_t s) {
@@ -460,15 +508,15 @@ int launch_gemm3_fwd(const float* x, long m, int din, long x_ld, const float* w,
     const float* tw = static_cast<const float*>(table);
     static const char* mw = dev_knob("KGCN_GEMM3_MW");         // development: "2" = the 8-wave workgroup
     if (!(mw && mw[0] == '2')) {
-      const long nt64 = (m + 63) / 64;
-      const long cap = 2L * kNumCU;
-      const dim3 grid((unsigned)(nt64 < cap ? nt64 : cap), (unsigned)((dout + G3_BN - 1) / G3_BN));
-      if (xvec)
-        hipLaunchKernelGGL((gemm3_fwd_kernel<true, true, 1>), grid, dim3(256), lds, s, x, m, din, x_ld, tw, w_ld, trans_w,
-                           bias, y, dout, y_ld, act, G3Dact{});
-      else
+      if (xvec) {
+        g3_table_launch<0>(x, m, din, x_ld, tw, w_ld, trans_w, bias, y, dout, y_ld, act, G3Dact{}, s);
+      } else {
+        const long nt64 = (m + 63) / 64;
+        const long cap = 2L * kNumCU;
+        const dim3 grid((unsigned)(nt64 < cap ? nt64 : cap), (unsigned)((dout + G3_BN - 1) / G3_BN));
         hipLaunchKernelGGL((gemm3_fwd_kernel<false, true, 1>), grid, dim3(256), lds, s, x, m, din, x_ld, tw, w_ld, trans_w,
                            bias, y, dout, y_ld, act, G3Dact{});
+      }
       return check_launch("gemm3_fwd_kernel");
     }
     const dim3 grid((unsigned)(ntiles < kNumCU ? ntiles : kNumCU), (unsigned)((dout + G3_BN - 1) / G3_BN));
@@ -510,17 +558,9 @@ int launch_gemm3_dx_dact(const float* grad, const float* act_out, float* dpre, l
   da.c0 = dact == KGCN_ACT_TANH ? 1.f : 0.f;
   da.c1 = dact == KGCN_ACT_SIGMOID ? 1.f : 0.f;
   da.c2 = -1.f;
-  const long nt64 = (m + 63) / 64;
-  const long cap = 2L * kNumCU;
-  const dim3 grid((unsigned)(nt64 < cap ? nt64 : cap), (unsigned)((n + G3_BN - 1) / G3_BN));
-  const size_t lds = 2 * (size_t)G3_XP * 16;
   const float* tw = static_cast<const float*>(table);
-  if (dact == KGCN_ACT_RELU)
-    hipLaunchKernelGGL((gemm3_fwd_kernel<true, true, 1, 2>), grid, dim3(256), lds, s, base, m, k, ld, tw, 0L, 1, nullptr, dx, n,
-                       dx_ld, KGCN_ACT_NONE, da);
-  else
-    hipLaunchKernelGGL((gemm3_fwd_kernel<true, true, 1, 1>), grid, dim3(256), lds, s, base, m, k, ld, tw, 0L, 1, nullptr, dx, n,
-                       dx_ld, KGCN_ACT_NONE, da);
+  if (dact == KGCN_ACT_RELU) g3_table_launch<2>(base, m, k, ld, tw, 0L, 1, nullptr, dx, n, dx_ld, KGCN_ACT_NONE, da, s);
+  else g3_table_launch<1>(base, m, k, ld, tw, 0L, 1, nullptr, dx, n, dx_ld, KGCN_ACT_NONE, da, s);
   return check_launch("gemm3_fwd_kernel(dact)");
 }
 

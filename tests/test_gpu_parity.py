@@ -333,7 +333,10 @@ def test_bconv_and_bspmdt_values_gradients():
                                         (129, 256, 50), (5, 7, 2), (4096, 128, 128), (10000, 256, 256),
                                         (333, 100, 300), (2049, 259, 130), (64, 512, 96), (5003, 256, 50), (4100, 128, 64),
                                         (4500, 200, 7), (20000, 512, 2), (4096, 50, 12), (128, 256, 10), (3000, 1024, 5), (777, 64, 16),
-                                        (4096, 12, 50), (1000, 3, 64), (513, 16, 300)])
+                                        (4096, 12, 50), (1000, 3, 64), (513, 16, 300),
+                                        # launch shapes of the table GEMM (gemm3.hip: g3_table_launch): 64- / 128-column blocks over
+                                        # few rows, with a ragged last block; whole rounds + a narrow-block launch over the rest
+                                        (1500, 256, 200), (12000, 300, 256), (36160, 256, 256), (47000, 256, 200)])
 def test_dense_fwd_bwd(M, din, dout):
     from kgcn_amd import ops
     rng = np.random.default_rng(M + din)
