@@ -380,12 +380,13 @@ def test_graphed_step_with_captured_rccl_allreduce(tmp_path):
 
 @pytest.mark.parametrize("route", [1, 2])
 @pytest.mark.parametrize("B,N,F,W,with_en", [(30, 10, 3, 50, False), (64, 32, 40, 48, True), (1, 5, 7, 13, True), (200, 16, 5, 50, True),
-                                             (37, 17, 64, 50, True), (1500, 10, 3, 50, True), (301, 7, 9, 64, True)])
+                                             (37, 17, 64, 50, True), (1500, 10, 3, 50, True), (301, 7, 9, 64, True),
+                                             (2000, 10, 3, 50, True)])
 def test_cross_layer_stack_equals_layer_by_layer(B, N, F, W, with_en, route):
     """example_model/model.py's node-level body (3 x GraphConv, BatchNormalization with its moving statistics, GraphDense,
     GraphGather) through the cross-layer kernels (one forward, one backward launch; route 1: csrc/stack.hip, one graph per
-    workgroup trip, plain FMAs; route 2: csrc/stack_tile.hip, 64-row tiles of whole graphs on the f32 MFMA -- more tiles than
-    CUs and a ragged last tile in the 1,500-graph case) against the same modules run one by one: logits, d features and every parameter gradient; non-trivial moving statistics / gamma / beta /
+    workgroup trip, plain FMAs; route 2: csrc/stack_tile.hip, 64-row tiles of whole graphs on the f32 MFMA -- a ragged last tile in
+    the 1,500-graph case (250 tiles), more tiles than workgroups (334: second trips) in the 2,000-graph case) against the same modules run one by one: logits, d features and every parameter gradient; non-trivial moving statistics / gamma / beta /
     biases, true sizes (padded rows -> act(0) behind the normalisation), a dummy graph, 32 nodes / odd node counts / 64 input features.  The layer-by-layer route is itself checked against the fp64 model oracle above."""
     from kgcn_amd import layers, models
     from test_oracle_model import tox21_like_batch
@@ -444,7 +445,7 @@ def test_cross_layer_stack_equals_layer_by_layer(B, N, F, W, with_en, route):
         close(a, b, atol=2e-7, rel=2e-5, what="stack vs layers: grad %s" % n_)
 
 
-@pytest.mark.parametrize("T,nsel", [(30, 30), (300, 257), (1000, 1000), (5, 0)])
+@pytest.mark.parametrize("T,nsel", [(30, 30), (300, 257), (1000, 1000), (5, 0), (6000, 4096)])
 def test_batch_assemble_equals_per_container_gather(T, nsel):
     """kgcn_batch_assemble (all containers of a mini-batch + feature rows + registered tables in two launches) against the
     per-container kgcn_csr_gather_graphs and torch.index_select: bit-exact rowptr / entries / slot tables / graph_ptr of A,
