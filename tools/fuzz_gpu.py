@@ -113,6 +113,31 @@ for case in range(CASES):
     ctx = ("dense", M, di, do)
     check("dense fwd", y, x64 @ w64 + bd, ctx=ctx); check("dense dx", tx2.grad, g64 @ w64.T, ctx=ctx)
     check("dense dw", tw2.grad, x64.T @ g64, ctx=ctx); check("dense db", tb2.grad, g64.sum(0), ctx=ctx)
+    # ---- wide dense layer read out by GraphGather at 20,000 .. 120,000 node rows (several tiles per workgroup of the table GEMM) ----
+    if case % 4 == 0:
+        Ng = int(rng.choice([4, 7, 10, 32, 50]))
+        Tg = int(rng.integers(20_000, 120_000)) // Ng
+        dig, dog = [(256, 256), (84, 256), (300, 256), (256, 512), (128, 256), (256, 132)][int(rng.integers(0, 6))]
+        actg = ["sigmoid", "relu", "tanh"][int(rng.integers(0, 3))]
+        tee = bool(rng.integers(0, 2))
+        xg = rng.standard_normal((Tg, Ng, dig)).astype(np.float32)
+        wg = (rng.standard_normal((dig, dog)) / np.sqrt(dig)).astype(np.float32)
+        bg = rng.standard_normal(dog).astype(np.float32)
+        gpg, gyg = rng.standard_normal((Tg, dog)).astype(np.float32), rng.standard_normal((Tg, Ng, dog)).astype(np.float32)
+        txg, twg, tbg = (t32(a_).requires_grad_(True) for a_ in (xg, wg, bg))
+        yg, pg = ops.dense_gather(txg, twg, tbg, activation=actg)
+        ((pg * t32(gpg)).sum() + ((yg * t32(gyg)).sum() if tee else 0.0)).backward()
+        x64g = xg.astype(np.float64).reshape(Tg * Ng, dig)
+        fg = {"relu": lambda v: np.maximum(v, 0), "sigmoid": lambda v: 1 / (1 + np.exp(-v)), "tanh": np.tanh}[actg]
+        yrg = fg(x64g @ wg.astype(np.float64) + bg)
+        ygn = yg.detach().cpu().numpy().reshape(Tg * Ng, dog)
+        dfg = {"relu": (ygn > 0) * 1.0, "sigmoid": yrg * (1 - yrg), "tanh": 1 - yrg * yrg}[actg]
+        dpg = (np.repeat(gpg.astype(np.float64), Ng, axis=0) + (gyg.reshape(Tg * Ng, dog) if tee else 0.0)) * dfg
+        ctx = ("dense_gather", Tg, Ng, dig, dog, actg, tee)
+        check("dense_gather y", yg, yrg, atol=2e-6 * max(1.0, float(np.abs(yrg).max())), rel=2e-6, ctx=ctx)
+        check("dense_gather pooled", pg, yrg.reshape(Tg, Ng, dog).sum(1), ctx=ctx)
+        check("dense_gather dx", txg.grad, dpg @ wg.astype(np.float64).T, ctx=ctx)
+        check("dense_gather dw", twg.grad, x64g.T @ dpg, ctx=ctx); check("dense_gather db", tbg.grad, dpg.sum(0), ctx=ctx)
     # ---- device-side batch assembly ----------------------------------------------------------------------------------
     sel = rng.integers(-1, T, size=int(rng.integers(0, 3 * T + 2)))
     got = csr.gather(sel)
