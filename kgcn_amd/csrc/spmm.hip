@@ -546,7 +546,7 @@ static int ilog2_ceil(int v) {
 // slices of d/slices floats each (one workgroup per graph and slice) so that a tile stays within 20 KiB (8 waves / CU).
 struct TilePlan { bool ok; int vec; int slices; int nw; };
 static TilePlan tile_plan(const kgcn_csr_batch* a, int nch, const float* rhs, long rhs_ld, long rhs_gs, long rhs_cs,
-                          int d, const float* out, long out_ld, long out_gs, const float* aout) {
+                          int d, const float* out, long out_ld, long out_gs, const float* aout, bool whole_rows = false) {
   TilePlan p = {false, 4, 1, 1};
   if (d <= 0 || d > 1024 || a->rows <= 0 || a->cols <= 0) return p;
   const long all = rhs_ld | rhs_gs | out_ld | out_gs | rhs_cs | d;
@@ -555,7 +555,12 @@ static TilePlan tile_plan(const kgcn_csr_batch* a, int nch, const float* rhs, lo
   if (all % 4 == 0 && ptrs % 16 == 0) p.vec = 4;
   else if (all % 2 == 0 && ptrs % 8 == 0) p.vec = 2;
   else return p;
-  for (int sl = 1; sl <= 16; sl *= 2) {
+  // This kernel lives off occupancy (a wave per graph runs load -> LDS -> gather -> store with nothing overlapped inside it): for
+  // 17..32-node graphs 32-column slices (128-byte row segments, the CSR read once per slice) put 31 instead of 17 / 9 workgroups on
+  // a CU: d = 64: 0.62 -> 0.645 of the HBM peak, d = 128: 0.56 -> 0.64.  Not a general rule: 10-, 16- and 50-node graphs and
+  // 256-wide operands lose 4-25 % with narrower slices (profiles/r03_i_spmm_slices.txt).
+  const int sl0 = (!whole_rows && nch == 1 && p.vec == 4 && a->rows > 16 && a->rows <= 32 && (d == 64 || d == 128)) ? d / 32 : 1;
+  for (int sl = sl0; sl <= 16; sl *= 2) {
     if (d % sl != 0 || (d / sl) % p.vec != 0 || (sl > 1 && d / sl < 32)) break;
     if (d / sl > 64 * p.vec) continue;                  // one wave covers a row of the slice
     size_t lds = 0;
@@ -596,7 +601,8 @@ int launch_spmm_multi(const kgcn_csr_batch* a, int nch, const float* rhs, long r
     ch.cv[c] = reinterpret_cast<const int2*>(a[c].cv);
     ch.max_nnz[c] = a[c].max_nnz_per_graph;
   }
-  const TilePlan plan = tile_plan(a, nch, rhs, rhs_ld, rhs_gs, rhs_cs, d, out, out_ld, out_gs, dact ? aout : nullptr);
+  const TilePlan plan = tile_plan(a, nch, rhs, rhs_ld, rhs_gs, rhs_cs, d, out, out_ld, out_gs, dact ? aout : nullptr,
+                                  dotx != nullptr);      // the fused <rhs, dotx> needs a graph's whole rows in one workgroup
   if (plan.ok && (long)T * plan.slices <= 0x7fffffffL) {
     const int ds = d / plan.slices;
     size_t lds = 0;
