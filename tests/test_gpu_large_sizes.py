@@ -123,6 +123,19 @@ def test_gin_gat_maxpool_gather_whole_batch_equals_their_slices():
     _check_split(layers.GraphGather(), x, torch.randn((B_BIG, 48), device=dev(), generator=g), what="GraphGather")
 
 
+def test_decoders_whole_batch_equals_their_slices():
+    """GraphDecoderInnerProd / GraphDecoderDistMult (kgcn/layers.py:268-305): adj_hat[b] = (w *) X[b] X[b]^T of 60,000 graphs."""
+    from kgcn_amd import layers
+    x = _features(B_BIG, 24, 14)
+    g = torch.Generator(device=dev()); g.manual_seed(15)
+    up = torch.randn((B_BIG, N_NODES, N_NODES), device=dev(), generator=g)
+    _check_split(layers.GraphDecoderInnerProd(), x, up, what="GraphDecoderInnerProd")
+    torch.manual_seed(4)
+    dm = layers.GraphDecoderDistMult()
+    dm.build((B_BIG, N_NODES, 24), dev())
+    _check_split(dm, x, up, what="GraphDecoderDistMult", rel_par=5e-5)
+
+
 @pytest.mark.parametrize("din,dout,act", [(3, 50, "sigmoid"), (50, 50, "relu"), (64, 64, None), (81, 256, "sigmoid"), (256, 50, None),
                                           (50, 256, "tanh"), (256, 12, None), (12, 256, "relu"), (256, 256, "relu"), (512, 256, None),
                                           (128, 128, "sigmoid"), (256, 2, None)])
