@@ -336,7 +336,9 @@ def test_bconv_and_bspmdt_values_gradients():
                                         (4096, 12, 50), (1000, 3, 64), (513, 16, 300),
                                         # launch shapes of the table GEMM (gemm3.hip: g3_table_launch): 64- / 128-column blocks over
                                         # few rows, with a ragged last block; whole rounds + a narrow-block launch over the rest
-                                        (1500, 256, 200), (12000, 300, 256), (36160, 256, 256), (47000, 256, 200)])
+                                        (1500, 256, 200), (12000, 300, 256), (36160, 256, 256), (47000, 256, 200),
+                                        # narrow input, wide output: the register-split weight gradient (wgradx.hip), ragged last 16-row step
+                                        (50001, 81, 256), (4099, 96, 130)])
 def test_dense_fwd_bwd(M, din, dout):
     from kgcn_amd import ops
     rng = np.random.default_rng(M + din)
