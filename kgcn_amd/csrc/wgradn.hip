@@ -3,9 +3,12 @@
 //
 //   dW[din, dout] = x^T @ dy,   dbias[dout] = colsum(dy)           (per-workgroup partials, reduced in fixed order)
 //
+// Shipped: wgradnb_kernel (below) -- the register-split form of wgradx.hip with the roles exchanged; 49 us per call incl. the
+// second stage at m = 117,888 (the kernel above it in the file: 58; cfg4 step 1.477 against 1.491 ms).
+// DEV_KNOBS builds keep the first kernel (KGCN_WGRADN=lds) for A/B:
 // The f32-MFMA kernel of dense.hip cuts din into four 64-column blocks (each re-reading dy, x in 256-byte segments) and
 // spends 256 MFMAs of 64 cycles per 32 rows on a pipe it shares with the VALU: 146 us at m = 204,800 (HBM time 31 us).
-// Here a wave owns a [128 x 64] half of dW in 128 accumulator registers, two waves per SIMD (the two column halves of the
+// There a wave owns a [128 x 64] half of dW in 128 accumulator registers, two waves per SIMD (the two column halves of the
 // same rows) hide each other's vector work behind the other's MFMAs:
 //   * the batch rows are the MFMA K dimension, 16 rows per k-step with k = (row parity, row / 2) -- so that the lane layout
 //     of a coalesced load IS the fragment layout: a load instruction fetches two whole 512-byte half rows (lanes 0-31 the
@@ -21,6 +24,7 @@
 
 namespace kgcn {
 
+#ifdef KGCN_DEV_KNOBS
 constexpr int WN_LDS_WAVE = 4 * 3 * 64 * 16;               // (m-tile, piece) x 64 lanes x 16 bytes = 12 KB
 constexpr int WN_WAVES = 8;                                 // 4 row-range groups x 2 column halves
 
@@ -179,6 +183,124 @@ __global__ __launch_bounds__(512, 1) void wgradn_kernel(const float* __restrict_
   }
 }
 
+#endif  // KGCN_DEV_KNOBS
+
+// The register-split form (wgradx.hip: wgradxb_kernel) with the roles exchanged: wave w owns x block w (32 of the up to 256
+// input columns -- its own slice of the HBM stream, 8 coalesced row loads per 16 rows) and BOTH dy blocks (64 output columns,
+// the narrow operand: every wave of the workgroup loads and splits it, L1 / L2 hits); no LDS, no reduction across row-range
+// groups, one partial per workgroup.  k = (row parity, row / 2): the lane layout of the loads is the MFMA operand layout.
+__global__ __launch_bounds__(512, 2) void wgradnb_kernel(const float* __restrict__ x, long x_ld, const float* __restrict__ dy,
+                                                         long dy_ld, long m, int din, int dout, long steps_per_block,
+                                                         float* __restrict__ part_dw, float* __restrict__ part_db) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, hi = lane >> 5;
+  const int i0 = 32 * wave;                            // first x column (dW row) of this wave
+  const int kcol = i0 + li < din ? i0 + li : 0;
+  int ncol[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) ncol[nb] = 32 * nb + li < dout ? 32 * nb + li : 0;
+  const long nsteps = (m + 15) / 16;
+  const long s0 = (long)blockIdx.x * steps_per_block;
+  long s1 = s0 + steps_per_block;
+  if (s1 > nsteps) s1 = nsteps;
+  f32x16 acc[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+  float bsum[2] = {0.f, 0.f};
+  struct Raw { float a[8], b[2][8]; };
+  // uniform row pointers + one per-lane offset per operand block; full steps need no row clamp and no masks at all (columns
+  // beyond din / dout land in accumulator rows / columns that are never stored); the ragged last step of the tensors is peeled off
+  const unsigned offx = (unsigned)(hi * x_ld + kcol);
+  unsigned offy[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) offy[nb] = (unsigned)(hi * dy_ld + ncol[nb]);
+  auto load = [&](long s, Raw& r) __attribute__((always_inline)) {
+    const float* xs = x + s * 16 * x_ld;
+    const float* gs = dy + s * 16 * dy_ld;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      r.a[j] = xs[2 * j * x_ld + offx];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) r.b[nb][j] = gs[2 * j * dy_ld + offy[nb]];
+    }
+  };
+  auto load_tail = [&](long s, Raw& r) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      long row = s * 16 + 2 * j + hi;
+      row = row < m ? row : m - 1;
+      r.a[j] = x[row * x_ld + kcol];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) r.b[nb][j] = dy[row * dy_ld + ncol[nb]];
+    }
+  };
+  auto mma = [&](long s, Raw& r, auto tailc) __attribute__((always_inline)) {
+    constexpr bool TAIL = decltype(tailc)::value;
+    Frag3 fa, fb[2];
+    {
+      float u[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) u[j] = (!TAIL || s * 16 + 2 * j + hi < m) ? r.a[j] : 0.f;
+      split8(u, fa);
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[j] = (!TAIL || s * 16 + 2 * j + hi < m) ? r.b[nb][j] : 0.f;
+        bsum[nb] += v[j];
+      }
+      split8(v, fb[nb]);
+    }
+#define KGCN_WNB(PA, PB)                             \
+  acc[0] = mfma_bf16(fa.PA, fb[0].PB, acc[0]);      \
+  acc[1] = mfma_bf16(fa.PA, fb[1].PB, acc[1]);
+    KGCN_SPLIT_PRODUCTS(KGCN_WNB)
+#undef KGCN_WNB
+  };
+  const bool ragged_last = (m % 16 != 0) && s1 == nsteps && s0 < s1;
+  const long s1f = ragged_last ? s1 - 1 : s1;
+  if (s0 < s1f) {
+    // one step of lookahead; sched_barrier keeps the requests of step s + 1 in front of the arithmetic of step s
+    Raw r0, r1;
+    const long sl = s1f - 1;
+    load(s0, r0);
+    long s = s0;
+    for (; s + 1 < s1f; s += 2) {
+      load(s + 1, r1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(s, r0, std::false_type{});
+      __builtin_amdgcn_sched_barrier(0);
+      load(s + 2 < sl ? s + 2 : sl, r0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(s + 1, r1, std::false_type{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (s < s1f) mma(s, r0, std::false_type{});
+  }
+  if (ragged_last) {
+    Raw rt;
+    load_tail(s1 - 1, rt);
+    mma(s1 - 1, rt, std::true_type{});
+  }
+  float* pw = part_dw + (long)blockIdx.x * din * dout;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int n = 32 * nb + li;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = i0 + (i & 3) + 8 * (i >> 2) + 4 * hi;
+      if (k < din && n < dout) pw[(long)k * dout + n] = acc[nb][i];
+    }
+    if (part_db && wave == 0) {
+      const float b = bsum[nb] + __shfl_xor(bsum[nb], 32, 64);      // the two row parities of a column
+      if (hi == 0 && n < dout) part_db[(long)blockIdx.x * dout + n] = b;
+    }
+  }
+}
+
 bool wgradn_ok(const float* x, int din, long x_ld, int dout) {
   return dout <= 64 && din >= 128 && din <= 256 && din % 4 == 0 && x_ld % 4 == 0 && aligned16(x);
 }
@@ -186,6 +308,19 @@ bool wgradn_ok(const float* x, int din, long x_ld, int dout) {
 // nblocks partials ([nblocks][din*dout], [nblocks][dout]); nblocks <= kNumCU
 int launch_wgradn(const float* x, long x_ld, const float* dy, long dy_ld, long m, int din, int dout, float* part_dw,
                   float* part_db, int nblocks, hipStream_t s) {
+#ifdef KGCN_DEV_KNOBS
+  static const char* route = dev_knob("KGCN_WGRADN");            // development: "lds" = the kernel with the LDS transposition
+  const bool lds_route = route && route[0] == 'l';
+#else
+  const bool lds_route = false;
+#endif
+  if (!lds_route) {
+    const long nsteps = (m + 15) / 16, spb = (nsteps + nblocks - 1) / nblocks;
+    hipLaunchKernelGGL(wgradnb_kernel, dim3((unsigned)nblocks), dim3(512), 0, s, x, x_ld, dy, dy_ld, m, din, dout, spb, part_dw,
+                       part_db);
+    return check_launch("wgradnb_kernel");
+  }
+#ifdef KGCN_DEV_KNOBS
   const size_t frag_b = WN_WAVES * (size_t)WN_LDS_WAVE, red_b = (size_t)(4 * 8192 + 256) * 4;
   const size_t lds = frag_b > red_b ? frag_b : red_b;
   static thread_local bool attr_set = false;
@@ -197,6 +332,9 @@ int launch_wgradn(const float* x, long x_ld, const float* dy, long dy_ld, long m
   hipLaunchKernelGGL(wgradn_kernel, dim3((unsigned)nblocks), dim3(64 * WN_WAVES), lds, s, x, x_ld, dy, dy_ld, m, din, dout,
                      part_dw, part_db);
   return check_launch("wgradn_kernel");
+#else
+  return fail("wgradn: no route");
+#endif
 }
 
 }  // namespace kgcn
