@@ -138,6 +138,35 @@ for case in range(CASES):
         check("dense_gather pooled", pg, yrg.reshape(Tg, Ng, dog).sum(1), ctx=ctx)
         check("dense_gather dx", txg.grad, dpg @ wg.astype(np.float64).T, ctx=ctx)
         check("dense_gather dw", twg.grad, x64g.T @ dpg, ctx=ctx); check("dense_gather db", tbg.grad, dpg.sum(0), ctx=ctx)
+    # ---- register-split weight gradients (wgradx.hip / wgradn.hip: m >= 4096, narrow input or narrow output), ragged last step --
+    if case % 4 == 1:
+        if rng.integers(0, 2):
+            dir_, dor_ = int(rng.integers(65, 97)), int(rng.integers(129, 257))
+        else:
+            dir_, dor_ = 4 * int(rng.integers(32, 65)), int(rng.integers(1, 65))
+        Mr = int(rng.integers(4096, 60000))
+        actr = [None, "sigmoid", "relu", "tanh"][int(rng.integers(0, 4))]
+        need_x = bool(rng.integers(0, 2))
+        xr_ = rng.standard_normal((Mr, dir_)).astype(np.float32)
+        wr_ = (rng.standard_normal((dir_, dor_)) / np.sqrt(dir_)).astype(np.float32)
+        br_ = rng.standard_normal(dor_).astype(np.float32)
+        gr_ = rng.standard_normal((Mr, dor_)).astype(np.float32)
+        txr = t32(xr_).requires_grad_(need_x)
+        twr, tbr = t32(wr_).requires_grad_(True), t32(br_).requires_grad_(True)
+        yr_ = ops.dense(txr, twr, tbr, activation=actr)
+        yr_.backward(t32(gr_))
+        pre64 = xr_.astype(np.float64) @ wr_.astype(np.float64) + br_
+        f_ = {None: lambda z: z, "sigmoid": lambda z: 1 / (1 + np.exp(-z)), "relu": lambda z: np.maximum(z, 0), "tanh": np.tanh}[actr]
+        y64 = f_(pre64)
+        yg_ = yr_.detach().cpu().numpy()
+        d64 = {None: np.ones_like(y64), "sigmoid": y64 * (1 - y64), "relu": (yg_ > 0) * 1.0, "tanh": 1 - y64 ** 2}[actr]
+        dp64 = gr_.astype(np.float64) * d64
+        ctx = ("wgrad narrow", Mr, dir_, dor_, actr, need_x)
+        check("narrow dense fwd", yr_, y64, ctx=ctx)
+        check("narrow dense dw", twr.grad, xr_.astype(np.float64).T @ dp64, ctx=ctx)
+        check("narrow dense db", tbr.grad, dp64.sum(0), ctx=ctx)
+        if need_x:
+            check("narrow dense dx", txr.grad, dp64 @ wr_.astype(np.float64).T, ctx=ctx)
     # ---- device-side batch assembly ----------------------------------------------------------------------------------
     sel = rng.integers(-1, T, size=int(rng.integers(0, 3 * T + 2)))
     got = csr.gather(sel)
