@@ -205,10 +205,24 @@ __global__ __launch_bounds__(256) void ragged_gather_fwd_kernel(const float* __r
     const long b = i / dv;
     const int c = (int)(i - b * dv) * VEC;
     const int r0 = graph_ptr[b], r1 = graph_ptr[b + 1];
+    // the rows in the reference's order (one running sum per column: the fp32 result does not depend on this kernel's shape),
+    // four loads in flight per thread -- a thread walks up to N rows, and one dependent load at a time is all latency
     float acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-    for (int r = r0; r < r1; ++r) {
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+      float v[4][VEC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[u][j] = x[(long)(r + u) * d + c + j];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += v[u][j];
+    }
+    for (; r < r1; ++r) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) acc[j] += x[(long)r * d + c + j];
     }
