@@ -641,7 +641,9 @@ class _GinAggregate(torch.autograd.Function):
                                                  ptr(e) if ctx.has_eps else None, ptr(x), ptr(dx), ptr(one), ptr(wsp), wsb,
                                                  current_stream()), "kgcn_gin_aggregate_bwd_f32")
             if want_eps:
-                deps = one.expand(adj.num_channels).reshape(ctx.eps_shape).clone()
+                # one channel (the common case): the kernel's output IS the gradient tensor -- no device-to-device copy per layer
+                deps = one.reshape(ctx.eps_shape) if adj.num_channels == 1 else \
+                    one.expand(adj.num_channels).reshape(ctx.eps_shape).clone()
         return dx, deps, None
 
 
