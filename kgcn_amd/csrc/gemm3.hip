@@ -382,7 +382,12 @@ __global__ __launch_bounds__(256 * MW, 2) void gemm3_fwd_kernel(
           co.xrow = xrow_l;
           co.rowok = rowok_l;
           co.brow = brow_l;
+          // pinned: hipcc sinks these requests to the END of the chunk (shorter live ranges), i.e. right in front of the step that
+          // splits them -- two thirds of a chunk of lead time gone (the ISA showed the loads behind the last MFMAs and vmcnt(0)
+          // waits at the head of the next chunk)
+          __builtin_amdgcn_sched_barrier(0);
           g3_issue<XVEC, WTAB, DK>(RL, co, w, din, kl * G3_BK, da.ydiff);
+          __builtin_amdgcn_sched_barrier(0);
         } else if constexpr (slot == 18) {
           // one more chunk of x on its way from HBM: a single k chunk per workgroup in flight (16 KB) caps the
           // read rate at ~2 TB/s (latency x bytes in flight); this 4-byte load per 32-byte piece pulls the line
@@ -692,7 +697,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_wgrad_kernel(
           else if constexpr (slot == 12) write_tables(xq, wq, 0);
           else if constexpr (slot == 13) write_tables(xq, wq, 1);
           else if constexpr (slot == 14) write_tables(xq, wq, 2);
-          else if constexpr (slot == 16) issue(RL, c2);
+          else if constexpr (slot == 16) issue(RL, c2);      // (pinning these like the forward's: 1-2 % slower, measured)
         });
       });
       if (!have1) colsum = keep;                           // the re-split of the last chunk must not count twice
