@@ -443,14 +443,17 @@ int kgcn_ragged_gather_bwd_f32(const float* dout_grad, const int32_t* graph_ptr,
 
 /* -- loss definitions and optimiser update of the model files ---------------------------------------------- */
 /* example_model/model_multitask.py:66-79:  cost[b] = mask[b] * sum_t mask_label[b,t] * ce(logits[b,t], labels[b,t]) with
- * tf.nn.sigmoid_cross_entropy_with_logits (weighted == 0) or tf.nn.weighted_cross_entropy_with_logits(pos_weight);
+ * tf.nn.sigmoid_cross_entropy_with_logits (weighted == 0) or tf.nn.weighted_cross_entropy_with_logits(pos_weight):
+ * pos_weight_per_task [tasks] (device; the reference's info.pos_weight is one weight per label column,
+ * kgcn/data_util.py:563-568) or, when it is NULL, the scalar pos_weight for every task;
  * sums[0] = reduce_sum(cost) (cost_sum), sums[1] = reduce_mean(cost) over the PADDED batch (cost_opt, quirk Q5);
  * dlogits [batch, tasks] = d sums[0] / d logits.  mask_label may be NULL (all ones), cost [batch] may be NULL.
  * workspace >= kgcn_loss_workspace_bytes(batch); deterministic (block partials added in a fixed order). */
 int64_t kgcn_loss_workspace_bytes(int64_t batch);
 int kgcn_masked_sigmoid_ce_f32(const float* logits, const float* labels, const float* mask, const float* mask_label,
-                               int64_t batch, int32_t tasks, int32_t weighted, float pos_weight, float* cost, float* dlogits,
-                               float* sums, void* workspace, int64_t workspace_bytes, void* stream);
+                               int64_t batch, int32_t tasks, int32_t weighted, float pos_weight,
+                               const float* pos_weight_per_task, float* cost, float* dlogits, float* sums, void* workspace,
+                               int64_t workspace_bytes, void* stream);
 /* example_model/model.py:56-61:  cost[b] = mask[b] * softmax_cross_entropy(labels[b], logits[b]); same outputs. */
 int kgcn_masked_softmax_ce_f32(const float* logits, const float* labels, const float* mask, int64_t batch, int32_t classes,
                                float* cost, float* dlogits, float* sums, void* workspace, int64_t workspace_bytes,

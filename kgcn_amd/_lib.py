@@ -194,7 +194,7 @@ SIGNATURES = {
                                                   ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_loss_workspace_bytes": (c_i64, [c_i64]),
     "kgcn_masked_sigmoid_ce_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i32, c_i32, ctypes.c_float, c_f32p,
-                                                  c_f32p, c_f32p, ctypes.c_void_p, c_i64, ctypes.c_void_p]),
+                                                  c_f32p, c_f32p, c_f32p, ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_masked_softmax_ce_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_i32, c_f32p, c_f32p, c_f32p,
                                                   ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_sparse_softmax_ce_f32": (ctypes.c_int, [c_f32p, ctypes.c_void_p, c_f32p, c_i64, c_i32, c_f32p, c_f32p, c_f32p,

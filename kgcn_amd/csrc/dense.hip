@@ -44,6 +44,9 @@ void launch_wtable_split(const float* w, long w_ld, int trans_w, int din, int do
 int launch_gemm3_wgrad(const float* x, long x_ld, const float* dy, long dy_ld, long m, int din, int dout,
                        float* part_dw, float* part_db, int nblocks, hipStream_t s, const float* yact = nullptr,
                        int act = KGCN_ACT_NONE);
+bool gemmh_wgrad_ok(int din, int dout, long m);
+int launch_gemmh_wgrad(const float* x, long x_ld, const float* dy, long dy_ld, long m, int din, int dout, float* part_dw,
+                       float* part_db, int nblocks, hipStream_t s, const float* yact, int act);
 
 constexpr int BM = 128;      // rows per workgroup (32 per wave)
 constexpr int BN = 64;       // output columns per workgroup
@@ -794,6 +797,12 @@ static int dense_wgrad_impl(const float* x, int64_t x_ld, const float* dy, int64
     if (nb > chunks) nb = chunks;
     float* part_dw = static_cast<float*>(workspace);
     float* part_db = part_dw + nb * din * dout;
+    static const char* hknob = dev_knob("KGCN_GEMMH");         // development: "0" = the bf16 x 3 kernels only
+    if (!(hknob && hknob[0] == '0') && gemmh_wgrad_ok(din, dout, (long)m)) {
+      if (int rc = launch_gemmh_wgrad(x, (long)x_ld, dy, (long)dy_ld, (long)m, din, dout, part_dw, part_db, (int)nb, s, yact, act))
+        return rc;
+      return launch_reduce_pair(part_dw, (long)din * dout, dw, part_db, dout, dbias, (int)nb, s);
+    }
     if (int rc = launch_gemm3_wgrad(x, (long)x_ld, dy, (long)dy_ld, (long)m, din, dout, part_dw, part_db, (int)nb, s, yact,
                                     act))
       return rc;

@@ -29,6 +29,14 @@
 
 namespace kgcn {
 
+// the f16 two-piece kernels (gemmh.hip) take the shapes they were built for; their W' lives behind the bf16 section of the table
+bool gemmh_fwd_ok(const float* x, long m, int din, long x_ld, int dout);
+int launch_gemmh_fwd(const float* x, long m, int din, long x_ld, const void* tabh, const float* bias, float* y, int dout,
+                     long y_ld, int act, hipStream_t s);
+int launch_gemmh_dx_dact(const float* grad, const float* act_out, float* dpre, long m, int k, long ld, const void* tabh,
+                         float* dx, int n, long dx_ld, int dact, hipStream_t s, const float* pooled_grad, int n_nodes);
+int64_t wtable_bf16_bytes(int din, int dout);
+
 #ifdef KGCN_PROBE   // development: per-workgroup cycle sums per phase (tools/gemm3_probe.py)
 __device__ long long* g3_probe = nullptr;
 #define G3P_DECL long long pt_[4] = {0, 0, 0, 0}; long long pc_ = __builtin_readcyclecounter();
@@ -508,6 +516,10 @@ int launch_gemm3_fwd(const float* x, long m, int din, long x_ld, const float* w,
   }
   const long ntiles = (m + G3_BM - 1) / G3_BM;
   const bool xvec = (din % 4 == 0) && (x_ld % 4 == 0) && aligned16(x);
+  static const char* hknob = dev_knob("KGCN_GEMMH");           // development: "0" = the bf16 x 3 kernels only
+  if (table && !(hknob && hknob[0] == '0') && gemmh_fwd_ok(x, m, din, x_ld, dout))
+    return launch_gemmh_fwd(x, m, din, x_ld, static_cast<const char*>(table) + wtable_bf16_bytes(din, dout), bias, y, dout, y_ld,
+                            act, s);
   if (table) {
     const size_t lds = 2 * (size_t)G3_XP * 16;
     const float* tw = static_cast<const float*>(table);
@@ -552,6 +564,12 @@ int launch_gemm3_dx_dact(const float* grad, const float* act_out, float* dpre, l
                   dact != KGCN_ACT_NONE && dpre != grad && (grad || pooled_grad) &&
                   (!pooled_grad || (aligned16(pooled_grad) && n_nodes > 0));
   if (!ok) return -1;
+  static const char* hknob = dev_knob("KGCN_GEMMH");
+  if (!(hknob && hknob[0] == '0')) {
+    const int rc = launch_gemmh_dx_dact(grad, act_out, dpre, m, k, ld, static_cast<const char*>(table) + wtable_bf16_bytes(k, n), dx,
+                                        n, dx_ld, dact, s, pooled_grad, n_nodes);
+    if (rc >= 0) return rc;
+  }
   G3Dact da;
   const float* base = grad ? grad : act_out;             // the staging threads address everything relative to their x row
   da.ydiff = act_out - base;

@@ -36,7 +36,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 // dlogits[b,t] = d(sum_b cost[b]) / d logits[b,t]
 __global__ __launch_bounds__(kLossBlock) void sigmoid_ce_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
                                                                const float* __restrict__ mask, const float* __restrict__ mask_label,
-                                                               long B, int T, int weighted, float q, float* __restrict__ cost,
+                                                               long B, int T, int weighted, float q,
+                                                               const float* __restrict__ qvec, float* __restrict__ cost,
                                                                float* __restrict__ dlogits, float* __restrict__ part,
                                                                float* __restrict__ sums_direct) {
   __shared__ float red[kLossBlock];
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(kLossBlock) void sigmoid_ce_kernel(const float* __r
         ce = fmaxf(x, 0.f) - x * z + sp;
         dce = sg - z;
       } else {
-        const float lw = 1.f + (q - 1.f) * z;
+        const float lw = 1.f + ((qvec ? qvec[t] : q) - 1.f) * z;   // info.pos_weight is per TASK (kgcn/data_util.py:563-568)
         ce = (1.f - z) * x + lw * (sp + fmaxf(-x, 0.f));
         dce = (1.f - z) - lw * (1.f - sg);
       }
@@ -206,8 +207,8 @@ static int loss_args(const char* who, const void* logits, const void* labels, co
 
 extern "C" int kgcn_masked_sigmoid_ce_f32(const float* logits, const float* labels, const float* mask,
                                           const float* mask_label, int64_t batch, int32_t tasks, int32_t weighted,
-                                          float pos_weight, float* cost, float* dlogits, float* sums, void* workspace,
-                                          int64_t workspace_bytes, void* stream) {
+                                          float pos_weight, const float* pos_weight_per_task, float* cost, float* dlogits,
+                                          float* sums, void* workspace, int64_t workspace_bytes, void* stream) {
   if (int rc = loss_args("kgcn_masked_sigmoid_ce_f32", logits, labels, mask, batch, tasks, dlogits, sums, workspace,
                          workspace_bytes))
     return rc;
@@ -215,7 +216,8 @@ extern "C" int kgcn_masked_sigmoid_ce_f32(const float* logits, const float* labe
   float* part = static_cast<float*>(workspace);
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(sigmoid_ce_kernel, dim3(nb), dim3(kLossBlock), 0, s, logits, labels, mask, mask_label, (long)batch, tasks,
-                     weighted ? 1 : 0, pos_weight, cost, dlogits, part, nb == 1 ? sums : nullptr);
+                     weighted ? 1 : 0, pos_weight, weighted ? pos_weight_per_task : nullptr, cost, dlogits, part,
+                     nb == 1 ? sums : nullptr);
   if (int rc = check_launch("sigmoid_ce_kernel")) return rc;
   if (nb == 1) return 0;
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kLossBlock), 0, s, part, nb, (long)batch, sums);

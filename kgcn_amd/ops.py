@@ -1042,9 +1042,23 @@ class _MaskedCE(torch.autograd.Function):
         wsb = lib.kgcn_loss_workspace_bytes(B)
         ws = torch.empty((max(wsb, 4) // 4,), device=x.device, dtype=torch.float32)
         if kind == "sigmoid":
+            # info.pos_weight of the reference is one weight per label column (kgcn/data_util.py:563-568, consumed by
+            # example_model/model_multitask.py:72-76); a scalar is accepted too and applies to every task
+            qs, qv = 0.0, None
+            if pos_weight is not None:
+                if torch.is_tensor(pos_weight) or hasattr(pos_weight, "__len__"):
+                    qv = torch.as_tensor(pos_weight, dtype=torch.float32).reshape(-1)
+                    if qv.numel() == 1:
+                        qs, qv = float(qv), None
+                    elif qv.numel() != W:
+                        raise _lib.KgcnHipError("pos_weight has %d entries for %d tasks" % (qv.numel(), W))
+                    else:
+                        qv = qv.to(x.device).contiguous()
+                else:
+                    qs = float(pos_weight)
             check(lib.kgcn_masked_sigmoid_ce_f32(ptr(x), ptr(z), ptr(mk), ptr(ml), B, W, 0 if pos_weight is None else 1,
-                                                 0.0 if pos_weight is None else float(pos_weight), None, ptr(dlog), ptr(sums),
-                                                 ptr(ws), wsb, current_stream()), "kgcn_masked_sigmoid_ce_f32")
+                                                 qs, ptr(qv), None, ptr(dlog), ptr(sums), ptr(ws), wsb, current_stream()),
+                  "kgcn_masked_sigmoid_ce_f32")
         else:
             check(lib.kgcn_masked_softmax_ce_f32(ptr(x), ptr(z), ptr(mk), B, W, None, ptr(dlog), ptr(sums), ptr(ws), wsb,
                                                  current_stream()), "kgcn_masked_softmax_ce_f32")

@@ -113,7 +113,7 @@ def _grad_of(t, ref, what, rel=2e-5):
 
 
 @pytest.mark.parametrize("ragged", [False, True])
-@pytest.mark.parametrize("pos_weight", [None, 2.5])
+@pytest.mark.parametrize("pos_weight", [None, 2.5, "per_task"])
 def test_model_multitask_tox21_shaped(pos_weight, ragged):
     """12 tasks, N = 50 padded with variable true sizes, F = 81, widths 256/256/256/50/50, masked labels,
     a dummy graph in the batch; logits, loss and every gradient vs the fp64 oracle (the PADDED formulation of the
@@ -123,6 +123,9 @@ def test_model_multitask_tox21_shaped(pos_weight, ragged):
     from test_oracle_model import tox21_like_batch
     rng = np.random.default_rng(44)
     x, adjs, labels, mask, mask_label, sizes = tox21_like_batch(rng, B=24, N=50, F=81, T=12)
+    if isinstance(pos_weight, str):          # the reference's info.pos_weight: one weight per label column (kgcn/data_util.py:563-568)
+        pos_weight = (np.nansum(mask_label, 0) - np.nansum(labels * mask_label, 0) + 0.01) / (np.nansum(labels * mask_label, 0) + 0.01)
+        assert pos_weight.shape == (12,) and len(set(np.round(pos_weight, 3))) > 3
     p = NETS.multitask_init(rng, 81, 12)
     for k in ("b1", "b2", "b4"):
         p[k] = [rng.standard_normal(p[k][0].shape) * 0.1]

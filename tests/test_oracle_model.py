@@ -81,7 +81,7 @@ def tox21_like_batch(rng, B=6, N=12, F=7, T=3):
     return x, K.normalize_adj(adjs), labels, mask, mask_label, sizes
 
 
-@pytest.mark.parametrize("pos_weight", [None, 3.0])
+@pytest.mark.parametrize("pos_weight", [None, 3.0, "per_task"])
 def test_multitask_backward_finite_difference(pos_weight):
     rng = np.random.default_rng(11)
     x, adjs, labels, mask, mask_label, sizes = tox21_like_batch(rng)
@@ -89,6 +89,8 @@ def test_multitask_backward_finite_difference(pos_weight):
     for k in ("b1", "b2", "b4"):
         p[k] = [rng.standard_normal(p[k][0].shape) * 0.1]
     p["beta"] = rng.standard_normal(p["beta"].shape) * 0.1
+    if isinstance(pos_weight, str):          # info.pos_weight of the reference: one weight per label column (kgcn/data_util.py:563-568)
+        pos_weight = rng.uniform(0.5, 4.0, size=labels.shape[1])
     args = (x, adjs, labels, mask, mask_label, sizes, pos_weight)
     c = NETS.multitask_forward(p, *args)
     g = NETS.multitask_backward(p, c, x, adjs, labels, mask, mask_label, pos_weight)
