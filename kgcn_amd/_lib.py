@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # -DKGCN_DEV_KNOBS (make DEV_KNOBS=1) -- the shipped build ignores them.  Anything set here is reported by
 # active_overrides() (bench.py prints it in its JSON line) and warned about once at import, because a stray variable
 # changes summation order / which binary produced the numbers.
-DEV_ENV_VARS = ("KGCN_HIP_LIB", "KGCN_DENSE_ROUTE", "KGCN_GEMM3_MW", "KGCN_GEMM3_CUT", "KGCN_WGRADX", "KGCN_WGRADN")
+DEV_ENV_VARS = ("KGCN_HIP_LIB", "KGCN_DENSE_ROUTE", "KGCN_GEMM3_MW", "KGCN_GEMM3_CUT", "KGCN_WGRADX", "KGCN_WGRADN", "KGCN_GEMMH")
 LIB_PATH = os.environ.get("KGCN_HIP_LIB") or os.path.join(_HERE, "csrc", "libkgcn_hip.so")
 
 

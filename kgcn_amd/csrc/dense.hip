@@ -797,8 +797,8 @@ static int dense_wgrad_impl(const float* x, int64_t x_ld, const float* dy, int64
     if (nb > chunks) nb = chunks;
     float* part_dw = static_cast<float*>(workspace);
     float* part_db = part_dw + nb * din * dout;
-    static const char* hknob = dev_knob("KGCN_GEMMH");         // development: "0" = the bf16 x 3 kernels only
-    if (!(hknob && hknob[0] == '0') && gemmh_wgrad_ok(din, dout, (long)m)) {
+    static const char* hknob = dev_knob("KGCN_GEMMH");         // development: see gemm3.hip ("w" = the f16 weight gradient)
+    if (!(hknob && !strchr(hknob, 'w')) && gemmh_wgrad_ok(din, dout, (long)m)) {
       if (int rc = launch_gemmh_wgrad(x, (long)x_ld, dy, (long)dy_ld, (long)m, din, dout, part_dw, part_db, (int)nb, s, yact, act))
         return rc;
       return launch_reduce_pair(part_dw, (long)din * dout, dw, part_db, dout, dbias, (int)nb, s);

@@ -24,6 +24,7 @@
 // 0.54 ms -- the workgroup-wide lockstep (barrier per chunk, y stores of all waves at once) keeps the
 // two from overlapping fully; that is where the remaining time is.
 #include <cstdlib>
+#include <cstring>
 
 #include "kgcn_common.h"
 
@@ -516,8 +517,8 @@ int launch_gemm3_fwd(const float* x, long m, int din, long x_ld, const float* w,
   }
   const long ntiles = (m + G3_BM - 1) / G3_BM;
   const bool xvec = (din % 4 == 0) && (x_ld % 4 == 0) && aligned16(x);
-  static const char* hknob = dev_knob("KGCN_GEMMH");           // development: "0" = the bf16 x 3 kernels only
-  if (table && !(hknob && hknob[0] == '0') && gemmh_fwd_ok(x, m, din, x_ld, dout))
+  static const char* hknob = dev_knob("KGCN_GEMMH");           // development: the f16 kernels to use, e.g. "fw" (f forward / dX, d dX with act', w weight gradient); "0" = none
+  if (table && !(hknob && !strchr(hknob, 'f')) && gemmh_fwd_ok(x, m, din, x_ld, dout))
     return launch_gemmh_fwd(x, m, din, x_ld, static_cast<const char*>(table) + wtable_bf16_bytes(din, dout), bias, y, dout, y_ld,
                             act, s);
   if (table) {
@@ -565,7 +566,7 @@ int launch_gemm3_dx_dact(const float* grad, const float* act_out, float* dpre, l
                   (!pooled_grad || (aligned16(pooled_grad) && n_nodes > 0));
   if (!ok) return -1;
   static const char* hknob = dev_knob("KGCN_GEMMH");
-  if (!(hknob && hknob[0] == '0')) {
+  if (!(hknob && !strchr(hknob, 'd'))) {
     const int rc = launch_gemmh_dx_dact(grad, act_out, dpre, m, k, ld, static_cast<const char*>(table) + wtable_bf16_bytes(k, n), dx,
                                         n, dx_ld, dact, s, pooled_grad, n_nodes);
     if (rc >= 0) return rc;

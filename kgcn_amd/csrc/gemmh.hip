@@ -316,7 +316,9 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
 
 // x: 16-byte aligned rows of <= 256 columns (din % 4 == 0, x_ld % 4 == 0); the table holds the f16 section for (din, dout)
 bool gemmh_fwd_ok(const float* x, long m, int din, long x_ld, int dout) {
-  return din % 4 == 0 && din <= GH_KMAX && din >= 32 && x_ld % 4 == 0 && aligned16(x) && dout > 128 && m >= 4 * GH_BM;
+  // one 64-row tile per workgroup and fewer workgroups than CUs is the regime of gemm3's 64 x 64 column cut (sparse.py's 4,457
+  // rows: 0.320 ms per step with it, 0.332 ms through this kernel)
+  return din % 4 == 0 && din <= GH_KMAX && din >= 32 && x_ld % 4 == 0 && aligned16(x) && dout > 128 && m >= (long)kNumCU * GH_BM;
 }
 
 template <int DK>
@@ -420,7 +422,8 @@ __global__ __launch_bounds__(512, 2) void gemmh_wgrad_kernel(const float* __rest
     const float* ys = DACT ? yact + s * 16 * dy_ld : nullptr;
     // uniform row pointers + ONE per-lane byte offset per operand block.  (hipcc still spends a 64-bit vector add per load on
     // them -- loop strength reduction makes per-lane pointer inductions out of `uniform base + lane offset`; buffer loads with a
-    // scalar row offset have no vector address arithmetic at all but cost 75 spilled registers in this kernel: measured, not kept)
+    // scalar row offset, as the forward kernel uses them, have no vector address arithmetic at all but cost 75 spilled
+    // registers in THIS kernel in both forms tried -- descriptor per step, descriptor per launch: measured, not kept)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float* xr = xs + j * x_ld;
@@ -475,8 +478,11 @@ __global__ __launch_bounds__(512, 2) void gemmh_wgrad_kernel(const float* __rest
     float mx = fmaxf(stepmax, __shfl_xor(stepmax, 32, 64));      // both lane halves hold rows of the same column
     mx = fmaxf(c.run, mx);
     c.run = mx;
-    int kn = c.k;
-    if (mx > c.lim) kn = 13 - __builtin_amdgcn_frexp_expf(mx);   // the maximum lands in [2^12, 2^13): two bits of headroom
+    // A column that has only seen zeros keeps (k, lim) = (0, 0): its limit must NOT be recomputed from k = 0 when another
+    // column of the wave brings it here -- 2^15 would then wave through its first real values unscaled (f16 denormals: the
+    // cfg4 batch, whose padded gradient rows are zero, lost four digits of dW this way).
+    if (!(mx > c.lim)) return 0;
+    const int kn = 13 - __builtin_amdgcn_frexp_expf(mx);         // the maximum lands in [2^12, 2^13): two bits of headroom
     const int d = kn - c.k;
     c.k = kn;
     c.lim = __builtin_ldexpf(1.0f, 15 - kn);

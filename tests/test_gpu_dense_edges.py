@@ -19,7 +19,10 @@ from test_gpu_parity import _row_close, close, dev, t32
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(4100, 256, 256), (300, 256, 256), (4101, 81, 256), (4100, 256, 50), (1500, 300, 256), (4100, 512, 96)]
+# (16,500 / 16,450 rows: the f16 two-piece kernels of gemmh.hip take the wide layers from 16,384 rows -- 256 tiles of 64 -- on;
+#  below that the bf16 x 3 kernels of gemm3.hip run, with the weight table from 1,024 rows)
+SHAPES = [(4100, 256, 256), (300, 256, 256), (4101, 81, 256), (4100, 256, 50), (1500, 300, 256), (4100, 512, 96),
+          (16500, 256, 256), (16450, 84, 256), (16390, 128, 192)]
 ACTS = {None: 0, "sigmoid": 1, "relu": 2, "tanh": 3}
 
 
@@ -90,7 +93,8 @@ def test_bf16_split_dense_kernels_edge_values(case, M, din, dout):
 
 
 @pytest.mark.parametrize("act", ["sigmoid", "relu", "tanh"])
-@pytest.mark.parametrize("M,din,dout", [(4100, 256, 256), (4101, 300, 256), (333, 256, 256), (4100, 256, 50), (2050, 81, 256)])
+@pytest.mark.parametrize("M,din,dout", [(4100, 256, 256), (4101, 300, 256), (333, 256, 256), (4100, 256, 50), (2050, 81, 256),
+                                        (16500, 256, 256), (16401, 256, 192)])
 def test_dense_dx_dact_all_routes(act, M, din, dout):
     """act(x W + b) with the activation in the GEMM epilogue and its derivative riding in the dX GEMM (kgcn_dense_dx_dact_f32);
     din = 300 > 256: two column blocks stage the same gradient rows, only blockIdx.y == 0 stores d pre-activation
@@ -120,7 +124,7 @@ def test_dense_dx_dact_all_routes(act, M, din, dout):
 
 
 @pytest.mark.parametrize("act", ["sigmoid", "relu", "tanh"])
-@pytest.mark.parametrize("M,din,dout", [(4100, 256, 256), (4101, 84, 256), (333, 100, 300), (2050, 300, 256)])
+@pytest.mark.parametrize("M,din,dout", [(4100, 256, 256), (4101, 84, 256), (333, 100, 300), (2050, 300, 256), (16500, 256, 256)])
 def test_dense_wgrad_with_fused_activation_derivative(act, M, din, dout):
     """act(x W + b) whose INPUT needs no gradient (the first layer of a model): d pre-activation is formed inside the wide
     weight-gradient GEMM's staging (kgcn_dense_wgrad_dact_f32) -- dW / dbias vs fp64 and vs the unfused route (activation backward
@@ -150,7 +154,8 @@ def test_dense_wgrad_with_fused_activation_derivative(act, M, din, dout):
     close(res[True][2], res[False][2], atol=0, rel=3e-6, what="fused vs unfused dbias")
 
 
-@pytest.mark.parametrize("M,din,dout", [(4100, 256, 256), (300, 256, 256), (4100, 81, 256), (4100, 256, 50)])
+@pytest.mark.parametrize("M,din,dout", [(4100, 256, 256), (300, 256, 256), (4100, 81, 256), (4100, 256, 50), (16500, 256, 256),
+                                        (16450, 84, 256)])
 def test_bf16_split_dense_kernels_non_finite(M, din, dout):
     """+-inf splits into (inf, NaN, NaN), NaN into three NaNs: every output element that depends on a non-finite input is
     non-finite, every other element is untouched (include/kgcn_hip.h)."""

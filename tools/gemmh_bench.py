@@ -124,6 +124,18 @@ for M in [int(r) for r in args.rows.split(",")]:
         xs = x.clone()
         xs[:, 3] *= 1e-9
         xs[M // 2:] *= 64.0
+        dz = dy.clone()
+        dz *= (torch.rand((M, 1), device=dev, generator=g) < 0.5)          # whole zero rows (padding rows of a padded batch)
+        dz[:37] = 0                                                        # ... and at the head of the first row range
+        dz *= torch.exp(3.0 * torch.randn((M, 1), device=dev, generator=g))       # heavy-tailed row magnitudes
+        f3 = lambda: check(lib.kgcn_dense_wgrad_f32(ptr(x), din, ptr(dz), dout, M, din, dout, ptr(dw), ptr(db), ptr(wgs), wgb,
+                                                    current_stream()))
+        f3(); torch.cuda.synchronize()
+        if not args.quick:
+            refw = torch.zeros((din, dout), dtype=torch.float64, device=dev)
+            for s in range(0, M, 32768):
+                refw += x[s:s + 32768].double().t() @ dz[s:s + 32768].double()
+            r["wgrad_zero_rows_err"] = relerr(dw, refw)
         f2 = lambda: check(lib.kgcn_dense_wgrad_f32(ptr(xs), din, ptr(dy), dout, M, din, dout, ptr(dw), ptr(db), ptr(wgs), wgb,
                                                     current_stream()))
         f2(); torch.cuda.synchronize()
