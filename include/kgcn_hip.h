@@ -531,6 +531,13 @@ int kgcn_gcn_stack_bwd_f32(const kgcn_csr_batch* at, const float* x, const int32
                            int32_t num_layers, float* const* layer_out, const float* dlast, int32_t gather, float* dx,
                            float* dparams, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Measurement aid (bench.py / tools/abi_roofline.py price a dense call against the pipe it really runs on): the number of
+ * matrix-pipe products per fp32 product of the kernel the library routes this call to, operands assumed 16-byte aligned with
+ * the W table present -- 3: f16 two-piece kernels (gemmh.hip, 2.5 PF / 3), 6: bf16 three-piece kernels (gemm3 / gemmn /
+ * wgradn / wgradx, 2.5 PF / 6), 1: v_mfma_f32_32x32x2_f32 kernels (157.3 TF), 0: no matrix pipe (read-out layers).
+ * kind 0: y = act(x W + b) / dx = dy W^T (din = contraction width), 1: dx with the activation derivative, 2: weight gradient. */
+int kgcn_dense_mfma_products(int32_t kind, int64_t m, int32_t din, int32_t dout);
+
 /* dW, dbias of act(x W + b) when the layer INPUT needs no gradient (first layer of a model): d pre-activation = dy * act'(act_out)
  * is formed while the weight-gradient GEMM stages the gradient rows, so it never exists in HBM.  Wide layers only
  * (kgcn_dense_wgrad_dact_supported(din, dout) != 0); otherwise run kgcn_act_bwd_f32 + kgcn_dense_wgrad_f32.  dy and act_out

@@ -192,6 +192,7 @@ SIGNATURES = {
     "kgcn_ragged_gather_bwd_workspace_bytes": (c_i64, [c_i32]),
     "kgcn_ragged_gather_bwd_f32": (ctypes.c_int, [c_f32p, c_i32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32p,
                                                   ctypes.c_void_p, c_i64, ctypes.c_void_p]),
+    "kgcn_dense_mfma_products": (ctypes.c_int, [c_i32, c_i64, c_i32, c_i32]),
     "kgcn_loss_workspace_bytes": (c_i64, [c_i64]),
     "kgcn_masked_sigmoid_ce_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i32, c_i32, ctypes.c_float, c_f32p,
                                                   c_f32p, c_f32p, c_f32p, ctypes.c_void_p, c_i64, ctypes.c_void_p]),

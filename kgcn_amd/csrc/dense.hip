@@ -714,6 +714,25 @@ extern "C" int kgcn_dense_fwd_act_f32(const float* x, int64_t m, int32_t din, in
   return dense_fwd_impl(x, m, din, x_ld, w, w_ld, trans_w, bias, y, dout, y_ld, act, nullptr, 0, stream);
 }
 
+namespace kgcn { bool gemmh_fwd_ok(const float* x, long m, int din, long x_ld, int dout); }
+
+extern "C" int kgcn_dense_mfma_products(int32_t kind, int64_t m, int32_t din, int32_t dout) {
+  if (m <= 0 || din <= 0 || dout <= 0) return 0;
+  const float* aligned = reinterpret_cast<const float*>(uintptr_t(256));      // stands for a 16-byte aligned operand
+  const long ld = (din + 3) & ~3;
+  if (kind == 0 || kind == 1) {
+    if (kind == 0 && (skinny_n_ok(din, dout, 0) || skinny_k_ok(din, dout))) return 0;
+    if (wide_layer(din, dout)) return (m >= 1024 && din % 4 == 0 && gemmh_fwd_ok(aligned, (long)m, din, ld, dout)) ? 3 : 6;
+    if (gemmn_pays(aligned, din, ld, dout) && m >= 1024) return 6;
+    return 1;
+  }
+  if (skinny_n_ok(din, dout, 0)) return 0;
+  if (wgradx_ok(din, dout, ld, dout) && m >= 4096) return 6;
+  if (din > 64 && dout > 128) return gemmh_wgrad_ok(din, dout, (long)m) ? 3 : 6;
+  if (wgradn_ok(aligned, din, ld, dout) && m >= 4096) return 6;
+  return 1;
+}
+
 extern "C" int64_t kgcn_dense_wgrad_workspace_bytes(int64_t m, int32_t din, int32_t dout) {
   if (m <= 0 || din <= 0 || dout <= 0) return 0;
   long rpc;

@@ -611,13 +611,326 @@ __global__ __launch_bounds__(512, 2) void gemmh_wgrad_kernel(const float* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same weight gradient with every value split ONCE (gemmh_wgradl_kernel, the shipped route without a fused activation
+// derivative).  In the register kernel above each x fragment is split by the four waves that multiply with it and each dy
+// fragment by two: ~200 vector instructions per wave and 16 rows, 2.4 * 10^7 per launch at 117,888 rows -- VALU-bound at 88-94 us
+// (profiles/r04_gemmh_history.txt).  Here a STAGE of 32 rows is split once and shared through LDS:
+//   * wave w loads dy tile w (32 columns; waves 4-7 also x tile w - 4) of the stage as coalesced dword fragments, keeps the
+//     online column scales of ITS tiles, splits, and writes the (high, low) fragments lane-linearly to the stage buffer
+//     [12 tiles][2 k-steps][2 pieces][1 KiB] (48 KB, two buffers) next to the tiles' current exponents;
+//   * every wave then multiplies its [64 x 64] block out of the other buffer: 8 fragment reads and 12 MFMAs per k-step; a wave
+//     that finds an exponent of one of its tiles changed rescales its accumulators first (exact, rare);
+//   * raw fragments travel two stages ahead of the split (three register sets), one barrier per stage.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int GWL_BUF = 12 * 2 * 2 * 64;             // u32x4 entries of one stage buffer
+constexpr size_t GWL_LDS = 2 * (size_t)GWL_BUF * 16 + 2 * 12 * 32 * 4;
+
+__global__ __launch_bounds__(512, 2) void gemmh_wgradl_kernel(const float* __restrict__ x, long x_ld, const float* __restrict__ dy,
+                                                              long dy_ld, long m, int din, int dout, long stages_per_block,
+                                                              float* __restrict__ part_dw, float* __restrict__ part_db) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  u32x4* lbuf = reinterpret_cast<u32x4*>(dsm);
+  int* kbuf = reinterpret_cast<int*>(dsm + 2 * (size_t)GWL_BUF * 16);           // [2][12][32]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, li = lane & 31, hi = lane >> 5;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int i0 = blockIdx.y * 128, j0 = blockIdx.z * 256;
+  const bool has_x = wave >= 4;                         // uniform: this wave also stages an x tile
+  const long nfull = m / 32;                            // stages without a row mask
+  const long s0 = (long)blockIdx.x * stages_per_block;
+  long s1 = s0 + stages_per_block;
+  if (s1 > nfull) s1 = nfull;
+  const bool tail_here = (m % 32 != 0) && blockIdx.x == gridDim.x - 1;           // the ragged last stage: last row range
+
+  // ---- staging side: columns of this wave's tiles (clamped: what a column beyond the matrix contributes is never stored) ----
+  const int cy = j0 + 32 * wave + li, cx = i0 + 32 * (wave & 3) + li;
+  const unsigned offy = 4u * (unsigned)(8 * hi * dy_ld + (cy < dout ? cy : dout - 1));
+  const unsigned offx = 4u * (unsigned)(8 * hi * x_ld + (cx < din ? cx : din - 1));
+  struct Raw { float y[2][8], a[2][8]; };
+  auto at = [](const float* base, unsigned byte_off) __attribute__((always_inline)) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+  };
+  auto load = [&](long st, Raw& r) __attribute__((always_inline)) {
+    if constexpr (GH_VARIANT == 7) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { r.y[q][j] = 1e-3f * (float)(lane + j + (int)st); r.a[q][j] = 0.5f + (float)j; }
+      return;
+    }
+    // (plain pointers: uniform row pointer + one per-lane byte offset.  Buffer loads with scalar row offsets, as the forward
+    // kernel uses them, cost this kernel 185 spilled registers -- as they did the register-split kernel above)
+    const float* gs = dy + st * 32 * dy_ld;
+    const float* xs = x + st * 32 * x_ld;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.y[q][j] = at(gs + (16 * q + j) * dy_ld, offy);
+    if (has_x) {                                         // ONE uniform branch around the sixteen x requests
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.a[q][j] = at(xs + (16 * q + j) * x_ld, offx);
+    }
+  };
+  auto load_tail = [&](long st, Raw& r) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const long row = st * 32 + 16 * q + 8 * hi + j;
+        const bool ok = row < m;
+        const long rc = ok ? row : m - 1;
+        const float vy = dy[rc * dy_ld + (cy < dout ? cy : dout - 1)];
+        const float vx = x[rc * x_ld + (cx < din ? cx : din - 1)];
+        r.y[q][j] = ok ? vy : 0.f;
+        r.a[q][j] = ok ? vx : 0.f;
+      }
+  };
+  auto max8 = [&](const float (&v)[8]) __attribute__((always_inline)) {
+    float t;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(t) : "v"(v[0]), "v"(v[1]), "v"(v[2]));
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(t) : "v"(t), "v"(v[3]), "v"(v[4]));
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(t) : "v"(t), "v"(v[5]), "v"(v[6]));
+    asm("v_max_f32 %0, %1, |%2|" : "=v"(t) : "v"(t), "v"(v[7]));
+    return t;
+  };
+  auto rescale_col = [&](GhCol& c, float stepmax) __attribute__((always_inline)) {
+    float mx = fmaxf(stepmax, __shfl_xor(stepmax, 32, 64));      // both lane halves hold rows of the same column
+    mx = fmaxf(c.run, mx);
+    c.run = mx;
+    if (!(mx > c.lim)) return;                                   // (a column of zeros keeps (k, lim) = (0, 0): see above)
+    const int kn = 13 - __builtin_amdgcn_frexp_expf(mx);
+    c.k = kn;
+    c.lim = __builtin_ldexpf(1.0f, 15 - kn);
+  };
+  GhCol sy{0, 0.f, 0.f}, sx{0, 0.f, 0.f};
+  float bsum = 0.f;
+  const bool want_bsum = part_db && blockIdx.y == 0;
+  // staging in two parts: the scale check (vector maxima, a rare wave-uniform branch) and the emission of one fragment
+  auto split_check = [&](Raw& r) __attribute__((always_inline)) {
+    const float my = fmaxf(max8(r.y[0]), max8(r.y[1]));
+    float mx = 0.f;
+    if (has_x) mx = fmaxf(max8(r.a[0]), max8(r.a[1]));
+    const bool over = my > sy.lim || (has_x && mx > sx.lim);
+    if (__builtin_amdgcn_ballot_w64(over) != 0) {                 // wave-uniform, rare after the first stage
+      rescale_col(sy, my);
+      if (has_x) rescale_col(sx, mx);
+    }
+  };
+  auto emit = [&](const float (&v)[8], int k, int tile, int q, int buf) __attribute__((always_inline)) {
+    if constexpr (GH_VARIANT == 6) { if (v[0] != 1.2345e-30f) return; }
+    u32x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned hh, ll;
+      splith_pair(__builtin_ldexpf(v[2 * e], k), __builtin_ldexpf(v[2 * e + 1], k), hh, ll);
+      h[e] = hh; l[e] = ll;
+    }
+    u32x4* d = lbuf + (size_t)buf * GWL_BUF + (size_t)((tile * 2 + q) * 2) * 64 + lane;
+    d[0] = h; d[64] = l;
+  };
+  auto emit_y = [&](Raw& r, int q, int buf) __attribute__((always_inline)) {
+    emit(r.y[q], sy.k, 4 + wave, q, buf);
+    if (want_bsum) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bsum += r.y[q][j];
+    }
+    if (q == 1) kbuf[buf * 12 * 32 + (4 + wave) * 32 + li] = sy.k;
+  };
+  auto emit_x = [&](Raw& r, int q, int buf) __attribute__((always_inline)) {
+    if (has_x) {                                                  // uniform
+      emit(r.a[q], sx.k, wave & 3, q, buf);
+      if (q == 1) kbuf[buf * 12 * 32 + (wave & 3) * 32 + li] = sx.k;
+    }
+  };
+  auto split = [&](Raw& r, int buf) __attribute__((always_inline)) {
+    split_check(r);
+    emit_y(r, 0, buf); emit_y(r, 1, buf); emit_x(r, 0, buf); emit_x(r, 1, buf);
+  };
+
+  // ---- multiplying side: the [64 x 64] block of x tiles 2 wr, 2 wr + 1 and dy tiles 2 wc, 2 wc + 1 ----------------------------
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+  int ka[2] = {0, 0}, kb2[2] = {0, 0};                  // exponents the accumulators are scaled with
+  auto mult_check = [&](int buf) __attribute__((always_inline)) {
+    const int* kb = kbuf + buf * 12 * 32;
+    int na[2], nb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { na[t] = kb[(2 * wr + t) * 32 + li]; nb[t] = kb[(4 + 2 * wc + t) * 32 + li]; }
+    const bool changed = na[0] != ka[0] || na[1] != ka[1] || nb[0] != kb2[0] || nb[1] != kb2[1];
+    if (__builtin_amdgcn_ballot_w64(changed) != 0) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int da = na[mt] - ka[mt];
+#pragma unroll
+        for (int r16 = 0; r16 < 16; ++r16) {
+          const int dr = __shfl(da, (r16 & 3) + 8 * (r16 >> 2) + 4 * hi, 64);    // the x column of this accumulator row
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt][r16] = __builtin_ldexpf(acc[mt][nt][r16], dr + (nb[nt] - kb2[nt]));
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { ka[t] = na[t]; kb2[t] = nb[t]; }
+    }
+  };
+  struct Frags { u32x4 ah[2], al[2], bh[2], bl[2]; };
+  auto read_frags = [&](Frags& f, int q, int buf) __attribute__((always_inline)) {
+    const u32x4* b = lbuf + (size_t)buf * GWL_BUF;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const u32x4* ea = b + (size_t)(((2 * wr + t) * 2 + q) * 2) * 64 + lane;
+      const u32x4* eb = b + (size_t)(((4 + 2 * wc + t) * 2 + q) * 2) * 64 + lane;
+      f.ah[t] = ea[0]; f.al[t] = ea[64]; f.bh[t] = eb[0]; f.bl[t] = eb[64];
+    }
+  };
+  // the twelve MFMAs of a k-step in two halves (smallest terms first)
+  auto mma_lo = [&](const Frags& f) __attribute__((always_inline)) {
+    if constexpr (GH_VARIANT == 5) { acc[0][0][0] += __uint_as_float(f.al[0][0] ^ f.bh[0][0] ^ f.ah[1][1] ^ f.bl[1][1]); return; }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_f16(f.al[mt], f.bh[nt], acc[mt][nt]);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[0][nt] = mfma_f16(f.ah[0], f.bl[nt], acc[0][nt]);
+  };
+  auto mma_hi = [&](const Frags& f) __attribute__((always_inline)) {
+    if constexpr (GH_VARIANT == 5) { acc[1][1][0] += __uint_as_float(f.ah[0][2] ^ f.bh[1][3] ^ f.al[1][2] ^ f.bl[0][3]); return; }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[1][nt] = mfma_f16(f.ah[1], f.bl[nt], acc[1][nt]);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_f16(f.ah[mt], f.bh[nt], acc[mt][nt]);
+  };
+  auto multiply = [&](int buf) __attribute__((always_inline)) {
+    mult_check(buf);
+    Frags f;
+    read_frags(f, 0, buf); mma_lo(f); mma_hi(f);
+    read_frags(f, 1, buf); mma_lo(f); mma_hi(f);
+  };
+
+  int buf = 0;
+  if (s0 < s1) {
+    const long sl = s1 - 1;                              // requests past the range repeat its last stage (valid, unused)
+    Raw r0, r1, r2;
+    load(s0, r0);
+    load(s0 + 1 < sl ? s0 + 1 : sl, r1);
+    load(s0 + 2 < sl ? s0 + 2 : sl, r2);
+    split(r0, 0);
+    gh_barrier_lds();
+    // iteration for stage s: request stage s + 3 into the set stage s came from, split stage s + 1 into the other buffer,
+    // multiply stage s.  No exit between a request and its use; stages past the range are requested (clamped) but neither
+    // split nor multiplied.
+    // Steady state (stages s, s + 1 both inside the range): the vector work of staging stage s + 1 is laid BETWEEN the
+    // MFMAs of stage s, six at a time -- the matrix pipe runs beside the vector ALU, and with the halves of a stage one after
+    // the other both waves of a SIMD collided on each pipe in turn (75 us at 117,888 rows; WAIT_ANY 42 %).
+    auto iter_fast = [&](long s, Raw& rnext, Raw& rfree) __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_barrier(0);
+      load(s + 3 < sl ? s + 3 : sl, rfree);
+      __builtin_amdgcn_sched_barrier(0);
+      split_check(rnext);
+      mult_check(buf);
+      Frags f;
+      read_frags(f, 0, buf);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_lo(f);
+      emit_y(rnext, 0, buf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_hi(f);
+      emit_y(rnext, 1, buf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(f, 1, buf);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_lo(f);
+      emit_x(rnext, 0, buf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_hi(f);
+      emit_x(rnext, 1, buf ^ 1);
+      gh_barrier_lds();
+      buf ^= 1;
+    };
+    auto iter = [&](long s, Raw& rnext, Raw& rfree) __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_barrier(0);
+      load(s + 3 < sl ? s + 3 : sl, rfree);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < s1) split(rnext, buf ^ 1);             // uniform
+      if (s < s1) multiply(buf);
+      gh_barrier_lds();
+      buf ^= 1;
+    };
+    long s = s0;
+    for (; s + 3 < s1; s += 3) {                          // stages s .. s + 3 exist: no guards
+      iter_fast(s, r1, r0);
+      iter_fast(s + 1, r2, r1);
+      iter_fast(s + 2, r0, r2);
+    }
+    for (; s < s1; s += 3) {
+      iter(s, r1, r0);
+      iter(s + 1, r2, r1);
+      iter(s + 2, r0, r2);
+    }
+    // (the loop leaves `buf` wherever its last, possibly idle, iterations put it: every wave agrees, nothing is pending)
+  }
+  if (tail_here) {
+    Raw rt;
+    load_tail(nfull, rt);
+    if (!has_x) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rt.a[q][j] = 0.f;
+    }
+    split(rt, buf);
+    gh_barrier_lds();
+    multiply(buf);
+  }
+
+  // ---- the workgroup's partial dW block, unscaled -----------------------------------------------------------------
+  float* pw = part_dw + (long)blockIdx.x * din * dout;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r16 = 0; r16 < 16; ++r16) {
+      const int rr = (r16 & 3) + 8 * (r16 >> 2) + 4 * hi;
+      const int kr = __shfl(ka[mt], rr, 64);
+      const int row = i0 + 64 * wr + 32 * mt + rr;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int col = j0 + 64 * wc + 32 * nt + li;
+        if (row < din && col < dout) pw[(long)row * dout + col] = __builtin_ldexpf(acc[mt][nt][r16], -(kr + kb2[nt]));
+      }
+    }
+  if (want_bsum) {
+    const float v = bsum + __shfl_xor(bsum, 32, 64);
+    if (hi == 0 && cy < dout) part_db[(long)blockIdx.x * dout + cy] = v;
+  }
+}
+
 bool gemmh_wgrad_ok(int din, int dout, long m) { return din > 96 && dout > 128 && m >= 4096; }
 
 // nblocks row ranges; partial layout as gemm3_wgrad: part_dw[nblocks][din][dout], part_db[nblocks][dout]
 int launch_gemmh_wgrad(const float* x, long x_ld, const float* dy, long dy_ld, long m, int din, int dout, float* part_dw,
                        float* part_db, int nblocks, hipStream_t s, const float* yact, int act) {
-  const long nsteps = (m + 15) / 16, spb = (nsteps + nblocks - 1) / nblocks;
   const dim3 grid((unsigned)nblocks, (unsigned)((din + 127) / 128), (unsigned)((dout + 255) / 256));
+  static const char* lknob = dev_knob("KGCN_WGRADL");          // development: "0" = the register-split kernel only
+  if (!(yact && act != KGCN_ACT_NONE) && !(lknob && lknob[0] == '0')) {
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemmh_wgradl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kLdsBytes);
+      attr_set = true;
+    }
+    const long nfull = m / 32, spb = (nfull + nblocks - 1) / nblocks;
+    hipLaunchKernelGGL(gemmh_wgradl_kernel, grid, dim3(512), GWL_LDS, s, x, x_ld, dy, dy_ld, m, din, dout, spb, part_dw, part_db);
+    return check_launch("gemmh_wgradl_kernel");
+  }
+  const long nsteps = (m + 15) / 16, spb = (nsteps + nblocks - 1) / nblocks;
   const float c0 = act == KGCN_ACT_TANH ? 1.f : 0.f, c1 = act == KGCN_ACT_SIGMOID ? 1.f : 0.f, c2 = -1.f;
   if (yact && act != KGCN_ACT_NONE)
     hipLaunchKernelGGL(gemmh_wgrad_kernel<true>, grid, dim3(512), 0, s, x, x_ld, dy, dy_ld, m, din, dout, spb, part_dw, part_db,

@@ -34,8 +34,15 @@ __device__ __forceinline__ void wtableh_tile(const float* __restrict__ w, long w
   auto at = [&](int k) __attribute__((always_inline)) {
     return (n < dout && k < din) ? (trans_w ? w[(long)n * w_ld + k] : w[(long)k * w_ld + n]) : 0.f;
   };
+  // column maxima: 8 independent loads in flight per thread (a serial loop over k made this launch 20 us of latency)
   float mx = 0.f;
-  for (int k = part; k < din; k += 8) mx = fmaxf(mx, fabsf(at(k)));
+  for (int k0 = part; k0 < din; k0 += 64) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = at(k0 + 8 * u);            // at() returns 0 beyond din
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mx = fmaxf(mx, fabsf(v[u]));
+  }
   red[part][li] = mx;
   __syncthreads();
 #pragma unroll

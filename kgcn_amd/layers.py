@@ -18,6 +18,7 @@ from torch import nn
 from . import ops
 from .batched_csr import BatchedAdjacency, BatchedCSR, as_batched_adjacency
 
+allow_local_batch_statistics = False      # see GraphBatchNormalization.forward: learning phase 1 under data parallelism
 enabled_batched = False
 enabled_bspmm = False
 enabled_bconv = False
@@ -502,6 +503,16 @@ class GraphBatchNormalization(nn.Module):
         gamma, beta = (self.gamma, self.beta) if training else (self.gamma.detach(), self.beta.detach())
         phase = _learning_phase if self.learning_phase is None else int(self.learning_phase)
         if phase:
+            # Batch statistics are statistics of the GLOBAL batch; under data parallelism each rank sees its shard only.  The
+            # named model files run this layer in learning phase 0 (quirk Q6), so the BASELINE configurations never get here; a
+            # phase-1 model on several ranks would silently diverge from the single-process result (the backward through the
+            # statistics needs the same exchange) -- refused rather than approximated.
+            import torch.distributed as _dist
+            if _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1 and not allow_local_batch_statistics:
+                raise RuntimeError("GraphBatchNormalization with batch statistics (learning phase 1) under %d data-parallel ranks: "
+                                   "the statistics of a rank's shard are not those of the global batch.  Run the layer in learning "
+                                   "phase 0 (what the reference's TF1 graph mode does), or set kgcn_amd.layers."
+                                   "allow_local_batch_statistics = True to accept per-rank statistics knowingly" % _dist.get_world_size())
             mean, var = ops.graph_bn_stats(x.detach(), en)
             with torch.no_grad():
                 self.moving_mean.mul_(self.momentum).add_(mean, alpha=1.0 - self.momentum)

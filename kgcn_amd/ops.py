@@ -587,8 +587,10 @@ class _GraphConvFused(torch.autograd.Function):
         T, N, din = x.shape
         dout = w.shape[1]
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(w)
-        db = torch.empty((dout,), device=x.device, dtype=torch.float32)
+        # dW and dbias are the two halves of ONE buffer: the data-parallel exchange all-reduces it where it lies
+        # (parallel.GradBucket recognises gradients that already form a contiguous run: no pack / unpack launches)
+        dwb = torch.empty((din * dout + dout,), device=x.device, dtype=torch.float32)
+        dw, db = dwb[:din * dout].view(din, dout), dwb[din * dout:]
         wsb = lib.kgcn_graphconv_bwd_workspace_bytes(T, din, dout)
         wsp = torch.empty((max(wsb, 4) // 4,), device=x.device, dtype=torch.float32)
         check(lib.kgcn_graphconv_bwd_f32(ctx.csr.transpose().padded4().desc(), ptr(x), ptr(w),

@@ -53,6 +53,24 @@ class GradBucket:
             self._flat = torch.empty((self.total,), dtype=torch.float32, device=like.device)
         return self._flat
 
+    @staticmethod
+    def _contiguous_run(grads):
+        """The gradients as ONE flat tensor if they are contiguous, consecutive slices of the same storage (in order); else None."""
+        g0 = grads[0]
+        if g0.dtype != torch.float32 or not all(g.is_contiguous() and g.dtype == torch.float32 for g in grads):
+            return None
+        try:
+            base = g0.untyped_storage().data_ptr()
+        except Exception:                                        # noqa: BLE001
+            return None
+        nxt = g0.data_ptr()
+        for g in grads:
+            if g.untyped_storage().data_ptr() != base or g.data_ptr() != nxt:
+                return None
+            nxt += g.numel() * 4
+        total = sum(g.numel() for g in grads)
+        return torch.as_strided(g0, (total,), (1,), g0.storage_offset()) if len(grads) > 1 else g0.view(-1)
+
     def _views(self, flat):
         if self.flat_params is not None:
             return self.flat_params.grad_views
@@ -76,6 +94,20 @@ class GradBucket:
         grads = [p.grad for p in self.params]
         if any(g is None for g in grads):
             raise RuntimeError("GradBucket: a parameter has no gradient")
+        run = self._contiguous_run(grads) if self.flat_params is None else None
+        if run is not None:
+            # the backward already left the gradients as consecutive slices of one buffer (the fused GraphConv backward writes
+            # [dW | dbias] into one allocation): scale and all-reduce THAT -- the pack and unpack launches disappear
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+            if world == 1 and weight is not None and float(weight) != 1.0:
+                raise ValueError("a single rank owns the whole batch: its weight must be 1")
+            # equal shards on RCCL: the mean is the collective's own reduction (AVG), no scale launch; gloo has no AVG
+            avg = world > 1 and weight is None and dist.get_backend(group) == "nccl"
+            if world > 1 and not avg:
+                run.mul_(1.0 / world if weight is None else float(weight))
+            if dist.is_initialized():
+                dist.all_reduce(run, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group)
+            return run
         flat = self._buffer(grads[0])
         views = self._views(flat)
         torch._foreach_copy_(views, grads)

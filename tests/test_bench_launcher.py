@@ -26,9 +26,11 @@ def _run(*args, timeout=240):
                           stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=ROOT)
 
 
-@pytest.mark.parametrize("config,scaling,graphs", [("cfg2", "weak", 1000), ("cfg4", "weak", 0), ("cfg2", "strong", 25), ("cfg1", "weak", 0)])
-def test_bench_spawns_its_ranks_and_prints_one_line(config, scaling, graphs):
-    args = ["--gpus", "2", "--dry", "--device", "cpu", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+@pytest.mark.parametrize("config,scaling,graphs,ranks", [("cfg2", "weak", 1000, 2), ("cfg4", "weak", 0, 2), ("cfg2", "strong", 25, 2),
+                                                         ("cfg1", "weak", 0, 2), ("cfg3", "weak", 0, 2), ("cfg5", "weak", 0, 2),
+                                                         ("cfg2", "strong", 27, 8), ("cfg4", "weak", 0, 8)])
+def test_bench_spawns_its_ranks_and_prints_one_line(config, scaling, graphs, ranks):
+    args = ["--gpus", str(ranks), "--dry", "--device", "cpu", "--backend", "gloo", "--steps", "3", "--warmup", "1",
             "--config", config, "--scaling", scaling]
     if graphs:
         args += ["--graphs", str(graphs)]
@@ -37,13 +39,17 @@ def test_bench_spawns_its_ranks_and_prints_one_line(config, scaling, graphs):
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
     res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["scaling"] == scaling
-    assert res["config"]["dry"] is True and res["config"]["parallelism"] == "dp2"
+    assert res["n_gpus"] == ranks and res["steps"] == 3 and res["warmup"] == 1 and res["scaling"] == scaling
+    assert res["config"]["dry"] is True and res["config"]["parallelism"] == "dp%d" % ranks
     assert res["config"]["exchanges_checked"] >= 3          # every exchange compared with the analytic weighted mean
     col = res["collective"]
-    assert col["ranks"] == 2 and col["backend"] == "gloo" and col["bucket_floats"] > 0
+    assert col["ranks"] == ranks and col["backend"] == "gloo" and col["bucket_floats"] > 0
     assert col["allreduce_us_standalone"]["median"] > 0
-    assert len(col["per_rank_ms_per_step"]["all"]) == 2
+    assert len(col["per_rank_ms_per_step"]["all"]) == ranks
+    eff = col["efficiency_expectation"]                     # what the exchange costs a step: bounds the N-rank loss
+    assert 0 < eff["weak"]["at_8_ranks"] <= 1 and eff["exchange_us"] > 0 and 0 < eff["exchange_over_step"]
+    assert (eff["strong"]["at_8_ranks"] is not None) == (config == "cfg2")
+    assert set(col["env"]) == {"HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG"} and col["env"]["NCCL_DEBUG"] == "WARN"
     assert res["config"]["library"]["dev_overrides"] == {}
 
 
@@ -64,6 +70,18 @@ def test_bench_without_a_gpu_fails_inside_the_spawned_ranks():
     r = _run("--gpus", "2", "--steps", "1", "--warmup", "0")
     assert r.returncode != 0
     assert "rank 0 of 2" in r.stderr and "rank 1 of 2" in r.stderr and "needs a GPU" in r.stderr
+    assert "the 2-rank launch failed" in r.stderr
+
+
+def test_a_failing_rank_is_named_in_the_launchers_stderr():
+    """a rank that dies with an exception (here: rank 1 cannot parse its poisoned environment) prints its traceback tagged with
+    its rank id before the launcher tears the others down"""
+    env = _clean_env()
+    env["KGCN_BENCH_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry", "--device", "cpu", "--backend", "gloo", "--steps", "1",
+                        "--warmup", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240, cwd=ROOT)
+    assert r.returncode != 0
+    assert "[bench.py rank 1/2]" in r.stderr and "KGCN_BENCH_FAIL_RANK" in r.stderr
 
 
 def test_bench_refuses_a_mismatched_launcher():

@@ -196,3 +196,18 @@ def test_pack_cache_is_keyed_on_content_and_bounded():
         assert a is not b
     finally:
         B.pack_cache = old
+
+
+def test_batch_statistics_under_data_parallel_ranks_are_refused(monkeypatch):
+    """training-mode GraphBatchNormalization (kgcn/layers.py:199-208 in Keras learning phase 1) needs the statistics
+    of the GLOBAL batch; with several data-parallel ranks the layer refuses instead of normalising with its shard's statistics
+    (the check sits in front of the first kernel call, so it runs without a GPU)."""
+    import torch
+    import torch.distributed as dist
+    from kgcn_amd import layers
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda *a, **k: 2)
+    bn = layers.GraphBatchNormalization(learning_phase=1)
+    with pytest.raises(RuntimeError, match="data-parallel ranks"):
+        bn(torch.zeros(3, 4, 5))
+    assert layers.allow_local_batch_statistics is False

@@ -52,6 +52,44 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
+def _worker_run(rank, world, port, outdir):
+    """gradients that already lie as consecutive slices of ONE buffer (what the fused GraphConv backward leaves: [dW | dbias]):
+    the exchange reduces that buffer in place -- no pack, no unpack -- for equal and for weighted shards"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kgcn_amd.parallel import GradBucket
+    ok = True
+    for weight in (None, 0.25 if rank == 0 else 0.75):
+        pw, pb = torch.nn.Parameter(torch.zeros(5, 7)), torch.nn.Parameter(torch.zeros(1, 7))
+        buf = torch.arange(42, dtype=torch.float32) * (rank + 1)
+        pw.grad, pb.grad = buf[:35].view(5, 7), buf[35:].view(1, 7)
+        bucket = GradBucket([pw, pb])
+        assert bucket._contiguous_run([pw.grad, pb.grad]) is not None
+        out = bucket.all_reduce_mean(weight=weight)
+        base = torch.arange(42, dtype=torch.float32)
+        want = base * 1.5 if weight is None else base * (0.25 * 1 + 0.75 * 2)
+        ok = ok and out.data_ptr() == buf.data_ptr() and bucket._flat is None            # reduced where it lay
+        ok = ok and torch.allclose(buf, want) and torch.allclose(pw.grad.reshape(-1), want[:35]) and torch.allclose(pb.grad.reshape(-1), want[35:])
+    # separate allocations fall back to the packed path
+    pw, pb = torch.nn.Parameter(torch.zeros(5, 7)), torch.nn.Parameter(torch.zeros(1, 7))
+    pw.grad, pb.grad = torch.ones(5, 7) * (rank + 1), torch.ones(1, 7) * (rank + 1)
+    b2 = GradBucket([pw, pb])
+    ok = ok and b2._contiguous_run([pw.grad, pb.grad]) is None
+    b2.all_reduce_mean()
+    ok = ok and torch.allclose(pw.grad, torch.full((5, 7), 1.5))
+    with open(os.path.join(outdir, "rank%d.txt" % rank), "w") as f:
+        f.write(str(int(ok)))
+    dist.destroy_process_group()
+
+
+def test_dp_contiguous_gradient_run_is_reduced_in_place_world2(tmp_path):
+    mp.spawn(_worker_run, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / ("rank%d.txt" % r)).read() == "1"
+
+
 def test_dp_gradient_allreduce_world2(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)

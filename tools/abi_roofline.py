@@ -5,10 +5,17 @@ and priced with its ALGORITHMIC traffic and arithmetic from the arguments alone:
   bytes  operands read once + results written once (fp32), CSR structure 8 B / stored entry + 4 B / row
   flops  2 m din dout for a contraction, 2 nnz d for an aggregation
 
-  frac_hbm  = bytes / t / 8 TB/s           frac_mfma = flops / t / 157.3 TFLOP/s  (the f32 matrix rate: the kernels of
-  gemm3.hip run the exact 3 x bf16 split on the bf16 pipe, 2.5 PF / 6 products = 417 TF, and may exceed 1.0 here)
+  floors    t_hbm = bytes / 8 TB/s;  t_mfma = flops x products / 2.5 PFLOP/s for the split kernels -- products per fp32 product
+            from the library itself (kgcn_dense_mfma_products: 3 for the f16 two-piece kernels, 6 for the bf16 three-piece
+            ones) -- or flops / 157.3 TFLOP/s for the f32-MFMA kernels
+  bound     the LARGER floor is the call's roofline; frac = that floor / measured time (<= 1 by construction of the floors)
 
-usage (tools/config_bench.py --roofline):  rec = instrument(); step(); rows = rec.rows()"""
+Timing: calls that only overwrite their outputs (the GEMMs and aggregations: REPEATABLE) are issued `repeat` times back to back
+inside ONE event bracket -- the per-launch time of a busy device with warm clocks, within a launch gap of what rocprofv3 reports
+for the same kernel inside the captured step (a single bracketed launch after a device-wide sync read 10-20 % high:
+profiles/r03_n_cfg4_bench.json against r03_n_cfg4_rocprof.txt); everything else is bracketed once.
+
+usage (bench.py, tools/config_bench.py --roofline):  rec = instrument(); step(); rows = rec.rows()"""
 import ctypes
 
 import torch
@@ -17,6 +24,26 @@ from kgcn_amd import _lib
 
 HBM = 8.0e12
 F32_MFMA = 157.3e12
+F16_MFMA = 2.5e15              # dense f16 / bf16 matrix rate (MI355X_MICROARCH.md)
+REPEATABLE = ("kgcn_dense_fwd", "kgcn_dense_dx_dact", "kgcn_dense_wgrad", "kgcn_bspmm", "kgcn_gin_aggregate", "kgcn_graphconv_")
+
+
+def _products(name, a):
+    """matrix-pipe products per fp32 product of the kernel behind a dense call (0: none / not a dense call)."""
+    q = _lib.lib.kgcn_dense_mfma_products
+    if name in ("kgcn_dense_fwd_f32", "kgcn_dense_fwd_act_f32", "kgcn_dense_fwd_ws_f32", "kgcn_dense_fwd_tab_f32"):
+        return q(0, a[1], a[2], a[9])
+    if name == "kgcn_dense_dx_dact_gather_f32":
+        return q(1, a[4], a[5], a[9])
+    if name in ("kgcn_dense_dx_dact_f32", "kgcn_dense_dx_dact_tab_f32"):
+        return q(1, a[2], a[3], a[7])
+    if name == "kgcn_dense_wgrad_f32":
+        return q(2, a[4], a[5], a[6])
+    if name == "kgcn_dense_wgrad_dact_f32":
+        return q(2, a[6], a[7], a[8])
+    if name in ("kgcn_graphconv_fwd_f32", "kgcn_graphconv_bwd_f32", "kgcn_gcn_stack_fwd_f32", "kgcn_gcn_stack_bwd_f32"):
+        return 6                                   # fused / stack kernels: bf16 split (FULL shape) or f32 MFMA; priced on the faster pipe
+    return 0
 
 
 def _csr(arg, i=0):
@@ -191,18 +218,20 @@ def _cost(name, a):
 
 
 class Recorder:
-    def __init__(self):
-        self.calls = []            # (name, shape, bytes, flops, ms)
+    def __init__(self, repeat=8):
+        self.calls = []            # (name, shape, bytes, flops, ms per launch, products, launches timed)
         self.on = False
         self.other = set()
         self.originals = {}
+        self.repeat = repeat
 
     def rows(self):
         """Calls of the recorded step merged by (entry point, shape), largest time first."""
         agg = {}
-        for name, shape, b, f, ms in self.calls:
+        for name, shape, b, f, ms, prod, reps in self.calls:
             k = (name, shape)
-            r = agg.setdefault(k, {"entry": name, "shape": shape, "calls": 0, "us": 0.0, "bytes": 0, "flops": 0})
+            r = agg.setdefault(k, {"entry": name, "shape": shape, "calls": 0, "us": 0.0, "bytes": 0, "flops": 0,
+                                   "mfma_products": prod, "launches_timed_per_call": reps})
             r["calls"] += 1; r["us"] += ms * 1e3; r["bytes"] += b; r["flops"] += f
         out = []
         for r in sorted(agg.values(), key=lambda r: -r["us"]):
@@ -210,21 +239,26 @@ class Recorder:
             r["us"] = round(r["us"], 1)
             r["GB_per_s"] = round(r["bytes"] / t / 1e9, 1)
             r["TFLOP_per_s"] = round(r["flops"] / t / 1e12, 2)
-            r["frac_hbm"] = round(r["bytes"] / t / HBM, 3)
-            r["frac_mfma_f32"] = round(r["flops"] / t / F32_MFMA, 3)
-            r["bound"] = "hbm" if r["frac_hbm"] >= r["frac_mfma_f32"] else "mfma"
+            t_hbm = r["bytes"] / HBM
+            p = r["mfma_products"]
+            t_mfma = r["flops"] * p / F16_MFMA if p >= 3 else (r["flops"] / F32_MFMA if p == 1 else 0.0)
+            r["frac_hbm"] = round(t_hbm / t, 3)
+            r["frac_mfma"] = round(t_mfma / t, 3)
+            r["mfma_peak_TFLOPs"] = round(F16_MFMA / p / 1e12, 1) if p >= 3 else (157.3 if p == 1 else None)
+            r["bound"] = "hbm" if t_hbm >= t_mfma else "mfma"
+            r["frac"] = max(r["frac_hbm"], r["frac_mfma"])
             out.append(r)
         return out
 
 
-def instrument():
+def instrument(repeat=8):
     """Wrap every compute entry point of the loaded library; returns the Recorder (set .on = True around one step)."""
-    rec = Recorder()
+    rec = Recorder(repeat)
     lib = _lib.lib
     for name in _lib.SIGNATURES:
         fn = getattr(lib, name)
-        if name.endswith(("_bytes", "_supported", "_floats")) or name in ("kgcn_abi_version", "kgcn_last_error",
-                                                                          "kgcn_build_arch"):
+        if name.endswith(("_bytes", "_supported", "_floats", "_products")) or name in ("kgcn_abi_version", "kgcn_last_error",
+                                                                                       "kgcn_build_arch"):
             continue
 
         def wrapper(*a, _fn=fn, _name=name):
@@ -234,13 +268,17 @@ def instrument():
             if cost is None:
                 rec.other.add(_name)
                 return _fn(*a)
+            reps = rec.repeat if _name.startswith(REPEATABLE) else 1
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if reps > 1:
+                _fn(*a)                              # one untimed launch: clocks up, weight tables / operands in cache as in a step
             e0.record()
-            rc = _fn(*a)
+            for _ in range(reps):
+                rc = _fn(*a)
             e1.record()
             e1.synchronize()
-            rec.calls.append((_name, cost[2], cost[0], cost[1], e0.elapsed_time(e1)))
+            rec.calls.append((_name, cost[2], cost[0], cost[1], e0.elapsed_time(e1) / reps, _products(_name, a), reps))
             return rc
         rec.originals[name] = fn
         setattr(lib, name, wrapper)
