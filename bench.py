@@ -672,13 +672,14 @@ class _ModelStep:
 
     def _eager_step(self):
         from kgcn_amd import ops
-        self.opt.zero_grad(set_to_none=False)
+        self.opt.zero_grad(set_to_none=True)
         ops.weight_tables.refresh()
         if self.assemble_in_step:
             self.sb.assemble()
         logits = self.model(self.sb.features, self.sb.adjacency, **self.kw)
         cost_opt, _ = self.loss_fn(logits, self.labels, self.mask)
-        cost_opt.backward()
+        with ops.deferred_reductions():
+            cost_opt.backward()
         self.opt.step(packed=train_exchange(self.bucket, self.opt, self.weight))
 
     def step(self, ev=None):

@@ -531,6 +531,16 @@ int kgcn_gcn_stack_bwd_f32(const kgcn_csr_batch* at, const float* x, const int32
                            int32_t num_layers, float* const* layer_out, const float* dlast, int32_t gather, float* dx,
                            float* dparams, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Deferred second stages of PARAMETER gradients.  Every weight-gradient entry point (kgcn_dense_wgrad*_f32, kgcn_graphconv_bwd_f32)
+ * ends by adding its per-workgroup partials in a fixed order -- a 5-7 us launch each, 7-9 per training step of the model files.
+ * kgcn_reduce_defer(1) (PROCESS-wide -- frameworks run backward nodes on worker threads --; returns the previous setting) makes those calls QUEUE that second stage instead: dw /
+ * dbias are then NOT valid, and the workspaces must stay untouched, until kgcn_reduce_flush(stream) has added all queued
+ * partials in ONE launch (same order of additions: bit-identical results).  kgcn_reduce_pending(): queued second stages.
+ * The reference has no counterpart (TF sums gradients inside its executor, core.py:124); used by kgcn_amd.train. */
+int kgcn_reduce_defer(int32_t on);
+int kgcn_reduce_pending(void);
+int kgcn_reduce_flush(void* stream);
+
 /* Measurement aid (bench.py / tools/abi_roofline.py price a dense call against the pipe it really runs on): the number of
  * matrix-pipe products per fp32 product of the kernel the library routes this call to, operands assumed 16-byte aligned with
  * the W table present -- 3: f16 two-piece kernels (gemmh.hip, 2.5 PF / 3), 6: bf16 three-piece kernels (gemm3 / gemmn /

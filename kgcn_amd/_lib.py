@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # -DKGCN_DEV_KNOBS (make DEV_KNOBS=1) -- the shipped build ignores them.  Anything set here is reported by
 # active_overrides() (bench.py prints it in its JSON line) and warned about once at import, because a stray variable
 # changes summation order / which binary produced the numbers.
-DEV_ENV_VARS = ("KGCN_HIP_LIB", "KGCN_DENSE_ROUTE", "KGCN_GEMM3_MW", "KGCN_GEMM3_CUT", "KGCN_WGRADX", "KGCN_WGRADN", "KGCN_GEMMH")
+DEV_ENV_VARS = ("KGCN_HIP_LIB", "KGCN_DENSE_ROUTE", "KGCN_GEMM3_MW", "KGCN_GEMM3_CUT", "KGCN_WGRADX", "KGCN_WGRADN", "KGCN_GEMMH", "KGCN_WGRADL")
 LIB_PATH = os.environ.get("KGCN_HIP_LIB") or os.path.join(_HERE, "csrc", "libkgcn_hip.so")
 
 
@@ -193,6 +193,9 @@ SIGNATURES = {
     "kgcn_ragged_gather_bwd_f32": (ctypes.c_int, [c_f32p, c_i32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32p,
                                                   ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_dense_mfma_products": (ctypes.c_int, [c_i32, c_i64, c_i32, c_i32]),
+    "kgcn_reduce_defer": (ctypes.c_int, [c_i32]),
+    "kgcn_reduce_pending": (ctypes.c_int, []),
+    "kgcn_reduce_flush": (ctypes.c_int, [ctypes.c_void_p]),
     "kgcn_loss_workspace_bytes": (c_i64, [c_i64]),
     "kgcn_masked_sigmoid_ce_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i32, c_i32, ctypes.c_float, c_f32p,
                                                   c_f32p, c_f32p, c_f32p, ctypes.c_void_p, c_i64, ctypes.c_void_p]),

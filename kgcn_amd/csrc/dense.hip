@@ -15,8 +15,10 @@
 // The K index is permuted (half hi = l>>5 owns k in [16*hi, 16*hi+16) of every 32-wide chunk) so
 // that a lane's 16 A values are contiguous in LDS (4 x ds_read_b128 instead of 16 x ds_read_b32);
 // A and B use the same permutation, so the sum over k is unchanged.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "kgcn_common.h"
 
@@ -502,9 +504,105 @@ int launch_reduce_partials2(const float* part, int nparts, long n, float* out, c
   return check_launch("reduce_partials_kernel");
 }
 
+// ---- deferred second stages ------------------------------------------------------------------------------------------
+// The weight / bias gradients of a training step are read once, by the optimiser at its end, but every weight-gradient call
+// finished its own partials with a 5-7 us launch: 9 per step of model_multitask.py (51 us of 1.31 ms), 7 of sparse.py (42 us of
+// 0.34 ms).  With kgcn_reduce_defer(1) those second stages are QUEUED (host side, per thread) and kgcn_reduce_flush adds all of
+// them in ONE launch; the caller keeps the workspaces alive until then and reads no gradient before it.
+constexpr int kMaxReduceJobs = 24;
+struct ReduceJobs {
+  const float* part[kMaxReduceJobs];
+  float* out[kMaxReduceJobs];
+  long n[kMaxReduceJobs];
+  int nparts[kMaxReduceJobs];
+  int block0[kMaxReduceJobs + 1];       // first workgroup of every job (32 outputs per workgroup)
+  int njobs;
+};
+
+__global__ __launch_bounds__(256) void reduce_partials_multi_kernel(ReduceJobs jb) {
+  __shared__ float red[8][33];
+  int j = 0;
+  while (j + 1 < jb.njobs && (int)blockIdx.x >= jb.block0[j + 1]) ++j;          // uniform
+  const float* __restrict__ src = jb.part[j];
+  const long nn = jb.n[j];
+  const int nparts = jb.nparts[j];
+  const int oi = threadIdx.x & 31, pg = threadIdx.x >> 5;
+  const long o = (long)((int)blockIdx.x - jb.block0[j]) * 32 + oi;
+  float s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s[u] = 0.f;
+  if (o < nn) {                          // the same order of additions as reduce_partials_kernel: bit-identical results
+    int p = pg;
+    for (; p + 56 < nparts; p += 64) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += src[(long)(p + 8 * u) * nn + o];
+    }
+    for (; p < nparts; p += 8) s[0] += src[(long)p * nn + o];
+  }
+  red[pg][oi] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (pg == 0 && o < nn) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q][oi];
+    jb.out[j][o] = t;
+  }
+}
+
+// PROCESS-wide, not per thread: PyTorch runs the backward nodes of a device on its autograd worker thread, the caller switches
+// deferral on from another one.  One training loop per process (one process per GPU) is the contract; the mutex only keeps the
+// queue itself consistent.
+struct PendingReduce { const float* part; int nparts; long n; float* out; };
+static std::atomic<bool> g_defer_reduce{false};
+static std::mutex g_pending_mutex;
+static PendingReduce g_pending[256];
+static int g_npending = 0;
+
+static int flush_pending_locked(hipStream_t s) {
+  int done = 0;
+  while (done < g_npending) {
+    ReduceJobs jb{};
+    int blocks = 0, nj = 0;
+    for (; nj < kMaxReduceJobs && done + nj < g_npending; ++nj) {
+      const PendingReduce& p = g_pending[done + nj];
+      jb.part[nj] = p.part; jb.out[nj] = p.out; jb.n[nj] = p.n; jb.nparts[nj] = p.nparts; jb.block0[nj] = blocks;
+      blocks += (int)((p.n + 31) / 32);
+    }
+    jb.block0[nj] = blocks;
+    jb.njobs = nj;
+    if (blocks > 0) {
+      hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, s, jb);
+      if (int rc = check_launch("reduce_partials_multi_kernel")) { g_npending = 0; return rc; }
+    }
+    done += nj;
+  }
+  g_npending = 0;
+  return 0;
+}
+
+// the second stage of a PARAMETER gradient: queued while deferral is on, launched otherwise
+int reduce_or_defer(const float* part, int nparts, long n, float* out, hipStream_t s) {
+  if (!g_defer_reduce.load()) return launch_reduce_partials(part, nparts, n, out, s);
+  std::lock_guard<std::mutex> lock(g_pending_mutex);
+  if (g_npending == 256)
+    if (int rc = flush_pending_locked(s)) return rc;
+  g_pending[g_npending++] = PendingReduce{part, nparts, n, out};
+  return 0;
+}
+static int flush_pending(hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_pending_mutex);
+  return flush_pending_locked(s);
+}
+
 }  // namespace kgcn
 
 using namespace kgcn;
+
+extern "C" int kgcn_reduce_defer(int32_t on) {
+  return g_defer_reduce.exchange(on != 0) ? 1 : 0;
+}
+extern "C" int kgcn_reduce_pending(void) { return g_npending; }
+extern "C" int kgcn_reduce_flush(void* stream) { return flush_pending(as_stream(stream)); }
 
 // wide layers take the bf16-split GEMM of gemm3.hip (W pre-split into the fragment table of wtable.hip when the caller
 // provides the workspace for it)
@@ -695,8 +793,20 @@ extern "C" int kgcn_dense_fwd_ws_f32(const float* x, int64_t m, int32_t din, int
 
 // dW and dbias partials of one layer in ONE launch (either output may be NULL)
 namespace kgcn {
+// ... now, whatever the deferral state: for results the SAME call reads back (batch normalisation's d gamma / d beta enter its dx)
+int launch_reduce_pair_now(const float* part_dw, long n_dw, float* dw, const float* part_db, long n_db, float* dbias,
+                           int nparts, hipStream_t s);
 int launch_reduce_pair(const float* part_dw, long n_dw, float* dw, const float* part_db, long n_db, float* dbias,
                        int nparts, hipStream_t s) {
+  if (g_defer_reduce.load()) {                           // a training step: all second stages in one launch at its end
+    if (dw) if (int rc = reduce_or_defer(part_dw, nparts, n_dw, dw, s)) return rc;
+    if (dbias) if (int rc = reduce_or_defer(part_db, nparts, n_db, dbias, s)) return rc;
+    return 0;
+  }
+  return launch_reduce_pair_now(part_dw, n_dw, dw, part_db, n_db, dbias, nparts, s);
+}
+int launch_reduce_pair_now(const float* part_dw, long n_dw, float* dw, const float* part_db, long n_db, float* dbias,
+                           int nparts, hipStream_t s) {
   if (dw && dbias) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n_dw + n_db + 31) / 32)), dim3(256), 0, s, part_dw,
                        nparts, n_dw, dw, part_db, n_db, dbias);
@@ -879,8 +989,8 @@ static int dense_wgrad_impl(const float* x, int64_t x_ld, const float* dy, int64
                      (long)m, din, dout, rpc, part_dw, part_db);
   if (int rc = check_launch("dense_wgrad_kernel")) return rc;
   if (dw)
-    if (int rc = launch_reduce_partials(part_dw, nchunks, (long)din * dout, dw, s)) return rc;
+    if (int rc = reduce_or_defer(part_dw, nchunks, (long)din * dout, dw, s)) return rc;
   if (dbias)
-    if (int rc = launch_reduce_partials(part_db, nchunks, dout, dbias, s)) return rc;
+    if (int rc = reduce_or_defer(part_db, nchunks, dout, dbias, s)) return rc;
   return 0;
 }

@@ -32,6 +32,8 @@
 namespace kgcn {
 
 int launch_reduce_partials(const float* part, int nparts, long n, float* out, hipStream_t s);
+int launch_reduce_pair(const float* part_dw, long n_dw, float* dw, const float* part_db, long n_db, float* dbias, int nparts,
+                       hipStream_t s);
 int launch_reduce_partials2(const float* part, int nparts, long n, float* out, const float* part2, long n2,
                             float* out2, hipStream_t s);
 
@@ -1654,5 +1656,5 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
                        at->graph_ptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
                        at->rows, din, dout, at->max_nnz_per_graph, pack);
   if (int rc = check_launch("graphconv_bwd_kernel")) return rc;
-  return launch_reduce_partials2(part_dw, blocks, (long)din * dout, dw, part_db, dout, dbias, s);
+  return launch_reduce_pair(part_dw, (long)din * dout, dw, part_db, dout, dbias, blocks, s);      // (queued inside a deferral scope)
 }

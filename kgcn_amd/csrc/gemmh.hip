@@ -385,7 +385,7 @@ int launch_gemmh_dx_dact(const float* grad, const float* act_out, float* dpre, l
 // ------------------------------------------------------------------------------------------------------------------
 struct GhCol {           // per lane and fragment: one column of an operand
   int k;                 // scale exponent
-  float lim;             // |v| <= lim  <=>  |v| 2^k <= 2^15
+  float lim;             // |v| <= lim  <=>  |v| 2^k <= 65504 (the largest f16)
   float run;             // running maximum of |v| over the rows seen so far
 };
 
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(512, 2) void gemmh_wgrad_kernel(const float* __rest
     const int kn = 13 - __builtin_amdgcn_frexp_expf(mx);         // the maximum lands in [2^12, 2^13): two bits of headroom
     const int d = kn - c.k;
     c.k = kn;
-    c.lim = __builtin_ldexpf(1.0f, 15 - kn);
+    c.lim = __builtin_ldexpf(0.99951171875f, 16 - kn);      // |v| 2^k <= 65504, the largest f16: 8x above the new maximum
     return d;
   };
   auto mma = [&](long s, Raw& r, auto tailc) __attribute__((always_inline)) {
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(512, 2) void gemmh_wgradl_kernel(const float* __res
     if (!(mx > c.lim)) return;                                   // (a column of zeros keeps (k, lim) = (0, 0): see above)
     const int kn = 13 - __builtin_amdgcn_frexp_expf(mx);
     c.k = kn;
-    c.lim = __builtin_ldexpf(1.0f, 15 - kn);
+    c.lim = __builtin_ldexpf(0.99951171875f, 16 - kn);      // |v| 2^k <= 65504, the largest f16: 8x above the new maximum
   };
   GhCol sy{0, 0.f, 0.f}, sx{0, 0.f, 0.f};
   float bsum = 0.f;
@@ -912,7 +912,8 @@ __global__ __launch_bounds__(512, 2) void gemmh_wgradl_kernel(const float* __res
   }
 }
 
-bool gemmh_wgrad_ok(int din, int dout, long m) { return din > 96 && dout > 128 && m >= 4096; }
+// (below ~16k rows the 128 row ranges are a handful of stages each: sparse.py's 4,457 rows ran 15.6 us here, ~10 in gemm3's kernel)
+bool gemmh_wgrad_ok(int din, int dout, long m) { return din > 96 && dout > 128 && m >= 16384; }
 
 // nblocks row ranges; partial layout as gemm3_wgrad: part_dw[nblocks][din][dout], part_db[nblocks][dout]
 int launch_gemmh_wgrad(const float* x, long x_ld, const float* dy, long dy_ld, long m, int din, int dout, float* part_dw,

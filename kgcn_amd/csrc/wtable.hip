@@ -23,18 +23,21 @@ __host__ __device__ inline long wtable_entries(int din, int dout) {
 }
 
 
-// f16 section: one workgroup (256 threads) per 32-column tile.  Column maxima over k through LDS, then wave w splits the
-// k-steps w, w + 4, ... of the tile.
-__device__ __forceinline__ void wtableh_tile(const float* __restrict__ w, long w_ld, int trans_w, int din, int dout, int nt,
+// f16 section: FOUR workgroups (256 threads) per 32-column tile, each splitting a quarter of the tile's k-steps (one per wave and
+// trip).  Every one of them computes the column maxima over all k itself -- the 32 KB column block comes from L2, and the launch
+// is latency: with one workgroup per tile (four sequential k-step trips behind the maxima) it took 17 us of a training step.
+constexpr int WTH_SPLIT = 4;
+__device__ __forceinline__ void wtableh_tile(const float* __restrict__ w, long w_ld, int trans_w, int din, int dout, int job,
                                              unsigned char* __restrict__ sec) {
   __shared__ float red[8][32];
+  const int nt = job / WTH_SPLIT, part_ks = job % WTH_SPLIT;
   const int tid = threadIdx.x, li = tid & 31, part = tid >> 5;
   const int nt32 = gh_nt32(dout), kse = gh_kse(din);
   const int n = 32 * nt + li;
   auto at = [&](int k) __attribute__((always_inline)) {
     return (n < dout && k < din) ? (trans_w ? w[(long)n * w_ld + k] : w[(long)k * w_ld + n]) : 0.f;
   };
-  // column maxima: 8 independent loads in flight per thread (a serial loop over k made this launch 20 us of latency)
+  // column maxima: 8 independent loads in flight per thread
   float mx = 0.f;
   for (int k0 = part; k0 < din; k0 += 64) {
     float v[8];
@@ -50,9 +53,9 @@ __device__ __forceinline__ void wtableh_tile(const float* __restrict__ w, long w
   const int kc = scale_exp(mx);
   u32x4* tab = reinterpret_cast<u32x4*>(sec);
   int* kctab = reinterpret_cast<int*>(sec + gh_table_blocks(din, dout) * 1024);
-  if (tid < 32) kctab[n] = kc;
+  if (tid < 32 && part_ks == 0) kctab[n] = kc;
   const int lane = tid & 63, hi = lane >> 5, wave = tid >> 6;
-  for (int ks = wave; ks < kse; ks += 4) {
+  for (int ks = 4 * part_ks + wave; ks < kse; ks += 4 * WTH_SPLIT) {
     u32x4 h, l;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void wtable_split_multi_kernel(WtJobs jb, int 
   u32x4* __restrict__ table = jb.table[q];
   if ((int)blockIdx.x >= nb3) {                 // the f16 section: one workgroup per 32-column tile of this job
     const int nt = (int)blockIdx.x - nb3;
-    if (nt < gh_nt32(dout))
+    if (nt < WTH_SPLIT * gh_nt32(dout))
       wtableh_tile(w, w_ld, trans_w, din, dout, nt, reinterpret_cast<unsigned char*>(table) + wtable_entries(din, dout) * 16);
     return;
   }
@@ -146,7 +149,7 @@ int64_t wtable_bytes(int din, int dout) { return wtable_bf16_bytes(din, dout) + 
 void launch_wtable_split(const float* w, long w_ld, int trans_w, int din, int dout, void* workspace, hipStream_t s) {
   const long threads = wtable_entries(din, dout) / 3;
   const int nb3 = (int)((threads + 255) / 256);
-  hipLaunchKernelGGL(wtable_split_kernel, dim3((unsigned)(nb3 + gh_nt32(dout))), dim3(256), 0, s, w, w_ld, trans_w, din,
+  hipLaunchKernelGGL(wtable_split_kernel, dim3((unsigned)(nb3 + WTH_SPLIT * gh_nt32(dout))), dim3(256), 0, s, w, w_ld, trans_w, din,
                      dout, static_cast<u32x4*>(workspace), nb3);
 }
 
@@ -172,7 +175,7 @@ extern "C" int kgcn_wtable_split_multi(const kgcn_wtable_job* jobs, int32_t num_
       if (gh_nt32(j.n) > most_nt) most_nt = gh_nt32(j.n);
     }
     const int nb3 = (int)((most + 255) / 256);
-    hipLaunchKernelGGL(wtable_split_multi_kernel, dim3((unsigned)(nb3 + most_nt), n), dim3(256), 0, as_stream(stream), jb, nb3);
+    hipLaunchKernelGGL(wtable_split_multi_kernel, dim3((unsigned)(nb3 + WTH_SPLIT * most_nt), n), dim3(256), 0, as_stream(stream), jb, nb3);
     if (int rc = check_launch("wtable_split_multi_kernel")) return rc;
   }
   return 0;

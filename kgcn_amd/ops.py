@@ -40,6 +40,80 @@ def _side_stream(device):
     return _side_streams[key]
 
 
+# ---- deferred second stages of the parameter gradients (kgcn_reduce_defer / kgcn_reduce_flush, include/kgcn_hip.h) -----------
+_deferred_keep = []            # workspaces whose partials are still queued
+
+
+class deferred_reductions:
+    """with ops.deferred_reductions(): loss.backward()  -- the weight-gradient calls inside queue their second stages; leaving the
+    block adds all of them in ONE launch.  Parameter gradients are valid only after the block (kgcn_amd.train uses it around the
+    backward pass of a training step; plain autograd code never sees deferral)."""
+
+    def __enter__(self):
+        self.prev = lib.kgcn_reduce_defer(0 if _no_defer_debug() else 1)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            flush_reductions()
+        finally:
+            lib.kgcn_reduce_defer(self.prev)
+        return False
+
+
+def _no_defer_debug():
+    import os
+    v = os.environ.get("KGCN_NO_DEFER", "")
+    if v == "1":
+        return True
+    if v == "capture":
+        return torch.cuda.is_current_stream_capturing()
+    if v == "eager":
+        return not torch.cuda.is_current_stream_capturing()
+    return False
+
+
+def flush_reductions():
+    check(lib.kgcn_reduce_flush(current_stream()), "kgcn_reduce_flush")
+    _deferred_keep.clear()
+
+
+def _keep_until_flush(t):
+    if lib.kgcn_reduce_pending() > 0:
+        _deferred_keep.append(t)
+
+
+# How often each parameter tensor entered a deferral-capable op since the step began: a parameter used TWICE receives two
+# gradient contributions that autograd adds INSIDE the backward pass -- before the flush -- so only single-use parameters may wait
+# (model_multitask.py's ragged execution runs dense2 on the valid rows and once more on the padding representative).
+_param_uses = {}
+
+
+def _count_use(*params):
+    for p in params:
+        if p is not None:
+            _param_uses[id(p)] = _param_uses.get(id(p), 0) + 1
+
+
+def _single_use(*params):
+    return all(p is None or _param_uses.get(id(p), 0) == 1 for p in params)
+
+
+class _no_deferral_unless:
+    """switches deferral off around one C call whose results are consumed inside the backward pass"""
+
+    def __init__(self, ok):
+        self.ok = ok
+
+    def __enter__(self):
+        self.prev = None if self.ok else lib.kgcn_reduce_defer(0)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            lib.kgcn_reduce_defer(self.prev)
+        return False
+
+
 def join_side_streams():
     """Make the current stream wait for every weight gradient still running on a side stream."""
     for key in list(_side_pending):
@@ -325,6 +399,7 @@ class WeightTables:
 
     def refresh(self):
         import ctypes
+        _param_uses.clear()                            # a training step begins here (kgcn_amd.train calls refresh() first)
         live = []
         for key, e in list(self.entries.items()):
             p = e.ref()
@@ -378,6 +453,12 @@ class _Dense(torch.autograd.Function):
         ctx.act = int(act)
         ctx.save_for_backward(x2d, w, y if act else x2d)
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        # the second stage of dW / dbias may only wait (ops.deferred_reductions) when NOTHING reads them inside the backward pass:
+        # true for leaf parameters, false for a weight that is itself computed (the concatenated kernels of a multi-channel
+        # GraphConv: autograd slices its gradient right away)
+        ctx.defer_ok = bool(w.is_leaf and (bias is None or bias.is_leaf))
+        ctx.defer_ids = (w, bias)
+        _count_use(w, bias)
         return y
 
     @staticmethod
@@ -434,7 +515,7 @@ class _Dense(torch.autograd.Function):
     @staticmethod
     def _wgrad(ctx, x2d, w, gy, yact, m, din, dout, need_w, need_b, fuse_dact):
         db = None
-        if True:
+        with _no_deferral_unless(getattr(ctx, "defer_ok", False) and _single_use(*ctx.defer_ids)):
             wsb = lib.kgcn_dense_wgrad_workspace_bytes(m, din, dout)
             wsp = torch.empty((max(wsb, 4) // 4,), device=gy.device, dtype=torch.float32)
             dw = torch.empty_like(w) if need_w else None
@@ -446,6 +527,7 @@ class _Dense(torch.autograd.Function):
                 check(lib.kgcn_dense_wgrad_f32(ptr(x2d), din, ptr(gy), dout, m, din, dout, ptr(dw),
                                                ptr(db), ptr(wsp), wsb, current_stream()),
                       "kgcn_dense_wgrad_f32")
+            _keep_until_flush(wsp)
             if db is not None:
                 db = db.reshape(ctx.bias_shape)
         return dw, db
@@ -485,6 +567,9 @@ class _DenseGather(torch.autograd.Function):
         ctx.act, ctx.T, ctx.N = int(act), int(T), int(N)
         ctx.save_for_backward(x2d, w, y)
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        ctx.defer_ok = bool(w.is_leaf and (bias is None or bias.is_leaf))
+        ctx.defer_ids = (w, bias)
+        _count_use(w, bias)
         ctx.set_materialize_grads(False)
         return y.view(T, N, dout), pooled
 
@@ -577,6 +662,9 @@ class _GraphConvFused(torch.autograd.Function):
                                          ptr(out), current_stream()), "kgcn_graphconv_fwd_f32")
         ctx.csr = csr
         ctx.bias_shape = tuple(bias.shape)
+        ctx.defer_ok = bool(w.is_leaf and bias.is_leaf)
+        ctx.defer_ids = (w, bias)
+        _count_use(w, bias)
         ctx.save_for_backward(x, w)
         return out
 
@@ -593,9 +681,11 @@ class _GraphConvFused(torch.autograd.Function):
         dw, db = dwb[:din * dout].view(din, dout), dwb[din * dout:]
         wsb = lib.kgcn_graphconv_bwd_workspace_bytes(T, din, dout)
         wsp = torch.empty((max(wsb, 4) // 4,), device=x.device, dtype=torch.float32)
-        check(lib.kgcn_graphconv_bwd_f32(ctx.csr.transpose().padded4().desc(), ptr(x), ptr(w),
-                                         ptr(g), din, dout, ptr(dx), ptr(dw), ptr(db), ptr(wsp),
-                                         wsb, current_stream()), "kgcn_graphconv_bwd_f32")
+        with _no_deferral_unless(ctx.defer_ok and _single_use(*ctx.defer_ids)):
+            check(lib.kgcn_graphconv_bwd_f32(ctx.csr.transpose().padded4().desc(), ptr(x), ptr(w),
+                                             ptr(g), din, dout, ptr(dx), ptr(dw), ptr(db), ptr(wsp),
+                                             wsb, current_stream()), "kgcn_graphconv_bwd_f32")
+        _keep_until_flush(wsp)
         return dx, dw, db.reshape(ctx.bias_shape), None
 
 

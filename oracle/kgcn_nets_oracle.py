@@ -162,3 +162,84 @@ def sparse_backward(p, c, channels, sizes, labels):
         dh, g["w%d" % i], g["b%d" % i] = K.graphconv_bwd(c["in%d" % (i - 1)], adjs, p["w%d" % i], p["b%d" % i], dh)[:3]
     g["dnet"] = dh[0]
     return g
+
+
+# -------------------------------------------------------------------------------------------------
+# model_gin.py (example_model/model_gin.py:40-78): two blocks [GINAggregate - GraphDense - relu - GraphDense - relu], each block
+# output read out by GraphGather, concat, Dense(classes), masked softmax cross entropy (mean over the padded batch, quirk Q5)
+# -------------------------------------------------------------------------------------------------
+def gin_init(rng, in_dim, width, classes=2, channels=1):
+    p = {"eps": [rng.standard_normal(channels) * 0.3 for _ in range(2)]}
+    d = in_dim
+    for i in range(4):
+        if i == 2:
+            d = width
+        p["k%d" % i] = K.glorot_uniform(rng, d, width).astype(np.float64)
+        p["c%d" % i] = rng.standard_normal(width) * 0.1
+        d = width
+    p["ok"], p["ob"] = K.glorot_uniform(rng, 2 * width, classes).astype(np.float64), rng.standard_normal(classes) * 0.1
+    return p
+
+
+def _gin_block_diag(adjs, n):
+    return [K.block_diag_csr(adjs, c, n, np.float64) for c in range(len(adjs[0]))]
+
+
+def gin_forward(p, x, adjs, labels, mask):
+    """TEST INFRASTRUCTURE.  layers.py:461-472 (default branch: eps_c x + A_c x, summed over the channels) on a block-diagonal CSR."""
+    B, N, _ = x.shape
+    A = _gin_block_diag(adjs, N)
+    c = {"A": A}
+    h = np.asarray(x, np.float64).reshape(B * N, -1)
+    pools = []
+    for blk in range(2):
+        c["in%d" % blk] = h
+        a = sum(p["eps"][blk][ch] * h + A[ch] @ h for ch in range(len(A)))
+        c["a%d" % blk] = a
+        z0 = a @ p["k%d" % (2 * blk)] + p["c%d" % (2 * blk)]
+        r0 = np.maximum(z0, 0)
+        z1 = r0 @ p["k%d" % (2 * blk + 1)] + p["c%d" % (2 * blk + 1)]
+        r1 = np.maximum(z1, 0)
+        c["z0_%d" % blk], c["r0_%d" % blk], c["z1_%d" % blk], c["r1_%d" % blk] = z0, r0, z1, r1
+        pools.append(r1.reshape(B, N, -1).sum(axis=1))
+        h = r1
+    c["pool"] = np.concatenate(pools, axis=1)
+    c["logits"] = c["pool"] @ p["ok"] + p["ob"]
+    z = c["logits"] - c["logits"].max(axis=1, keepdims=True)
+    logp = z - np.log(np.exp(z).sum(axis=1, keepdims=True))
+    cost = mask * -(labels * logp).sum(axis=1)
+    c["softmax"] = np.exp(logp)
+    c["cost_opt"], c["cost_sum"] = cost.mean(), cost.sum()
+    return c
+
+
+def gin_backward(p, c, x, adjs, labels, mask, relu_masks=None):
+    """relu_masks: {(block, layer): bool array} taken from another implementation's activations (a pre-activation of 1e-9
+    may flip its sign between fp32 and fp64); None = the oracle's own."""
+    B, N, _ = x.shape
+    A = c["A"]
+    W = p["k0"].shape[1]
+    g = {"eps": [np.zeros(len(A)), np.zeros(len(A))]}
+    dlogits = (mask / B)[:, None] * (c["softmax"] * labels.sum(axis=1, keepdims=True) - labels)
+    g["ok"], g["ob"] = c["pool"].T @ dlogits, dlogits.sum(axis=0)
+    dpool = dlogits @ p["ok"].T
+    dh = None                                            # gradient handed down from the block above
+    for blk in (1, 0):
+        dr1 = np.repeat(dpool[:, blk * W:(blk + 1) * W], N, axis=0)
+        if dh is not None:
+            dr1 = dr1 + dh
+        m1 = (c["z1_%d" % blk] > 0) if relu_masks is None else relu_masks[(blk, 1)].reshape(B * N, -1)
+        dz1 = dr1 * m1
+        g["k%d" % (2 * blk + 1)], g["c%d" % (2 * blk + 1)] = c["r0_%d" % blk].T @ dz1, dz1.sum(axis=0)
+        dr0 = dz1 @ p["k%d" % (2 * blk + 1)].T
+        m0 = (c["z0_%d" % blk] > 0) if relu_masks is None else relu_masks[(blk, 0)].reshape(B * N, -1)
+        dz0 = dr0 * m0
+        g["k%d" % (2 * blk)], g["c%d" % (2 * blk)] = c["a%d" % blk].T @ dz0, dz0.sum(axis=0)
+        da = dz0 @ p["k%d" % (2 * blk)].T
+        hin = c["in%d" % blk]
+        dh = 0
+        for ch in range(len(A)):
+            g["eps"][blk][ch] = (da * hin).sum()
+            dh = dh + p["eps"][blk][ch] * da + A[ch].T @ da
+    g["dx"] = np.asarray(dh).reshape(x.shape)
+    return g

@@ -51,3 +51,28 @@ def unflatten_adjs(z, prefix=""):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# ---- measured errors of the GPU comparisons (test_gpu_parity.close) -----------------------------------------------------------
+ACCURACY = {}
+
+
+def record_accuracy(what, err, tol, mag):
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    e = ACCURACY.setdefault(test, {}).setdefault(what or "-", {"max_abs_err": 0.0, "tolerance": tol, "ref_max_abs": mag, "calls": 0})
+    e["max_abs_err"] = max(e["max_abs_err"], err)
+    e["tolerance"] = min(e["tolerance"], tol)
+    e["ref_max_abs"] = max(e["ref_max_abs"], mag)
+    e["calls"] += 1
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not ACCURACY:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        json.dump(ACCURACY, open(os.path.join(out, "accuracy_tests.json"), "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass

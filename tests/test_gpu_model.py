@@ -278,6 +278,52 @@ def test_graphed_train_step_other_models(kind):
     assert costs[-1] < costs[0]
 
 
+@pytest.mark.parametrize("kind", ["GCN", "GCN-split", "GIN", "multitask-ragged"])
+def test_deferred_second_stages_leave_every_gradient_unchanged(kind):
+    """ops.deferred_reductions (one second-stage launch per training step) must be invisible: every parameter gradient of a
+    backward pass inside the block is BIT-equal to the one taken without deferral -- also where a gradient is read inside the
+    pass (batch normalisation's d gamma / d beta enter its dx; the concatenated kernels of a multi-channel GraphConv are sliced
+    by autograd; the ragged multitask model uses its last dense layer twice)."""
+    from kgcn_amd import data_util as D, models, ops
+    torch.manual_seed(3)
+    if kind == "multitask-ragged":
+        from test_oracle_model import tox21_like_batch
+        x, adj0, labels, mask, mask_label, sizes = tox21_like_batch(np.random.default_rng(5), B=24, N=50, F=81, T=12)
+        model = models.MultitaskGCN(1, 12, ragged=True).to(dev())
+        x0, kw = t32(x), {"enabled_node_nums": torch.as_tensor(sizes)}
+        loss = lambda lg: models.masked_sigmoid_ce(lg, t32(labels), t32(mask), t32(mask_label), 1.0)[0]
+    else:
+        raw = load_golden("g1_synthetic_raw.npz")
+        chans, _ = D.build_adjs({"dense_adj": raw["dense_adj"].astype(np.int64), "max_node_num": 10},
+                                split_adj_flag=(kind == "GCN-split"))
+        ds = D.DeviceGraphDataset(chans, raw["feature"], device=dev())
+        model = {"GCN": models.GCN, "GCN-split": models.GCN, "GIN": models.GIN}[kind](len(chans)).to(dev())
+        lab = t32(raw["label"][:30].astype(np.float32))
+        mask = torch.ones(30, device=dev())
+        loss = lambda lg: models.masked_softmax_ce(lg, lab, mask)[0]
+        adj0, x0 = ds.batch(np.arange(30), 30)
+        kw = {}
+
+    def grads(defer):
+        for p in model.parameters():
+            p.grad = None
+        ops.weight_tables.refresh()
+        cost = loss(model(x0, adj0, **kw))
+        if defer:
+            with ops.deferred_reductions():
+                cost.backward()
+        else:
+            cost.backward()
+        torch.cuda.synchronize()
+        return [(n, p.grad.clone()) for n, p in model.named_parameters()]
+
+    grads(False)
+    for trial in range(3):
+        plain, waited = grads(False), grads(True)
+        for (n, a), (_, b) in zip(plain, waited):
+            assert torch.equal(a, b), (kind, trial, n, float((a - b).abs().max()))
+
+
 def test_model_py_layer_calls_through_the_kgcn_import_path():
     """The layer-call sequence of example_model/model.py:41-55, written against `import kgcn.layers` exactly as the
     reference writes it (keyword adj=, enabled_node_nums / max_node_num on the BN layer), must run on the HIP path and

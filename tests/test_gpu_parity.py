@@ -26,11 +26,17 @@ def t32(a):
 
 
 def close(got, ref, atol=ATOL, rel=0.0, what=""):
+    """max-abs comparison; every call also records (measured error, tolerance, magnitude of the reference) under the running
+    test's id -- conftest.py writes the record to gpurun_out/accuracy_tests.json at the end of the session (the round's copy:
+    profiles/r04_accuracy.json), so that a tolerance can be read against what was measured."""
+    import conftest
     got = got.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(got) else np.asarray(got, np.float64)
     ref = np.asarray(ref, np.float64)
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
-    tol = atol + rel * (np.abs(ref).max() if ref.size else 0.0)
-    err = np.abs(got - ref).max() if ref.size else 0.0
+    mag = float(np.abs(ref).max()) if ref.size else 0.0
+    tol = atol + rel * mag
+    err = float(np.abs(got - ref).max()) if ref.size else 0.0
+    conftest.record_accuracy(what, err, tol, mag)
     assert err <= tol, "%s: max abs err %.3e > %.3e" % (what, err, tol)
     return err
 

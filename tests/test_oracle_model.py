@@ -152,3 +152,31 @@ def test_block_diagonal_known_answer_from_reference_docstring():
     expect = np.zeros((5, 10))
     expect[0, 2], expect[1, 3], expect[2, 1], expect[3, 2], expect[4, 3] = 4, 5, 1, 2, 3
     np.testing.assert_array_equal(net, expect)
+
+
+def test_gin_model_backward_finite_difference():
+    """oracle/kgcn_nets_oracle.gin_* (example_model/model_gin.py:40-78; the checker of the full-size cfg5 GPU test) against
+    central differences of its own forward, and its aggregation against the per-graph K.gin_fwd."""
+    rng = np.random.default_rng(3)
+    B, N, F, W = 7, 10, 6, 5
+    adjs = K.synth_ring_graphs(rng, B, N)
+    x = rng.standard_normal((B, N, F))
+    labels = np.eye(2)[rng.integers(0, 2, B)]
+    mask = (rng.random(B) < 0.8).astype(np.float64)
+    p = NETS.gin_init(rng, F, W)
+    c = NETS.gin_forward(p, x, adjs, labels, mask)
+    np.testing.assert_allclose(c["a0"].reshape(B, N, F), K.gin_fwd(x, adjs, p["eps"][0]), rtol=0, atol=1e-12)
+    g = NETS.gin_backward(p, c, x, adjs, labels, mask)
+    f = lambda q: NETS.gin_forward(q, x, adjs, labels, mask)["cost_opt"]
+    h = 1e-6
+    for k, idx in [("k0", (1, 2)), ("c0", (3,)), ("k1", (0, 4)), ("k2", (2, 2)), ("c3", (1,)), ("ok", (7, 1)), ("ob", (0,))]:
+        q = {kk: (v.copy() if hasattr(v, "copy") else [e.copy() for e in v]) for kk, v in p.items()}
+        q[k][idx] += h; up = f(q); q[k][idx] -= 2 * h; dn = f(q)
+        assert abs((up - dn) / (2 * h) - g[k][idx]) < 1e-6 * max(1.0, abs(g[k][idx])), (k, idx)
+    for blk in range(2):
+        q = {kk: (v.copy() if hasattr(v, "copy") else [e.copy() for e in v]) for kk, v in p.items()}
+        q["eps"][blk][0] += h; up = f(q); q["eps"][blk][0] -= 2 * h; dn = f(q)
+        assert abs((up - dn) / (2 * h) - g["eps"][blk][0]) < 1e-6 * max(1.0, abs(g["eps"][blk][0]))
+    xq = x.copy(); xq[2, 3, 1] += h; up = NETS.gin_forward(p, xq, adjs, labels, mask)["cost_opt"]
+    xq[2, 3, 1] -= 2 * h; dn = NETS.gin_forward(p, xq, adjs, labels, mask)["cost_opt"]
+    assert abs((up - dn) / (2 * h) - g["dx"][2, 3, 1]) < 1e-6

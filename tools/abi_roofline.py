@@ -202,6 +202,8 @@ def _cost(name, a):
         return 16 * c.max_nnz_per_graph * a[2], 0, "sel=%d" % a[2]
     if name == "kgcn_wtable_split_multi":
         return 2 << 20, 0, "jobs=%d" % a[1]         # weights in, bf16 tables out: a few MB (nominal figure), launch latency
+    if name == "kgcn_reduce_flush":
+        return 8 << 20, 0, "queued second stages: %d" % _lib.lib.kgcn_reduce_pending()     # partials in, gradients out (nominal figure)
     if name == "kgcn_loss_grad_f32":
         return 8 * a[4], a[4], "n=%d" % a[4]
     if name == "kgcn_batch_assemble":
@@ -258,7 +260,8 @@ def instrument(repeat=8):
     for name in _lib.SIGNATURES:
         fn = getattr(lib, name)
         if name.endswith(("_bytes", "_supported", "_floats", "_products")) or name in ("kgcn_abi_version", "kgcn_last_error",
-                                                                                       "kgcn_build_arch"):
+                                                                                       "kgcn_build_arch", "kgcn_reduce_defer",
+                                                                                       "kgcn_reduce_pending"):
             continue
 
         def wrapper(*a, _fn=fn, _name=name):

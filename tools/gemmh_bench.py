@@ -136,6 +136,7 @@ for M in [int(r) for r in args.rows.split(",")]:
             for s in range(0, M, 32768):
                 refw += x[s:s + 32768].double().t() @ dz[s:s + 32768].double()
             r["wgrad_zero_rows_err"] = relerr(dw, refw)
+        r["wgrad_heavy_tail_us"] = timeit(f3)
         f2 = lambda: check(lib.kgcn_dense_wgrad_f32(ptr(xs), din, ptr(dy), dout, M, din, dout, ptr(dw), ptr(db), ptr(wgs), wgb,
                                                     current_stream()))
         f2(); torch.cuda.synchronize()
