@@ -80,6 +80,15 @@ typedef struct kgcn_csr_batch {
                                 reads 4 consecutive slots, so rows longer than 4 entries share the
                                 first pass(es) and the others never branch */
   const int32_t* graph_ptr;  /* device, [T + 1]: graph_ptr[t] = rowptr[t*M] */
+  /* Block structure of a block-diagonal one-graph container (the ragged-compact batches, kgcn_ragged_compact_csr); NULL /
+   * 0 everywhere else.  The rows are cut into num_blocks ROW BLOCKS of whole molecules: block k = rows
+   * [block_ptr[k], block_ptr[k+1]) holds the molecules whose first row lies in [k*block_rows, (k+1)*block_rows) -- at
+   * most block_rows_max = block_rows + n_nodes - 1 rows, and no adjacency entry leaves its block.  The aggregation
+   * kernels stage a block's rhs rows in LDS once and gather there (spmm.hip, spmm_block_kernel); an entry that does
+   * leave its block (a container built by hand) is gathered from memory instead, so the result never depends on it. */
+  const int32_t* block_ptr;  /* device, [num_blocks + 1], non-decreasing, block_ptr[num_blocks] = rows */
+  int32_t num_blocks;
+  int32_t block_rows_max;
 } kgcn_csr_batch;
 
 /* -- library info ------------------------------------------------------------------------ */
@@ -422,6 +431,12 @@ int kgcn_ragged_plan(const kgcn_csr_batch* src, const int32_t* sizes, const int3
 int kgcn_ragged_compact_csr(const kgcn_csr_batch* src, const int32_t* sel, int32_t num_sel, const int32_t* graph_ptr,
                             const int32_t* entry_ptr, int32_t capacity_rows, int32_t* dst_rowptr, int32_t* dst_cv,
                             int64_t dst_cv_capacity, int32_t* status, void* stream);
+/* The row blocks of a ragged-compact batch (kgcn_csr_batch.block_ptr): block_ptr [kgcn_ragged_num_blocks(capacity_rows) + 1]
+ * from the plan's graph_ptr [num_sel + 1]; blocks past the valid rows cover the padding rows in steps of
+ * KGCN_RAGGED_BLOCK_ROWS.  Every block holds at most KGCN_RAGGED_BLOCK_ROWS + n_nodes - 1 rows. */
+#define KGCN_RAGGED_BLOCK_ROWS 64
+int32_t kgcn_ragged_num_blocks(int32_t capacity_rows);
+int kgcn_ragged_blocks(const int32_t* graph_ptr, int32_t num_sel, int32_t capacity_rows, int32_t* block_ptr, void* stream);
 /* dst [capacity_rows, d] <- the valid rows of src [num_source_graphs, n_nodes, d] (feed.py:127-133 layout), zeros on the
  * rows >= R. */
 int kgcn_ragged_compact_rows_f32(const float* src, const int32_t* sel, int32_t num_sel, int32_t n_nodes, int32_t d,

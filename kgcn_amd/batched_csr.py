@@ -116,6 +116,8 @@ class BatchedCSR:
         self._refillable = False        # static_like(): contents change under the same object
         self.slots = None               # row_pad == 4: int32 [T*M] slot table (see include/kgcn_hip.h)
         self.graph_ptr = None           # row_pad == 4: int32 [T+1]
+        self.block_ptr = None           # ragged-compact containers: int32 [num_blocks + 1] row blocks of whole molecules
+        self.block_rows_max = 0         # ... and the most rows a block can hold (kgcn_csr_batch.block_ptr, include/kgcn_hip.h)
 
     # ---- construction -------------------------------------------------------------------------
     @classmethod
@@ -465,6 +467,7 @@ class BatchedCSR:
         cv = torch.stack((self.cv[:, 0], values.detach().contiguous().view(torch.int32)), dim=1)
         out = BatchedCSR(self.rowptr, cv.contiguous(), self.num_graphs, self.rows, self.cols,
                          self.max_nnz, perm=self.perm, host=None)
+        out.block_ptr, out.block_rows_max = self.block_ptr, self.block_rows_max
         out._struct_src = self if self._struct_src is None else self._struct_src
         out._vals = values.detach()
         return out
@@ -485,7 +488,10 @@ class BatchedCSR:
                                        self.row_pad, 0, self.nnz, self.rowptr.data_ptr(),
                                        self.cv.data_ptr() if self.nnz else 0,
                                        self.slots.data_ptr() if self.slots is not None else 0,
-                                       self.graph_ptr.data_ptr() if self.graph_ptr is not None else 0)
+                                       self.graph_ptr.data_ptr() if self.graph_ptr is not None else 0,
+                                       self.block_ptr.data_ptr() if self.block_ptr is not None else 0,
+                                       int(self.block_ptr.numel()) - 1 if self.block_ptr is not None else 0,
+                                       self.block_rows_max if self.block_ptr is not None else 0)
         return self._desc
 
     def algorithmic_bytes(self):

@@ -371,6 +371,38 @@ extern "C" int kgcn_ragged_compact_csr(const kgcn_csr_batch* src, const int32_t*
   return check_launch("ragged_csr_kernel");
 }
 
+// Row blocks of whole molecules (kgcn_csr_batch.block_ptr): block k starts at the first molecule whose first row is >= k * S.
+// Thread t <= T owns boundary b_t = graph_ptr[t] (b_T = R) and writes it to every k in (floor(b_{t-1} / S), floor(b_t / S)]
+// (t = 0: k = 0) -- each k <= floor(R / S) has exactly one writer; thread T also lays the blocks of the padding rows behind R.
+__global__ __launch_bounds__(256) void ragged_blocks_kernel(const int* __restrict__ graph_ptr, int T, int capacity_rows, int nblocks,
+                                                            int* __restrict__ block_ptr) {
+  constexpr int S = KGCN_RAGGED_BLOCK_ROWS;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t > T) return;
+  const int b = graph_ptr[t];
+  const int k0 = t == 0 ? 0 : graph_ptr[t - 1] / S + 1;
+  for (int k = k0; k <= b / S && k <= nblocks; ++k) block_ptr[k] = b < capacity_rows ? b : capacity_rows;
+  if (t == T) {
+    int k = b / S + 1;
+    for (long row = b; k <= nblocks; ++k, row += S) block_ptr[k] = row < capacity_rows ? (int)row : capacity_rows;
+  }
+}
+
+extern "C" int32_t kgcn_ragged_num_blocks(int32_t capacity_rows) {
+  return capacity_rows <= 0 ? 0 : (capacity_rows + KGCN_RAGGED_BLOCK_ROWS - 1) / KGCN_RAGGED_BLOCK_ROWS + 2;
+}
+
+extern "C" int kgcn_ragged_blocks(const int32_t* graph_ptr, int32_t num_sel, int32_t capacity_rows, int32_t* block_ptr,
+                                  void* stream) {
+  if (num_sel < 0 || capacity_rows < 0) return fail("kgcn_ragged_blocks: negative size");
+  if (capacity_rows == 0) return 0;
+  if (!graph_ptr || !block_ptr) return fail("kgcn_ragged_blocks: NULL operand");
+  const int nb = kgcn_ragged_num_blocks(capacity_rows);
+  hipLaunchKernelGGL(ragged_blocks_kernel, dim3((unsigned)((num_sel + 1 + 255) / 256)), dim3(256), 0, as_stream(stream), graph_ptr,
+                     num_sel, capacity_rows, nb, block_ptr);
+  return check_launch("ragged_blocks_kernel");
+}
+
 extern "C" int kgcn_ragged_compact_rows_f32(const float* src, const int32_t* sel, int32_t num_sel, int32_t n_nodes,
                                             int32_t d, const int32_t* graph_ptr, int32_t capacity_rows, float* dst,
                                             void* stream) {

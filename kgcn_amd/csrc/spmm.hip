@@ -364,6 +364,210 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Block kernel: the ragged-compact batches (ONE block-diagonal matrix of whole molecules, ragged.hip) with their block
+// structure (kgcn_csr_batch.block_ptr): a workgroup stages the rhs rows of one row block -- the molecules starting inside
+// 64 consecutive rows, <= 64 + N - 1 rows -- times act'(aout) in a backward launch, its CSR entries and row offsets in LDS
+// ONCE, then every row gathers from LDS.  The row-chunk kernel above re-reads a row from L2 / HBM once per neighbour and,
+// in a backward launch, the saved activations as well: 617 MB for 361 MB of work at 117,888 x 256 (x 1.71; forward x 1.37,
+// profiles/r03_n_cfg4_rocprof.txt); here every rhs byte is requested once.
+// blockIdx.x = block * nslices + slice; a slice is ds columns (one 128 / 256-byte segment per row), so the slices of a block
+// land on different XCDs at the same time and share the DRAM pages of its rows.
+// Entries whose column lies outside the staged rows (never in a batch ragged.hip built) and rows beyond the LDS capacity
+// (blocks longer than rows_cap) are gathered from memory.
+// ------------------------------------------------------------------------------------------------
+// One workgroup per (block, slice).  The requests go out in dependency order: the block's extent (two scalar loads), then its rhs
+// rows -- the bulk -- and row offsets at once, and the (column, value) pairs, whose address needs a row offset, while those are in
+// flight.  Tried and dropped (profiles/r04_spmm_block.txt): several items per workgroup with the next item's rows prefetched into
+// registers behind the aggregation of the current one -- 100 / 135 us instead of 68 / 83 (forward / adjoint at d = 256): with the
+// registers that costs only two workgroups fit a CU, and the aggregation itself (two dependent LDS reads per entry), not the
+// load latency, is what a workgroup spends its time in.
+constexpr int SPB_MAXE = 3;              // (column, value) pairs per lane on their way to LDS: ecap <= 768
+
+template <int VEC, int LPR, bool DACT>
+__global__ __launch_bounds__(256) void spmm_block_kernel(
+    const int* __restrict__ rowptr, const int2* __restrict__ cv, const int* __restrict__ block_ptr, int nitems, int nslices,
+    int ds, int rows_cap, int ecap, const float* __restrict__ rhs, long rhs_ld, float* __restrict__ out, long out_ld,
+    float beta, const float* __restrict__ self_scale, int act, const float* __restrict__ aout, int dact) {
+  using V = typename SpVec<VEC>::T;
+  constexpr int MAXV = VEC == 4 ? 8 : 12;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* tile = reinterpret_cast<float*>(smem);
+  int2* ecv = reinterpret_cast<int2*>(smem + (((size_t)rows_cap * ds * 4 + 15) & ~(size_t)15));
+  int* rp = reinterpret_cast<int*>(ecv + ecap);
+  auto ldv = [](const float* p) { return *reinterpret_cast<const V*>(p); };
+  auto stv = [](float* p, V v) { *reinterpret_cast<V*>(p) = v; };
+  const int tid = threadIdx.x;
+  const int it = blockIdx.x;                           // item = (block, slice)
+  const int k = it / nslices;
+  const int col0 = (it - k * nslices) * ds;
+  const int row_lo = block_ptr[k], n = block_ptr[k + 1] - row_lo;      // uniform: scalar loads
+  if (n <= 0) return;
+  const int nt = n < rows_cap ? n : rows_cap;          // rows of the block that live in LDS
+  const int dv = ds / VEC;
+  const int step_r = 256 / dv, step_c = 256 - step_r * dv;
+  const int r_first = tid / dv, c_first = tid - r_first * dv;
+  auto value = [&](long row, int col) __attribute__((always_inline)) {    // rhs (.) act'(aout) at (row, col)
+    const long o = row * rhs_ld + col;
+    V v = ldv(rhs + o);
+    if constexpr (DACT) {
+      const V a = ldv(aout + o);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] *= act_dout(a[j], dact);
+    }
+    return v;
+  };
+  V pv[MAXV], pa[DACT ? MAXV : 1];
+  int2 pe[SPB_MAXE];
+  int pr = 0;
+  // ---- stage: requests into registers first (rows and row offsets, then the entries), LDS writes after -----------------------
+  const int nv = nt * dv;
+  {
+    int r = r_first, cc = c_first;
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+      // (lanes past the tile's end repeat its last vector: no predicated register, whose undefined half cost the forward
+      // kernel 120 registers of copies)
+      const bool in = tid + 256 * u < nv;
+      const long o = (long)(row_lo + (in ? r : nt - 1)) * rhs_ld + col0 + (in ? cc : dv - 1) * VEC;
+      pv[u] = ldv(rhs + o);
+      if constexpr (DACT) pa[u] = ldv(aout + o);
+      r += step_r; cc += step_c;
+      if (cc >= dv) { cc -= dv; ++r; }
+    }
+  }
+  if (tid <= nt) pr = rowptr[row_lo + tid];
+  const int e_lo = rowptr[row_lo], cnt = rowptr[row_lo + n] - e_lo;    // uniform: scalar loads, beside the vector requests
+  const bool ecv_lds = cnt <= ecap;
+  if (ecv_lds) {
+#pragma unroll
+    for (int u = 0; u < SPB_MAXE; ++u)
+      if (tid + 256 * u < cnt) pe[u] = cv[e_lo + tid + 256 * u];
+  }
+#pragma unroll
+  for (int u = 0; u < MAXV; ++u) {
+    if (tid + 256 * u < nv) {
+      V v = pv[u];
+      if constexpr (DACT) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] *= act_dout(pa[u][j], dact);
+      }
+      stv(tile + (size_t)(tid + 256 * u) * VEC, v);
+    }
+  }
+  if (nv > MAXV * 256) {                               // what the registers do not hold: straight from memory
+    int i = tid + MAXV * 256;
+    int r = i / dv, cc = i - r * dv;
+#pragma unroll 1
+    for (; i < nv; i += 256) {
+      stv(tile + (size_t)i * VEC, value(row_lo + r, col0 + cc * VEC));
+      r += step_r; cc += step_c;
+      if (cc >= dv) { cc -= dv; ++r; }
+    }
+  }
+  if (ecv_lds) {
+#pragma unroll
+    for (int u = 0; u < SPB_MAXE; ++u)
+      if (tid + 256 * u < cnt) ecv[tid + 256 * u] = pe[u];
+  }
+  if (tid <= nt) rp[tid] = pr - e_lo;
+  __syncthreads();
+
+  constexpr int RPW = 256 / LPR;
+  const int sub = tid / LPR, cl = tid % LPR;
+  const float sscale = self_scale ? self_scale[0] : 0.f;
+  const int c = cl * VEC;
+  auto finish = [&](V acc, long row, int col) __attribute__((always_inline)) {
+    float* o = out + row * out_ld + col;
+    if (beta != 0.f) acc += ldv(o);
+    if (act != KGCN_ACT_NONE) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] = act_fwd(acc[j], act);
+    }
+    stv(o, acc);
+  };
+  // a row entirely from memory, entries in stored order (the same additions as the LDS path): rows beyond the LDS capacity,
+  // rows with an entry that leaves the staged block, items with more entries than the LDS buffer holds
+  auto slow_row = [&](long row, int col) __attribute__((always_inline)) {
+    V acc;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    const int s = rowptr[row], e = rowptr[row + 1];
+#pragma unroll 1
+    for (int q = s; q < e; ++q) {
+      const int2 p = cv[q];
+      acc += __int_as_float(p.y) * value(p.x, col);
+    }
+    if (self_scale) acc += sscale * value(row, col);
+    finish(acc, row, col);
+  };
+  // aggregate out of LDS: 256 / LPR rows at a time, two rows per lane group and four entries per row in flight (the dependent
+  // pair of LDS reads per entry -- (column, value), then the row -- is what a lane group waits for)
+  {
+    if (c >= ds) return;
+    if (!ecv_lds) {                                                    // item-uniform
+#pragma unroll 1
+      for (int r = sub; r < n; r += RPW) slow_row(row_lo + r, col0 + c);
+      return;
+    }
+#pragma unroll 1
+    for (int r0 = sub; r0 < nt; r0 += 2 * RPW) {
+      int s[2], len[2];
+      V acc[2];
+      bool left[2] = {false, false};                                   // an entry of the row leaves the staged block
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int r = r0 + u * RPW;
+        s[u] = 0; len[u] = 0;
+        if (r < nt) { s[u] = rp[r]; len[u] = rp[r + 1] - s[u]; }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[u][j] = 0.f;
+      }
+      const int lmax = len[0] > len[1] ? len[0] : len[1];
+#pragma unroll 1
+      for (int q = 0; q < lmax; q += 4) {
+        int2 p[2][4];
+        V xv[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            p[u][j] = make_int2(row_lo, 0);
+            if (q + j < len[u]) p[u][j] = ecv[s[u] + q + j];
+          }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            unsigned lc = (unsigned)(p[u][j].x - row_lo);
+            if (lc >= (unsigned)nt) { left[u] = true; lc = 0; }
+            xv[u][j] = ldv(tile + (size_t)lc * ds + c);
+          }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            // past the row's end: value 0 times the block's first row -- a finite row contributes exactly 0; a row with a
+            // non-finite entry there must not: select instead of multiplying
+            const float v = __int_as_float(p[u][j].y);
+            const V t = acc[u] + v * xv[u][j];
+            if (q + j < len[u]) acc[u] = t;
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int r = r0 + u * RPW;
+        if (r >= nt) continue;
+        if (left[u]) { slow_row(row_lo + r, col0 + c); continue; }
+        if (self_scale) acc[u] += sscale * ldv(tile + (size_t)r * ds + c);
+        finish(acc[u], row_lo + r, col0 + c);
+      }
+    }
+#pragma unroll 1
+    for (int r = nt + sub; r < n; r += RPW) slow_row(row_lo + r, col0 + c);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // generic CSR-vector gather kernel: LPR = 2^lpr_log2 lanes per row, VEC floats per lane
 // ------------------------------------------------------------------------------------------------
 template <int VEC>
@@ -600,6 +804,48 @@ int launch_spmm_multi(const kgcn_csr_batch* a, int nch, const float* rhs, long r
     ch.rowptr[c] = a[c].rowptr;
     ch.cv[c] = reinterpret_cast<const int2*>(a[c].cv);
     ch.max_nnz[c] = a[c].max_nnz_per_graph;
+  }
+  // ragged-compact batches with their block structure: every rhs row staged once (spmm_block_kernel)
+  if (nch == 1 && T == 1 && a->block_ptr && a->num_blocks > 0 && a->block_rows_max > 0 && !dotx) {
+    const long all = rhs_ld | out_ld | d;
+    const uintptr_t ptrs = reinterpret_cast<uintptr_t>(rhs) | reinterpret_cast<uintptr_t>(out) |
+                           (dact ? reinterpret_cast<uintptr_t>(aout) : 0);
+    const int vec = (all % 4 == 0 && ptrs % 16 == 0) ? 4 : (all % 2 == 0 && ptrs % 8 == 0) ? 2 : 0;
+    const int rows_cap = a->block_rows_max < 255 ? a->block_rows_max : 255;      // (one row offset per lane)
+    // slice width: whole rows while the tile stays within 24 KiB (>= 6 workgroups per CU), else 64 / 32 columns
+    int ds = 0;
+    if (vec) {
+      if ((long)rows_cap * d * 4 <= 24 * 1024 && d / vec <= 64) ds = d;
+#ifndef SPB_SLICE32
+      else if (vec == 4 && d % 64 == 0 && (long)rows_cap * 64 * 4 <= 40 * 1024) ds = 64;
+#endif
+      else if (vec == 4 && d % 32 == 0 && (long)rows_cap * 32 * 4 <= 40 * 1024) ds = 32;
+    }
+    if (ds && (long)a->num_blocks * (d / ds) <= 0x7fffffffL) {
+      const int nslices = d / ds, dv = ds / vec;
+      int ecap = rows_cap * 6;
+      if (ecap > SPB_MAXE * 256) ecap = SPB_MAXE * 256;
+      const size_t lds = (((size_t)rows_cap * ds * 4 + 15) & ~(size_t)15) + (size_t)ecap * 8 +
+                         (size_t)(rows_cap + 1) * 4;
+      const int nitems = a->num_blocks * nslices;
+      const dim3 grid((unsigned)nitems);
+#define KGCN_BLK2(VEC, LPR, DACT)                                                                                       \
+  hipLaunchKernelGGL((spmm_block_kernel<VEC, LPR, DACT>), grid, dim3(256), lds, stream, a->rowptr,                       \
+                     reinterpret_cast<const int2*>(a->cv), a->block_ptr, nitems, nslices, ds, rows_cap, ecap, rhs, rhs_ld, out, \
+                     out_ld, beta, self_scale, act, aout, dact)
+#define KGCN_BLK(VEC, LPR)                                                                                              \
+  {                                                                                                                     \
+    if (dact != KGCN_ACT_NONE) KGCN_BLK2(VEC, LPR, true); else KGCN_BLK2(VEC, LPR, false);                              \
+  }
+      if (vec == 4) {
+        if (dv <= 8) KGCN_BLK(4, 8) else if (dv <= 16) KGCN_BLK(4, 16) else if (dv <= 32) KGCN_BLK(4, 32) else KGCN_BLK(4, 64)
+      } else {
+        if (dv <= 8) KGCN_BLK(2, 8) else if (dv <= 16) KGCN_BLK(2, 16) else if (dv <= 32) KGCN_BLK(2, 32) else KGCN_BLK(2, 64)
+      }
+#undef KGCN_BLK
+#undef KGCN_BLK2
+      return check_launch("spmm_block_kernel");
+    }
   }
   const TilePlan plan = tile_plan(a, nch, rhs, rhs_ld, rhs_gs, rhs_cs, d, out, out_ld, out_gs, dact ? aout : nullptr,
                                   dotx != nullptr);      // the fused <rhs, dotx> needs a graph's whole rows in one workgroup

@@ -21,6 +21,8 @@ zeros) and no adjacency entry touches a node >= n_b (checked on the device when 
 Not defined on this layout: GraphMaxPooling (its implicit-zero rule counts the padded columns) and
 GraphBatchNormalization in training phase WITHOUT enabled_node_nums (its statistics would include the padded rows).
 """
+import os
+
 import numpy as np
 
 from . import _lib
@@ -92,8 +94,22 @@ def _compact_csr(src, sel_dev, B, graph_ptr, entry_ptr, capacity, rowptr, cv, st
                "kgcn_ragged_compact_csr")
 
 
-def _container(rowptr, cv, capacity):
-    return BatchedCSR(rowptr, cv, 1, capacity, capacity, max(int(cv.shape[0]), 1))
+def _container(rowptr, cv, capacity, block_ptr=None, n_nodes=0):
+    c = BatchedCSR(rowptr, cv, 1, capacity, capacity, max(int(cv.shape[0]), 1))
+    if block_ptr is not None and os.environ.get("KGCN_SPMM_BLOCKS") != "0":          # (development A/B: the row-chunk kernel)
+        # the row blocks of whole molecules: the aggregation kernels stage a block's rows in LDS once (csrc/spmm.hip, spmm_block_kernel)
+        c.block_ptr, c.block_rows_max = block_ptr, _lib.KGCN_RAGGED_BLOCK_ROWS + max(int(n_nodes), 1) - 1
+    return c
+
+
+def _new_block_ptr(capacity, device):
+    import torch
+    return torch.zeros(_lib.lib.kgcn_ragged_num_blocks(int(capacity)) + 1, dtype=torch.int32, device=device)
+
+
+def _blocks(graph_ptr, B, capacity, block_ptr):
+    _lib.check(_lib.lib.kgcn_ragged_blocks(_lib.ptr(graph_ptr), B, capacity, _lib.ptr(block_ptr), _lib.current_stream()),
+               "kgcn_ragged_blocks")
 
 
 def default_capacity(sizes, batch_size, n_nodes):
@@ -138,16 +154,19 @@ def compact(features, adj, enabled_node_nums, capacity=None, check=True):
     graph_ptr = torch.empty(B + 1, **i32)
     ws = torch.empty(max(_lib.lib.kgcn_ragged_workspace_bytes(B), 8) // 4, **i32)
     status = torch.zeros(1, **i32)
+    block_ptr = _new_block_ptr(capacity, dev)
     chans = []
-    for ch in a.channels:
+    for ic, ch in enumerate(a.channels):
         entry_ptr = torch.empty(B + 1, **i32)
         _plan(ch, sizes_dev, None, B, graph_ptr, entry_ptr, ws)
+        if ic == 0:
+            _blocks(graph_ptr, B, capacity, block_ptr)
         pair = []
         for src in (ch, ch.transpose()):
             rowptr = torch.empty(capacity + 1, **i32)
             cv = torch.empty((src.nnz, 2), **i32)
             _compact_csr(src, None, B, graph_ptr, entry_ptr, capacity, rowptr, cv, status)
-            pair.append(_container(rowptr, cv, capacity))
+            pair.append(_container(rowptr, cv, capacity, block_ptr, N))
         pair[0]._t, pair[1]._t = pair[1], pair[0]
         chans.append(pair[0])
     feat = None
@@ -208,12 +227,14 @@ class StaticRaggedBatch:
         self._graph_ptr = torch.zeros(B + 1, **i32)
         self._ws = torch.empty(max(_lib.lib.kgcn_ragged_workspace_bytes(B), 8) // 4, **i32)
         self.status = torch.zeros(1, **i32)
+        self._block_ptr = _new_block_ptr(cap, dev)
+        _blocks(self._graph_ptr, B, cap, self._block_ptr)         # an empty batch until load(): padding rows only
         self._chan = []
         chans = []
         for src in dataset.channels:
             worst = B * max(src.max_nnz, 1)
             entry_ptr = torch.zeros(B + 1, **i32)
-            pair = [_container(torch.zeros(cap + 1, **i32), torch.zeros((worst, 2), **i32), cap) for _ in range(2)]
+            pair = [_container(torch.zeros(cap + 1, **i32), torch.zeros((worst, 2), **i32), cap, self._block_ptr, N) for _ in range(2)]
             pair[0]._t, pair[1]._t = pair[1], pair[0]
             for c in pair:
                 c._refillable = True
@@ -252,8 +273,10 @@ class StaticRaggedBatch:
         -- capturable (GraphedTrainStep(capture_assembly=True))."""
         from .data_util import _fill_tables
         ds, B = self.dataset, self.batch_size
-        for src, src_t, entry_ptr, pair in self._chan:
+        for ic, (src, src_t, entry_ptr, pair) in enumerate(self._chan):
             _plan(src, ds.sizes_dev, self._sel_dev, B, self._graph_ptr, entry_ptr, self._ws)
+            if ic == 0:
+                _blocks(self._graph_ptr, B, self.capacity, self._block_ptr)
             for s, c in ((src, pair[0]), (src_t, pair[1])):
                 _compact_csr(s, self._sel_dev, B, self._graph_ptr, entry_ptr, self.capacity, c.rowptr, c.cv, self.status)
         if self.features is not None:

@@ -182,6 +182,8 @@ def _cost(name, a):
         return 16 * a[8] // 4 + 8 * a[5], 0, "sel=%d capacity=%d" % (a[2], a[5])
     if name == "kgcn_ragged_plan":
         return 16 * a[3], 0, "sel=%d" % a[3]
+    if name == "kgcn_ragged_blocks":
+        return 4 * a[1] + 4 * (a[2] // 64 + 3), 0, "sel=%d capacity=%d" % (a[1], a[2])
     if name in ("kgcn_gcn_stack_fwd_f32", "kgcn_gcn_stack_bwd_f32"):
         bwd = name.endswith("bwd_f32")
         c = _csr(a[0])
@@ -261,7 +263,7 @@ def instrument(repeat=8):
         fn = getattr(lib, name)
         if name.endswith(("_bytes", "_supported", "_floats", "_products")) or name in ("kgcn_abi_version", "kgcn_last_error",
                                                                                        "kgcn_build_arch", "kgcn_reduce_defer",
-                                                                                       "kgcn_reduce_pending"):
+                                                                                       "kgcn_reduce_pending", "kgcn_ragged_num_blocks"):
             continue
 
         def wrapper(*a, _fn=fn, _name=name):
