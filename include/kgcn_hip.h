@@ -259,6 +259,10 @@ int kgcn_gram_bwd_f32(const float* x, int32_t num_graphs, int32_t n_nodes, int32
 /* kgcn/layers.py:163-164: out[b, :] = sum_n x[b, n, :] (padding rows included). */
 int kgcn_graph_gather_fwd_f32(const float* x, int64_t batch, int32_t n_nodes, int32_t d,
                               float* out, void* stream);
+/* the same into a column block of a wider tensor: out[b * out_ld + c] (tf.concat of several read-outs, model_gin.py:61, without
+ * the concatenation pass) */
+int kgcn_graph_gather_fwd_ld_f32(const float* x, int64_t batch, int32_t n_nodes, int32_t d, float* out, int64_t out_ld,
+                                 void* stream);
 /* dx[b, n, :] = dout[b, :] */
 int kgcn_graph_gather_bwd_f32(const float* dout_grad, int64_t batch, int32_t n_nodes, int32_t d,
                               float* dx, void* stream);
@@ -341,9 +345,12 @@ int kgcn_dense_dx_dact_tab_f32(const float* grad, const float* act_out, int64_t 
  * kgcn_dense_dx_dact_gather_supported(m, din, dout); table: kgcn_dense_fwd_workspace_bytes(dout, din) bytes, already split
  * (table_ready != 0, kgcn_wtable_split_multi) or a workspace the call splits into. */
 int kgcn_dense_dx_dact_gather_supported(int64_t m, int32_t din, int32_t dout);
-int kgcn_dense_dx_dact_gather_f32(const float* grad, const float* pooled_grad, int32_t n_nodes, const float* act_out, int64_t m,
-                                  int32_t dout, int64_t ld, const float* w, int64_t w_ld, int32_t din, float* dx, int64_t dx_ld,
-                                  int32_t act, float* dpre, void* table, int64_t table_bytes, int32_t table_ready, void* stream);
+/* pooled_ld: row stride of pooled_grad [graphs, dout] in floats (a multiple of 4, >= dout: the gradient of a column block of a
+ * wider read-out tensor -- model_gin.py:61 concatenates the read-outs of its blocks -- is used where it lies) */
+int kgcn_dense_dx_dact_gather_f32(const float* grad, const float* pooled_grad, int64_t pooled_ld, int32_t n_nodes,
+                                  const float* act_out, int64_t m, int32_t dout, int64_t ld, const float* w, int64_t w_ld,
+                                  int32_t din, float* dx, int64_t dx_ld, int32_t act, float* dpre, void* table,
+                                  int64_t table_bytes, int32_t table_ready, void* stream);
 /* stand-alone forms: y = act(x) over n floats; dpre = grad (.) act'(act_out) (dpre may alias grad) */
 int kgcn_act_fwd_f32(const float* x, int64_t n, int32_t act, float* y, void* stream);
 int kgcn_act_bwd_f32(const float* act_out, const float* grad, int64_t n, int32_t act, float* dpre, void* stream);

@@ -34,7 +34,7 @@ int launch_narrow_wgrad(const float* x, const float* dy, long m, int din, int do
                         int nblocks, hipStream_t s);
 int launch_gemm3_dx_dact(const float* grad, const float* act_out, float* dpre, long m, int k, long ld, const void* table,
                          float* dx, int n, long dx_ld, int dact, hipStream_t s, const float* pooled_grad = nullptr,
-                         int n_nodes = 0);
+                         int n_nodes = 0, long pooled_ld = 0);
 bool gemmn_pays(const float* x, int din, long x_ld, int dout);
 int launch_gemmn_fwd(const float* x, long m, int din, long x_ld, const void* table, const float* bias, float* y, int dout,
                      long y_ld, int act, hipStream_t s);
@@ -738,7 +738,8 @@ extern "C" int kgcn_dense_dx_dact_gather_supported(int64_t m, int32_t din, int32
   return (m >= 1024 && din > 0 && dout > 0 && dout % 4 == 0 && table_pays(dout, din)) ? 1 : 0;
 }
 
-extern "C" int kgcn_dense_dx_dact_gather_f32(const float* grad, const float* pooled_grad, int32_t n_nodes, const float* act_out,
+extern "C" int kgcn_dense_dx_dact_gather_f32(const float* grad, const float* pooled_grad, int64_t pooled_ld, int32_t n_nodes,
+                                             const float* act_out,
                                              int64_t m, int32_t dout, int64_t ld, const float* w, int64_t w_ld, int32_t din,
                                              float* dx, int64_t dx_ld, int32_t act, float* dpre, void* table, int64_t table_bytes,
                                              int32_t table_ready, void* stream) {
@@ -748,13 +749,14 @@ extern "C" int kgcn_dense_dx_dact_gather_f32(const float* grad, const float* poo
                 "kgcn_dense_dx_dact_f32)", (long long)m, din, dout);
   if (!pooled_grad || n_nodes <= 0 || m % n_nodes != 0)
     return fail("kgcn_dense_dx_dact_gather_f32: pooled gradient / %d nodes per graph do not match %lld rows", n_nodes, (long long)m);
+  if (pooled_ld < dout || pooled_ld % 4 != 0) return fail("kgcn_dense_dx_dact_gather_f32: pooled_ld=%lld (>= dout, a multiple of 4)", (long long)pooled_ld);
   if (!act_out || !w || !dx || !dpre) return fail("kgcn_dense_dx_dact_gather_f32: NULL operand");
   if (dpre == grad) return fail("kgcn_dense_dx_dact_gather_f32: dpre must not alias grad");
   if (ld < dout || dx_ld < din || w_ld < dout) return fail("kgcn_dense_dx_dact_gather_f32: leading dimension too small");
   if (!table || table_bytes < wtable_bytes(dout, din)) return fail("kgcn_dense_dx_dact_gather_f32: table / workspace too small");
   if (!table_ready) launch_wtable_split(w, (long)w_ld, 1, dout, din, table, as_stream(stream));
   const int rc = launch_gemm3_dx_dact(grad, act_out, dpre, (long)m, dout, (long)ld, table, dx, din, (long)dx_ld, act,
-                                      as_stream(stream), pooled_grad, n_nodes);
+                                      as_stream(stream), pooled_grad, n_nodes, (long)pooled_ld);
   if (rc < 0) return fail("kgcn_dense_dx_dact_gather_f32: operands must be 16-byte aligned with ld %% 4 == 0");
   return rc;
 }

@@ -35,7 +35,7 @@ bool gemmh_fwd_ok(const float* x, long m, int din, long x_ld, int dout);
 int launch_gemmh_fwd(const float* x, long m, int din, long x_ld, const void* tabh, const float* bias, float* y, int dout,
                      long y_ld, int act, hipStream_t s);
 int launch_gemmh_dx_dact(const float* grad, const float* act_out, float* dpre, long m, int k, long ld, const void* tabh,
-                         float* dx, int n, long dx_ld, int dact, hipStream_t s, const float* pooled_grad, int n_nodes);
+                         float* dx, int n, long dx_ld, int dact, hipStream_t s, const float* pooled_grad, int n_nodes, long pooled_ld);
 int64_t wtable_bf16_bytes(int din, int dout);
 
 #ifdef KGCN_PROBE   // development: per-workgroup cycle sums per phase (tools/gemm3_probe.py)
@@ -560,15 +560,16 @@ int launch_gemm3_fwd(const float* x, long m, int din, long x_ld, const float* w,
 // shape / alignment is not one the fused form takes (the caller then runs the activation backward on its own).
 // pooled_grad != nullptr: gathered gradient (see G3Dact), `grad` may then be nullptr (nothing handed on besides the read-out)
 int launch_gemm3_dx_dact(const float* grad, const float* act_out, float* dpre, long m, int k, long ld, const void* table,
-                         float* dx, int n, long dx_ld, int dact, hipStream_t s, const float* pooled_grad, int n_nodes) {
+                         float* dx, int n, long dx_ld, int dact, hipStream_t s, const float* pooled_grad, int n_nodes, long pooled_ld) {
+  if (pooled_ld <= 0) pooled_ld = k;                    // contiguous [graphs, k]
   const bool ok = (k % 4 == 0) && (ld % 4 == 0) && (!grad || aligned16(grad)) && aligned16(act_out) && aligned16(dpre) && table &&
                   dact != KGCN_ACT_NONE && dpre != grad && (grad || pooled_grad) &&
-                  (!pooled_grad || (aligned16(pooled_grad) && n_nodes > 0));
+                  (!pooled_grad || (aligned16(pooled_grad) && n_nodes > 0 && pooled_ld % 4 == 0 && pooled_ld >= k));
   if (!ok) return -1;
   static const char* hknob = dev_knob("KGCN_GEMMH");
   if (!(hknob && !strchr(hknob, 'd'))) {
     const int rc = launch_gemmh_dx_dact(grad, act_out, dpre, m, k, ld, static_cast<const char*>(table) + wtable_bf16_bytes(k, n), dx,
-                                        n, dx_ld, dact, s, pooled_grad, n_nodes);
+                                        n, dx_ld, dact, s, pooled_grad, n_nodes, pooled_ld);
     if (rc >= 0) return rc;
   }
   G3Dact da;
@@ -576,7 +577,7 @@ int launch_gemm3_dx_dact(const float* grad, const float* act_out, float* dpre, l
   da.ydiff = act_out - base;
   da.pdiff = dpre - base;
   da.bc = pooled_grad;
-  da.bc_ld = k;
+  da.bc_ld = pooled_ld;
   da.bc_n = n_nodes > 0 ? n_nodes : 1;
   da.bc_only = grad ? 0 : 1;
   da.c0 = dact == KGCN_ACT_TANH ? 1.f : 0.f;

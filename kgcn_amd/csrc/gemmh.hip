@@ -352,17 +352,17 @@ int launch_gemmh_fwd(const float* x, long m, int din, long x_ld, const void* tab
 // output width (the contraction), n = its input width; `tabh` = the f16 table of W^T.  Returns -1 when the operands do not
 // fit the kernel (the caller falls back to gemm3 / the unfused route).
 int launch_gemmh_dx_dact(const float* grad, const float* act_out, float* dpre, long m, int k, long ld, const void* tabh,
-                         float* dx, int n, long dx_ld, int dact, hipStream_t s, const float* pooled_grad, int n_nodes) {
+                         float* dx, int n, long dx_ld, int dact, hipStream_t s, const float* pooled_grad, int n_nodes, long pooled_ld) {
   const float* base = grad ? grad : act_out;
   if (!(gemmh_fwd_ok(base, m, k, ld, n) && (!grad || aligned16(grad)) && aligned16(act_out) && aligned16(dpre) && tabh &&
         dact != KGCN_ACT_NONE && dpre != grad && (grad || pooled_grad) &&
-        (!pooled_grad || (aligned16(pooled_grad) && n_nodes > 0))))
+        (!pooled_grad || (aligned16(pooled_grad) && n_nodes > 0 && pooled_ld % 4 == 0))))
     return -1;
   GhDact da;
   da.ydiff = act_out - base;
   da.pdiff = dpre - base;
   da.bc = pooled_grad;
-  da.bc_ld = k;
+  da.bc_ld = pooled_ld;
   da.bc_n = n_nodes > 0 ? n_nodes : 1;
   da.bc_only = grad ? 0 : 1;
   da.c0 = dact == KGCN_ACT_TANH ? 1.f : 0.f;

@@ -23,7 +23,7 @@ int fail(const char* fmt, ...) {
 template <int VEC>
 __global__ __launch_bounds__(256) void gather_fwd_kernel(const float* __restrict__ x, long batch,
                                                          int n_nodes, int d,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, long out_ld) {
   const int dv = d / VEC;
   const long total = batch * dv;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(const float* __restrict
       }
     }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) out[b * d + c + j] = acc[j];
+    for (int j = 0; j < VEC; ++j) out[b * out_ld + c + j] = acc[j];
   }
 }
 
@@ -154,23 +154,35 @@ extern "C" int kgcn_abi_version(void) { return KGCN_HIP_ABI_VERSION; }
 extern "C" const char* kgcn_last_error(void) { return error_buffer(); }
 extern "C" const char* kgcn_build_arch(void) { return "gfx950"; }
 
-extern "C" int kgcn_graph_gather_fwd_f32(const float* x, int64_t batch, int32_t n_nodes, int32_t d,
-                                         float* out, void* stream) {
-  if (batch < 0 || n_nodes < 0 || d < 0) return fail("kgcn_graph_gather_fwd_f32: negative shape");
+static int gather_fwd_impl(const char* who, const float* x, int64_t batch, int32_t n_nodes, int32_t d, float* out, int64_t out_ld,
+                           void* stream) {
+  if (batch < 0 || n_nodes < 0 || d < 0) return fail("%s: negative shape", who);
   if (batch == 0 || d == 0) return 0;
-  if (!out || (!x && n_nodes > 0)) return fail("kgcn_graph_gather_fwd_f32: NULL operand");
-  const bool v4 = (d % 4 == 0) && aligned16(x) && aligned16(out);
-  const bool v2 = (d % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) % 8 == 0);
+  if (!out || (!x && n_nodes > 0)) return fail("%s: NULL operand", who);
+  if (out_ld < d) return fail("%s: out_ld=%lld smaller than d=%d", who, (long long)out_ld, d);
+  const bool v4 = (d % 4 == 0) && (out_ld % 4 == 0) && aligned16(x) && aligned16(out);
+  const bool v2 = (d % 2 == 0) && (out_ld % 2 == 0) &&
+                  ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) % 8 == 0);
   if (v4)
     hipLaunchKernelGGL((gather_fwd_kernel<4>), dim3(grid_for(batch * (d / 4))), dim3(256), 0,
-                       as_stream(stream), x, (long)batch, n_nodes, d, out);
+                       as_stream(stream), x, (long)batch, n_nodes, d, out, (long)out_ld);
   else if (v2)
     hipLaunchKernelGGL((gather_fwd_kernel<2>), dim3(grid_for(batch * (d / 2))), dim3(256), 0,
-                       as_stream(stream), x, (long)batch, n_nodes, d, out);
+                       as_stream(stream), x, (long)batch, n_nodes, d, out, (long)out_ld);
   else
     hipLaunchKernelGGL((gather_fwd_kernel<1>), dim3(grid_for(batch * d)), dim3(256), 0,
-                       as_stream(stream), x, (long)batch, n_nodes, d, out);
+                       as_stream(stream), x, (long)batch, n_nodes, d, out, (long)out_ld);
   return check_launch("gather_fwd_kernel");
+}
+
+extern "C" int kgcn_graph_gather_fwd_f32(const float* x, int64_t batch, int32_t n_nodes, int32_t d,
+                                         float* out, void* stream) {
+  return gather_fwd_impl("kgcn_graph_gather_fwd_f32", x, batch, n_nodes, d, out, d, stream);
+}
+
+extern "C" int kgcn_graph_gather_fwd_ld_f32(const float* x, int64_t batch, int32_t n_nodes, int32_t d, float* out,
+                                            int64_t out_ld, void* stream) {
+  return gather_fwd_impl("kgcn_graph_gather_fwd_ld_f32", x, batch, n_nodes, d, out, out_ld, stream);
 }
 
 extern "C" int kgcn_graph_gather_bwd_f32(const float* dout_grad, int64_t batch, int32_t n_nodes,

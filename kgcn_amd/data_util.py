@@ -440,6 +440,13 @@ class BlockDiagonalBatch:
         self.features = features
         self.sizes = sizes
         self.segments = segments        # BatchedCSR [1 graph, B rows, sumN cols] of ones
+        self._segments_adj = None
+
+    def segments_adjacency(self):
+        """The indicator as a one-channel BatchedAdjacency (what ops.bconv takes: aggregation with an activation epilogue)."""
+        if self._segments_adj is None:
+            self._segments_adj = BatchedAdjacency([self.segments])
+        return self._segments_adj
 
 
 def block_diagonal_batch(size, adj_row, adj_column, adj_values, adj_elem_len, adj_degrees, feature_row,

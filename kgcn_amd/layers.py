@@ -230,13 +230,14 @@ class GraphDense(nn.Module):
         return ops.activation(y, self.activation)          # the model's activation follows the zero padding
 
 
-def graph_dense_gather(dense_layer, inputs):
+def graph_dense_gather(dense_layer, inputs, join=None, join_col=0):
     """GraphDense (with its fused activation) + GraphGather as one op (ops.dense_gather): -> (layer output [B, N, D], pooled
     [B, D]).  The backward of a wide layer forms d pooled's broadcast inside its dX GEMM.  `dense_layer`: a GraphDense applied
-    without enabled_node_nums."""
+    without enabled_node_nums.  join / join_col: the read-out goes into a column block of the buffer `join` (ops.join_columns)."""
     if not dense_layer.built:
         dense_layer.build(inputs.shape, inputs.device)
-    return ops.dense_gather(inputs, dense_layer.kernel, dense_layer.bias, activation=dense_layer.activation)
+    return ops.dense_gather(inputs, dense_layer.kernel, dense_layer.bias, activation=dense_layer.activation, join=join,
+                            join_col=join_col)
 
 
 class GINAggregate(nn.Module):

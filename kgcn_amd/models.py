@@ -87,6 +87,9 @@ class GCN(nn.Module):
         return self.out(layer)
 
 
+_GIN_JOIN = __import__("os").environ.get("KGCN_GIN_JOIN") != "0"          # (development A/B: "0" = torch.cat of the read-outs)
+
+
 class GIN(nn.Module):
     """example_model/model_gin.py:29-78."""
 
@@ -102,13 +105,17 @@ class GIN(nn.Module):
         adjs = layers._pack(adjs, features)
         layer = features
         outs = []
+        # tf.concat of the two read-outs (model_gin.py:61): each is written into its column block of ONE buffer (and its gradient
+        # read out of the column block of d buffer): no concatenation pass, no copies of the strided gradient blocks
+        width = self.dense[1].output_dim
+        joined = features.new_empty((features.shape[0], 2 * width)) if width % 4 == 0 and _GIN_JOIN else None
         for blk in range(2):
             layer = self.agg[blk](layer, adj=adjs)
             layer = self.dense[2 * blk](layer)
             # the block output is read out (and, for block 0, passed on): d pooled joins the gradient inside the layer's dX GEMM
-            layer, pooled = layers.graph_dense_gather(self.dense[2 * blk + 1], layer)
+            layer, pooled = layers.graph_dense_gather(self.dense[2 * blk + 1], layer, join=joined, join_col=blk * width)
             outs.append(pooled)
-        return self.out(torch.cat(outs, dim=1))
+        return self.out(torch.cat(outs, dim=1) if joined is None else ops.join_columns(joined, outs))
 
 
 def masked_sigmoid_ce(logits, labels, mask, mask_label, pos_weight=None):
@@ -181,9 +188,10 @@ class SparseGCN(nn.Module):
                 net = self.bns[i](net)
             if conv.activation is None:
                 net = ops.activation(net, "relu")
-        net = self.bn(self.dense(net))[0]
-        net = ops.bspmm(batch.segments, net.unsqueeze(0))       # per-molecule node sum (:83-94)
-        net = torch.tanh(net.reshape(len(batch.sizes), -1))
+        net = self.bn(self.dense(net))
+        net = net.reshape(net.shape[1], net.shape[2])           # (a view: indexing [0] costs a zero fill + a copy in backward)
+        # per-molecule node sum (:83-94) with tf.tanh (:95) in the aggregation's epilogue; its derivative rides in the adjoint
+        net = ops.bconv(batch.segments_adjacency(), net, net.shape[1], activation="tanh")
         return self.out(net)                                    # probabilities = softmax(logits)
 
 

@@ -545,7 +545,9 @@ class _DenseGather(torch.autograd.Function):
     (kgcn_dense_dx_dact_gather_f32) instead of being written out by kgcn_graph_gather_bwd(_add)_f32 and read back."""
 
     @staticmethod
-    def forward(ctx, x2d, w, bias, act, T, N):
+    def forward(ctx, x2d, w, bias, act, T, N, join=None, join_col=0):
+        # join: a [T, wide] buffer whose columns join_col .. join_col + dout receive the read-out (the concatenation of several
+        # read-outs, model_gin.py:61, without a concatenation pass: see join_columns)
         x2d, w = _f32c(x2d, "x"), _f32c(w, "w")
         m, din = x2d.shape
         dout = w.shape[1]
@@ -562,8 +564,16 @@ class _DenseGather(torch.autograd.Function):
             wsb, wsp = _dense_ws(din, dout, x2d.device)
             check(lib.kgcn_dense_fwd_ws_f32(ptr(x2d), m, din, din, ptr(w), dout, 0, ptr(b), ptr(y), dout,
                                             dout, int(act), ptr(wsp), wsb, current_stream()), "kgcn_dense_fwd_ws_f32")
-        pooled = torch.empty((T, dout), device=x2d.device, dtype=torch.float32)
-        check(lib.kgcn_graph_gather_fwd_f32(ptr(y), T, N, dout, ptr(pooled), current_stream()), "kgcn_graph_gather_fwd_f32")
+        if join is None:
+            pooled = torch.empty((T, dout), device=x2d.device, dtype=torch.float32)
+            check(lib.kgcn_graph_gather_fwd_f32(ptr(y), T, N, dout, ptr(pooled), current_stream()), "kgcn_graph_gather_fwd_f32")
+        else:
+            if join.dtype != torch.float32 or join.dim() != 2 or join.shape[0] != T or not join.is_contiguous() or \
+                    join_col < 0 or join_col + dout > join.shape[1]:
+                raise _lib.KgcnHipError("join buffer %s does not take a [%d, %d] read-out at column %d" % (tuple(join.shape), T, dout, join_col))
+            pooled = join[:, join_col:join_col + dout]
+            check(lib.kgcn_graph_gather_fwd_ld_f32(ptr(y), T, N, dout, pooled.data_ptr(), join.shape[1], current_stream()),
+                  "kgcn_graph_gather_fwd_ld_f32")
         ctx.act, ctx.T, ctx.N = int(act), int(T), int(N)
         ctx.save_for_backward(x2d, w, y)
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
@@ -580,9 +590,17 @@ class _DenseGather(torch.autograd.Function):
         dout = w.shape[1]
         T, N = ctx.T, ctx.N
         if gy is None and gp is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         gy = None if gy is None else _f32c(gy.reshape(m, dout), "grad")
-        gp = None if gp is None else _f32c(gp, "grad")
+        gp_ld = dout
+        if gp is not None:
+            # a column block of a wider gradient (the backward of join_columns / torch.cat) is read where it lies
+            strided = gp.dtype == torch.float32 and gp.dim() == 2 and gp.stride(1) == 1 and gp.stride(0) % 4 == 0 and \
+                gp.stride(0) >= dout and gp.data_ptr() % 16 == 0
+            if strided and ctx.act and ctx.needs_input_grad[0] and lib.kgcn_dense_dx_dact_gather_supported(m, din, dout):
+                gp_ld = gp.stride(0)
+            else:
+                gp = _f32c(gp, "grad")
         dx = dw = db = None
         need_x = ctx.needs_input_grad[0]
         if gp is not None and ctx.act and need_x and lib.kgcn_dense_dx_dact_gather_supported(m, din, dout):
@@ -593,7 +611,7 @@ class _DenseGather(torch.autograd.Function):
             if tab is None:
                 tb, tab = _dense_ws(dout, din, x2d.device)
                 ready = 0
-            check(lib.kgcn_dense_dx_dact_gather_f32(ptr(gy), ptr(gp), N, ptr(y), m, dout, dout, ptr(w), dout, din, ptr(dx), din,
+            check(lib.kgcn_dense_dx_dact_gather_f32(ptr(gy), gp.data_ptr(), gp_ld, N, ptr(y), m, dout, dout, ptr(w), dout, din, ptr(dx), din,
                                                     ctx.act, ptr(dpre), ptr(tab), tb, ready, current_stream()),
                   "kgcn_dense_dx_dact_gather_f32")
             g = dpre
@@ -626,14 +644,44 @@ class _DenseGather(torch.autograd.Function):
         need_b = ctx.bias_shape is not None and ctx.needs_input_grad[2]
         if need_w or need_b:
             dw, db = _Dense._wgrad(ctx, x2d, w, g, y, m, din, dout, need_w, need_b, False)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def dense_gather(x3d, w, bias=None, activation=None):
+def dense_gather(x3d, w, bias=None, activation=None, join=None, join_col=0):
     """GraphDense followed by GraphGather on [T, N, din] inputs: -> (y [T, N, dout], pooled [T, dout]); use y only if the layer
-    output is also handed on."""
+    output is also handed on.  join / join_col: write the read-out into columns join_col.. of the [T, wide] buffer `join`
+    (pooled is then that column block; combine the blocks with join_columns)."""
     T, N, din = x3d.shape
-    return _DenseGather.apply(x3d.reshape(T * N, din), w, bias, act_code(activation), T, N)
+    return _DenseGather.apply(x3d.reshape(T * N, din), w, bias, act_code(activation), T, N, join, int(join_col))
+
+
+class _JoinColumns(torch.autograd.Function):
+    """tf.concat(parts, axis=1) of column blocks that were WRITTEN INTO `buf` by their producers (dense_gather(join=buf)): nothing
+    is copied, the gradient of part i is the column block i of the gradient -- a strided view its consumer reads in place."""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        col = 0
+        for p in parts:
+            if p.data_ptr() != buf.data_ptr() + 4 * col or p.shape[0] != buf.shape[0] or p.stride(0) != buf.stride(0):
+                raise _lib.KgcnHipError("join_columns: part at column %d was not produced into the join buffer" % col)
+            col += p.shape[1]
+        if col != buf.shape[1]:
+            raise _lib.KgcnHipError("join_columns: the parts cover %d of %d columns" % (col, buf.shape[1]))
+        ctx.widths = [p.shape[1] for p in parts]
+        return buf.view(buf.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        out, col = [], 0
+        for wd in ctx.widths:
+            out.append(g[:, col:col + wd])
+            col += wd
+        return (None,) + tuple(out)
+
+
+def join_columns(buf, parts):
+    return _JoinColumns.apply(buf, *parts)
 
 
 # -------------------------------------------------------------------------------------------------

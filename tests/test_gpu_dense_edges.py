@@ -355,3 +355,35 @@ def test_dense_gather_gradient_joins_inside_the_dx_gemm(act, T, N, din, dout, te
     close(tx.grad, (dpre @ w.astype(np.float64).T).reshape(T, N, din), atol=1e-5, rel=2e-5, what="dense_gather d inputs")
     close(tw.grad, x.astype(np.float64).reshape(T * N, din).T @ dpre, atol=1e-4, rel=2e-5, what="dense_gather dW")
     close(tb.grad, dpre.sum(0), atol=1e-4, rel=2e-5, what="dense_gather dbias")
+
+
+@pytest.mark.parametrize("act,T,N,d", [("relu", 500, 10, 256), ("sigmoid", 130, 32, 256), ("relu", 60, 10, 52)])
+def test_read_outs_joined_in_one_buffer_equal_concatenation(act, T, N, d):
+    """model_gin.py:61 concatenates the read-outs of its blocks.  ops.dense_gather(join=buf, join_col=..) writes each read-out into its
+    column block of one buffer and ops.join_columns hands the buffer on: the same values as torch.cat, and the gradient of every
+    block -- a strided column block of d buffer, read in place by kgcn_dense_dx_dact_gather_f32 -- the same bits as through the
+    concatenation (same kernels, same operands; only the pooled gradient's row stride differs)."""
+    from kgcn_amd import ops
+    rng = np.random.default_rng(T + d)
+    xs = [rng.standard_normal((T, N, d)).astype(np.float32) for _ in range(2)]
+    ws = [(rng.standard_normal((d, d)) / np.sqrt(d)).astype(np.float32) for _ in range(2)]
+    bs = [rng.standard_normal(d).astype(np.float32) for _ in range(2)]
+    head = t32(rng.standard_normal((2 * d, 3)))
+    res = []
+    for joined in (False, True):
+        tx = [t32(a).requires_grad_(True) for a in xs]
+        tw = [t32(a).requires_grad_(True) for a in ws]
+        tb = [t32(a).requires_grad_(True) for a in bs]
+        buf = torch.empty((T, 2 * d), device=dev()) if joined else None
+        parts, ys = [], []
+        for i in range(2):
+            y, p = ops.dense_gather(tx[i], tw[i], tb[i], activation=act, join=buf, join_col=i * d)
+            parts.append(p); ys.append(y)
+        cat = ops.join_columns(buf, parts) if joined else torch.cat(parts, dim=1)
+        loss = (torch.tanh(cat @ head)).sum() + (ys[0] * 0.5).sum()          # block 0 is handed on as well
+        loss.backward()
+        res.append([cat.detach().clone()] + [t.grad.clone() for t in tx + tw + tb])
+    for a, b in zip(*res):
+        assert torch.equal(a, b), float((a - b).abs().max())
+    with pytest.raises(Exception, match="join"):
+        ops.join_columns(torch.empty((T, 2 * d), device=dev()), [res[0][0][:, :d], res[0][0][:, d:]])

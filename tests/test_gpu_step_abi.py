@@ -105,7 +105,7 @@ def test_step_entry_points_validate_before_launching():
     tab = torch.zeros(int(lib.kgcn_dense_fwd_workspace_bytes(256, 256)) // 4, device=dev())
     args = dict(m=4096, dout=256, ld=256, w_ld=256, din=256, dx_ld=256)
     def call(grad, gp, n_nodes, act=2, m=4096):
-        return lib.kgcn_dense_dx_dact_gather_f32(ptr(grad), ptr(gp), n_nodes, ptr(big), m, 256, 256, ptr(big), 256, 256, ptr(big), 256,
+        return lib.kgcn_dense_dx_dact_gather_f32(ptr(grad), ptr(gp), 256, n_nodes, ptr(big), m, 256, 256, ptr(big), 256, 256, ptr(big), 256,
                                                  act, ptr(big.clone()), ptr(tab), tab.numel() * 4, 0, current_stream())
     assert call(None, None, 10) != 0 and b"pooled gradient" in lib.kgcn_last_error()
     assert call(None, big, 7) != 0                                     # 4096 rows are not whole graphs of 7 nodes

@@ -34,7 +34,7 @@ def _products(name, a):
     if name in ("kgcn_dense_fwd_f32", "kgcn_dense_fwd_act_f32", "kgcn_dense_fwd_ws_f32", "kgcn_dense_fwd_tab_f32"):
         return q(0, a[1], a[2], a[9])
     if name == "kgcn_dense_dx_dact_gather_f32":
-        return q(1, a[4], a[5], a[9])
+        return q(1, a[5], a[6], a[10])
     if name in ("kgcn_dense_dx_dact_f32", "kgcn_dense_dx_dact_tab_f32"):
         return q(1, a[2], a[3], a[7])
     if name == "kgcn_dense_wgrad_f32":
@@ -92,7 +92,7 @@ def _cost(name, a):
         m, din, dout = a[1], a[2], a[9]
         return 4 * (m * din + m * dout + din * dout), 2 * m * din * dout, "m=%d %d->%d%s" % (m, din, dout, " T" if a[6] else "")
     if name == "kgcn_dense_dx_dact_gather_f32":
-        m, dout, din = a[4], a[5], a[9]
+        m, dout, din = a[5], a[6], a[10]
         return 4 * m * (dout * (3 if a[0] else 2) + din), 2 * m * din * dout, "m=%d %d<-%d gathered%s" % (m, din, dout, "+g" if a[0] else "")
     if name in ("kgcn_dense_dx_dact_f32", "kgcn_dense_dx_dact_tab_f32"):
         m, dout, din = a[2], a[3], a[7]
@@ -115,7 +115,7 @@ def _cost(name, a):
         c = _csr(a[0]); d = a[3]
         b, f = _spmm(c, d)
         return b, f * a[1], "C=%d T=%d N=%d d=%d" % (a[1], c.num_graphs, c.rows, d)
-    if name == "kgcn_graph_gather_fwd_f32":
+    if name in ("kgcn_graph_gather_fwd_f32", "kgcn_graph_gather_fwd_ld_f32"):
         B, N, d = a[1], a[2], a[3]
         return 4 * (B * N * d + B * d), B * N * d, "B=%d N=%d d=%d" % (B, N, d)
     if name == "kgcn_graph_gather_bwd_f32":

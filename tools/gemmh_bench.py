@@ -94,7 +94,7 @@ for M in [int(r) for r in args.rows.split(",")]:
         if M % 10 == 0 and lib.kgcn_dense_dx_dact_gather_supported(M, din, dout):
             pooled = torch.randn((M // 10, dout), device=dev, generator=g) * 1e-3
             for with_g, name in ((True, "dx_gather"), (False, "dx_gather_only")):
-                f = lambda: check(lib.kgcn_dense_dx_dact_gather_f32(ptr(dy) if with_g else None, ptr(pooled), 10, ptr(y), M, dout,
+                f = lambda: check(lib.kgcn_dense_dx_dact_gather_f32(ptr(dy) if with_g else None, ptr(pooled), dout, 10, ptr(y), M, dout,
                                                                     dout, ptr(w), dout, din, ptr(dx), din, 1, ptr(dpre), ptr(ws2),
                                                                     wsb2, 0, current_stream()))
                 f(); torch.cuda.synchronize()
