@@ -271,3 +271,27 @@ def test_tiny_ragged_batch_takes_the_unfused_route():
     ref = 1 / (1 + np.exp(-K.graphconv_fwd_fast(x, adjs, [conv.w[0].detach().cpu().numpy()], [conv.bias[0].detach().cpu().numpy()])))
     valid = (np.arange(8)[None, :] < sizes[:, None])[:, :, None]
     close(rb.expand(out, fill="zero").cpu().numpy() * valid, ref * valid, atol=2e-6, what="tiny ragged GraphConv")
+
+
+@pytest.mark.parametrize("T", [1, 63, 1024, 1025, 4096, 8192, 8193, 20000])
+def test_plan_scans_one_launch_and_three_stage_forms(T):
+    """kgcn_ragged_plan: graph_ptr / entry_ptr = exclusive scans of the valid rows / stored entries of the selected graphs (with
+    dummy selections and sizes beyond the padded size) -- the one-workgroup form (<= 8,192 graphs) and the three-stage form."""
+    from kgcn_amd import data_util as D
+    from kgcn_amd._lib import lib, ptr, check, current_stream
+    rng = np.random.default_rng(T)
+    G, N = 500, 12
+    chans, _ = D.build_adjs({"dense_adj": (rng.random((G, N, N)) < 0.2).astype(np.int64), "max_node_num": N})
+    src = D.DeviceGraphDataset(chans, None, device=dev()).channels[0]
+    sizes = rng.integers(-2, N + 4, size=G).astype(np.int32)
+    sel = rng.integers(-1, G, size=T).astype(np.int32)
+    rp = src.rowptr.cpu().numpy().astype(np.int64)
+    n = np.where(sel >= 0, np.clip(sizes[np.maximum(sel, 0)], 0, N), 0)
+    e = np.where(sel >= 0, rp[np.maximum(sel, 0) * N + n] - rp[np.maximum(sel, 0) * N], 0)
+    i32 = dict(dtype=torch.int32, device=dev())
+    gp, ep = torch.full((T + 1,), -7, **i32), torch.full((T + 1,), -7, **i32)
+    ws = torch.empty(max(lib.kgcn_ragged_workspace_bytes(T), 8) // 4, **i32)
+    check(lib.kgcn_ragged_plan(src.desc(), ptr(torch.tensor(sizes, **i32)), ptr(torch.tensor(sel, **i32)), T, ptr(gp), ptr(ep),
+                               ptr(ws), ws.numel() * 4, current_stream()))
+    assert np.array_equal(gp.cpu().numpy(), np.concatenate([[0], np.cumsum(n)]))
+    assert np.array_equal(ep.cpu().numpy(), np.concatenate([[0], np.cumsum(e)]))
