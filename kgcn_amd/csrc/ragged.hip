@@ -76,56 +76,10 @@ __global__ __launch_bounds__(kRScan) void ragged_plan_count_kernel(
   if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-// Batches of up to 8,192 graphs (cfg4: 4,096): the whole plan in ONE launch of one 1,024-thread workgroup -- the three stages
-// below are three dependent ~5 us launches at the head of every training step.  Thread i owns graphs i, i + 1024, ...: all
-// their loads are requested first, then one workgroup scan per 1,024 graphs with a running carry.
-constexpr int kPlanOne = 1024, kPlanOneIter = 8;
-__global__ __launch_bounds__(kPlanOne) void ragged_plan_one_kernel(
-    const int* __restrict__ src_rowptr, const int* __restrict__ sizes, const int* __restrict__ sel, int T, int M,
-    int* __restrict__ graph_ptr, int* __restrict__ entry_ptr) {
-  __shared__ int2 wave_tot[kPlanOne / kWave];
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  int2 v[kPlanOneIter];
-#pragma unroll
-  for (int i = 0; i < kPlanOneIter; ++i) {
-    const int t = i * kPlanOne + threadIdx.x;
-    v[i] = make_int2(0, 0);
-    if (t < T) {
-      const int g = sel ? sel[t] : t;
-      if (g >= 0) {
-        const int n = clampi(sizes[g], 0, M);
-        const int* rp = src_rowptr + (long)g * M;
-        v[i] = make_int2(n, rp[n] - rp[0]);
-      }
-    }
-  }
-  int2 carry = make_int2(0, 0);
-#pragma unroll
-  for (int i = 0; i < kPlanOneIter; ++i) {
-    if (i * kPlanOne >= T) break;                       // uniform
-    int2 inc = v[i];
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const int ux = __shfl_up(inc.x, o, kWave), uy = __shfl_up(inc.y, o, kWave);
-      if (lane >= o) { inc.x += ux; inc.y += uy; }
-    }
-    if (lane == kWave - 1) wave_tot[wave] = inc;
-    __syncthreads();
-    int2 base = carry, tot = make_int2(0, 0);
-#pragma unroll
-    for (int w = 0; w < kPlanOne / kWave; ++w) {
-      const int2 tw = wave_tot[w];
-      if (w < wave) { base.x += tw.x; base.y += tw.y; }
-      tot.x += tw.x; tot.y += tw.y;
-    }
-    __syncthreads();
-    const int t = i * kPlanOne + threadIdx.x;
-    if (t < T) { graph_ptr[t] = base.x + inc.x - v[i].x; entry_ptr[t] = base.y + inc.y - v[i].y; }
-    carry.x += tot.x; carry.y += tot.y;
-  }
-  if (threadIdx.x == 0) { graph_ptr[T] = carry.x; entry_ptr[T] = carry.y; }
-}
-
+// (One launch for the whole plan -- a single 1,024-thread workgroup that walks selection -> size -> row offsets for 8 graphs per
+// thread and scans -- was tried for batches of <= 8,192 graphs: 10.6 us warm against 12.8 for the three launches, but 34 us inside
+// the step, where the dataset's row offsets are cold: 8,192 scattered loads through ONE CU's address translation.  The count
+// stage's 16+ workgroups spread them over as many CUs.)
 // stage 2: one workgroup scans the block totals; the grand totals go to graph_ptr[T] / entry_ptr[T]
 __global__ __launch_bounds__(kRScan) void ragged_plan_scan_kernel(int2* __restrict__ block_sums, int nb,
                                                                   int* __restrict__ rows_total, int* __restrict__ entries_total) {
@@ -389,11 +343,6 @@ extern "C" int kgcn_ragged_plan(const kgcn_csr_batch* src, const int32_t* sizes,
   const int64_t need = kgcn_ragged_workspace_bytes(num_sel);
   if (!workspace || workspace_bytes < need)
     return fail("kgcn_ragged_plan: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
-  if (num_sel <= kPlanOne * kPlanOneIter) {
-    hipLaunchKernelGGL(ragged_plan_one_kernel, dim3(1), dim3(kPlanOne), 0, s, src->rowptr, sizes, sel, num_sel, src->rows, graph_ptr,
-                       entry_ptr);
-    return check_launch("ragged_plan_one_kernel");
-  }
   const int nb = (num_sel + kRScan - 1) / kRScan;
   int2* bs = static_cast<int2*>(workspace);
   hipLaunchKernelGGL(ragged_plan_count_kernel, dim3(nb), dim3(kRScan), 0, s, src->rowptr, sizes, sel, num_sel, src->rows,

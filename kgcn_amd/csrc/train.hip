@@ -148,25 +148,15 @@ __device__ __forceinline__ void adam_tf_update(float& p, float& m, float& v, flo
   p = __builtin_fmaf(-lr_t, m / (__builtin_sqrtf(v) + eps), p);
 }
 
-// The step counter t advances inside the update kernel (a one-thread launch of its own cost 4 us per step: 3.5 % of cfg1's step).
-// Every workgroup reads t when it starts; when it is done it adds 1 << 40 to the counter, and the workgroup that finds all the
-// others there takes the arrivals out again and adds the tick.  No workgroup can still be about to read t at that point, and
-// between launches the counter holds t alone (t < 2^40).
-constexpr long long kAdamArrive = 1LL << 40;
-__device__ __forceinline__ long long adam_step_of(const long long* counter) { return (*counter & (kAdamArrive - 1)) + 1; }
-__device__ __forceinline__ void adam_arrive(long long* counter, long long nblocks, bool tick) {
-  __syncthreads();                                                       // this workgroup's lanes are done
-  if (tick && threadIdx.x == 0) {
-    const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(counter), (unsigned long long)kAdamArrive);
-    if ((long long)(old >> 40) == nblocks - 1)
-      atomicAdd(reinterpret_cast<unsigned long long*>(counter), (unsigned long long)(1 - nblocks * kAdamArrive));
-  }
-}
+// (The step counter is advanced by a one-thread launch behind the update.  Advancing it from the update kernel's last workgroup --
+// every workgroup adds an arrival to the counter's upper bits, the one that completes the count takes them out and ticks -- was
+// tried: 3,584 same-address atomics at ~12 ns each made the update 48 us instead of 8 + 4, profiles/r04_p_cfg4_rocprof.txt.)
+__device__ __forceinline__ long long adam_step_of(const long long* counter) { return *counter + 1; }
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                       float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
-                                                      long long* __restrict__ counter) {
+                                                      const long long* __restrict__ counter) {
   __shared__ float lr_s;
   if (threadIdx.x == 0) {
     const double t = (double)adam_step_of(counter);
@@ -197,7 +187,6 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, con
       p[i] = pj; m[i] = mj; v[i] = vj;
     }
   }
-  adam_arrive(counter, (long long)gridDim.x, true);
 }
 
 __global__ void adam_tick_kernel(long long* counter) { *counter += 1; }
@@ -296,7 +285,7 @@ struct AdamSegs {
 
 __global__ __launch_bounds__(256) void adam_tf_multi_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                             AdamSegs sg, float lr, float b1, float b2, float eps,
-                                                            long long* __restrict__ counter, int tick) {
+                                                            const long long* __restrict__ counter) {
   __shared__ float lr_s;
   if (threadIdx.x == 0) {
     const double t = (double)adam_step_of(counter);
@@ -313,7 +302,6 @@ __global__ __launch_bounds__(256) void adam_tf_multi_kernel(float* __restrict__ 
     adam_tf_update(pj, mj, vj, g[i], lr_t, b1, b2, c1, c2, eps);
     p[off + i] = pj; m[off + i] = mj; v[off + i] = vj;
   }
-  adam_arrive(counter, (long long)gridDim.x * gridDim.y, tick != 0);
 }
 
 extern "C" int kgcn_adam_tf_multi_f32(float* params, float* m, float* v, int64_t n, const kgcn_adam_segment* segments,
@@ -337,16 +325,12 @@ extern "C" int kgcn_adam_tf_multi_f32(float* params, float* m, float* v, int64_t
     }
     long blocks = (most + 255) / 256;
     if (blocks > 2L * kNumCU) blocks = 2L * kNumCU;
-    // (the launch that holds the last segments advances the step counter when its last workgroup is done)
     hipLaunchKernelGGL(adam_tf_multi_kernel, dim3((unsigned)blocks, cnt), dim3(256), 0, s, params, m, v, sg, lr, beta1, beta2, eps,
-                       reinterpret_cast<long long*>(step_counter), base + cnt >= num_segments ? 1 : 0);
+                       reinterpret_cast<const long long*>(step_counter));
     if (int rc = check_launch("adam_tf_multi_kernel")) return rc;
   }
-  if (num_segments == 0) {
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<long long*>(step_counter));
-    return check_launch("adam_tick_kernel");
-  }
-  return 0;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<long long*>(step_counter));
+  return check_launch("adam_tick_kernel");
 }
 
 extern "C" int kgcn_adam_tf_f32(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1,
@@ -360,14 +344,14 @@ extern "C" int kgcn_adam_tf_f32(float* params, const float* grads, float* m, flo
     long blocks = ((vec ? n / 4 : n) + 255) / 256;
     if (blocks > (long)kNumCU * 8) blocks = (long)kNumCU * 8;
     if (blocks < 1) blocks = 1;
-    long long* ctr = reinterpret_cast<long long*>(step_counter);
+    const long long* ctr = reinterpret_cast<const long long*>(step_counter);
     if (vec)
       hipLaunchKernelGGL(adam_tf_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, params, grads, m, v, (long)n, lr,
                          beta1, beta2, eps, ctr);
     else
       hipLaunchKernelGGL(adam_tf_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, params, grads, m, v, (long)n, lr,
                          beta1, beta2, eps, ctr);
-    return check_launch("adam_tf_kernel");              // (its last workgroup advances the step counter)
+    if (int rc = check_launch("adam_tf_kernel")) return rc;
   }
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<long long*>(step_counter));
   return check_launch("adam_tick_kernel");

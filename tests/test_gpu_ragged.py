@@ -274,9 +274,9 @@ def test_tiny_ragged_batch_takes_the_unfused_route():
 
 
 @pytest.mark.parametrize("T", [1, 63, 1024, 1025, 4096, 8192, 8193, 20000])
-def test_plan_scans_one_launch_and_three_stage_forms(T):
+def test_plan_scans_of_small_and_multi_block_selections(T):
     """kgcn_ragged_plan: graph_ptr / entry_ptr = exclusive scans of the valid rows / stored entries of the selected graphs (with
-    dummy selections and sizes beyond the padded size) -- the one-workgroup form (<= 8,192 graphs) and the three-stage form."""
+    dummy selections and sizes beyond the padded size), from one scan block to many."""
     from kgcn_amd import data_util as D
     from kgcn_amd._lib import lib, ptr, check, current_stream
     rng = np.random.default_rng(T)
