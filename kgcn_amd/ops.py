@@ -348,7 +348,11 @@ class WeightTables:
     the weight's torch version counter is the one seen at the refresh (copy_ / load_state_dict bump it); otherwise dense()
     splits on its own as before.  Only weights a dense() call touched since the previous refresh are split again (a second live
     model costs nothing).  Inside a captured hipGraph the refresh is part of the graph, so every replay rebuilds the
-    tables from the weights it is about to use."""
+    tables from the weights it is about to use.
+    WHO MUST CALL invalidate(): anything that writes a registered weight WITHOUT bumping its version counter between refresh() and
+    the forward pass of the same step -- writes through `.data` (p.data.copy_, dist.broadcast(p.data)), custom optimisers working on raw
+    pointers.  kgcn_amd.train.TFAdam does; torch.optim optimisers and copy_ / load_state_dict on the parameter itself bump the
+    counter.  A write that does neither makes dense() multiply with the tables of the OLD weights, with no error."""
 
     def __init__(self):
         self.epoch = 0

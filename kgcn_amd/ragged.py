@@ -113,8 +113,11 @@ def _blocks(graph_ptr, B, capacity, block_ptr):
 
 
 def default_capacity(sizes, batch_size, n_nodes):
-    """A row capacity that a batch of `batch_size` graphs drawn from a dataset with these sizes exceeds with negligible
-    probability (mean + 6 sigma of the sum: 1e-9 per batch; load() raises if it ever happens), rounded up to a multiple of 64, never above the padded row count + 1."""
+    """A row capacity that a batch of `batch_size` graphs drawn INDEPENDENTLY AND UNIFORMLY from a dataset with these sizes exceeds
+    with negligible probability (mean + 6 sigma of the sum: 1e-9 per batch), rounded up to a multiple of 64, never above the padded
+    row count + 1.  The assumption is the sampling: batches bucketed or sorted by size exceed it routinely, and
+    StaticRaggedBatch.stage() then raises ValueError (before anything is written) -- such callers pass
+    capacity=batch_size * n_nodes + 1 (the padded bound, always sufficient) to static_ragged_batch()."""
     sizes = np.asarray(sizes, np.float64)
     if sizes.size == 0:
         return 64
@@ -144,11 +147,20 @@ def compact(features, adj, enabled_node_nums, capacity=None, check=True):
         R = int(np.clip(sz, 0, N).sum())
     if sizes_dev.numel() != B:
         raise ValueError("enabled_node_nums has %d entries for a batch of %d graphs" % (sizes_dev.numel(), B))
+    if a.values is not None:
+        # differentiable adjacency values (integrated gradients over `adjs`, kgcn/visualization.py:207-210): the compact container
+        # would bake the stored values in and d values would silently be dropped -- that path stays on the padded layout
+        raise ValueError("the batch carries differentiable adjacency values: the ragged-compact layout has no d values path "
+                         "(build the model with ragged=False for integrated gradients over the adjacency)")
+    if R is None and (capacity is not None or not check):
+        # an explicit capacity must be checked BEFORE the device writes rows [0, R]: ragged_csr_kernel / ragged_rows_kernel
+        # write dst[r0 + r] unbounded (one host read of R)
+        R = int(sizes_dev.clamp(0, N).sum().item())
     if capacity is None:
         if R is None:
             R = int(sizes_dev.clamp(0, N).sum().item())
         capacity = (R + 1 + 3) // 4 * 4
-    elif R is not None and R + 1 > capacity:
+    elif R + 1 > capacity:
         raise ValueError("batch holds %d valid rows, capacity %d needs one more for the padding representative" % (R, capacity))
     i32 = dict(device=dev, dtype=torch.int32)
     graph_ptr = torch.empty(B + 1, **i32)
@@ -195,7 +207,8 @@ def enter(enabled, features, adjs, enabled_node_nums):
     sizes are given), the arguments unchanged and rb = None otherwise."""
     if isinstance(adjs, RaggedBatch):
         rb = adjs
-    elif enabled and enabled_node_nums is not None:
+    elif enabled and enabled_node_nums is not None and getattr(adjs, "values", None) is None:
+        # (differentiable adjacency values -- integrated gradients over `adjs` -- stay on the padded layout: see compact())
         rb = compact(features, adjs, enabled_node_nums)
     else:
         return features, adjs, enabled_node_nums, None

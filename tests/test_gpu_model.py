@@ -54,7 +54,7 @@ def test_model_py_gradients_and_adam_trajectory(batch):
         cost_opt, cost_sum = models.masked_softmax_ce(logits, tl, tm)
         cost_opt.backward()
         if step == 0:
-            close(logits, c["logits"], atol=2e-5, what="logits")
+            close(logits, c["logits"], atol=1e-5, what="logits")      # measured 1.1e-6 (profiles/r04_accuracy.json)
             assert abs(float(cost_opt) - c["cost_opt"]) < 5e-6 and abs(float(cost_sum) - c["cost_sum"]) < 1e-4
             for k, t in _named(model).items():
                 ref = g[k][0] if isinstance(g[k], list) else g[k]
@@ -145,7 +145,9 @@ def test_model_multitask_tox21_shaped(pos_weight, ragged):
         model.dense2.kernel.copy_(t32(p["k5"])); model.dense2.bias.copy_(t32(p["c5"]))
         model.out.kernel.copy_(t32(p["ok"])); model.out.bias.copy_(t32(p["ob"]))
     logits = model(tx, adjs, enabled_node_nums=en)
-    close(logits, c["logits"], atol=5e-5, what="multitask logits")
+    # logits reach 61: one fp32 ulp there is 3.8e-6 and six 256-wide layers sit in front of them -- the bound is RELATIVE to the
+    # largest logit, 1e-6 (measured 5.2e-7 padded, 1.6e-7 ragged; profiles/r04_accuracy.json)
+    close(logits, c["logits"], atol=1e-6 * max(1.0, float(np.abs(c["logits"]).max())), what="multitask logits")
     cost_opt, cost_sum = models.masked_sigmoid_ce(logits, t32(labels), t32(mask), t32(mask_label), pos_weight)
     assert abs(float(cost_opt) - c["cost_opt"]) < 1e-5 * max(1.0, abs(c["cost_opt"]))
     assert abs(float(cost_sum) - c["cost_sum"]) < 1e-5 * max(1.0, abs(c["cost_sum"]))
@@ -189,7 +191,7 @@ def test_model_sparse_block_diagonal(mode):
         model.out.kernel.copy_(t32(p["ok"])); model.out.bias.copy_(t32(p["ob"]))
     logits = model(batch)
     c = NETS.sparse_forward(p, net, chans, sizes, labels)
-    close(logits, c["logits"], atol=5e-5, what="sparse logits")
+    close(logits, c["logits"], atol=1e-5, what="sparse logits")      # measured 8.4e-7
     loss = models.sparse_softmax_ce_sum(logits, torch.as_tensor(labels, device=dev()))
     assert abs(float(loss) - c["loss"]) < 1e-5 * max(1.0, abs(c["loss"]))
     loss.backward()
@@ -360,7 +362,7 @@ def test_model_py_layer_calls_through_the_kgcn_import_path():
         net["out"].kernel.copy_(t32(p["ok"])); net["out"].bias.copy_(t32(p["ob"]))
     logits = build_model(t32(x), adjs)
     c = M.forward(p, x.astype(np.float64), adjs, z["labels"].astype(np.float64), z["mask"].astype(np.float64))
-    close(logits, c["logits"], atol=2e-5, what="logits through kgcn.layers")
+    close(logits, c["logits"], atol=1e-5, what="logits through kgcn.layers")      # measured 4.0e-7
     assert type(net["conv"][0]).__module__ == "kgcn_amd.layers"
 
 

@@ -295,3 +295,25 @@ def test_plan_scans_of_small_and_multi_block_selections(T):
                                ptr(ws), ws.numel() * 4, current_stream()))
     assert np.array_equal(gp.cpu().numpy(), np.concatenate([[0], np.cumsum(n)]))
     assert np.array_equal(ep.cpu().numpy(), np.concatenate([[0], np.cumsum(e)]))
+
+
+def test_compact_checks_an_explicit_capacity_before_writing_and_refuses_differentiable_values():
+    """(1) sizes on the device + an explicit capacity: the row count is read back BEFORE the device kernels write rows
+    [0, R] (they are not bounded by the capacity); (2) adjacency values as differentiable inputs have no d values path on the compact
+    layout: compact() raises, a ragged model falls back to the padded layout (the gradient still arrives)."""
+    from kgcn_amd import ragged, models
+    from kgcn_amd.batched_csr import BatchedAdjacency
+    rng = np.random.default_rng(8)
+    x, adjs, _, _, _, sizes = tox21_like_batch(rng, B=6, N=10, F=3, T=2)
+    R = int(sizes.sum())
+    with pytest.raises(ValueError, match="capacity"):
+        ragged.compact(t32(x), adjs, torch.as_tensor(sizes, device=dev()), capacity=R, check=False)
+    a = BatchedAdjacency.from_adjs(adjs, device=dev())
+    vals = [ch.values.clone().requires_grad_(True) for ch in a.channels]
+    av = a.with_values(vals)
+    with pytest.raises(ValueError, match="differentiable adjacency values"):
+        ragged.compact(t32(x), av, sizes)
+    model = models.GCN(1, ragged=True).to(dev())
+    out = model(t32(x), av, enabled_node_nums=torch.as_tensor(sizes))
+    out.sum().backward()
+    assert vals[0].grad is not None and float(vals[0].grad.abs().max()) > 0
