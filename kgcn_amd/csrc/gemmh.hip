@@ -20,23 +20,27 @@
 // every one of them depends on the non-finite input --, all other outputs are untouched.
 //
 // gemmh_fwd_kernel (y = act(x W + b), dx = dy W^T, and the backward form with g (.) act'(a) [+ d pooled] as the operand):
-//   one workgroup = 4 waves = a tile of 64 rows x all K <= 256 columns of x, persistent over tiles, two workgroups per CU.
-//   * the WHOLE tile travels HBM -> registers as sixteen 1 KiB rows per wave (lane = 4 consecutive columns: one dwordx4 per
-//     row and lane, the best streaming pattern measured on this chip) while the previous tile is multiplied: 64 KB in
-//     flight per workgroup instead of the 16 KB k chunks of gemm3;
+//   WEIGHT-STATIONARY.  One workgroup = 8 waves, persistent over 64-row tiles; wave w owns the 32 output columns 32 w .. +31 and
+//   keeps its slice of W' -- the h and l fragments of all 16 k-steps, 128 registers, read once from the fragment table of
+//   wtable.hip -- for the whole launch.  (The first two forms re-read W' fragments from L2 for every tile: 86-90 us with the TCP
+//   miss path moving 591 MB per launch; vmcnt counts in order, so a wave whose x tile is in flight cannot wait for W' fragments
+//   requested later.  profiles/r04_gemmh_history.txt)
+//   * a tile's rows travel HBM -> registers as 1 KiB rows (lane = 4 consecutive columns, one dwordx4 buffer load per row and lane:
+//     no address arithmetic, rows past the end read as 0), eight rows per wave, requested before the previous tile is multiplied;
 //   * a row belongs to one wave, so its maximum is a DPP wave reduction and its scale a SCALAR; split = v_ldexp,
 //     v_cvt_pk_f16_f32, 2 x v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32 per pair of values (3.5 per value; bf16 x 3: 5.5);
-//   * pieces land in LDS in MFMA A-operand order (1 KiB block per (m-tile, k-step, piece), slots XOR-rotated so that the
-//     8-byte writes of a row and the 16-byte fragment reads are both conflict-free); W' arrives pre-split from the fragment
-//     table of wtable.hip (L2 resident), one k-step ahead; wave w owns the 64 output columns 64 w .. +63 of the 64 rows:
-//     12 MFMAs per k-step (2 x 2 tiles x 3 products, smallest terms first);
-//   * epilogue: v_ldexp by -(kr + kc), + bias, activation, stores.
-// gemmh_wgrad_kernel (dW = x^T dy, db = colsum dy): no LDS.  The batch rows are the contraction index: with lane (li, hi)
+//   * pieces land in LDS ONCE per tile in MFMA A-operand order (1 KiB block per (m-tile, k-step, piece), slots XOR-rotated so that
+//     the 8-byte writes of a row and the 16-byte fragment reads are both conflict-free) next to the rows' exponents; every wave
+//     then multiplies the whole tile with its columns: 2 m-tiles x 16 k-steps x 3 products (smallest terms first);
+//   * epilogue: v_ldexp by -(kr + kc), + bias, activation, buffer stores.  The LDS hand-over is s_waitcnt lgkmcnt(0) + s_barrier
+//     (gh_barrier_lds): __syncthreads() would also drain vmcnt -- the next tile's rows and this tile's stores.
+// gemmh_wgrad_kernel<DACT> (dW = x^T dy, db = colsum dy): no LDS.  The batch rows are the contraction index: with lane (li, hi)
 //   reading x[r + 8 hi + j][c + li], j = 0..7, a coalesced dword load IS the MFMA operand layout (wgradx.hip), so a wave
 //   splits its own operands in registers and runs without barriers.  Scales are per COLUMN here and not known in advance:
 //   every lane keeps the scale of its column(s) and a limit; when a value exceeds the limit (first step, rarely later) the
 //   wave rescales its accumulators (exact) and goes on -- the online form of the row scale above.  One partial dW per
-//   workgroup (written unscaled), fixed-order second stage as everywhere.
+//   workgroup (written unscaled), fixed-order second stage as everywhere.  Shipped for the fused act' form; the plain weight
+//   gradient takes gemmh_wgradl_kernel below (every value split once, shared through LDS).
 #include "gemmh.h"
 
 namespace kgcn {
@@ -63,8 +67,8 @@ __device__ __forceinline__ void wave_umax4(unsigned& a, unsigned& b, unsigned& c
 }
 
 #ifndef GH_VARIANT
-#define GH_VARIANT 0             // development (tools/gemmh_variants.sh): 1 no W' loads in the k loop, 2 no y stores,
-#endif                           // 3 no x loads, 4 no MFMAs -- what each part of the kernel costs
+#define GH_VARIANT 0             // development (tools/gemmh_variants.sh): 2 no y stores, 3 no x loads (forward); 5 no MFMAs, 6 no
+#endif                           // split, 7 no loads (gemmh_wgradl) -- what each part of the kernels costs
 constexpr int GH_BM = 64;        // rows per tile
 constexpr int GH_KMAX = 256;     // widest x row one lane quad layout covers (64 lanes x 4 columns)
 
