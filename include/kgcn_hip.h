@@ -351,6 +351,18 @@ int kgcn_dense_dx_dact_gather_f32(const float* grad, const float* pooled_grad, i
                                   const float* act_out, int64_t m, int32_t dout, int64_t ld, const float* w, int64_t w_ld,
                                   int32_t din, float* dx, int64_t dx_ld, int32_t act, float* dpre, void* table,
                                   int64_t table_bytes, int32_t table_ready, void* stream);
+/* The same dX contraction where the product is only needed for an inner product (d epsilon of a GINAggregate, kgcn/layers.py:469
+ * <d out, x>, in front of an activated wide layer whose input needs no gradient -- the first block of example_model/model_gin.py):
+ *   dot_out[0] = < (grad (.) act'(act_out)) @ w^T , dotx >       dotx [m, din] (row stride dotx_ld, 16-byte aligned rows)
+ * d pre-activation is written to dpre as in kgcn_dense_dx_dact_f32; the [m, din] product never exists in HBM.
+ * kgcn_dense_dx_dact_dot_supported(m, din, dout); workspace >= kgcn_dense_dx_dact_dot_workspace_bytes(m, din) (one partial per
+ * workgroup, fixed-order second stage); table as for kgcn_dense_dx_dact_gather_f32. */
+int kgcn_dense_dx_dact_dot_supported(int64_t m, int32_t din, int32_t dout);
+int64_t kgcn_dense_dx_dact_dot_workspace_bytes(int64_t m, int32_t din);
+int kgcn_dense_dx_dact_dot_f32(const float* grad, const float* act_out, int64_t m, int32_t dout, int64_t ld, const float* w,
+                               int64_t w_ld, int32_t din, const float* dotx, int64_t dotx_ld, int32_t act, float* dpre,
+                               void* table, int64_t table_bytes, int32_t table_ready, float* dot_out, void* workspace,
+                               int64_t workspace_bytes, void* stream);
 /* stand-alone forms: y = act(x) over n floats; dpre = grad (.) act'(act_out) (dpre may alias grad) */
 int kgcn_act_fwd_f32(const float* x, int64_t n, int32_t act, float* y, void* stream);
 int kgcn_act_bwd_f32(const float* act_out, const float* grad, int64_t n, int32_t act, float* dpre, void* stream);
@@ -441,7 +453,8 @@ int kgcn_ragged_compact_csr(const kgcn_csr_batch* src, const int32_t* sel, int32
 /* The row blocks of a ragged-compact batch (kgcn_csr_batch.block_ptr): block_ptr [kgcn_ragged_num_blocks(capacity_rows) + 1]
  * from the plan's graph_ptr [num_sel + 1]; blocks past the valid rows cover the padding rows in steps of
  * KGCN_RAGGED_BLOCK_ROWS.  Every block holds at most KGCN_RAGGED_BLOCK_ROWS + n_nodes - 1 rows. */
-#define KGCN_RAGGED_BLOCK_ROWS 64
+#define KGCN_RAGGED_BLOCK_ROWS 32
+int32_t kgcn_ragged_block_rows(void);                 /* KGCN_RAGGED_BLOCK_ROWS of the library that was loaded */
 int32_t kgcn_ragged_num_blocks(int32_t capacity_rows);
 int kgcn_ragged_blocks(const int32_t* graph_ptr, int32_t num_sel, int32_t capacity_rows, int32_t* block_ptr, void* stream);
 /* dst [capacity_rows, d] <- the valid rows of src [num_source_graphs, n_nodes, d] (feed.py:127-133 layout), zeros on the

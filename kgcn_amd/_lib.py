@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # -DKGCN_DEV_KNOBS (make DEV_KNOBS=1) -- the shipped build ignores them.  Anything set here is reported by
 # active_overrides() (bench.py prints it in its JSON line) and warned about once at import, because a stray variable
 # changes summation order / which binary produced the numbers.
-DEV_ENV_VARS = ("KGCN_HIP_LIB", "KGCN_DENSE_ROUTE", "KGCN_GEMM3_MW", "KGCN_GEMM3_CUT", "KGCN_WGRADX", "KGCN_WGRADN", "KGCN_GEMMH", "KGCN_WGRADL", "KGCN_SPMM_BLOCKS", "KGCN_GIN_JOIN")
+DEV_ENV_VARS = ("KGCN_HIP_LIB", "KGCN_DENSE_ROUTE", "KGCN_GEMM3_MW", "KGCN_GEMM3_CUT", "KGCN_WGRADX", "KGCN_WGRADN", "KGCN_GEMMH", "KGCN_WGRADL", "KGCN_SPMM_BLOCKS", "KGCN_GIN_JOIN", "KGCN_GIN_DOT")
 LIB_PATH = os.environ.get("KGCN_HIP_LIB") or os.path.join(_HERE, "csrc", "libkgcn_hip.so")
 
 
@@ -77,7 +77,6 @@ class WtableJob(ctypes.Structure):
 
 
 ASSEMBLE_MAX_CSR, ASSEMBLE_MAX_TABLES = 4, 6
-KGCN_RAGGED_BLOCK_ROWS = 64          # include/kgcn_hip.h
 
 
 class AssemblePlan(ctypes.Structure):
@@ -161,6 +160,11 @@ SIGNATURES = {
     "kgcn_dense_dx_dact_gather_supported": (ctypes.c_int, [c_i64, c_i32, c_i32]),
     "kgcn_dense_dx_dact_gather_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i64, c_i32, c_f32p, c_i64, c_i32, c_i64, c_f32p, c_i64, c_i32,
                                                      c_f32p, c_i64, c_i32, c_f32p, ctypes.c_void_p, c_i64, c_i32, ctypes.c_void_p]),
+    "kgcn_dense_dx_dact_dot_supported": (ctypes.c_int, [c_i64, c_i32, c_i32]),
+    "kgcn_dense_dx_dact_dot_workspace_bytes": (c_i64, [c_i64, c_i32]),
+    "kgcn_dense_dx_dact_dot_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i64, c_i32, c_i64, c_f32p, c_i64, c_i32, c_f32p, c_i64, c_i32,
+                                                  c_f32p, ctypes.c_void_p, c_i64, c_i32, c_f32p, ctypes.c_void_p, c_i64,
+                                                  ctypes.c_void_p]),
     "kgcn_dense_fwd_tab_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i64, c_f32p, c_i64, c_i32, c_f32p, c_f32p, c_i32,
                                               c_i64, c_i32, ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_wtable_split_multi": (ctypes.c_int, [ctypes.c_void_p, c_i32, ctypes.c_void_p]),
@@ -190,6 +194,7 @@ SIGNATURES = {
                                         ctypes.c_void_p]),
     "kgcn_ragged_compact_csr": (ctypes.c_int, [_CSRP, c_i32p, c_i32, c_i32p, c_i32p, c_i32, c_i32p, c_i32p, c_i64, c_i32p,
                                                ctypes.c_void_p]),
+    "kgcn_ragged_block_rows": (c_i32, []),
     "kgcn_ragged_num_blocks": (c_i32, [c_i32]),
     "kgcn_ragged_blocks": (ctypes.c_int, [c_i32p, c_i32, c_i32, c_i32p, ctypes.c_void_p]),
     "kgcn_ragged_compact_rows_f32": (ctypes.c_int, [c_f32p, c_i32p, c_i32, c_i32, c_i32, c_i32p, c_i32, c_f32p,

@@ -761,6 +761,62 @@ extern "C" int kgcn_dense_dx_dact_gather_f32(const float* grad, const float* poo
   return rc;
 }
 
+// d epsilon of a GINAggregate in front of an activated wide layer whose INPUT needs no gradient (the first block of model_gin.py):
+// <(grad (.) act'(act_out)) W^T, dotx> with the product never stored (gemmh.hip, dot form); d pre-activation is written as usual.
+namespace kgcn {
+int launch_gemmh_dx_dact(const float* grad, const float* act_out, float* dpre, long m, int k, long ld, const void* tabh, float* dx,
+                         int n, long dx_ld, int dact, hipStream_t s, const float* pooled_grad, int n_nodes, long pooled_ld,
+                         float* dot_part);
+int gemmh_dot_parts(long m, int dout);
+int64_t wtable_bf16_bytes(int din, int dout);
+__global__ __launch_bounds__(256) void dx_dot_final_kernel(const float* __restrict__ part, int nparts, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+}  // namespace kgcn
+
+extern "C" int kgcn_dense_dx_dact_dot_supported(int64_t m, int32_t din, int32_t dout) {
+  // (the f16 weight-stationary kernel only: wide layer, >= 16,384 rows; dout = the contraction here)
+  return (din > 128 && din <= 256 && din % 4 == 0 && dout % 4 == 0 && dout >= 32 && dout <= 256 && m >= (int64_t)kNumCU * 64) ? 1 : 0;
+}
+
+extern "C" int64_t kgcn_dense_dx_dact_dot_workspace_bytes(int64_t m, int32_t din) {
+  return (int64_t)gemmh_dot_parts((long)m, din) * 4;
+}
+
+extern "C" int kgcn_dense_dx_dact_dot_f32(const float* grad, const float* act_out, int64_t m, int32_t dout, int64_t ld, const float* w,
+                                          int64_t w_ld, int32_t din, const float* dotx, int64_t dotx_ld, int32_t act, float* dpre,
+                                          void* table, int64_t table_bytes, int32_t table_ready, float* dot_out, void* workspace,
+                                          int64_t workspace_bytes, void* stream) {
+  if (act <= KGCN_ACT_NONE || act > KGCN_ACT_TANH) return fail("kgcn_dense_dx_dact_dot_f32: activation code %d", act);
+  if (!kgcn_dense_dx_dact_dot_supported(m, din, dout))
+    return fail("kgcn_dense_dx_dact_dot_f32: shape m=%lld %d -> %d has no fused form (kgcn_dense_dx_dact_f32 + kgcn_dot_f32)",
+                (long long)m, din, dout);
+  if (!grad || !act_out || !w || !dotx || !dpre || !dot_out) return fail("kgcn_dense_dx_dact_dot_f32: NULL operand");
+  if (dpre == grad) return fail("kgcn_dense_dx_dact_dot_f32: dpre must not alias grad");
+  if (ld < dout || dotx_ld < din || w_ld < dout || dotx_ld % 4 != 0 || !aligned16(dotx))
+    return fail("kgcn_dense_dx_dact_dot_f32: leading dimension too small / dotx not 16-byte aligned rows");
+  if (!table || table_bytes < wtable_bytes(dout, din)) return fail("kgcn_dense_dx_dact_dot_f32: table / workspace too small");
+  if (!workspace || workspace_bytes < kgcn_dense_dx_dact_dot_workspace_bytes(m, din))
+    return fail("kgcn_dense_dx_dact_dot_f32: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                (long long)kgcn_dense_dx_dact_dot_workspace_bytes(m, din));
+  hipStream_t s = as_stream(stream);
+  if (!table_ready) launch_wtable_split(w, (long)w_ld, 1, dout, din, table, s);
+  float* part = static_cast<float*>(workspace);
+  const int rc = launch_gemmh_dx_dact(grad, act_out, dpre, (long)m, dout, (long)ld,
+                                      static_cast<const char*>(table) + wtable_bf16_bytes(dout, din), const_cast<float*>(dotx), din,
+                                      (long)dotx_ld, act, s, nullptr, 0, 0, part);
+  if (rc < 0) return fail("kgcn_dense_dx_dact_dot_f32: operands must be 16-byte aligned with ld %% 4 == 0");
+  if (rc) return rc;
+  hipLaunchKernelGGL(dx_dot_final_kernel, dim3(1), dim3(256), 0, s, part, gemmh_dot_parts((long)m, din), dot_out);
+  return check_launch("dx_dot_final_kernel");
+}
+
 extern "C" int kgcn_dense_dx_dact_f32(const float* grad, const float* act_out, int64_t m, int32_t dout, int64_t ld,
                                       const float* w, int64_t w_ld, int32_t din, float* dx, int64_t dx_ld, int32_t act,
                                       float* dpre, void* workspace, int64_t workspace_bytes, void* stream) {

@@ -35,7 +35,8 @@ bool gemmh_fwd_ok(const float* x, long m, int din, long x_ld, int dout);
 int launch_gemmh_fwd(const float* x, long m, int din, long x_ld, const void* tabh, const float* bias, float* y, int dout,
                      long y_ld, int act, hipStream_t s);
 int launch_gemmh_dx_dact(const float* grad, const float* act_out, float* dpre, long m, int k, long ld, const void* tabh,
-                         float* dx, int n, long dx_ld, int dact, hipStream_t s, const float* pooled_grad, int n_nodes, long pooled_ld);
+                         float* dx, int n, long dx_ld, int dact, hipStream_t s, const float* pooled_grad, int n_nodes, long pooled_ld,
+                         float* dot_part);
 int64_t wtable_bf16_bytes(int din, int dout);
 
 #ifdef KGCN_PROBE   // development: per-workgroup cycle sums per phase (tools/gemm3_probe.py)
@@ -569,7 +570,7 @@ int launch_gemm3_dx_dact(const float* grad, const float* act_out, float* dpre, l
   static const char* hknob = dev_knob("KGCN_GEMMH");
   if (!(hknob && !strchr(hknob, 'd'))) {
     const int rc = launch_gemmh_dx_dact(grad, act_out, dpre, m, k, ld, static_cast<const char*>(table) + wtable_bf16_bytes(k, n), dx,
-                                        n, dx_ld, dact, s, pooled_grad, n_nodes, pooled_ld);
+                                        n, dx_ld, dact, s, pooled_grad, n_nodes, pooled_ld, nullptr);
     if (rc >= 0) return rc;
   }
   G3Dact da;

@@ -72,7 +72,10 @@ __device__ __forceinline__ void wave_umax4(unsigned& a, unsigned& b, unsigned& c
 constexpr int GH_BM = 64;        // rows per tile
 constexpr int GH_KMAX = 256;     // widest x row one lane quad layout covers (64 lanes x 4 columns)
 
-struct GhDact { long ydiff, pdiff; float c0, c1, c2; const float* bc; long bc_ld; int bc_n, bc_only; };
+// dot_part != nullptr (backward forms): the product is NOT stored; its inner product with `y` (read as an [m, dout] operand of the
+// same row stride) is accumulated instead, one partial per workgroup -- d epsilon of a GINAggregate whose input needs no gradient
+// (kgcn/layers.py:469: <d out, x>; the d out tensor then never exists in HBM).
+struct GhDact { long ydiff, pdiff; float c0, c1, c2; const float* bc; long bc_ld; int bc_n, bc_only; float* dot_part; };
 
 // LDS slot of row rr32 (0..31 of its m-tile), lane half hi, in the block of k-step ks: XOR-rotated by (2 ks + hi) mod 16
 __device__ __forceinline__ int gh_slot(int rr32, int ks, int hi) { return (rr32 ^ ((2 * ks + hi) & 15)) + 32 * hi; }
@@ -222,6 +225,7 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
       rowk[rr] = k;                                      // same value from every lane
     }
   };
+  float dotacc = 0.f;
   auto compute = [&](long tt, int buf) __attribute__((always_inline)) {
     const u32x4* lds = reinterpret_cast<const u32x4*>(dsm) + (size_t)buf * GH_PIECES;
     const int* rowk = rowk_base + 64 * buf;
@@ -285,7 +289,22 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
     else if (act == KGCN_ACT_RELU) apply(std::integral_constant<int, KGCN_ACT_RELU>{});
     else if (act == KGCN_ACT_TANH) apply(std::integral_constant<int, KGCN_ACT_TANH>{});
     if (GH_VARIANT == 2 && acc[0][0] != 1.2345e-30f) return;
-    if (col < dout) {
+    if (DK != 0 && da.dot_part) {                        // uniform: <product, y operand> instead of the stores
+      if (col < dout) {
+        const __amdgpu_buffer_rsrc_t rz = gh_rows(y, row0, GH_BM, m, y_ld);   // rows >= m: read as 0
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            float z[4];
+#pragma unroll
+            for (int rj = 0; rj < 4; ++rj)
+              z[rj] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rz, (int)voff_y, (32 * mt + rj + 8 * rq) * ldy4, 0));
+#pragma unroll
+            for (int rj = 0; rj < 4; ++rj) dotacc = __builtin_fmaf(acc[mt][4 * rq + rj], z[rj], dotacc);
+          }
+      }
+    } else if (col < dout) {
       const __amdgpu_buffer_rsrc_t ry = gh_rows(y, row0, GH_BM, m, y_ld);     // rows >= m: dropped by the descriptor
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -316,6 +335,27 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
     gh_barrier_lds();
     t += G;
   }
+  if constexpr (DK != 0) {
+    if (da.dot_part) {                                   // uniform.  Fixed order: lanes (butterfly), then the eight waves
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) dotacc += __shfl_xor(dotacc, o, 64);
+      float* red = reinterpret_cast<float*>(dsm);        // (every wave is behind the loop's last barrier: the tile buffers are free)
+      if (lane == 0) red[wave] = dotacc;
+      __syncthreads();
+      if (tid == 0) {
+        float s8 = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) s8 += red[w8];
+        da.dot_part[(long)blockIdx.y * gridDim.x + blockIdx.x] = s8;
+      }
+    }
+  }
+}
+
+// workgroups of a launch over m rows and `dout` output columns (= partials of the dot form)
+int gemmh_dot_parts(long m, int dout) {
+  const long ntiles = (m + GH_BM - 1) / GH_BM;
+  return (int)((ntiles < kNumCU ? ntiles : kNumCU) * ((dout + 255) / 256));
 }
 
 // x: 16-byte aligned rows of <= 256 columns (din % 4 == 0, x_ld % 4 == 0); the table holds the f16 section for (din, dout)
@@ -356,7 +396,10 @@ int launch_gemmh_fwd(const float* x, long m, int din, long x_ld, const void* tab
 // output width (the contraction), n = its input width; `tabh` = the f16 table of W^T.  Returns -1 when the operands do not
 // fit the kernel (the caller falls back to gemm3 / the unfused route).
 int launch_gemmh_dx_dact(const float* grad, const float* act_out, float* dpre, long m, int k, long ld, const void* tabh,
-                         float* dx, int n, long dx_ld, int dact, hipStream_t s, const float* pooled_grad, int n_nodes, long pooled_ld) {
+                         float* dx, int n, long dx_ld, int dact, hipStream_t s, const float* pooled_grad, int n_nodes, long pooled_ld,
+                         float* dot_part) {
+  // dot_part != nullptr: `dx` is READ ([m, n], row stride dx_ld) and <product, dx> goes to dot_part[workgroups of the launch]
+  // (gemmh_dot_parts(m, n) floats) instead of the product being stored
   const float* base = grad ? grad : act_out;
   if (!(gemmh_fwd_ok(base, m, k, ld, n) && (!grad || aligned16(grad)) && aligned16(act_out) && aligned16(dpre) && tabh &&
         dact != KGCN_ACT_NONE && dpre != grad && (grad || pooled_grad) &&
@@ -372,6 +415,7 @@ int launch_gemmh_dx_dact(const float* grad, const float* act_out, float* dpre, l
   da.c0 = dact == KGCN_ACT_TANH ? 1.f : 0.f;
   da.c1 = dact == KGCN_ACT_SIGMOID ? 1.f : 0.f;
   da.c2 = -1.f;
+  da.dot_part = dot_part;
   if (dact == KGCN_ACT_RELU) return gh_fwd_launch<2>(base, m, k, ld, tabh, nullptr, dx, n, dx_ld, KGCN_ACT_NONE, da, s);
   return gh_fwd_launch<1>(base, m, k, ld, tabh, nullptr, dx, n, dx_ld, KGCN_ACT_NONE, da, s);
 }

@@ -392,6 +392,8 @@ __global__ __launch_bounds__(256) void ragged_blocks_kernel(const int* __restric
   }
 }
 
+extern "C" int32_t kgcn_ragged_block_rows(void) { return KGCN_RAGGED_BLOCK_ROWS; }
+
 extern "C" int32_t kgcn_ragged_num_blocks(int32_t capacity_rows) {
   return capacity_rows <= 0 ? 0 : (capacity_rows + KGCN_RAGGED_BLOCK_ROWS - 1) / KGCN_RAGGED_BLOCK_ROWS + 2;
 }

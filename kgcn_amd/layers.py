@@ -274,6 +274,22 @@ class GINAggregate(nn.Module):
         return ops.gin_aggregate(inputs, eps, a)
 
 
+def gin_graph_dense(agg_layer, dense_layer, inputs, adj=None):
+    """GINAggregate followed by GraphDense (with its fused activation) as one op (ops.gin_dense) -- example_model/model_gin.py:45-50.
+    When the inputs need no gradient (a model's first block) d epsilon = <d out, x> is accumulated inside the dense layer's dX GEMM
+    and the gradient of the aggregation's output never exists in HBM; in every other case this IS the two layers one after the other.
+    `dense_layer`: a GraphDense applied without enabled_node_nums."""
+    if not agg_layer.built:
+        agg_layer.build(inputs.shape, inputs.device)
+    if not dense_layer.built:
+        dense_layer.build(inputs.shape, inputs.device)
+    a = _pack(adj, inputs)
+    if (enabled_bconv or enabled_bspmm or enabled_batched) or len(agg_layer.epsilon) != 1 or a.num_channels != 1:
+        return dense_layer(agg_layer(inputs, adj=a))
+    return ops.gin_dense(inputs, agg_layer.epsilon[0].reshape(1), a, dense_layer.kernel, dense_layer.bias,
+                         activation=dense_layer.activation)
+
+
 class GraphMaxPooling(nn.Module):
     """kgcn/layers.py:122-153: out[b,i,k] = sum_c max_j dense(A[b][c] .* X[b][:,k])[i,j] -- the maximum
     of a_ij * x_jk over node i's stored neighbours (0 is a candidate unless the row is full)."""

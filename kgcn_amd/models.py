@@ -110,8 +110,8 @@ class GIN(nn.Module):
         width = self.dense[1].output_dim
         joined = features.new_empty((features.shape[0], 2 * width)) if width % 4 == 0 and _GIN_JOIN else None
         for blk in range(2):
-            layer = self.agg[blk](layer, adj=adjs)
-            layer = self.dense[2 * blk](layer)
+            # (block 0: the features need no gradient, so d epsilon is formed inside the dense layer's dX GEMM -- layers.gin_graph_dense)
+            layer = layers.gin_graph_dense(self.agg[blk], self.dense[2 * blk], layer, adj=adjs)
             # the block output is read out (and, for block 0, passed on): d pooled joins the gradient inside the layer's dX GEMM
             layer, pooled = layers.graph_dense_gather(self.dense[2 * blk + 1], layer, join=joined, join_col=blk * width)
             outs.append(pooled)

@@ -795,6 +795,84 @@ def gin_aggregate(x, eps, adj):
     return _GinAggregate.apply(x, eps, adj)
 
 
+_GIN_DOT = __import__("os").environ.get("KGCN_GIN_DOT") != "0"           # (development A/B: "0" = the two separate ops)
+
+
+class _GinDense(torch.autograd.Function):
+    """GINAggregate followed by an activated wide GraphDense, for an input that needs NO gradient (the first block of
+    example_model/model_gin.py:45-50): y = act((eps x + A x) W + b).  The gradient of the aggregation's output is then only needed for
+    d eps = <d out, x> (kgcn/layers.py:469): the layer's dX GEMM accumulates that inner product instead of storing its product
+    (kgcn_dense_dx_dact_dot_f32) -- the [rows, din] tensor is neither written nor read back by a dot kernel.  Use gin_dense():
+    it falls back to the two separate ops whenever a condition of this form does not hold."""
+
+    @staticmethod
+    def forward(ctx, x, eps, adj, w, bias, act):
+        x, w = _f32c(x, "inputs"), _f32c(w, "w")
+        T, N, din = x.shape
+        m, dout = T * N, w.shape[1]
+        e = _f32c(eps, "epsilon").reshape(-1)
+        agg = torch.empty((m, din), device=x.device, dtype=torch.float32)
+        check(lib.kgcn_gin_aggregate_f32(adj.desc_array(False), 1, ptr(x), din, ptr(e), ptr(agg), current_stream()),
+              "kgcn_gin_aggregate_f32")
+        b = None if bias is None else _f32c(bias, "bias").reshape(-1)
+        y = torch.empty((m, dout), device=x.device, dtype=torch.float32)
+        tab, tb = weight_tables.lookup(w, 0)
+        if tab is not None:
+            check(lib.kgcn_dense_fwd_tab_f32(ptr(agg), m, din, din, ptr(w), dout, 0, ptr(b), ptr(y), dout, dout, int(act), ptr(tab), tb,
+                                             current_stream()), "kgcn_dense_fwd_tab_f32")
+        else:
+            weight_tables.register(w)
+            wsb, wsp = _dense_ws(din, dout, x.device)
+            check(lib.kgcn_dense_fwd_ws_f32(ptr(agg), m, din, din, ptr(w), dout, 0, ptr(b), ptr(y), dout, dout, int(act), ptr(wsp), wsb,
+                                            current_stream()), "kgcn_dense_fwd_ws_f32")
+        ctx.act, ctx.eps_shape = int(act), tuple(eps.shape)
+        ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        ctx.defer_ok = bool(w.is_leaf and (bias is None or bias.is_leaf))
+        ctx.defer_ids = (w, bias)
+        _count_use(w, bias)
+        ctx.save_for_backward(x, agg, w, y)
+        return y.view(T, N, dout)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, agg, w, y = ctx.saved_tensors
+        m, din = agg.shape
+        dout = w.shape[1]
+        gy = _f32c(gy.reshape(m, dout), "grad")
+        dpre = torch.empty_like(gy)
+        deps = torch.empty((1,), device=gy.device, dtype=torch.float32)
+        tab, tb = weight_tables.lookup(w, 1)
+        ready = 1
+        if tab is None:
+            tb, tab = _dense_ws(dout, din, gy.device)
+            ready = 0
+        wsb = lib.kgcn_dense_dx_dact_dot_workspace_bytes(m, din)
+        wsp = torch.empty((max(wsb, 4) // 4,), device=gy.device, dtype=torch.float32)
+        check(lib.kgcn_dense_dx_dact_dot_f32(ptr(gy), ptr(y), m, dout, dout, ptr(w), dout, din, ptr(x), din, ctx.act, ptr(dpre),
+                                             ptr(tab), tb, ready, ptr(deps), ptr(wsp), wsb, current_stream()),
+              "kgcn_dense_dx_dact_dot_f32")
+        need_w = ctx.needs_input_grad[3]
+        need_b = ctx.bias_shape is not None and ctx.needs_input_grad[4]
+        dw = db = None
+        if need_w or need_b:
+            dw, db = _Dense._wgrad(ctx, agg, w, dpre, y, m, din, dout, need_w, need_b, False)
+        return None, (deps.reshape(ctx.eps_shape) if ctx.needs_input_grad[1] else None), None, dw, db, None
+
+
+def gin_dense(x, eps, adj, w, bias=None, activation=None):
+    """-> act((eps x + A x) @ w + bias), [T, N, dout]; eps: the GINAggregate's epsilon of ONE adjacency channel.  The fused backward
+    (no d out tensor: see _GinDense) when x needs no gradient, eps does, the layer is activated and wide enough; else the two ops."""
+    T, N, din = x.shape
+    act = act_code(activation)
+    fused = (not x.requires_grad and eps is not None and eps.requires_grad and eps.numel() == 1 and adj.num_channels == 1 and act and
+             torch.is_grad_enabled() and x.dtype == torch.float32 and _GIN_DOT and
+             bool(lib.kgcn_dense_dx_dact_dot_supported(T * N, din, w.shape[1])))
+    if fused:
+        return _GinDense.apply(x, eps, adj, w, bias, act)
+    h = gin_aggregate(x, eps, adj)
+    return dense(h.reshape(T * N, din), w, bias, activation=activation).reshape(T, N, w.shape[1])
+
+
 # -------------------------------------------------------------------------------------------------
 # GraphMaxPooling
 # -------------------------------------------------------------------------------------------------

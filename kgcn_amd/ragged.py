@@ -98,7 +98,7 @@ def _container(rowptr, cv, capacity, block_ptr=None, n_nodes=0):
     c = BatchedCSR(rowptr, cv, 1, capacity, capacity, max(int(cv.shape[0]), 1))
     if block_ptr is not None and os.environ.get("KGCN_SPMM_BLOCKS") != "0":          # (development A/B: the row-chunk kernel)
         # the row blocks of whole molecules: the aggregation kernels stage a block's rows in LDS once (csrc/spmm.hip, spmm_block_kernel)
-        c.block_ptr, c.block_rows_max = block_ptr, _lib.KGCN_RAGGED_BLOCK_ROWS + max(int(n_nodes), 1) - 1
+        c.block_ptr, c.block_rows_max = block_ptr, _lib.lib.kgcn_ragged_block_rows() + max(int(n_nodes), 1) - 1
     return c
 
 

@@ -387,3 +387,49 @@ def test_read_outs_joined_in_one_buffer_equal_concatenation(act, T, N, d):
         assert torch.equal(a, b), float((a - b).abs().max())
     with pytest.raises(Exception, match="join"):
         ops.join_columns(torch.empty((T, 2 * d), device=dev()), [res[0][0][:, :d], res[0][0][:, d:]])
+
+
+@pytest.mark.parametrize("act,T,N,d,dout", [("relu", 2000, 10, 256, 256), ("sigmoid", 1700, 10, 256, 256), ("relu", 640, 32, 160, 256),
+                                             ("relu", 300, 10, 256, 256)])
+def test_gin_dense_d_epsilon_inside_the_dx_gemm(act, T, N, d, dout):
+    """ops.gin_dense = GINAggregate + activated GraphDense (model_gin.py:45-50).  With inputs that need no gradient d epsilon =
+    <d out, x> (kgcn/layers.py:469) is accumulated by the dX GEMM (kgcn_dense_dx_dact_dot_f32: the product is never stored); the last
+    case is below the fused form's size and takes the two ops.  Checked against the two separate ops (same d pre-activation kernel:
+    dW / dbias bit-equal) and against fp64 for y and d epsilon."""
+    from kgcn_amd import ops
+    from kgcn_amd.batched_csr import BatchedAdjacency
+    from oracle import kgcn_oracle as K
+    rng = np.random.default_rng(T + d)
+    adjs = K.synth_mol_graphs(rng, T, N, 1)
+    a = BatchedAdjacency.from_adjs(adjs, device=dev())
+    x = rng.standard_normal((T, N, d)).astype(np.float32)
+    w = (rng.standard_normal((d, dout)) / np.sqrt(d)).astype(np.float32)
+    b = (rng.standard_normal(dout) * 0.1).astype(np.float32)
+    gy = rng.standard_normal((T, N, dout)).astype(np.float32)
+    res = []
+    for fused in (True, False):
+        tx = t32(x).requires_grad_(not fused)                      # an input that needs a gradient takes the two separate ops
+        eps = t32(np.array([0.3])).requires_grad_(True)
+        tw, tb = t32(w).requires_grad_(True), t32(b).requires_grad_(True)
+        y = ops.gin_dense(tx, eps, a, tw, tb, activation=act)
+        assert (y.grad_fn.name().startswith("_GinDense")) == (fused and T * N >= 16384)
+        (y * t32(gy)).sum().backward()
+        res.append((y.detach(), eps.grad.clone(), tw.grad.clone(), tb.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])
+    # fp64: y and d epsilon
+    A = np.zeros((T, N, N))
+    for t, chans in enumerate(adjs):
+        idx, val, _ = chans[0]
+        np.add.at(A[t], (np.asarray(idx)[:, 0], np.asarray(idx)[:, 1]), np.asarray(val, np.float64))
+    x64 = x.astype(np.float64)
+    agg = 0.3 * x64 + A @ x64
+    pre = agg.reshape(T * N, d) @ w.astype(np.float64) + b
+    f = {"relu": lambda v: np.maximum(v, 0), "sigmoid": lambda v: 1 / (1 + np.exp(-v))}[act]
+    yr = f(pre)
+    ygpu = res[0][0].cpu().numpy().reshape(T * N, dout).astype(np.float64)
+    dpre = gy.reshape(T * N, dout) * ((ygpu > 0) if act == "relu" else yr * (1 - yr))
+    deps = float(((dpre @ w.astype(np.float64).T) * x64.reshape(T * N, d)).sum())
+    scale = float(np.abs(((dpre @ w.astype(np.float64).T) * x64.reshape(T * N, d))).sum())
+    close(res[0][0], yr.reshape(T, N, dout), atol=2e-6 * max(1.0, float(np.abs(yr).max())), rel=2e-6, what="gin_dense y")
+    for r, name in ((res[0], "fused"), (res[1], "two ops")):
+        assert abs(float(r[1]) - deps) <= 2e-6 * scale, (name, float(r[1]), deps, scale)

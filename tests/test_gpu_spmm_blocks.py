@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from kgcn_amd._lib import lib, ptr, current_stream, check, KGCN_RAGGED_BLOCK_ROWS
+from kgcn_amd._lib import lib, ptr, current_stream, check
 from test_gpu_parity import dev, t32
 from test_oracle_model import tox21_like_batch
 
@@ -48,7 +48,7 @@ def test_block_table_covers_every_row_with_whole_molecules():
         a = rb.adjacency.channels[0]
         bp = a.block_ptr.cpu().numpy()
         gp = rb.graph_ptr.cpu().numpy()
-        assert a.transpose().block_ptr is a.block_ptr and a.block_rows_max == KGCN_RAGGED_BLOCK_ROWS + N - 1
+        assert a.transpose().block_ptr is a.block_ptr and a.block_rows_max == lib.kgcn_ragged_block_rows() + N - 1
         assert bp[0] == 0 and bp[-1] == rb.capacity and np.all(np.diff(bp) >= 0) and np.diff(bp).max() <= a.block_rows_max
         assert len(bp) == lib.kgcn_ragged_num_blocks(rb.capacity) + 1
         R = int(gp[-1])
@@ -56,7 +56,7 @@ def test_block_table_covers_every_row_with_whole_molecules():
         assert np.all(np.isin(inside, gp))                              # molecule boundaries only
         for k, b in enumerate(bp[:-1]):
             if b < R:
-                assert b >= k * KGCN_RAGGED_BLOCK_ROWS and (b == 0 or gp[np.searchsorted(gp, b) - 1] < k * KGCN_RAGGED_BLOCK_ROWS)
+                assert b >= k * lib.kgcn_ragged_block_rows() and (b == 0 or gp[np.searchsorted(gp, b) - 1] < k * lib.kgcn_ragged_block_rows())
 
 
 @pytest.mark.parametrize("B,N,d", [(300, 50, 256), (300, 50, 64), (300, 50, 50), (300, 50, 84), (120, 50, 32), (64, 50, 6),

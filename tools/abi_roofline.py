@@ -35,7 +35,7 @@ def _products(name, a):
         return q(0, a[1], a[2], a[9])
     if name == "kgcn_dense_dx_dact_gather_f32":
         return q(1, a[5], a[6], a[10])
-    if name in ("kgcn_dense_dx_dact_f32", "kgcn_dense_dx_dact_tab_f32"):
+    if name in ("kgcn_dense_dx_dact_f32", "kgcn_dense_dx_dact_tab_f32", "kgcn_dense_dx_dact_dot_f32"):
         return q(1, a[2], a[3], a[7])
     if name == "kgcn_dense_wgrad_f32":
         return q(2, a[4], a[5], a[6])
@@ -94,6 +94,9 @@ def _cost(name, a):
     if name == "kgcn_dense_dx_dact_gather_f32":
         m, dout, din = a[5], a[6], a[10]
         return 4 * m * (dout * (3 if a[0] else 2) + din), 2 * m * din * dout, "m=%d %d<-%d gathered%s" % (m, din, dout, "+g" if a[0] else "")
+    if name == "kgcn_dense_dx_dact_dot_f32":
+        m, dout, din = a[2], a[3], a[7]           # reads grad, act_out and dotx, writes dpre; the [m, din] product is not stored
+        return 4 * (3 * m * dout + m * din + din * dout), 2 * m * din * dout, "m=%d %d->%d T dact=%d dot" % (m, dout, din, a[10])
     if name in ("kgcn_dense_dx_dact_f32", "kgcn_dense_dx_dact_tab_f32"):
         m, dout, din = a[2], a[3], a[7]
         return 4 * (3 * m * dout + m * din + din * dout), 2 * m * din * dout, "m=%d %d->%d T dact=%d" % (m, dout, din, a[10])
@@ -183,7 +186,7 @@ def _cost(name, a):
     if name == "kgcn_ragged_plan":
         return 16 * a[3], 0, "sel=%d" % a[3]
     if name == "kgcn_ragged_blocks":
-        return 4 * a[1] + 4 * (a[2] // 64 + 3), 0, "sel=%d capacity=%d" % (a[1], a[2])
+        return 4 * a[1] + 4 * (a[2] // 32 + 3), 0, "sel=%d capacity=%d" % (a[1], a[2])
     if name in ("kgcn_gcn_stack_fwd_f32", "kgcn_gcn_stack_bwd_f32"):
         bwd = name.endswith("bwd_f32")
         c = _csr(a[0])
@@ -263,7 +266,7 @@ def instrument(repeat=8):
         fn = getattr(lib, name)
         if name.endswith(("_bytes", "_supported", "_floats", "_products")) or name in ("kgcn_abi_version", "kgcn_last_error",
                                                                                        "kgcn_build_arch", "kgcn_reduce_defer",
-                                                                                       "kgcn_reduce_pending", "kgcn_ragged_num_blocks"):
+                                                                                       "kgcn_reduce_pending", "kgcn_ragged_num_blocks", "kgcn_ragged_block_rows"):
             continue
 
         def wrapper(*a, _fn=fn, _name=name):
