@@ -622,7 +622,7 @@ def traffic_of(cfg, entry, products):
 def roofline_from_rows(rows, unpriced, cfg=None):
     if not rows:
         return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
-    top = rows[0]
+    top = next((r for r in rows if not r.get("nominal")), rows[0])     # largest time among the calls with real byte / flop figures
     mfma = top["bound"] == "mfma"
     traffic, kernel, stale = traffic_of(cfg, top["entry"], top["mfma_products"]) if cfg else (None, None, None)
     return {"bound": top["bound"], "kernel": "%s [%s] x%d per step" % (top["entry"], top["shape"], top["calls"]),

@@ -25,6 +25,7 @@ from kgcn_amd import _lib
 HBM = 8.0e12
 F32_MFMA = 157.3e12
 F16_MFMA = 2.5e15              # dense f16 / bf16 matrix rate (MI355X_MICROARCH.md)
+NOMINAL = ("kgcn_reduce_flush", "kgcn_wtable_split_multi")
 REPEATABLE = ("kgcn_dense_fwd", "kgcn_dense_dx_dact", "kgcn_dense_wgrad", "kgcn_bspmm", "kgcn_gin_aggregate", "kgcn_graphconv_")
 
 
@@ -254,6 +255,7 @@ class Recorder:
             r["mfma_peak_TFLOPs"] = round(F16_MFMA / p / 1e12, 1) if p >= 3 else (157.3 if p == 1 else None)
             r["bound"] = "hbm" if t_hbm >= t_mfma else "mfma"
             r["frac"] = max(r["frac_hbm"], r["frac_mfma"])
+            r["nominal"] = r["entry"] in NOMINAL          # launch-latency calls priced with a nominal byte figure: never "the dominant kernel"
             out.append(r)
         return out
 
