@@ -151,7 +151,8 @@ class GraphConv(nn.Module):
                     self._agg_pad.device != inputs.device:
                 self._agg_pad = self.w[0].new_zeros((dp - din - 1, dout))          # constant: allocated and zeroed once
             pad = self._agg_pad
-            wa = torch.cat([t for c in range(C) for t in (self.w[c], self.bias[c], pad)], dim=0)
+            wa = ops.stack_rows(self.w[0], self.bias[0], pad) if C == 1 else \
+                torch.cat([t for c in range(C) for t in (self.w[c], self.bias[c], pad)], dim=0)
             return ops.dense(z[0] if C == 1 else torch.cat(z, dim=1), wa, None, activation=act).reshape(B, N, dout)
         if C == 1:
             fw = ops.dense(x2d, self.w[0], self.bias[0])

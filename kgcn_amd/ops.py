@@ -459,8 +459,8 @@ class _Dense(torch.autograd.Function):
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
         # the second stage of dW / dbias may only wait (ops.deferred_reductions) when NOTHING reads them inside the backward pass:
         # true for leaf parameters, false for a weight that is itself computed (the concatenated kernels of a multi-channel
-        # GraphConv: autograd slices its gradient right away)
-        ctx.defer_ok = bool(w.is_leaf and (bias is None or bias.is_leaf))
+        # GraphConv: autograd slices its gradient right away; stack_rows' output is sliced into views only: see _StackRows)
+        ctx.defer_ok = bool((w.is_leaf or getattr(w, "_kgcn_defer_safe", False)) and (bias is None or bias.is_leaf))
         ctx.defer_ids = (w, bias)
         _count_use(w, bias)
         return y
@@ -535,6 +535,29 @@ class _Dense(torch.autograd.Function):
             if db is not None:
                 db = db.reshape(ctx.bias_shape)
         return dw, db
+
+
+class _StackRows(torch.autograd.Function):
+    """[w; bias; pad] along dim 0 (the operand of an aggregate-first GraphConv, layers.py) with a backward that hands out ROW BLOCKS
+    of the incoming gradient as views -- nothing reads the gradient's data inside the backward pass, so the second stage of the
+    weight-gradient GEMM that produces it may wait for the step's one reduction launch like a leaf parameter's (the output carries
+    `_kgcn_defer_safe`; torch.cat's backward does the same slicing, but that is torch's business and not a contract)."""
+
+    @staticmethod
+    def forward(ctx, w, bias, pad):
+        ctx.rows = (w.shape[0], bias.shape[0])
+        return torch.cat([w, bias, pad], dim=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        n0, n1 = ctx.rows
+        return g[:n0], g[n0:n0 + n1], None
+
+
+def stack_rows(w, bias, pad):
+    out = _StackRows.apply(w, bias, pad)
+    out._kgcn_defer_safe = bool(w.is_leaf and bias.is_leaf)
+    return out
 
 
 def dense(x2d, w, bias=None, activation=None):
