@@ -518,11 +518,9 @@ class Cfg2:
             tj = json.load(open(tpath))
             if tj.get("graphs_per_launch") == T:      # PMC-measured HBM bytes of the same launch shape
                 traffic = {k: v.get("bytes") for k, v in tj.items() if isinstance(v, dict)}
-                import hashlib
-                h = hashlib.sha256()
-                for f in ("fused.hip", "spmm.hip", "dense.hip", "kgcn_common.h"):
-                    h.update(open(os.path.join(ROOT, "kgcn_amd", "csrc", f), "rb").read())
-                traffic_stale = tj.get("kernel_sources_sha256") != h.hexdigest()
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import source_hash                     # comments and white space do not count
+                traffic_stale = tj.get("kernel_sources_sha256") != source_hash.sources_sha256(source_hash.CFG2_FILES)
         fwd_st = stats([e[0].elapsed_time(e[1]) for e in evs])
         bwd_st = stats([e[1].elapsed_time(e[2]) for e in evs])
         fwd_ms, bwd_ms = fwd_st["mean_ms"], bwd_st["mean_ms"]
@@ -595,10 +593,9 @@ _KERNEL_OF = {("kgcn_dense_fwd", 3): "gemmh_fwd_kernel<0", ("kgcn_dense_dx_dact"
 
 
 def kernel_sources_sha256():
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "kgcn_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "kgcn_amd", "csrc", "*.h"))):
-        h.update(open(f, "rb").read())
-    return h.hexdigest()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import source_hash                                 # every .hip / .h under kgcn_amd/csrc, comments and white space removed
+    return source_hash.sources_sha256()
 
 
 def traffic_of(cfg, entry, products):

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void dot_final_kernel(const float* __restrict_
   __shared__ float red[4];
   float s = 0.f;
   // eight loads in flight per lane, added in the order of the plain loop (same bits): 20,000 per-graph partials of the fused d eps
-  // took 23.6 us as 78 dependent load-add steps (profiles/r04_q_cfg5_rocprof.txt)
+  // took 23.6 us as 78 dependent load-add steps (rocprofv3, cfg5 step)
   int i = threadIdx.x;
   for (; i + 7 * 256 < nparts; i += 8 * 256) {
     float v[8];

@@ -150,7 +150,7 @@ __device__ __forceinline__ void adam_tf_update(float& p, float& m, float& v, flo
 
 // (The step counter is advanced by a one-thread launch behind the update.  Advancing it from the update kernel's last workgroup --
 // every workgroup adds an arrival to the counter's upper bits, the one that completes the count takes them out and ticks -- was
-// tried: 3,584 same-address atomics at ~12 ns each made the update 48 us instead of 8 + 4, profiles/r04_q_cfg4_rocprof.txt.)
+// tried: 3,584 same-address atomics at ~12 ns each made the update 48 us instead of 8 + 4, DESIGN.md lesson 30 / section 3.)
 __device__ __forceinline__ long long adam_step_of(const long long* counter) { return *counter + 1; }
 
 template <bool VEC>

@@ -115,15 +115,13 @@ if "pmc_grbm" in dur:
 
 # HBM bytes per launch of every kernel with both PMC passes -> <dir>/traffic.json (copied to profiles/traffic_<cfg>.json; bench.py
 # fills `roofline.traffic` from it and flags it stale when the kernel sources changed since)
-import hashlib
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import source_hash
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-h = hashlib.sha256()
-for f in sorted(glob.glob(os.path.join(root, "kgcn_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "kgcn_amd", "csrc", "*.h"))):
-    h.update(open(f, "rb").read())
 tj = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (tools/profile_config.sh): FETCH_SIZE and WRITE_SIZE collected in "
                   "separate runs, KiB units, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md (HBM section); averages over "
                   "the dispatches of the timed steps",
-      "workload": bench["config"]["workload"] if bench else None, "kernels": {}, "kernel_sources_sha256": h.hexdigest()}
+      "workload": bench["config"]["workload"] if bench else None, "kernels": {}, "kernel_sources_sha256": source_hash.sources_sha256()}
 for k, (ps, v) in st.items():
     c = pmc.get(k, {})
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:

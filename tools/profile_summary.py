@@ -86,10 +86,7 @@ if bench:
         print("spmm_tile_kernel: forward %.1f us = %.4f of HBM peak, adjoint %.1f us = %.4f (HIP events, median)" % (
             sp["forward"]["median_ms"] * 1e3, sp["forward"]["frac"], sp["adjoint"]["median_ms"] * 1e3, sp["adjoint"]["frac"]))
 # the kernel sources these byte counts were measured on: bench.py flags the figures as stale when they change
-import hashlib
-_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_h = hashlib.sha256()
-for _f in ("fused.hip", "spmm.hip", "dense.hip", "kgcn_common.h"):
-    _h.update(open(os.path.join(_root, "kgcn_amd", "csrc", _f), "rb").read())
-traffic["kernel_sources_sha256"] = _h.hexdigest()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import source_hash
+traffic["kernel_sources_sha256"] = source_hash.sources_sha256(source_hash.CFG2_FILES)
 json.dump(traffic, open(os.path.join(src, "traffic_cfg2.json"), "w"), indent=1)
