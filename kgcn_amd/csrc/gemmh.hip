@@ -66,6 +66,16 @@ __device__ __forceinline__ void wave_umax4(unsigned& a, unsigned& b, unsigned& c
   d = (unsigned)__builtin_amdgcn_readlane((int)d, 63);
 }
 
+#ifdef KGCN_PROBE   // development: per-wave cycle sums per phase of gemmh_wgradl_kernel (tools/gemmh_probe.py)
+__device__ long long* gh_probe = nullptr;
+#define GHP_DECL long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long pc_ = __builtin_readcyclecounter();
+#define GHP(k) { const long long n_ = __builtin_readcyclecounter(); pt_[k] += n_ - pc_; pc_ = n_; }
+#define GHP_FLUSH if (gh_probe && lane == 0) { for (int k_ = 0; k_ < 8; ++k_) gh_probe[(((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8 + k_] = pt_[k_]; }
+#else
+#define GHP_DECL
+#define GHP(k)
+#define GHP_FLUSH
+#endif
 #ifndef GH_VARIANT
 #define GH_VARIANT 0             // development (tools/gemmh_variants.sh): 2 no y stores, 3 no x loads (forward); 5 no MFMAs, 6 no
 #endif                           // split, 7 no loads (gemmh_wgradl) -- what each part of the kernels costs
@@ -864,6 +874,7 @@ __global__ __launch_bounds__(512, 2) void gemmh_wgradl_kernel(const float* __res
   };
 
   int buf = 0;
+  GHP_DECL
   if (s0 < s1) {
     const long sl = s1 - 1;                              // requests past the range repeat its last stage (valid, unused)
     Raw r0, r1, r2;
@@ -880,27 +891,35 @@ __global__ __launch_bounds__(512, 2) void gemmh_wgradl_kernel(const float* __res
     // the other both waves of a SIMD collided on each pipe in turn (75 us at 117,888 rows; WAIT_ANY 42 %).
     auto iter_fast = [&](long s, Raw& rnext, Raw& rfree) __attribute__((always_inline)) {
       __builtin_amdgcn_sched_barrier(0);
+      GHP(7)                                              // (loop overhead / what the previous iteration left)
       load(s + 3 < sl ? s + 3 : sl, rfree);
       __builtin_amdgcn_sched_barrier(0);
+      GHP(0)
       split_check(rnext);
+      GHP(1)
       mult_check(buf);
       Frags f;
       read_frags(f, 0, buf);
       __builtin_amdgcn_sched_barrier(0);
+      GHP(2)
       mma_lo(f);
       emit_y(rnext, 0, buf ^ 1);
       __builtin_amdgcn_sched_barrier(0);
       mma_hi(f);
       emit_y(rnext, 1, buf ^ 1);
       __builtin_amdgcn_sched_barrier(0);
+      GHP(3)
       read_frags(f, 1, buf);
       __builtin_amdgcn_sched_barrier(0);
+      GHP(4)
       mma_lo(f);
       emit_x(rnext, 0, buf ^ 1);
       __builtin_amdgcn_sched_barrier(0);
       mma_hi(f);
       emit_x(rnext, 1, buf ^ 1);
+      GHP(5)
       gh_barrier_lds();
+      GHP(6)
       buf ^= 1;
     };
     auto iter = [&](long s, Raw& rnext, Raw& rfree) __attribute__((always_inline)) {
@@ -939,6 +958,7 @@ __global__ __launch_bounds__(512, 2) void gemmh_wgradl_kernel(const float* __res
     multiply(buf);
   }
 
+  GHP_FLUSH
   // ---- the workgroup's partial dW block, unscaled -----------------------------------------------------------------
   float* pw = part_dw + (long)blockIdx.x * din * dout;
 #pragma unroll
@@ -991,3 +1011,10 @@ int launch_gemmh_wgrad(const float* x, long x_ld, const float* dy, long dy_ld, l
 }
 
 }  // namespace kgcn
+
+#ifdef KGCN_PROBE
+extern "C" int kgcn_gh_probe_set(void* buf) {
+  long long* p = static_cast<long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(kgcn::gh_probe), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
