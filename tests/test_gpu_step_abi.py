@@ -119,3 +119,33 @@ def test_step_entry_points_validate_before_launching():
     plan.row_floats[0] = 8
     assert lib.kgcn_batch_assemble(plan, ptr(torch.zeros(4, dtype=torch.int32, device=dev())), 4, None, 0, current_stream()) != 0
     torch.cuda.synchronize()
+
+
+def test_dx_dact_dot_and_strided_gather_argument_checks():
+    """kgcn_dense_dx_dact_dot_f32 / kgcn_graph_gather_fwd_ld_f32 / kgcn_ragged_blocks refuse what they cannot do, with a message."""
+    from kgcn_amd._lib import lib, ptr, current_stream
+    m, d = 16384, 256
+    assert lib.kgcn_dense_dx_dact_dot_supported(m, d, d) == 1
+    assert lib.kgcn_dense_dx_dact_dot_supported(m - 64, d, d) == 0 and lib.kgcn_dense_dx_dact_dot_supported(m, 50, 50) == 0
+    big = torch.zeros(m * d, device=dev())
+    tab = torch.zeros(int(lib.kgcn_dense_fwd_workspace_bytes(d, d)) // 4, device=dev())
+    ws = torch.zeros(max(int(lib.kgcn_dense_dx_dact_dot_workspace_bytes(m, d)), 4) // 4, device=dev())
+    out = torch.zeros(1, device=dev())
+
+    def call(act=2, mm=m, dotx=big, wsb=None, dotx_ld=d):
+        return lib.kgcn_dense_dx_dact_dot_f32(ptr(big), ptr(big), mm, d, d, ptr(big), d, d, ptr(dotx), dotx_ld, act, ptr(big.clone()),
+                                              ptr(tab), tab.numel() * 4, 0, ptr(out), ptr(ws), ws.numel() * 4 if wsb is None else wsb,
+                                              current_stream())
+    assert call() == 0
+    assert call(act=0) != 0 and b"activation" in lib.kgcn_last_error()
+    assert call(mm=1000) != 0 and b"no fused form" in lib.kgcn_last_error()
+    assert call(dotx=None) != 0 and b"NULL" in lib.kgcn_last_error()
+    assert call(wsb=4) != 0 and b"workspace" in lib.kgcn_last_error()
+    assert call(dotx_ld=d + 2) != 0                                   # rows of dotx must stay 16-byte aligned
+    x = torch.zeros((8, 5, 12), device=dev())
+    o = torch.zeros((8, 40), device=dev())
+    assert lib.kgcn_graph_gather_fwd_ld_f32(ptr(x), 8, 5, 12, ptr(o), 40, current_stream()) == 0
+    assert lib.kgcn_graph_gather_fwd_ld_f32(ptr(x), 8, 5, 12, ptr(o), 8, current_stream()) != 0 and b"out_ld" in lib.kgcn_last_error()
+    assert lib.kgcn_ragged_blocks(None, 4, 64, ptr(torch.zeros(8, dtype=torch.int32, device=dev())), current_stream()) != 0
+    assert lib.kgcn_ragged_num_blocks(0) == 0 and lib.kgcn_ragged_num_blocks(65) == (65 + lib.kgcn_ragged_block_rows() - 1) // lib.kgcn_ragged_block_rows() + 2
+    torch.cuda.synchronize()
