@@ -27,6 +27,7 @@
 namespace kgcn {
 
 int launch_reduce_partials(const float* part, int nparts, long n, float* out, hipStream_t s);
+int reduce_or_defer(const float* part, int nparts, long n, float* out, hipStream_t s);   // (dense.hip: queued inside a deferral scope)
 
 // LDS floats of one weight block: kind 0/1: W [din x 65] + b [64]; kind 2: scale [64] + shift [64]
 __host__ __device__ inline int sk_wblock(int kind, int din) { return kind == 2 ? 128 : din * SK_WLD + 64; }
@@ -525,7 +526,7 @@ extern "C" int kgcn_gcn_stack_bwd_f32(const kgcn_csr_batch* at, const float* x, 
   if (tiles) {
     if (int rc = launch_stack2_bwd(p.a, p.tile, at->rowptr, cvp, x, enabled, (long)at->num_graphs, dlast, dx, part, blocks, s))
       return rc;
-    return launch_reduce_partials(part, blocks, p.a.ptotal, dparams, s);
+    return reduce_or_defer(part, blocks, p.a.ptotal, dparams, s);
   }
 #define KGCN_SK_BWD(NQ)                                                                                               \
   {                                                                                                                   \
@@ -550,5 +551,5 @@ extern "C" int kgcn_gcn_stack_bwd_f32(const kgcn_csr_batch* at, const float* x, 
   }
 #undef KGCN_SK_BWD
   if (int rc = check_launch("stack_bwd_kernel")) return rc;
-  return launch_reduce_partials(part, blocks, p.a.ptotal, dparams, s);
+  return reduce_or_defer(part, blocks, p.a.ptotal, dparams, s);
 }

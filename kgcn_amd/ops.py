@@ -1187,6 +1187,10 @@ class _GcnStack(torch.autograd.Function):
         ctx.save_for_backward(x, *outs, *[p for p in params if p is not None])
         ctx.param_none = [p is None for p in params]
         ctx.param_shapes = [None if p is None else tuple(p.shape) for p in params]
+        # (the gradients are views of ONE buffer nothing reads inside the pass: its second stage may wait -- see deferred_reductions)
+        ctx.defer_ok = all(p is None or p.is_leaf for p in params)
+        ctx.defer_ids = tuple(params)
+        _count_use(*params)
         return pooled if gather else outs[-1]
 
     @staticmethod
@@ -1206,9 +1210,11 @@ class _GcnStack(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         wsb = lib.kgcn_gcn_stack_bwd_workspace_bytes(x.shape[0], arr, len(spec))
         ws = torch.empty((max(wsb, 4) // 4,), device=g.device, dtype=torch.float32)
-        check(lib.kgcn_gcn_stack_bwd_f32(ctx.csr.transpose().desc(), ptr(x), ptr(ctx.enabled), arr, len(spec), optr, ptr(g),
-                                         1 if ctx.gather else 0, ptr(dx), ptr(dparams), ptr(ws), wsb, current_stream()),
-              "kgcn_gcn_stack_bwd_f32")
+        with _no_deferral_unless(ctx.defer_ok and _single_use(*ctx.defer_ids)):
+            check(lib.kgcn_gcn_stack_bwd_f32(ctx.csr.transpose().desc(), ptr(x), ptr(ctx.enabled), arr, len(spec), optr, ptr(g),
+                                             1 if ctx.gather else 0, ptr(dx), ptr(dparams), ptr(ws), wsb, current_stream()),
+                  "kgcn_gcn_stack_bwd_f32")
+            _keep_until_flush(ws)
         grads, off = [], 0
         for l, (kind, act, din, dout, eps) in enumerate(spec):
             nw = dout if kind == 2 else din * dout
