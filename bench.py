@@ -675,7 +675,7 @@ class _ModelStep:
             self.sb.assemble()
         logits = self.model(self.sb.features, self.sb.adjacency, **self.kw)
         cost_opt, _ = self.loss_fn(logits, self.labels, self.mask)
-        with ops.deferred_reductions():
+        with ops.deferred_reductions(root=cost_opt):
             cost_opt.backward()
         self.opt.step(packed=train_exchange(self.bucket, self.opt, self.weight))
 

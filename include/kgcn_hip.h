@@ -20,13 +20,25 @@
  *    implicit synchronisation.  Entry points are re-entrant.
  *  - return value: 0 = ok, non-zero = error; text via kgcn_last_error().  No exception crosses
  *    the ABI.
- *  - all tensors are IEEE fp32, indices int32.  Contractions accumulate in fp32 and are evaluated either
- *    with v_mfma_f32_32x32x2_f32 (kgcn_dense_* up to 128 output columns) or -- in the fused GraphConv
- *    kernels and in the wide-layer GEMMs of kgcn_dense_* -- on the bf16 matrix pipe with an EXACT 3-way
- *    bf16 split of every fp32 operand (v = p1 + p2 + p3, 8+8+8 significand bits)
- *    and the six products a_i b_j with i + j <= 4: the neglected terms are below 2^-23 |a b|, i.e. one
- *    fp32 rounding of the product -- no reduced-precision inputs, measured error vs fp64 identical to
- *    the f32-MFMA path (profiles/r01_g_accuracy.json).
+ *  - all tensors are IEEE fp32, indices int32; every contraction accumulates in fp32.  Three evaluation routes,
+ *    chosen per call from the shapes (kgcn_dense_mfma_products(kind, m, din, dout) reports the route of a dense call:
+ *    1, 6 or 3 matrix-pipe products per fp32 product):
+ *      (1) v_mfma_f32_32x32x2_f32 -- fp32 operands, exact products (kgcn_dense_* up to 128 output columns, the narrow
+ *          50-wide layers, the cross-layer stack kernels);
+ *      (2) bf16 x 3 -- an EXACT three-way bf16 split of every fp32 operand (v = p1 + p2 + p3, 8+8+8 significand bits) and
+ *          the six products a_i b_j with i + j <= 4; the neglected terms are below 2^-23 |a b|, one fp32 rounding of the
+ *          product (the fused GraphConv kernels kgcn_graphconv_*; kgcn_dense_* with more than 128 output columns below
+ *          16,384 rows, with 65..96 input columns, and the 256 -> 50 layers);
+ *      (3) f16 x 2 -- the wide-layer GEMMs of kgcn_dense_fwd_* / kgcn_dense_dx_dact_* / kgcn_dense_wgrad_* /
+ *          kgcn_dense_bwd_* at >= 16,384 rows: each operand is scaled by an exact power of two per ROW (x, gradients) or
+ *          per COLUMN (weights; both operands of a weight gradient) so that its largest magnitude lands in [2^14, 2^15),
+ *          split into two f16 pieces v' = h + l (22 significand bits) and multiplied as l*H + h*L + h*H.
+ *          Error of one dot product of length K:  <= 2^-23 sum_k |x_k w_k|  +  K * 2^-40 * max_k|x_k| * max_k|w_k|
+ *          (the second term: elements more than 2^14 below their row's / column's maximum keep fewer than 22 bits --
+ *          f16 denormal spacing).  For data within 2^14 of the row / column maximum this is fp32 arithmetic with one
+ *          rounding per product; the edge suite (exponent spread, denormals, heavy-tailed rows) is
+ *          tests/test_gpu_dense_edges.py, measured errors in profiles/r05_accuracy.json.
+ *    Routes (2) and (3) never see reduced-precision INPUTS: the splits are of the caller's fp32 values.
  *
  * Adjacency layout in HBM ("batched CSR", one per adjacency channel).  T graphs, each an
  * [rows x cols] sparse matrix (uniform, = the reference's max_node_num padding,
@@ -46,18 +58,24 @@
 extern "C" {
 #endif
 
-#define KGCN_HIP_ABI_VERSION 1
+/* 2 (round 5): kgcn_csr_batch grew block_ptr / num_blocks / block_rows_max (round 4), kgcn_dense_dx_dact_gather_f32 gained
+ * pooled_ld and kgcn_masked_sigmoid_ce_f32 gained pos_weight_per_task.  A binder built against version 1 must not call a
+ * version-2 library: compare kgcn_abi_version() with the KGCN_HIP_ABI_VERSION it was compiled against AND
+ * kgcn_csr_batch_size() with its own sizeof(kgcn_csr_batch) before the first call (kgcn_amd/_lib.py and
+ * tests/abi_consumer.c do both). */
+#define KGCN_HIP_ABI_VERSION 2
 
 /* Column index of the padding entries of a row-padded batch (see row_pad): they carry value 0 and
  * gather an all-zero row the fused kernels keep in LDS, so they contribute exactly 0 (never 0*inf). */
 #define KGCN_PAD_COL 32
 
-/* Non-finite inputs.  The fused GraphConv kernels and the wide-layer GEMMs contract on the bf16 matrix pipe with an EXACT
- * three-way split of every fp32 value (p1 + p2 + p3 == x bit for bit for finite x, six products per k-value); the other
- * kernels use fp32 MFMA / FMA.  For finite inputs both agree with fp32 arithmetic to one rounding.  +-inf splits into
- * (inf, NaN, NaN) and NaN into (NaN, NaN, NaN): every output element that depends on a non-finite input comes out
- * non-finite (NaN where fp32 arithmetic would give +-inf is possible), every other element is unaffected -- never a
- * silently finite wrong value (tests/test_gpu_parity.py::test_bf16_split_non_finite_inputs).  Padding entries of the
+/* Non-finite inputs, per route (see "Conventions").  bf16 x 3 (fused GraphConv kernels, route 2): p1 + p2 + p3 == x bit for
+ * bit for finite x; +-inf splits into (inf, NaN, NaN) and NaN into (NaN, NaN, NaN).  f16 x 2 (wide-layer GEMMs, route 3): a
+ * row of x / a column of W (a column of either operand in a weight gradient) that holds +-inf or NaN gets a meaningless
+ * scale and non-finite pieces, so EVERY output of that row / column is non-finite -- each of them depends on the non-finite
+ * input.  In all routes: every output element that depends on a non-finite input comes out non-finite (NaN where fp32
+ * arithmetic would give +-inf is possible), every other element is unaffected -- never a silently finite wrong value
+ * (tests/test_gpu_parity.py::test_bf16_split_non_finite_inputs, tests/test_gpu_dense_edges.py).  Padding entries of the
  * row-padded layout gather an all-zero row with value 0, so they contribute exactly 0 (never 0 * inf). */
 
 typedef struct kgcn_csr_batch {
@@ -93,6 +111,9 @@ typedef struct kgcn_csr_batch {
 
 /* -- library info ------------------------------------------------------------------------ */
 int kgcn_abi_version(void);
+/* sizeof(kgcn_csr_batch) as THIS library was compiled: a caller whose own sizeof differs was built against another layout
+ * of the descriptor (it grew in ABI version 2) and must not pass it in. */
+int64_t kgcn_csr_batch_size(void);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* kgcn_last_error(void);
 /* Name of the code-object architecture the kernels were built for ("gfx950"). */

@@ -33,6 +33,10 @@ c_i64 = ctypes.c_int64
 c_i32 = ctypes.c_int32
 
 
+# KGCN_HIP_ABI_VERSION this binding was written against (include/kgcn_hip.h); the library must report the same
+ABI_VERSION = 2
+
+
 class CsrBatch(ctypes.Structure):
     """struct kgcn_csr_batch (include/kgcn_hip.h)."""
     _fields_ = [
@@ -97,6 +101,7 @@ _PTRP = ctypes.POINTER(ctypes.c_void_p)
 # (tests/test_abi.py parses the header and compares).
 SIGNATURES = {
     "kgcn_abi_version": (ctypes.c_int, []),
+    "kgcn_csr_batch_size": (c_i64, []),
     "kgcn_last_error": (ctypes.c_char_p, []),
     "kgcn_build_arch": (ctypes.c_char_p, []),
     "kgcn_bspmm_f32": (ctypes.c_int, [_CSRP, c_f32p, c_i64, c_i64, c_i32, c_f32p, c_i64, c_i64,
@@ -255,8 +260,11 @@ def _load():
             raise ImportError("kgcn_amd: %s does not export %s (stale build?)" % (LIB_PATH, name)) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.kgcn_abi_version() != 1:
-        raise ImportError("kgcn_amd: ABI version mismatch: %d" % lib.kgcn_abi_version())
+    if lib.kgcn_abi_version() != ABI_VERSION:
+        raise ImportError("kgcn_amd: ABI version mismatch: library %d, binding %d" % (lib.kgcn_abi_version(), ABI_VERSION))
+    if lib.kgcn_csr_batch_size() != ctypes.sizeof(CsrBatch):
+        raise ImportError("kgcn_amd: kgcn_csr_batch is %d bytes in the library, %d in the binding (stale build?)"
+                          % (lib.kgcn_csr_batch_size(), ctypes.sizeof(CsrBatch)))
     return lib
 
 

@@ -161,6 +161,7 @@ static unsigned grid_for(long total_threads) {
 using namespace kgcn;
 
 extern "C" int kgcn_abi_version(void) { return KGCN_HIP_ABI_VERSION; }
+extern "C" int64_t kgcn_csr_batch_size(void) { return (int64_t)sizeof(kgcn_csr_batch); }
 extern "C" const char* kgcn_last_error(void) { return error_buffer(); }
 extern "C" const char* kgcn_build_arch(void) { return "gfx950"; }
 

@@ -45,11 +45,24 @@ _deferred_keep = []            # workspaces whose partials are still queued
 
 
 class deferred_reductions:
-    """with ops.deferred_reductions(): loss.backward()  -- the weight-gradient calls inside queue their second stages; leaving the
-    block adds all of them in ONE launch.  Parameter gradients are valid only after the block (kgcn_amd.train uses it around the
-    backward pass of a training step; plain autograd code never sees deferral)."""
+    """with ops.deferred_reductions(root=loss): loss.backward()  -- the weight-gradient calls inside queue their second stages;
+    leaving the block adds all of them in ONE launch.  Parameter gradients are valid only after the block (kgcn_amd.train uses
+    it around the backward pass of a training step; plain autograd code never sees deferral).
+
+    A gradient may only wait when NOTHING reads it inside the backward pass.  `root` (the tensor(s) backward() is about to be
+    called on) lets the block check that on the autograd graph itself: a parameter whose AccumulateGrad node has more than one
+    incoming edge (used twice -- by kgcn ops, by plain torch ops such as an L2 penalty or a tied torch.matmul, or both: autograd
+    ADDS the contributions inside the pass), that carries a tensor hook, or whose .grad already exists (accumulated in place
+    inside the pass) is excluded from deferral for this backward pass.  Without `root` only uses by kgcn ops are known
+    (_count_use): pass it whenever the model may contain anything else."""
+
+    def __init__(self, root=None):
+        self.root = root
 
     def __enter__(self):
+        _no_defer_params.clear()
+        if self.root is not None:
+            _no_defer_params.update(_readers_inside_backward(self.root))
         self.prev = lib.kgcn_reduce_defer(0 if _no_defer_debug() else 1)
         return self
 
@@ -58,7 +71,36 @@ class deferred_reductions:
             flush_reductions()
         finally:
             lib.kgcn_reduce_defer(self.prev)
+            _no_defer_params.clear()
         return False
+
+
+_no_defer_params = set()       # id() of parameters whose gradient is read inside the backward pass now running
+
+
+def _readers_inside_backward(root):
+    """id()s of the leaf tensors under `root` whose gradient contribution from a deferring op could be READ before the flush:
+    AccumulateGrad nodes with several incoming edges, tensor hooks, an existing .grad."""
+    roots = root if isinstance(root, (list, tuple)) else (root,)
+    edges, seen, stack = {}, set(), [t.grad_fn for t in roots if t is not None and t.grad_fn is not None]
+    while stack:
+        fn = stack.pop()
+        if fn in seen:
+            continue
+        seen.add(fn)
+        for nxt, _ in fn.next_functions:
+            if nxt is None:
+                continue
+            if hasattr(nxt, "variable"):                 # AccumulateGrad
+                edges[nxt] = edges.get(nxt, 0) + 1
+            elif nxt not in seen:
+                stack.append(nxt)
+    out = set()
+    for acc, n in edges.items():
+        v = acc.variable
+        if n > 1 or v.grad is not None or getattr(v, "_backward_hooks", None) or getattr(v, "_post_accumulate_grad_hooks", None):
+            out.add(id(v))
+    return out
 
 
 def _no_defer_debug():
@@ -96,7 +138,7 @@ def _count_use(*params):
 
 
 def _single_use(*params):
-    return all(p is None or _param_uses.get(id(p), 0) == 1 for p in params)
+    return all(p is None or (_param_uses.get(id(p), 0) == 1 and id(p) not in _no_defer_params) for p in params)
 
 
 class _no_deferral_unless:
@@ -461,8 +503,13 @@ class _Dense(torch.autograd.Function):
         # true for leaf parameters, false for a weight that is itself computed (the concatenated kernels of a multi-channel
         # GraphConv: autograd slices its gradient right away; stack_rows' output is sliced into views only: see _StackRows)
         ctx.defer_ok = bool((w.is_leaf or getattr(w, "_kgcn_defer_safe", False)) and (bias is None or bias.is_leaf))
-        ctx.defer_ids = (w, bias)
-        _count_use(w, bias)
+        # who receives this gradient: the operand itself, or -- for stack_rows' [w; bias; pad], a fresh tensor per call -- the
+        # PARAMETERS behind it (a GraphConv applied twice shares them: both contributions are added inside the pass)
+        under = getattr(w, "_kgcn_defer_params", None)
+        ctx.defer_ids = (w, bias) if under is None else tuple(under) + (bias,)
+        if under is None:
+            _count_use(w)
+        _count_use(bias)
         return y
 
     @staticmethod
@@ -557,6 +604,8 @@ class _StackRows(torch.autograd.Function):
 def stack_rows(w, bias, pad):
     out = _StackRows.apply(w, bias, pad)
     out._kgcn_defer_safe = bool(w.is_leaf and bias.is_leaf)
+    out._kgcn_defer_params = (w, bias)         # _Dense counts / checks THESE: `out` is a new tensor on every call
+    _count_use(w, bias)
     return out
 
 
@@ -1276,6 +1325,44 @@ def _loss_grad(dlog, g_opt, g_sum, batch):
     return out
 
 
+_pos_weight_cache = {}         # id(host object) -> (the object itself, content bytes, device, device tensor)
+
+
+def _pos_weight_operand(pos_weight, W, device):
+    """-> (scalar weight, per-task device tensor or None).  A HOST per-task pos_weight (list / numpy array / CPU tensor -- the
+    reference's info.pos_weight is a numpy array, kgcn/data_util.py:563-568) is uploaded ONCE and cached on its content: a
+    per-step torch.as_tensor(...).to(device) is a synchronous pageable copy every forward and an illegal operation inside a
+    hipGraph capture.  Device tensors are used where they lie (a 1-element one is broadcast on the device: no float() sync)."""
+    if pos_weight is None:
+        return 0.0, None
+    if torch.is_tensor(pos_weight) and pos_weight.is_cuda:
+        qv = pos_weight.detach().to(torch.float32).reshape(-1)
+        if qv.numel() == 1:
+            qv = qv.expand(W)
+        if qv.numel() != W:
+            raise _lib.KgcnHipError("pos_weight has %d entries for %d tasks" % (qv.numel(), W))
+        return 0.0, qv.contiguous()
+    if not (torch.is_tensor(pos_weight) or hasattr(pos_weight, "__len__")):
+        return float(pos_weight), None
+    host = torch.as_tensor(pos_weight, dtype=torch.float32).reshape(-1)
+    if host.numel() == 1:
+        return float(host), None
+    if host.numel() != W:
+        raise _lib.KgcnHipError("pos_weight has %d entries for %d tasks" % (host.numel(), W))
+    content = host.numpy().tobytes()
+    hit = _pos_weight_cache.get(id(pos_weight))
+    if hit is not None and hit[0] is pos_weight and hit[1] == content and hit[2] == device:
+        return 0.0, hit[3]
+    if torch.cuda.is_current_stream_capturing():
+        raise _lib.KgcnHipError("a host pos_weight was first seen (or changed) while a hipGraph is being captured: pass a device "
+                                "tensor, or run one eager step with this pos_weight before the capture")
+    if len(_pos_weight_cache) >= 64:
+        _pos_weight_cache.clear()
+    qv = host.to(device).contiguous()
+    _pos_weight_cache[id(pos_weight)] = (pos_weight, content, device, qv)
+    return 0.0, qv
+
+
 class _MaskedCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, mask, mask_label, kind, pos_weight):
@@ -1295,18 +1382,7 @@ class _MaskedCE(torch.autograd.Function):
         if kind == "sigmoid":
             # info.pos_weight of the reference is one weight per label column (kgcn/data_util.py:563-568, consumed by
             # example_model/model_multitask.py:72-76); a scalar is accepted too and applies to every task
-            qs, qv = 0.0, None
-            if pos_weight is not None:
-                if torch.is_tensor(pos_weight) or hasattr(pos_weight, "__len__"):
-                    qv = torch.as_tensor(pos_weight, dtype=torch.float32).reshape(-1)
-                    if qv.numel() == 1:
-                        qs, qv = float(qv), None
-                    elif qv.numel() != W:
-                        raise _lib.KgcnHipError("pos_weight has %d entries for %d tasks" % (qv.numel(), W))
-                    else:
-                        qv = qv.to(x.device).contiguous()
-                else:
-                    qs = float(pos_weight)
+            qs, qv = _pos_weight_operand(pos_weight, W, x.device)
             check(lib.kgcn_masked_sigmoid_ce_f32(ptr(x), ptr(z), ptr(mk), ptr(ml), B, W, 0 if pos_weight is None else 1,
                                                  qs, ptr(qv), None, ptr(dlog), ptr(sums), ptr(ws), wsb, current_stream()),
                   "kgcn_masked_sigmoid_ce_f32")

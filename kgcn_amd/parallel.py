@@ -80,6 +80,12 @@ class GradBucket:
             off += n
         return out
 
+    @staticmethod
+    def _use_avg(world, weight, group):
+        """equal shards on RCCL: the mean is the collective's own reduction (AVG), no scale launch; gloo has no AVG.  Depends only
+        on (world, weight, backend) -- identical on every rank."""
+        return bool(world > 1 and weight is None and dist.is_initialized() and dist.get_backend(group) == "nccl")
+
     def all_reduce_mean(self, group=None, weight=None, unpack=True):
         """flat <- concat(grads); all_reduce; scatter back into .grad (in place).  weight=None: plain mean over the
         ranks (equal shards).  weight=w_r (shard_weight: local padded graphs / global padded graphs): sum_r w_r g_r,
@@ -101,8 +107,7 @@ class GradBucket:
             world = dist.get_world_size(group) if dist.is_initialized() else 1
             if world == 1 and weight is not None and float(weight) != 1.0:
                 raise ValueError("a single rank owns the whole batch: its weight must be 1")
-            # equal shards on RCCL: the mean is the collective's own reduction (AVG), no scale launch; gloo has no AVG
-            avg = world > 1 and weight is None and dist.get_backend(group) == "nccl"
+            avg = self._use_avg(world, weight, group)
             if world > 1 and not avg:
                 run.mul_(1.0 / world if weight is None else float(weight))
             if dist.is_initialized():
@@ -114,12 +119,16 @@ class GradBucket:
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         if world == 1 and weight is not None and float(weight) != 1.0:
             raise ValueError("a single rank owns the whole batch: its weight must be 1")
-        if world > 1:
+        # ONE formulation whichever buffer is reduced: which of the two paths a rank takes depends on the layout its own backward
+        # left the gradients in (kernel routes can differ between ranks: graphconv_fused_supported looks at the LOCAL batch) --
+        # the collective's reduction op and the pre-scale may only depend on what every rank agrees on (world, weight, backend)
+        avg = self._use_avg(world, weight, group)
+        if world > 1 and not avg:
             flat.mul_(1.0 / world if weight is None else float(weight))
         if dist.is_initialized():
             # also with ONE rank: the collective is a no-op numerically but goes through RCCL (and, inside a hipGraph
             # capture, into the graph) -- the only way a 1-GPU box exercises the data-parallel path end to end
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group)
         if unpack:
             torch._foreach_copy_(grads, views)
         return flat

@@ -137,7 +137,7 @@ def train_step(model, optimizer, loss_fn, features, adjs, labels, mask, bucket=N
     cost_opt, cost_sum = loss_fn(logits, labels, mask)
     # .grad is None here (zero_grad above): backward's result tensors BECOME the gradients, nothing reads them before the block
     # ends -- so the second stages of all weight gradients can wait for one launch (ops.deferred_reductions)
-    with ops.deferred_reductions():
+    with ops.deferred_reductions(root=cost_opt):
         cost_opt.backward()
     optimizer.step(packed=_exchange(bucket, optimizer, shard_weight))
     return float(cost_sum.detach()), logits.detach()
@@ -207,7 +207,7 @@ class GraphedTrainStep:
         cost_opt, cost_sum = self.loss_fn(logits, self.labels, self.mask)
         if self._seed is None or self._seed.shape != cost_opt.shape:
             self._seed = torch.ones_like(cost_opt)     # persistent d cost / d cost = 1: no fill launch per step
-        with ops.deferred_reductions():            # one second-stage launch for all weight gradients of the step
+        with ops.deferred_reductions(root=cost_opt):   # one second-stage launch for all weight gradients of the step
             cost_opt.backward(self._seed)
         self.opt.step(packed=_exchange(self.bucket, self.opt, self.shard_weight))
         self.cost_sum, self.logits = cost_sum.detach(), logits.detach()

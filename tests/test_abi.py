@@ -18,6 +18,46 @@ def declared_functions():
     return sorted(set(names))
 
 
+def header_abi_version():
+    return int(re.search(r"#define\s+KGCN_HIP_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+
+
+def consumer_binary():
+    """tests/abi_consumer.bin, (re)built with plain gcc when it is missing or older than its source / the header."""
+    import __graft_entry__ as g
+    out = os.path.join(ROOT, "tests", "abi_consumer.bin")
+    srcs = (os.path.join(ROOT, "tests", "abi_consumer.c"), HEADER)
+    if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
+        if not os.path.exists("/usr/bin/gcc"):
+            pytest.skip("no gcc and no prebuilt abi_consumer.bin")
+        g.build_abi_consumer()
+    return out
+
+
+def run_consumer(mode):
+    import subprocess
+    p = subprocess.run([consumer_binary(), mode], capture_output=True, text=True, timeout=120)
+    facts = {}
+    for line in p.stdout.splitlines():
+        k, _, v = line.partition(" ")
+        facts[k] = v
+    return p.returncode, facts, p.stdout + p.stderr
+
+
+def test_c_consumer_sees_the_layout_the_binding_mirrors():
+    """A plain-C program compiled against include/kgcn_hip.h: its sizeof / offsetof of kgcn_csr_batch, the library's
+    kgcn_csr_batch_size() and the ctypes mirror in kgcn_amd/_lib.py must all agree -- layout drift that a ctypes-only test
+    cannot see (the struct grew in ABI version 2)."""
+    from kgcn_amd import _lib
+    rc, facts, text = run_consumer("layout")
+    assert rc == 0 and "OK" in facts, text
+    assert int(facts["header_abi_version"]) == int(facts["library_abi_version"]) == _lib.ABI_VERSION
+    assert int(facts["sizeof_csr_batch"]) == int(facts["library_csr_batch_size"]) == ctypes.sizeof(_lib.CsrBatch)
+    for field in ("nnz", "rowptr", "cv", "slots", "graph_ptr", "block_ptr", "num_blocks", "block_rows_max"):
+        assert int(facts["offsetof_" + field]) == getattr(_lib.CsrBatch, field).offset, field
+    assert "NULL" in facts["last_error"]
+
+
 def test_header_declares_the_path():
     names = declared_functions()
     for must in ("kgcn_bspmm_f32", "kgcn_bconv_f32", "kgcn_spmm_values_grad_f32", "kgcn_dense_fwd_f32",
@@ -32,7 +72,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert hasattr(lib, name), "libkgcn_hip.so does not export %s" % name
     assert sorted(_lib.SIGNATURES) == declared_functions(), "binding and header disagree"
-    assert _lib.lib.kgcn_abi_version() == 1
+    assert _lib.lib.kgcn_abi_version() == _lib.ABI_VERSION == header_abi_version()
+    assert _lib.lib.kgcn_csr_batch_size() == ctypes.sizeof(_lib.CsrBatch)
     assert _lib.lib.kgcn_build_arch() == b"gfx950"
 
 

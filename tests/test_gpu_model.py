@@ -326,6 +326,87 @@ def test_deferred_second_stages_leave_every_gradient_unchanged(kind):
             assert torch.equal(a, b), (kind, trial, n, float((a - b).abs().max()))
 
 
+def _grads_with_and_without_deferral(params, make_loss):
+    from kgcn_amd import ops
+
+    def grads(defer):
+        for p in params:
+            p.grad = None
+        ops.weight_tables.refresh()
+        cost = make_loss()
+        if defer:
+            with ops.deferred_reductions(root=cost):
+                cost.backward()
+        else:
+            cost.backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in params]
+
+    grads(False)
+    for trial in range(3):
+        plain, waited = grads(False), grads(True)
+        for i, (a, b) in enumerate(zip(plain, waited)):
+            assert torch.equal(a, b), (trial, i, float((a - b).abs().max()))
+    return plain
+
+
+def test_deferral_sees_a_graphconv_applied_twice_on_the_aggregate_first_route():
+    """stack_rows' [w; bias; pad] is a fresh tensor on every call, so counting ITS uses never saw that a
+    GraphConv on the aggregate-first route (din + 1 < dout, C == 1, >= 1,024 rows) applied twice in one step shares w / bias:
+    both weight gradients waited for the flush while autograd added the two views inside the pass.  The uses are counted on the
+    parameters behind the operand now, and the block checks the autograd graph (two edges into w's AccumulateGrad)."""
+    from kgcn_amd import layers
+    from oracle import kgcn_oracle as K
+    rng = np.random.default_rng(11)
+    T, N, F, H = 64, 20, 12, 32                      # 1,280 rows: aggregate-first (dp = 16 < 32)
+    adjs = K.synth_mol_graphs(rng, T, N, 2)
+    x = t32(rng.standard_normal((T, N, F)).astype(np.float32))
+    conv = layers.GraphConv(H, 1).to(dev())
+    lift = torch.nn.Parameter(t32(rng.standard_normal((H, F)).astype(np.float32) * 0.2))
+    g = t32(rng.standard_normal((T, N, H)).astype(np.float32))
+    conv(x, adj=adjs)                                 # build
+    params = [conv.w[0], conv.bias[0], lift]
+
+    def make_loss():
+        h = torch.tanh(conv(x, adj=adjs))
+        h2 = conv(h @ lift, adj=adjs)                 # the SAME layer again (weight sharing)
+        return (h2 * g).sum()
+
+    plain = _grads_with_and_without_deferral(params, make_loss)
+    # and the shared gradient is the sum of both uses: against the oracle
+    w, b = conv.w[0].detach().cpu().numpy().astype(np.float64), conv.bias[0].detach().cpu().numpy().astype(np.float64)
+    xn, ln, gn = x.cpu().numpy().astype(np.float64), lift.detach().cpu().numpy().astype(np.float64), g.cpu().numpy().astype(np.float64)
+    o1 = K.graphconv_fwd(xn, adjs, [w], [b])
+    h = np.tanh(o1)
+    dx2, dw2, db2 = K.graphconv_bwd(h @ ln, adjs, [w], [b], gn)
+    dh = dx2 @ ln.T
+    _, dw1, db1 = K.graphconv_bwd(xn, adjs, [w], [b], dh * (1.0 - h * h))
+    close(plain[0], dw1[0] + dw2[0], 0.0, 5e-6, "dW of a GraphConv used twice")
+    close(plain[1], db1[0] + db2[0], 0.0, 5e-6, "dbias of a GraphConv used twice")
+
+
+def test_deferral_sees_a_parameter_that_also_feeds_a_plain_torch_op():
+    """a kernel that is also read by a torch op in the same graph (an L2 penalty here) receives a second
+    contribution that autograd adds INSIDE the backward pass -- its weight gradient must not wait for the flush.  The same for a
+    parameter with a tensor hook (the hook reads the gradient inside the pass)."""
+    from kgcn_amd import layers
+    rng = np.random.default_rng(12)
+    m, din, dout = 20000, 256, 256                    # the wide-layer weight-gradient route (deferral-capable)
+    x = t32(rng.standard_normal((m, din)).astype(np.float32))
+    g = t32(rng.standard_normal((m, dout)).astype(np.float32))
+    w = torch.nn.Parameter(t32(rng.standard_normal((din, dout)).astype(np.float32) * 0.05))
+    b = torch.nn.Parameter(torch.zeros(dout, device=dev()))
+    from kgcn_amd import ops
+    _grads_with_and_without_deferral([w, b], lambda: (ops.dense(x, w, b, activation="relu") * g).sum() + 0.5 * (w * w).sum())
+    seen = []
+    h = w.register_hook(lambda gr: seen.append(float(gr.abs().sum())))
+    try:
+        _grads_with_and_without_deferral([w, b], lambda: (ops.dense(x, w, b, activation="relu") * g).sum())
+    finally:
+        h.remove()
+    assert len(set(seen)) == 1 and seen[0] > 0, seen   # the hook saw the FINISHED gradient every time, deferral on or off
+
+
 def test_model_py_layer_calls_through_the_kgcn_import_path():
     """The layer-call sequence of example_model/model.py:41-55, written against `import kgcn.layers` exactly as the
     reference writes it (keyword adj=, enabled_node_nums / max_node_num on the BN layer), must run on the HIP path and

@@ -149,3 +149,13 @@ def test_dx_dact_dot_and_strided_gather_argument_checks():
     assert lib.kgcn_ragged_blocks(None, 4, 64, ptr(torch.zeros(8, dtype=torch.int32, device=dev())), current_stream()) != 0
     assert lib.kgcn_ragged_num_blocks(0) == 0 and lib.kgcn_ragged_num_blocks(65) == (65 + lib.kgcn_ragged_block_rows() - 1) // lib.kgcn_ragged_block_rows() + 2
     torch.cuda.synchronize()
+
+
+def test_plain_c_consumer_calls_bspmm_on_the_device():
+    """tests/abi_consumer.c (gcc, include/kgcn_hip.h, no Python in the process): struct layout + version checks, then one
+    kgcn_bspmm_f32 call on a hand-built 2-graph batch (duplicate entry, empty rows) checked against products computed in C,
+    and a refused row_pad batch with its kgcn_last_error() text."""
+    from test_abi import run_consumer
+    rc, facts, text = run_consumer("bspmm")
+    assert rc == 0 and "OK" in facts, text
+    assert facts["bspmm_mismatches"].startswith("0 of")
