@@ -433,3 +433,36 @@ def test_gin_dense_d_epsilon_inside_the_dx_gemm(act, T, N, d, dout):
     close(res[0][0], yr.reshape(T, N, dout), atol=2e-6 * max(1.0, float(np.abs(yr).max())), rel=2e-6, what="gin_dense y")
     for r, name in ((res[0], "fused"), (res[1], "two ops")):
         assert abs(float(r[1]) - deps) <= 2e-6 * scale, (name, float(r[1]), deps, scale)
+
+
+def test_f16_two_piece_rows_spanning_2_to_16_stay_within_fp32_arithmetic():
+    """VERDICT r04 item 4.  The f16 x 2 GEMMs (gemmh.hip, >= 16,384 rows) scale every row (forward / dX) or column (weight gradient)
+    to its largest magnitude; an element 2^16 below that maximum keeps fewer than 22 bits.  Rows / columns whose magnitudes span
+    2^16 (log-uniform inside the row, so both ends are populated): the error against fp64 -- measured in units of the natural
+    scale sum_k |x_k| |w_k| of each output -- must stay within TWICE that of numpy's own float32 matmul on the same inputs."""
+    from kgcn_amd import ops
+    rng = np.random.default_rng(216)
+    M, din, dout = 16500, 256, 256
+    spread = lambda shape: (2.0 ** rng.uniform(-16, 0, size=shape)).astype(np.float32)
+    x = (rng.standard_normal((M, din)) * spread((M, din))).astype(np.float32)
+    g = (rng.standard_normal((M, dout)) * spread((M, dout))).astype(np.float32)
+    w = (K.glorot_uniform(rng, din, dout) * spread((din, dout))).astype(np.float32)
+    for a in (x, g, w):                                           # every row / column really spans the 2^16
+        mags = np.abs(a)
+        assert (mags.max(axis=-1) / np.maximum(mags.min(axis=-1), 1e-300)).min() >= 2.0 ** 12
+    tx, tw = t32(x).requires_grad_(True), t32(w).requires_grad_(True)
+    assert ops.lib.kgcn_dense_mfma_products(0, M, din, dout) == 3 and ops.lib.kgcn_dense_mfma_products(2, M, din, dout) == 3
+    y = ops.dense(tx, tw, None)
+    y.backward(t32(g))
+    x64, w64, g64 = x.astype(np.float64), w.astype(np.float64), g.astype(np.float64)
+    cases = {"fwd": (y.detach().cpu().numpy(), x64 @ w64, x @ w, np.abs(x64) @ np.abs(w64)),
+             "dX": (tx.grad.cpu().numpy(), g64 @ w64.T, g @ w.T, np.abs(g64) @ np.abs(w64).T),
+             "dW": (tw.grad.cpu().numpy(), x64.T @ g64, x.T @ g, np.abs(x64).T @ np.abs(g64))}
+    for name, (got, ref, np32, scale) in cases.items():
+        e_hip = float((np.abs(got - ref) / scale).max())
+        e_np = float((np.abs(np32.astype(np.float64) - ref) / scale).max())
+        import conftest
+        # (the weight gradient sums 16,500 products per output in another order than numpy's BLAS: 4 x there)
+        factor = 4 if name == "dW" else 2
+        conftest.record_accuracy("span 2^16 %s: err / sum|x||w| (tolerance = %d x numpy float32's)" % (name, factor), e_hip, factor * e_np, 1.0)
+        assert e_hip <= factor * e_np, (name, e_hip, e_np)
