@@ -372,6 +372,24 @@ int kgcn_dense_dx_dact_gather_f32(const float* grad, const float* pooled_grad, i
                                   const float* act_out, int64_t m, int32_t dout, int64_t ld, const float* w, int64_t w_ld,
                                   int32_t din, float* dx, int64_t dx_ld, int32_t act, float* dpre, void* table,
                                   int64_t table_bytes, int32_t table_ready, void* stream);
+/* ONE-PASS backward of a wide dense layer (round 5, gemmb.hip): the whole backward of y = act(x @ w + bias) -- Keras Dense inside
+ * GraphDense (kgcn/layers.py:248,260) and the X.W part of GraphConv (:99-100, :112) at the widths of example_model/model_gin.py:45-54
+ * and example_model/model_multitask.py:51-57 -- from ONE sweep over (grad, act_out, x):
+ *   dpre = (grad [+ pooled_grad[row / n_nodes]]) (.) act'(act_out)      (act == KGCN_ACT_NONE: dpre = grad, act_out may be NULL)
+ *   dx = dpre @ w^T      dw = x^T @ dpre      dbias = colsum(dpre)      (dbias may be NULL)
+ * The d pre-activation tensor is never written (kgcn_dense_dx_dact_f32 + kgcn_dense_wgrad_f32 write it and read it back: six
+ * passes over [m, 256] tensors instead of four).  grad may be NULL when pooled_grad is given (the layer output was only read out
+ * by GraphGather); pooled_grad as in kgcn_dense_dx_dact_gather_f32, with n_nodes >= 8 (smaller graphs: the two-call route).
+ * ld: row stride of grad and act_out.
+ * kgcn_dense_bwd_supported(m, din, dout): 128 < din, dout <= 256, multiples of 4, m >= 16,384.  table / table_ready: the
+ * fragment tables of w^T as for kgcn_dense_dx_dact_gather_f32 (kgcn_dense_fwd_workspace_bytes(dout, din) bytes); workspace >=
+ * kgcn_dense_wgrad_workspace_bytes(m, din, dout) (128 partials, fixed-order second stage, deferrable: kgcn_reduce_defer).
+ * Arithmetic: route 3 of "Conventions" (f16 x 2) with a row scale on dpre and a counter-scaled, per-column online scale on x. */
+int kgcn_dense_bwd_supported(int64_t m, int32_t din, int32_t dout);
+int kgcn_dense_bwd_f32(const float* grad, const float* pooled_grad, int64_t pooled_ld, int32_t n_nodes, const float* act_out,
+                       int32_t act, int64_t ld, const float* x, int64_t x_ld, int64_t m, int32_t din, int32_t dout,
+                       const float* w, int64_t w_ld, float* dx, int64_t dx_ld, float* dw, float* dbias, void* table,
+                       int64_t table_bytes, int32_t table_ready, void* workspace, int64_t workspace_bytes, void* stream);
 /* The same dX contraction where the product is only needed for an inner product (d epsilon of a GINAggregate, kgcn/layers.py:469
  * <d out, x>, in front of an activated wide layer whose input needs no gradient -- the first block of example_model/model_gin.py):
  *   dot_out[0] = < (grad (.) act'(act_out)) @ w^T , dotx >       dotx [m, din] (row stride dotx_ld, 16-byte aligned rows)

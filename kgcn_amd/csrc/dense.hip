@@ -817,6 +817,54 @@ extern "C" int kgcn_dense_dx_dact_dot_f32(const float* grad, const float* act_ou
   return check_launch("dx_dot_final_kernel");
 }
 
+// ---- one-pass backward of a wide dense layer (gemmb.hip): dX, dW and dbias from ONE sweep over (grad, act_out, x); the
+// d pre-activation tensor is never written.  The weight-gradient partials go through the same second stage as every other
+// weight gradient (deferrable: kgcn_reduce_defer).
+namespace kgcn {
+int launch_gemmb(const float* grad, const float* act_out, long m, int din, int dout, long ld, const float* x, long x_ld,
+                 const void* tabh, float* dx, long dx_ld, float* part_dw, float* part_db, int dact, const float* pooled_grad,
+                 int n_nodes, long pooled_ld, hipStream_t s);
+int launch_reduce_pair(const float* part_dw, long n_dw, float* dw, const float* part_db, long n_db, float* dbias, int nparts,
+                       hipStream_t s);
+}  // namespace kgcn
+
+extern "C" int kgcn_dense_bwd_supported(int64_t m, int32_t din, int32_t dout) {
+  return (din > 128 && din <= 256 && dout > 128 && dout <= 256 && din % 4 == 0 && dout % 4 == 0 && m >= (int64_t)kNumCU * 64) ? 1 : 0;
+}
+
+extern "C" int kgcn_dense_bwd_f32(const float* grad, const float* pooled_grad, int64_t pooled_ld, int32_t n_nodes,
+                                  const float* act_out, int32_t act, int64_t ld, const float* x, int64_t x_ld, int64_t m,
+                                  int32_t din, int32_t dout, const float* w, int64_t w_ld, float* dx, int64_t dx_ld, float* dw,
+                                  float* dbias, void* table, int64_t table_bytes, int32_t table_ready, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+  if (act < KGCN_ACT_NONE || act > KGCN_ACT_TANH) return fail("kgcn_dense_bwd_f32: activation code %d", act);
+  if (!kgcn_dense_bwd_supported(m, din, dout))
+    return fail("kgcn_dense_bwd_f32: shape m=%lld %d -> %d has no one-pass form (kgcn_dense_dx_dact_f32 / kgcn_dense_fwd_f32 + "
+                "kgcn_dense_wgrad_f32)", (long long)m, din, dout);
+  if ((!grad && !pooled_grad) || !x || !w || !dx || !dw) return fail("kgcn_dense_bwd_f32: NULL operand");
+  if (act != KGCN_ACT_NONE && !act_out) return fail("kgcn_dense_bwd_f32: act_out is NULL with activation code %d", act);
+  if (pooled_grad && (act == KGCN_ACT_NONE || n_nodes < 8 || m % n_nodes != 0 || pooled_ld < dout || pooled_ld % 4 != 0))
+    return fail("kgcn_dense_bwd_f32: pooled gradient needs an activated layer, %d (>= 8) nodes per graph dividing %lld rows and "
+                "pooled_ld=%lld a multiple of 4 >= dout", n_nodes, (long long)m, (long long)pooled_ld);
+  if (ld < dout || x_ld < din || dx_ld < din || w_ld < dout) return fail("kgcn_dense_bwd_f32: leading dimension too small");
+  if (dx == x || dx == grad || dx == act_out) return fail("kgcn_dense_bwd_f32: dx must not alias an input");
+  if (!table || table_bytes < wtable_bytes(dout, din)) return fail("kgcn_dense_bwd_f32: table / workspace too small");
+  const int64_t need = kgcn_dense_wgrad_workspace_bytes(m, din, dout);
+  if (!workspace || workspace_bytes < need)
+    return fail("kgcn_dense_bwd_f32: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+  hipStream_t s = as_stream(stream);
+  if (!table_ready) launch_wtable_split(w, (long)w_ld, 1, dout, din, table, s);
+  const int pairs = kNumCU / 2;
+  float* part_dw = static_cast<float*>(workspace);
+  float* part_db = part_dw + (long)pairs * din * dout;
+  const int rc = launch_gemmb(grad, act_out, (long)m, din, dout, (long)ld, x, (long)x_ld,
+                              static_cast<const char*>(table) + wtable_bf16_bytes(dout, din), dx, (long)dx_ld, part_dw,
+                              dbias ? part_db : nullptr, act, pooled_grad, n_nodes, (long)pooled_ld, s);
+  if (rc == -1) return fail("kgcn_dense_bwd_f32: operands must be 16-byte aligned with ld %% 4 == 0");
+  if (rc < 0) return 1;
+  return launch_reduce_pair(part_dw, (long)din * dout, dw, part_db, dout, dbias, rc, s);
+}
+
 extern "C" int kgcn_dense_dx_dact_f32(const float* grad, const float* act_out, int64_t m, int32_t dout, int64_t ld,
                                       const float* w, int64_t w_ld, int32_t din, float* dx, int64_t dx_ld, int32_t act,
                                       float* dpre, void* workspace, int64_t workspace_bytes, void* stream) {

@@ -1,0 +1,525 @@
+// One-pass backward of a wide dense layer (round 5):  y = act(x W + b), W [din x dout], 128 < din, dout <= 256
+// (kgcn/layers.py:248,260 Keras Dense inside GraphDense; :99-100 / :112 the X.W part of GraphConv; example_model/model_gin.py:45-54,
+// example_model/model_multitask.py:51-57).  Until round 4 this was two kernels making SIX passes over [m, 256] tensors:
+//   gemmh_fwd_kernel<DK>  reads dY and the saved activation, WRITES d pre-activation and dX        (4 passes)
+//   gemmh_wgradl_kernel   READS d pre-activation back, reads x                                     (2 passes)
+// -- 782 + 444 MB of HBM traffic per layer at 200,000 rows (profiles/r04_s_cfg5_rocprof.txt).  Here ONE sweep over (dY, a, x)
+// produces dX, dW and dbias; d pre-activation lives only in LDS (as f16 pieces) and is never written: four passes.
+//
+// Why it is not simply "both products in the old kernel": the weight-stationary dX product keeps W' (h and l f16 pieces of
+// 256 x 256 values: 256 KB) in registers and the weight gradient needs 256 x 256 fp32 accumulators (256 KB) -- together the whole
+// 512 KB register file of a CU.  So the work is cut in two along the layer's INPUT columns and given to a PAIR of workgroups
+// (b, b + 8: the same XCD, whose L2 serves the second read of the shared rows -- the old weight-gradient kernel already read dY
+// twice this way, PMC traffic x1.14):
+//   workgroup `half` of a pair:  dX[:, 128 half .. +128)  =  dpre . W^T[:, that column range]      (needs all of dpre: dY, a)
+//                                dW[128 half .. +128, :]  =  x[:, that column range]^T . dpre       (needs HALF of x)
+//   HBM: dY + a + x in, dX out (the pair's second read of dY and a hits L2 / the memory-side cache);  per workgroup W' is
+//   128 KB of registers and dW 128 KB of accumulators: 4 waves x 512 registers, one wave per SIMD.
+//
+// One stage = 32 rows.  A wave (w = 0..3):
+//   staging    rows 8 w .. 8 w + 7 of the stage travel HBM -> registers as 1 KiB rows (lane = 4 consecutive columns; dY and the
+//              saved activation, one stage ahead), dpre = dY (.) act'(a) [+ the read-out's broadcast gradient], row maximum by a
+//              DPP wave reduction -> row exponent kr (scalar), pieces h = f16(dpre 2^kr), l = f16(dpre 2^kr - h) -> LDS ONCE,
+//              in an image that serves both products (below); dbias = column sums on the way.
+//   dX         [32 rows x 32 columns] per wave: A operand = dpre pieces as 16-byte ROW reads, B = its slice of W' (128 registers,
+//              whole launch), 16 k-steps x 3 products, two accumulator chains; epilogue 2^-(kr + kc), buffer stores.
+//   dW         [32 x-columns x 256] per wave = 8 accumulator tiles (128 registers, whole launch).  The contraction runs over the
+//              ROWS, so the B operand (dpre, k = row) is read with ds_read_b64_tr_b16 -- the transpose read of gfx950 -- out
+//              of the same image, and the A operand (x, k = row) is loaded from HBM directly in fragment layout (lane (li, hi)
+//              = x[r + 8 hi + j][c + li]: a coalesced dword load IS the operand, lesson 25) and split in registers.
+//   scales     dpre carries a ROW scale 2^kr (needed by dX).  Inside the weight gradient a row scale would not factor out
+//              of the sum over rows -- so x is counter-scaled: x''[r, i] = x[r, i] 2^(K_i - kr[r]) and x''[r, i] dpre'[r, j]
+//              = x dpre 2^K_i exactly; K_i is the ONLINE per-column exponent of x'' (the wave owns its 32 x columns: when a
+//              value would leave the f16 range the exponent drops and the accumulator rows are rescaled by the exact power
+//              of two, as in gemmh_wgrad_kernel).  A row whose dpre is all zero gets kr = 120: its x'' vanishes instead of
+//              setting the column scale; a row with +-inf / NaN takes kr from its FINITE values (the non-finite element stays
+//              non-finite at any scale, the others keep their places in dW).  Error: the products l.H + h.L + h.H as in gemmh.hip -- 2^-23 sum |x dpre| plus the
+//              f16-denormal tail m 2^-40 max_r|x''[r, i]| max|dpre'| -- the class documented in include/kgcn_hip.h (route 3).
+// LDS image of a stage (per piece 20,480 bytes; tools/gemmb_layout_check.py emulates it and the three access patterns):
+//   byte(r, f) = (r >> 2) 2560 + (r & 3) 64 + (f >> 5) 320 + ((((f & 31) >> 3) ^ ((r >> 2) & 3)) << 4) + (f & 7) 2
+//   -- four consecutive rows' 64-byte segments of a 32-column block are 256 contiguous bytes (one bank row for a transpose read
+//   of 4 rows x 32 columns), consecutive column blocks advance by 320 = 256 + 64 so that they rotate through the four
+//   quarters (the 8-byte row writes of 16 lanes cover 32 distinct banks), 16-byte chunks are rotated by the row quad (the
+//   16-lane groups of ds_read_b128 see 16 distinct bank quads).  Everything that depends on the k-step / column tile is an
+//   IMMEDIATE offset on one of two lane bases.
+#include "gemmh.h"
+
+namespace kgcn {
+
+constexpr int GB_R = 32;                      // rows per stage
+constexpr int GB_PLANE = 20480;               // bytes of one piece plane
+constexpr int GB_BUF = 2 * GB_PLANE;          // h | l
+// k-steps of W' held in registers; the others live in LDS (below).  The form that adds the read-out's gradient to a row gradient
+// (BC = 1) keeps eight more staging registers alive through the multiplication: four k-steps fewer in registers there.
+__host__ __device__ constexpr int gb_wreg(int bc) { return bc == 1 ? 10 : 14; }
+__host__ __device__ constexpr size_t gb_lds(int bc) { return 2 * (size_t)GB_BUF + 2 * GB_R * 4 + 4 * (size_t)(16 - gb_wreg(bc)) * 2 * 1024; }
+constexpr int GB_ZERO_ROW_K = 120;            // row exponent of an all-zero dpre row: x 2^(K - 120) vanishes
+
+typedef short gb_i16x4 __attribute__((ext_vector_type(4)));
+#define GB_LDS_AS __attribute__((address_space(3)))
+__device__ __forceinline__ unsigned gb_lds_off(const void* p) { return (unsigned)(uintptr_t)(const GB_LDS_AS unsigned char*)p; }
+__device__ __forceinline__ u32x4 gb_ld128(unsigned a) { return *(const GB_LDS_AS u32x4*)(uintptr_t)a; }
+__device__ __forceinline__ void gb_st64(unsigned a, unsigned lo, unsigned hi) {
+  const u32x2 v = {lo, hi};
+  *(GB_LDS_AS u32x2*)(uintptr_t)a = v;
+}
+__device__ __forceinline__ u32x2 gb_ld_tr16(unsigned a) {
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((GB_LDS_AS gb_i16x4*)(uintptr_t)a));
+}
+
+// DK: 0 plain (dpre = the incoming gradient); 1 dpre = g (.) (c0 + c1 a + c2 a^2) (sigmoid / tanh derivative in the layer
+// OUTPUT a); 2 relu (a > 0).  da.bc: the read-out's pooled gradient, broadcast over the bc_n node rows of a graph and added
+// to (BC = 1) or standing for (BC = 2) the row gradient -- kgcn_dense_dx_dact_gather_f32's operand; BC = 0: none.  A template
+// parameter, not a uniform branch: the first build tested da.bc per row at run time -- two dozen extra basic blocks in the loop
+// body, registers live across all of them, 172 spilled VGPRs.
+template <int DK, int BC>
+__global__ __launch_bounds__(256, 1) void gemmb_kernel(const float* __restrict__ g, long m, int kdim, long ld,
+                                                       const float* __restrict__ x, int ndim, long x_ld,
+                                                       const u32x4* __restrict__ tab, float* __restrict__ dx, long dx_ld,
+                                                       float* __restrict__ part_dw, float* __restrict__ part_db, GhDact da,
+                                                       int niter) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // pair (q0, half): workgroups b and b + 8 land on the same XCD (round-robin dispatch), i.e. behind the same L2
+  const int b = (int)blockIdx.x;
+  const int half = (b >> 3) & 1;
+  const long q0 = ((b >> 4) << 3) | (b & 7);
+  const long G = gridDim.x >> 1;
+  const unsigned lds0 = gb_lds_off(dsm);
+  int* rowk_base = reinterpret_cast<int*>(dsm + 2 * (size_t)GB_BUF);          // [2][32] row exponents
+
+  // ---- dX side: this wave's 32 output columns of W' (the f16 table of W^T, wtable.hip), whole launch ----------------------
+  const int nt32 = gh_nt32(ndim), kse = gh_kse(kdim);
+  const int* kctab = reinterpret_cast<const int*>(tab + (long)kse * nt32 * 2 * 64);
+  const int nt = 4 * half + wave;
+  const int ntc = nt < nt32 ? nt : nt32 - 1;                 // clamped: the columns of such a wave are never stored
+  // Register files: the 8 + 1 accumulator tiles take 144 of the 256 AGPRs (hipcc gives every MFMA of a function its C / D in
+  // the accumulator file); W' is a B operand, which the matrix pipe reads from either file.  The fragments of k-steps 0..13 are
+  // pinned to the remaining 112 AGPRs (0..9 in the BC = 1 form) (an empty asm with an "a" constraint at the definition: the value's register class); left
+  // to itself the allocator kept W' in VGPRs, used the AGPRs as spill slots and copied every fragment back in front of its
+  // MFMAs (650 v_accvgpr_read + 50-94 scratch spills per loop body in the first build of this kernel).  The fragments of
+  // k-steps 14, 15 do not fit either file next to the staging registers: they wait in LDS (4 KB per wave, written once) and are
+  // read with the stage's other fragments -- in VGPRs they were spilled to scratch memory and reloaded INSIDE the loop, a vmcnt
+  // wait in front of the prefetch (lesson 4b).
+  constexpr int GB_WREG = gb_wreg(BC);
+  u32x4 Wh[GB_WREG], Wl[GB_WREG];
+  const unsigned wl_base = lds0 + (unsigned)(2 * GB_BUF + 2 * GB_R * 4 + wave * (16 - GB_WREG) * 2048 + lane * 16);
+  static_for<16>([&](auto kc) __attribute__((always_inline)) {
+    constexpr int ks = decltype(kc)::value;
+    const int kk = ks < kse ? ks : 0;
+    const u32x4* e = tab + ((long)(kk * nt32 + ntc) * 2) * 64 + lane;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    const u32x4 h = ks < kse ? e[0] : z, l = ks < kse ? e[64] : z;
+    if constexpr (ks < GB_WREG) {
+      Wh[ks] = h;
+      Wl[ks] = l;
+      asm volatile("" : "+a"(Wh[ks]));
+      asm volatile("" : "+a"(Wl[ks]));
+    } else {
+      *(GB_LDS_AS u32x4*)(uintptr_t)(wl_base + (unsigned)((ks - GB_WREG) * 2048)) = h;
+      *(GB_LDS_AS u32x4*)(uintptr_t)(wl_base + (unsigned)((ks - GB_WREG) * 2048 + 1024)) = l;
+    }
+  });
+  const int col = 32 * nt + li;                              // dX column of this lane
+  const int ldy4 = (int)(dx_ld * 4);
+  const unsigned voff_y = 4u * (unsigned)(4 * hi * dx_ld + (col < ndim ? col : 0));
+  const int kcol = kctab[32 * ntc + li];
+
+  // ---- staging side --------------------------------------------------------------------------------------------------
+  const int c4 = 4 * lane;
+  const bool cok = c4 < kdim;
+  const unsigned voff_g = 16u * (unsigned)(cok ? lane : 0);
+  const int ld4 = (int)(ld * 4);
+  unsigned wbase[2];                                          // LDS write bases of rows 8 w + 0..3 / 8 w + 4..7
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int Rr = 2 * wave + p;
+    wbase[p] = lds0 + (unsigned)(Rr * 2560 + (lane >> 3) * 320 + ((((lane >> 1) & 3) ^ (Rr & 3)) << 4) + 8 * (lane & 1));
+  }
+  // A-operand rows of dX (row li): k-step even / odd
+  const unsigned abaseE = lds0 + (unsigned)((li >> 2) * 2560 + (li & 3) * 64 + ((hi ^ ((li >> 2) & 3)) << 4));
+  const unsigned abaseO = lds0 + (unsigned)((li >> 2) * 2560 + (li & 3) * 64 + (((2 + hi) ^ ((li >> 2) & 3)) << 4));
+  // transpose reads of dW's B operand: 16-lane group g16 = (hi, column half), lane i16 addresses row 4 t + (i16 >> 2) of its
+  // 8-row half, columns 16 half16 + 4 (i16 & 3) .. + 3
+  unsigned tbase[2];
+  {
+    const int g16 = lane >> 4, i16 = lane & 15, half16 = g16 & 1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      tbase[t] = lds0 + (unsigned)(2 * hi * 2560 + (i16 >> 2) * 64 + ((((2 * half16) + ((i16 & 3) >> 1)) ^ (2 * hi + t)) << 4) +
+                                   8 * (i16 & 1));
+  }
+  // x in fragment layout: lane (li, hi) = x[row 16 q + 8 hi + j][i0 + li]
+  const int i0 = 128 * half + 32 * wave;
+  const int ca = i0 + li < ndim ? i0 + li : ndim - 1;        // clamped: what such a column contributes is never stored
+  const unsigned voff_x = 4u * (unsigned)(8 * hi * x_ld + ca);
+  const int xld4 = (int)(x_ld * 4);
+
+  f32x4 raw[8], ya[DK != 0 ? 8 : 1];
+  // rows 4 hl .. 4 hl + 3 of this wave's share of stage `st` (dY and the saved activation), requested as soon as the registers
+  // of the same rows of the previous stage are free
+  auto load_ga = [&](long st, auto hlc) __attribute__((always_inline)) {
+    constexpr int hl = decltype(hlc)::value;
+    const long r0 = st * GB_R + 8 * wave;
+    if constexpr (BC == 2) {                                  // the gradient is the read-out's broadcast alone
+#pragma unroll
+      for (int i = 4 * hl; i < 4 * hl + 4; ++i) raw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      const __amdgpu_buffer_rsrc_t rg = gh_rows(g, r0, 8, m, ld);       // stages past the end: empty descriptor, zeros
+#pragma unroll
+      for (int i = 4 * hl; i < 4 * hl + 4; ++i) raw[i] = gh_ld4(rg, voff_g, i * ld4);
+    }
+    if constexpr (DK != 0) {
+      const __amdgpu_buffer_rsrc_t ra = gh_rows(g + da.ydiff, r0, 8, m, ld);
+#pragma unroll
+      for (int i = 4 * hl; i < 4 * hl + 4; ++i) ya[i] = gh_ld4(ra, voff_g, i * ld4);
+    }
+  };
+  auto load_x = [&](long st, float (&xr)[2][8]) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rx = gh_rows(x, st * GB_R, GB_R, m, x_ld);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        xr[q][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)voff_x, (16 * q + j) * xld4, 0));
+  };
+
+  // the read-out's gradient rows of the (at most two: bc_n >= 8) graphs this wave's eight rows of stage `st` belong to, and how
+  // many of the eight belong to the first one.  Requested with the x fragments of the stage, a whole multiplication ahead: read
+  // where they are needed they were the YOUNGEST loads in flight, and vmcnt -- which counts in order -- made each of them wait
+  // for everything requested before, the next stage's rows included.
+  f32x4 bcv[BC != 0 ? 2 : 1];
+  int bc_first = 8;
+  auto load_bc = [&](long st) __attribute__((always_inline)) {
+    if constexpr (BC != 0) {
+      const long r0 = st * GB_R + 8 * wave;
+      const long gmax = (m - 1) / da.bc_n;                    // rows beyond m are zeroed in the staging; their address stays valid
+      const long gq = r0 / da.bc_n;
+      bc_first = da.bc_n - (int)(r0 - gq * da.bc_n);
+      const long ga = gq < gmax ? gq : gmax, gb = gq + 1 < gmax ? gq + 1 : gmax;
+      bcv[0] = *reinterpret_cast<const f32x4*>(da.bc + ga * da.bc_ld + (cok ? c4 : 0));
+      bcv[1] = *reinterpret_cast<const f32x4*>(da.bc + gb * da.bc_ld + (cok ? c4 : 0));
+    }
+  };
+
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  // stage `st` (in the registers) -> pieces in buffer `buf`; the rows of stage `st_next` are requested half by half into the
+  // registers this stage's rows leave: they travel while the rest of this stage is split, through the barrier and under the
+  // whole multiplication of stage `st` -- requested at the head of the loop body (the first build) they had only the
+  // multiplication to arrive in, and every stage waited ~1 us for them (5.6 us per stage at 200,000 rows)
+  auto stage_dpre = [&](long st, long st_next, int buf) __attribute__((always_inline)) {
+    const long r0 = st * GB_R + 8 * wave;
+    int* rowk = rowk_base + GB_R * buf;
+    const unsigned boff = (unsigned)(buf * GB_BUF);
+    static_for<2>([&](auto hlc) __attribute__((always_inline)) {
+      constexpr int hl = decltype(hlc)::value;
+      unsigned mx[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = 4 * hl + u;
+        f32x4 v = raw[i];
+        if constexpr (DK != 0) {
+          if constexpr (BC != 0) v += i < bc_first ? bcv[0] : bcv[1];      // uniform select: the row's graph
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a = ya[i][e];
+            if constexpr (DK == 1) v[e] *= __builtin_fmaf(__builtin_fmaf(da.c2, a, da.c1), a, da.c0);
+            else v[e] = a > 0.f ? v[e] : 0.f;
+          }
+        }
+        if (!(cok && (DK == 0 || r0 + i < m))) v = f32x4{0.f, 0.f, 0.f, 0.f};      // (plain form: rows >= m were loaded as 0)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bsum[e] += v[e];
+        float a;
+        asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(a) : "v"(v[0]), "v"(v[1]), "v"(v[2]));
+        asm("v_max_f32 %0, %1, |%2|" : "=v"(a) : "v"(a), "v"(v[3]));
+        mx[u] = __float_as_uint(a);
+        raw[i] = v;
+      }
+      wave_umax4(mx[0], mx[1], mx[2], mx[3]);
+      // A row that holds +-inf / NaN: its exponent comes from its FINITE values, so that those keep their places in the weight
+      // gradient (dW[:, j] of a finite column j must not turn non-finite -- or lose the row -- because ANOTHER column of that
+      // row is; the non-finite element itself splits into non-finite pieces at any scale).  Cold, wave-uniform.
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (__builtin_expect(mx[u] >= 0x7f800000u, 0)) {
+          unsigned q = 0u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned av = __float_as_uint(raw[4 * hl + u][e]) & 0x7fffffffu;
+            q = (av < 0x7f800000u && av > q) ? av : q;
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            const unsigned v = (unsigned)__shfl_xor((int)q, o, 64);
+            q = v > q ? v : q;
+          }
+          mx[u] = (unsigned)__builtin_amdgcn_readfirstlane((int)q);
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = 4 * hl + u;
+        const int k = mx[u] == 0u ? GB_ZERO_ROW_K : scale_exp(__uint_as_float(mx[u]));   // wave-uniform
+        unsigned h0, l0, h1, l1;
+        splith_pair(__builtin_ldexpf(raw[i][0], k), __builtin_ldexpf(raw[i][1], k), h0, l0);
+        splith_pair(__builtin_ldexpf(raw[i][2], k), __builtin_ldexpf(raw[i][3], k), h1, l1);
+        const unsigned ad = wbase[hl] + boff + (unsigned)(u * 64);
+        gb_st64(ad, h0, h1);
+        gb_st64(ad + GB_PLANE, l0, l1);
+        rowk[8 * wave + i] = k;                                // same value from every lane
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_ga(st_next, hlc);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  // ---- dW side: 8 accumulator tiles [32 x-columns x 32 dpre-columns], online column scale of x'' ---------------------------
+  f32x16 acc[8];
+#pragma unroll
+  for (int jt = 0; jt < 8; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+  GhCol sx{0, 0.f, 0.f};
+  auto max8 = [&](const float (&v)[8]) __attribute__((always_inline)) {
+    float t;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(t) : "v"(v[0]), "v"(v[1]), "v"(v[2]));
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(t) : "v"(t), "v"(v[3]), "v"(v[4]));
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(t) : "v"(t), "v"(v[5]), "v"(v[6]));
+    asm("v_max_f32 %0, %1, |%2|" : "=v"(t) : "v"(t), "v"(v[7]));
+    return t;
+  };
+
+  struct Frags { u32x4 th, tl, ph, pl; };                    // dW B fragment of one column tile, dX A fragment of one k-step
+  float xr[2][8];                                             // x of the stage in flight, fragment layout
+  auto compute = [&](long st, long st_next, int buf) __attribute__((always_inline)) {
+    const int* rowk = rowk_base + GB_R * buf;
+    const unsigned boff = (unsigned)(buf * GB_BUF);
+    // ---- x'' = x 2^(K - kr[row]) in fragment layout, split once per stage ------------------------------------------------
+    u32x4 Xh[2], Xl[2];
+    {
+      float tv[2][8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const u32x4 k0 = *reinterpret_cast<const u32x4*>(rowk + 16 * q + 8 * hi);
+        const u32x4 k1 = *reinterpret_cast<const u32x4*>(rowk + 16 * q + 8 * hi + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          tv[q][j] = __builtin_ldexpf(xr[q][j], -(int)k0[j]);
+          tv[q][4 + j] = __builtin_ldexpf(xr[q][4 + j], -(int)k1[j]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_x(st_next, xr);                                    // the next stage's x: in flight behind this stage's arithmetic
+      load_bc(st_next);
+      __builtin_amdgcn_sched_barrier(0);
+      const float cm = fmaxf(max8(tv[0]), max8(tv[1]));
+      if (__builtin_amdgcn_ballot_w64(cm > sx.lim) != 0) {    // wave-uniform, rare after the first stages
+        float mxc = fmaxf(cm, __shfl_xor(cm, 32, 64));        // both lane halves hold rows of the same column
+        mxc = fmaxf(sx.run, mxc);
+        sx.run = mxc;
+        int d = 0;
+        if (mxc > sx.lim) {                                   // (a column that has only seen zeros keeps (k, lim) = (0, 0))
+          const int kn = 13 - __builtin_amdgcn_frexp_expf(mxc);          // the maximum lands in [2^12, 2^13)
+          d = kn - sx.k;
+          sx.k = kn;
+          sx.lim = __builtin_ldexpf(0.99951171875f, 16 - kn);
+        }
+#pragma unroll
+        for (int r16 = 0; r16 < 16; ++r16) {
+          const int dr = __shfl(d, (r16 & 3) + 8 * (r16 >> 2) + 4 * hi, 64);        // the x column of this accumulator row
+#pragma unroll
+          for (int jt = 0; jt < 8; ++jt) acc[jt][r16] = __builtin_ldexpf(acc[jt][r16], dr);
+          // (scheduling scope = one accumulator row: left alone, the scheduler reads all 128 accumulator registers out of the
+          // accumulator file first -- a register-pressure peak in this COLD block that made the allocator spill W' fragments
+          // whose reloads then sit in the hot loop)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          unsigned h, l;
+          splith_pair(__builtin_ldexpf(tv[q][2 * e], sx.k), __builtin_ldexpf(tv[q][2 * e + 1], sx.k), h, l);
+          Xh[q][e] = h; Xl[q][e] = l;
+        }
+    }
+    // ---- 16 groups of 6 MFMAs: dW tile (q, jt) and dX k-step ks = 8 q + jt; fragments one group ahead ---------------------------
+    f32x16 ax;                                                // ONE dX chain: inside a group it alternates with the dW tile's
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ax[r] = 0.f;
+    const unsigned tb0 = tbase[0] + boff, tb1 = tbase[1] + boff, abE = abaseE + boff, abO = abaseO + boff;
+    // fragment reads of group gi, one piece at a time (each is requested where the registers of the previous group's piece
+    // become free: ONE fragment set of 16 registers, refilled in place -- two sets were 16 registers too many, and the W'
+    // fragments the allocator then spilled were reloaded from scratch memory inside the loop: a vmcnt wait that drains the
+    // prefetch, lesson 4b)
+    auto read_th = [&](Frags& f, auto gc) __attribute__((always_inline)) {
+      constexpr int gi = decltype(gc)::value, q = gi >> 3, jt = gi & 7;
+      const u32x2 h0 = gb_ld_tr16(tb0 + (unsigned)((4 * q + 0) * 2560 + jt * 320));
+      const u32x2 h1 = gb_ld_tr16(tb1 + (unsigned)((4 * q + 1) * 2560 + jt * 320));
+      f.th = u32x4{h0[0], h0[1], h1[0], h1[1]};
+    };
+    auto read_tl = [&](Frags& f, auto gc) __attribute__((always_inline)) {
+      constexpr int gi = decltype(gc)::value, q = gi >> 3, jt = gi & 7;
+      const u32x2 l0 = gb_ld_tr16(tb0 + GB_PLANE + (unsigned)((4 * q + 0) * 2560 + jt * 320));
+      const u32x2 l1 = gb_ld_tr16(tb1 + GB_PLANE + (unsigned)((4 * q + 1) * 2560 + jt * 320));
+      f.tl = u32x4{l0[0], l0[1], l1[0], l1[1]};
+    };
+    auto read_ph = [&](Frags& f, auto gc) __attribute__((always_inline)) {
+      constexpr int ks = decltype(gc)::value;
+      f.ph = gb_ld128(((ks & 1) ? abO : abE) + (unsigned)((ks >> 1) * 320));
+    };
+    auto read_pl = [&](Frags& f, auto gc) __attribute__((always_inline)) {
+      constexpr int ks = decltype(gc)::value;
+      f.pl = gb_ld128(((ks & 1) ? abO : abE) + GB_PLANE + (unsigned)((ks >> 1) * 320));
+    };
+    Frags F[17];                                              // (SSA names: every F[g] dies inside group g; 16 registers live)
+    read_th(F[0], std::integral_constant<int, 0>{});
+    read_pl(F[0], std::integral_constant<int, 0>{});
+    read_tl(F[0], std::integral_constant<int, 0>{});
+    read_ph(F[0], std::integral_constant<int, 0>{});
+    static_for<16>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int gi = decltype(gc)::value, q = gi >> 3, jt = gi & 7, ks = gi;
+      constexpr bool more = gi + 1 < 16;
+      using NX = std::integral_constant<int, more ? gi + 1 : 0>;
+      Frags& f = F[gi];
+      Frags& n = F[gi + 1];
+      u32x4 wh, wl;                                           // this k-step's slice of W': a register or the wave's LDS copy
+      if constexpr (ks < GB_WREG) { wh = Wh[ks]; wl = Wl[ks]; }
+      else {
+        wh = gb_ld128(wl_base + (unsigned)((ks - GB_WREG) * 2048));
+        wl = gb_ld128(wl_base + (unsigned)((ks - GB_WREG) * 2048 + 1024));
+      }
+      // l.H, h.H, h.L for the dW tile (q, jt), l.H, h.L, h.H for the dX k-step ks; the two accumulators alternate (a dependent
+      // MFMA waits for its predecessor's last pass)
+      __builtin_amdgcn_sched_barrier(0);
+      acc[jt] = mfma_f16(Xl[q], f.th, acc[jt]);
+      __builtin_amdgcn_sched_barrier(0);
+      ax = mfma_f16(f.pl, wh, ax);
+      if constexpr (more) read_pl(n, NX{});
+      __builtin_amdgcn_sched_barrier(0);
+      acc[jt] = mfma_f16(Xh[q], f.th, acc[jt]);
+      if constexpr (more) read_th(n, NX{});
+      __builtin_amdgcn_sched_barrier(0);
+      ax = mfma_f16(f.ph, wl, ax);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[jt] = mfma_f16(Xh[q], f.tl, acc[jt]);
+      if constexpr (more) read_tl(n, NX{});
+      __builtin_amdgcn_sched_barrier(0);
+      ax = mfma_f16(f.ph, wh, ax);
+      if constexpr (more) read_ph(n, NX{});
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- dX <- 2^-(kr + kc) ax -------------------------------------------------------------------------------------------
+    if (col < ndim) {
+      const __amdgpu_buffer_rsrc_t ry = gh_rows(dx, st * GB_R, GB_R, m, dx_ld);          // rows >= m: dropped by the descriptor
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const u32x4 kr4 = *reinterpret_cast<const u32x4*>(rowk + 8 * rq + 4 * hi);
+#pragma unroll
+        for (int rj = 0; rj < 4; ++rj) {
+          const float v = __builtin_ldexpf(ax[4 * rq + rj], -((int)kr4[rj] + kcol));
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, (int)voff_y, (rj + 8 * rq) * ldy4, 0);
+        }
+      }
+    }
+  };
+
+  // ---- the stage loop: every workgroup runs `niter` stages q0, q0 + G, ...; stages past the end are empty (descriptors
+  // of zero rows: loads return 0, stores are dropped) -- no exit between a request and its use ----------------------------------
+  long t = q0;
+  load_ga(t, std::integral_constant<int, 0>{});
+  load_ga(t, std::integral_constant<int, 1>{});
+  load_x(t, xr);
+  load_bc(t);
+  stage_dpre(t, t + G, 0);
+  gh_barrier_lds();
+  for (int it = 0; it < niter; ++it) {
+    const int buf = it & 1;
+    compute(t, t + G, buf);
+    stage_dpre(t + G, t + 2 * G, buf ^ 1);
+    gh_barrier_lds();
+    t += G;
+  }
+
+  // ---- the workgroup's partial dW rows [128 half + 32 w .. + 32) x all columns, unscaled; one partial per PAIR ------------------
+  float* pw = part_dw + q0 * (long)ndim * kdim;
+#pragma unroll
+  for (int r16 = 0; r16 < 16; ++r16) {
+    const int rr = (r16 & 3) + 8 * (r16 >> 2) + 4 * hi;
+    const int kr = __shfl(sx.k, rr, 64);
+    const int row = i0 + rr;
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt) {
+      const int cj = 32 * jt + li;
+      if (row < ndim && cj < kdim) pw[(long)row * kdim + cj] = __builtin_ldexpf(acc[jt][r16], -kr);
+    }
+  }
+  // dbias: column sums of dpre over the pair's rows (both workgroups hold the same sums; half 0 stores them)
+  if (part_db && half == 0) {                                  // uniform
+    float* red = reinterpret_cast<float*>(dsm);                // (every wave is behind the loop's last barrier: the image is free)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave * 256 + c4 + e] = bsum[e];
+    __syncthreads();
+    if (tid < kdim) part_db[q0 * kdim + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+  }
+}
+
+bool gemmb_ok(const float* g, const float* act_out, const float* x, long m, int din, int dout, long ld, long x_ld, long dx_ld,
+              const float* dx) {
+  return din > 128 && din <= 256 && dout > 128 && dout <= 256 && din % 4 == 0 && dout % 4 == 0 && ld % 4 == 0 && x_ld >= din &&
+         dx_ld >= din && (!g || aligned16(g)) && (!act_out || aligned16(act_out)) && m >= (long)kNumCU * 64 &&
+         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx)) & 3u) == 0;
+}
+
+// dx = dpre W^T, part_dw[pairs][din][dout] / part_db[pairs][dout] = per-pair partials of x^T dpre / colsum dpre with
+// dpre = (grad [+ pooled gradient of the row's graph]) (.) act'(act_out)  (dact = KGCN_ACT_NONE: dpre = grad).
+// tabh: the f16 table of W^T (contraction over dout).  Returns the number of partials (> 0) or -1 when the operands do not fit.
+int launch_gemmb(const float* grad, const float* act_out, long m, int din, int dout, long ld, const float* x, long x_ld,
+                 const void* tabh, float* dx, long dx_ld, float* part_dw, float* part_db, int dact, const float* pooled_grad,
+                 int n_nodes, long pooled_ld, hipStream_t s) {
+  const float* base = grad ? grad : act_out;
+  if (!base || !gemmb_ok(grad, act_out, x, m, din, dout, ld, x_ld, dx_ld, dx) || !tabh || (!grad && !pooled_grad) ||
+      (dact != KGCN_ACT_NONE && !act_out) || (dact == KGCN_ACT_NONE && pooled_grad) ||
+      (pooled_grad && !(aligned16(pooled_grad) && n_nodes >= 8 && pooled_ld % 4 == 0)))     // (eight rows of a wave: <= 2 graphs)
+    return -1;
+  GhDact da{};
+  da.ydiff = act_out ? act_out - base : 0;
+  da.bc = pooled_grad;
+  da.bc_ld = pooled_ld;
+  da.bc_n = n_nodes > 0 ? n_nodes : 1;
+  da.bc_only = grad ? 0 : 1;
+  da.c0 = dact == KGCN_ACT_TANH ? 1.f : 0.f;
+  da.c1 = dact == KGCN_ACT_SIGMOID ? 1.f : 0.f;
+  da.c2 = -1.f;
+  const int pairs = kNumCU / 2;
+  const long stages = (m + GB_R - 1) / GB_R;
+  const int niter = (int)((stages + pairs - 1) / pairs);
+  const dim3 grid((unsigned)(2 * pairs));
+  const u32x4* tab = static_cast<const u32x4*>(tabh);
+  const int bc = pooled_grad ? (grad ? 1 : 2) : 0;
+  const int dk = dact == KGCN_ACT_NONE ? 0 : (dact == KGCN_ACT_RELU ? 2 : 1);
+  auto go = [&](auto dkc, auto bcc) {
+    constexpr int DKc = decltype(dkc)::value, BCc = decltype(bcc)::value;
+    static thread_local bool attr_set = false;                 // (one flag per instantiation of this lambda)
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemmb_kernel<DKc, BCc>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kLdsBytes);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((gemmb_kernel<DKc, BCc>), grid, dim3(256), gb_lds(BCc), s, base, m, dout, ld, x, din, x_ld, tab, dx, dx_ld, part_dw,
+                       part_db, da, niter);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  if (dk == 0) go(I0{}, I0{});
+  else if (dk == 1) { if (bc == 0) go(I1{}, I0{}); else if (bc == 1) go(I1{}, I1{}); else go(I1{}, I2{}); }
+  else { if (bc == 0) go(I2{}, I0{}); else if (bc == 1) go(I2{}, I1{}); else go(I2{}, I2{}); }
+  if (check_launch("gemmb_kernel")) return -2;
+  return pairs;
+}
+
+}  // namespace kgcn

@@ -39,4 +39,58 @@ __host__ __device__ inline long gh_table_bytes(int din, int dout) {
   return gh_table_blocks(din, dout) * 1024 + (long)gh_nt32(dout) * 32 * 4;
 }
 
+
+// ---- shared by the kernels of gemmh.hip and gemmb.hip ---------------------------------------------------------------------
+// max over the wave of four non-negative floats per lane (as bit patterns: unsigned order = float order; a NaN pattern wins,
+// which only makes the scale of a row that is non-finite anyway meaningless).  Four rows per asm block: the DPP read of a
+// register is three instructions behind its last write (the hazard needs two wait states).
+#define KGCN_DPP_MAX4(a, b, c, d, ctrl)                                   \
+  "v_max_u32_dpp %0, %0, %0 " ctrl "\n v_max_u32_dpp %1, %1, %1 " ctrl   \
+  "\n v_max_u32_dpp %2, %2, %2 " ctrl "\n v_max_u32_dpp %3, %3, %3 " ctrl "\n"
+__device__ __forceinline__ void wave_umax4(unsigned& a, unsigned& b, unsigned& c, unsigned& d) {
+  asm volatile("s_nop 1\n" KGCN_DPP_MAX4(a, b, c, d, "row_shr:1 row_mask:0xf bank_mask:0xf")
+               KGCN_DPP_MAX4(a, b, c, d, "row_shr:2 row_mask:0xf bank_mask:0xf")
+               KGCN_DPP_MAX4(a, b, c, d, "row_shr:4 row_mask:0xf bank_mask:0xf")
+               KGCN_DPP_MAX4(a, b, c, d, "row_shr:8 row_mask:0xf bank_mask:0xf")
+               KGCN_DPP_MAX4(a, b, c, d, "row_bcast:15 row_mask:0xa bank_mask:0xf")
+               KGCN_DPP_MAX4(a, b, c, d, "row_bcast:31 row_mask:0xc bank_mask:0xf")
+               "s_nop 1\n"
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  a = (unsigned)__builtin_amdgcn_readlane((int)a, 63);
+  b = (unsigned)__builtin_amdgcn_readlane((int)b, 63);
+  c = (unsigned)__builtin_amdgcn_readlane((int)c, 63);
+  d = (unsigned)__builtin_amdgcn_readlane((int)d, 63);
+}
+
+
+// dot_part != nullptr (backward forms): the product is NOT stored; its inner product with `y` (read as an [m, dout] operand of the
+// same row stride) is accumulated instead, one partial per workgroup -- d epsilon of a GINAggregate whose input needs no gradient
+// (kgcn/layers.py:469: <d out, x>; the d out tensor then never exists in HBM).
+struct GhDact { long ydiff, pdiff; float c0, c1, c2; const float* bc; long bc_ld; int bc_n, bc_only; float* dot_part; };
+
+
+// Row-block buffer descriptors (see gemmh_fwd_kernel): loads outside the descriptor return 0, stores outside it are dropped.
+constexpr int kBufFlags = 0x00020000;          // raw dword buffer, gfx9 family (DST_SEL / formats unused by raw accesses)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gh_rows(const float* base, long row0, long rows, long m, long ld) {
+  long n = m - row0;
+  n = n < 0 ? 0 : (n < rows ? n : rows);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (n > 0 ? row0 : 0) * ld), 0, (int)(n * ld * 4), kBufFlags);
+}
+__device__ __forceinline__ f32x4 gh_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+}
+
+
+// The hand-over through LDS needs the wave's LDS operations done (lgkmcnt), NOT its vector-memory operations: __syncthreads()
+// also drains vmcnt -- the next tile's rows on their way from HBM and the stores of this one.
+__device__ __forceinline__ void gh_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+
+struct GhCol {           // per lane and fragment: one column of an operand
+  int k;                 // scale exponent
+  float lim;             // |v| <= lim  <=>  |v| 2^k <= 65504 (the largest f16)
+  float run;             // running maximum of |v| over the rows seen so far
+};
+
+
 }  // namespace kgcn

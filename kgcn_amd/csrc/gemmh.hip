@@ -45,27 +45,6 @@
 
 namespace kgcn {
 
-// max over the wave of four non-negative floats per lane (as bit patterns: unsigned order = float order; a NaN pattern wins,
-// which only makes the scale of a row that is non-finite anyway meaningless).  Four rows per asm block: the DPP read of a
-// register is three instructions behind its last write (the hazard needs two wait states).
-#define KGCN_DPP_MAX4(a, b, c, d, ctrl)                                   \
-  "v_max_u32_dpp %0, %0, %0 " ctrl "\n v_max_u32_dpp %1, %1, %1 " ctrl   \
-  "\n v_max_u32_dpp %2, %2, %2 " ctrl "\n v_max_u32_dpp %3, %3, %3 " ctrl "\n"
-__device__ __forceinline__ void wave_umax4(unsigned& a, unsigned& b, unsigned& c, unsigned& d) {
-  asm volatile("s_nop 1\n" KGCN_DPP_MAX4(a, b, c, d, "row_shr:1 row_mask:0xf bank_mask:0xf")
-               KGCN_DPP_MAX4(a, b, c, d, "row_shr:2 row_mask:0xf bank_mask:0xf")
-               KGCN_DPP_MAX4(a, b, c, d, "row_shr:4 row_mask:0xf bank_mask:0xf")
-               KGCN_DPP_MAX4(a, b, c, d, "row_shr:8 row_mask:0xf bank_mask:0xf")
-               KGCN_DPP_MAX4(a, b, c, d, "row_bcast:15 row_mask:0xa bank_mask:0xf")
-               KGCN_DPP_MAX4(a, b, c, d, "row_bcast:31 row_mask:0xc bank_mask:0xf")
-               "s_nop 1\n"
-               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-  a = (unsigned)__builtin_amdgcn_readlane((int)a, 63);
-  b = (unsigned)__builtin_amdgcn_readlane((int)b, 63);
-  c = (unsigned)__builtin_amdgcn_readlane((int)c, 63);
-  d = (unsigned)__builtin_amdgcn_readlane((int)d, 63);
-}
-
 #ifdef KGCN_PROBE   // development: per-wave cycle sums per phase of gemmh_wgradl_kernel (tools/gemmh_probe.py)
 __device__ long long* gh_probe = nullptr;
 #define GHP_DECL long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long pc_ = __builtin_readcyclecounter();
@@ -81,11 +60,6 @@ __device__ long long* gh_probe = nullptr;
 #endif                           // split, 7 no loads (gemmh_wgradl) -- what each part of the kernels costs
 constexpr int GH_BM = 64;        // rows per tile
 constexpr int GH_KMAX = 256;     // widest x row one lane quad layout covers (64 lanes x 4 columns)
-
-// dot_part != nullptr (backward forms): the product is NOT stored; its inner product with `y` (read as an [m, dout] operand of the
-// same row stride) is accumulated instead, one partial per workgroup -- d epsilon of a GINAggregate whose input needs no gradient
-// (kgcn/layers.py:469: <d out, x>; the d out tensor then never exists in HBM).
-struct GhDact { long ydiff, pdiff; float c0, c1, c2; const float* bc; long bc_ld; int bc_n, bc_only; float* dot_part; };
 
 // LDS slot of row rr32 (0..31 of its m-tile), lane half hi, in the block of k-step ks: XOR-rotated by (2 ks + hi) mod 16
 __device__ __forceinline__ int gh_slot(int rr32, int ks, int hi) { return (rr32 ^ ((2 * ks + hi) & 15)) + 32 * hi; }
@@ -105,22 +79,8 @@ __device__ __forceinline__ int gh_slot(int rr32, int ks, int hi) { return (rr32 
 // lane's column its ONE 32-bit voffset.  No vector address arithmetic, one address register per tensor instead of a 64-bit
 // pointer per access (32 y pointers next to 128 registers of W' were the spill source of the first build), and rows beyond m
 // need no clamps or masks: loads outside the descriptor return 0, stores outside it are dropped.
-constexpr int kBufFlags = 0x00020000;          // raw dword buffer, gfx9 family (DST_SEL / formats unused by raw accesses)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t gh_rows(const float* base, long row0, long rows, long m, long ld) {
-  long n = m - row0;
-  n = n < 0 ? 0 : (n < rows ? n : rows);
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (n > 0 ? row0 : 0) * ld), 0, (int)(n * ld * 4), kBufFlags);
-}
-__device__ __forceinline__ f32x4 gh_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
-}
-
 constexpr int GH_PIECES = 2 * 16 * 2 * 64;     // u32x4 entries of one LDS tile buffer: (m-tile, k-step, piece, slot)
 constexpr size_t GH_LDS = 2 * (size_t)GH_PIECES * 16 + 2 * 64 * 4;
-// The hand-over through LDS needs the wave's LDS operations done (lgkmcnt), NOT its vector-memory operations: __syncthreads()
-// also drains vmcnt -- the next tile's rows on their way from HBM and the stores of this one.
-__device__ __forceinline__ void gh_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 template <int DK, int NKS>
 __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restrict__ x, long m, int din, long x_ld,
                                                            const u32x4* __restrict__ tab, const float* __restrict__ bias,
@@ -441,12 +401,6 @@ int launch_gemmh_dx_dact(const float* grad, const float* act_out, float* dpre, l
 // (two bits of headroom), accumulators rescaled by the exact powers of two (x columns are accumulator ROWS: their deltas are
 // fetched across lanes).  Partials are written unscaled.
 // ------------------------------------------------------------------------------------------------------------------
-struct GhCol {           // per lane and fragment: one column of an operand
-  int k;                 // scale exponent
-  float lim;             // |v| <= lim  <=>  |v| 2^k <= 65504 (the largest f16)
-  float run;             // running maximum of |v| over the rows seen so far
-};
-
 template <bool DACT>
 __global__ __launch_bounds__(512, 2) void gemmh_wgrad_kernel(const float* __restrict__ x, long x_ld, const float* __restrict__ dy,
                                                              long dy_ld, long m, int din, int dout, long steps_per_block,

@@ -475,6 +475,46 @@ enabled_weight_tables = True
 weight_tables = WeightTables()
 
 
+# One-pass backward of the wide layers (kgcn_dense_bwd_f32, csrc/gemmb.hip): dX, dW and dbias from ONE sweep over (grad, act_out,
+# x) -- the d pre-activation tensor is never written and read back (six passes over [m, 256] tensors -> four).
+dense_bwd_fusion = True
+
+
+def _dense_bwd_fused_ok(x2d, w, gy, yact, gp=None, gp_ld=0, n_nodes=0):
+    m, din = x2d.shape
+    dout = w.shape[1]
+    if not (dense_bwd_fusion and lib.kgcn_dense_bwd_supported(m, din, dout)):
+        return False
+    ts = [t for t in (x2d, gy, yact) if t is not None]
+    if not all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in ts):
+        return False
+    return gp is None or (gp.data_ptr() % 16 == 0 and gp_ld % 4 == 0 and n_nodes >= 8)
+
+
+def _dense_bwd_fused(ctx, x2d, w, gy, yact, act, need_b, gp=None, gp_ld=0, n_nodes=0):
+    """-> (dx, dw, db) of y = act(x2d @ w + bias) from one launch (+ the deferrable second stage of dw / db)."""
+    m, din = x2d.shape
+    dout = w.shape[1]
+    dx = torch.empty_like(x2d)
+    dw = torch.empty_like(w)
+    db = torch.empty((dout,), device=x2d.device, dtype=torch.float32) if need_b else None
+    tab, tb = weight_tables.lookup(w, 1)
+    ready = 1
+    if tab is None:
+        tb, tab = _dense_ws(dout, din, x2d.device)
+        ready = 0
+    with _no_deferral_unless(getattr(ctx, "defer_ok", False) and _single_use(*ctx.defer_ids)):
+        wsb = lib.kgcn_dense_wgrad_workspace_bytes(m, din, dout)
+        wsp = torch.empty((max(wsb, 4) // 4,), device=x2d.device, dtype=torch.float32)
+        check(lib.kgcn_dense_bwd_f32(ptr(gy), None if gp is None else gp.data_ptr(), gp_ld, n_nodes, ptr(yact) if act else None,
+                                     int(act), dout, ptr(x2d), din, m, din, dout, ptr(w), dout, ptr(dx), din, ptr(dw), ptr(db),
+                                     ptr(tab), tb, ready, ptr(wsp), wsb, current_stream()), "kgcn_dense_bwd_f32")
+        _keep_until_flush(wsp)
+    if db is not None:
+        db = db.reshape(ctx.bias_shape)
+    return dx, dw, db
+
+
 class _Dense(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2d, w, bias, act=0):
@@ -519,6 +559,12 @@ class _Dense(torch.autograd.Function):
         m, din = x2d.shape
         dout = w.shape[1]
         dx = dw = db = None
+        need_b = ctx.bias_shape is not None and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not (side_stream_wgrad and m >= side_wgrad_min_rows) and \
+                _dense_bwd_fused_ok(x2d, w, gy, yact if ctx.act else None):
+            # wide layer that hands a gradient on: dX, dW and dbias in ONE pass over (gy, y, x)
+            dx, dw, db = _dense_bwd_fused(ctx, x2d, w, gy, yact, ctx.act, need_b)
+            return dx, dw, db, None
         # first layer of a model (no d inputs), wide layer: d pre-activation is formed while the weight-gradient GEMM stages
         # the gradient rows -- no elementwise pass over the [m, dout] tensor
         fuse_dact = bool(ctx.act) and not ctx.needs_input_grad[0] and wgrad_dact_fusion and \
@@ -679,6 +725,13 @@ class _DenseGather(torch.autograd.Function):
                 gp = _f32c(gp, "grad")
         dx = dw = db = None
         need_x = ctx.needs_input_grad[0]
+        need_b = ctx.bias_shape is not None and ctx.needs_input_grad[2]
+        if need_x and ctx.needs_input_grad[1] and (gp is None or (ctx.act and gp.dtype == torch.float32 and gp.dim() == 2 and
+                                                                  gp.stride(1) == 1)) and \
+                _dense_bwd_fused_ok(x2d, w, gy, y if ctx.act else None, gp, gp_ld if gp is not None else 0, N):
+            # the whole backward in one pass: the read-out's gradient joins (or stands for) the row gradient while the rows are staged
+            dx, dw, db = _dense_bwd_fused(ctx, x2d, w, gy, y, ctx.act, need_b, gp, gp_ld if gp is not None else 0, N)
+            return dx, dw, db, None, None, None, None, None
         if gp is not None and ctx.act and need_x and lib.kgcn_dense_dx_dact_gather_supported(m, din, dout):
             dx = torch.empty_like(x2d)
             dpre = torch.empty((m, dout), device=x2d.device, dtype=torch.float32)

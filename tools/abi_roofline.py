@@ -26,7 +26,7 @@ HBM = 8.0e12
 F32_MFMA = 157.3e12
 F16_MFMA = 2.5e15              # dense f16 / bf16 matrix rate (MI355X_MICROARCH.md)
 NOMINAL = ("kgcn_reduce_flush", "kgcn_wtable_split_multi")
-REPEATABLE = ("kgcn_dense_fwd", "kgcn_dense_dx_dact", "kgcn_dense_wgrad", "kgcn_bspmm", "kgcn_gin_aggregate", "kgcn_graphconv_")
+REPEATABLE = ("kgcn_dense_fwd", "kgcn_dense_dx_dact", "kgcn_dense_wgrad", "kgcn_dense_bwd_f32", "kgcn_bspmm", "kgcn_gin_aggregate", "kgcn_graphconv_")
 
 
 def _products(name, a):
@@ -40,6 +40,8 @@ def _products(name, a):
         return q(1, a[2], a[3], a[7])
     if name == "kgcn_dense_wgrad_f32":
         return q(2, a[4], a[5], a[6])
+    if name == "kgcn_dense_bwd_f32":
+        return 3                                   # gemmb.hip: f16 two-piece products for both contractions
     if name == "kgcn_dense_wgrad_dact_f32":
         return q(2, a[6], a[7], a[8])
     if name in ("kgcn_graphconv_fwd_f32", "kgcn_graphconv_bwd_f32", "kgcn_gcn_stack_fwd_f32", "kgcn_gcn_stack_bwd_f32"):
@@ -104,6 +106,12 @@ def _cost(name, a):
     if name == "kgcn_dense_wgrad_f32":
         m, din, dout = a[4], a[5], a[6]
         return 4 * (m * din + m * dout + din * dout), 2 * m * din * dout, "m=%d %dx%d" % (m, din, dout)
+    if name == "kgcn_dense_bwd_f32":
+        # ONE pass: reads grad (when given), act_out (activated layers) and x, writes dx; dW / dbias leave as 128 partials
+        m, din, dout, act = a[9], a[10], a[11], a[5]
+        reads = (1 if a[0] else 0) + (1 if act else 0)
+        return 4 * (m * dout * reads + 2 * m * din + 2 * din * dout), 4 * m * din * dout, \
+            "m=%d %d<->%d one-pass bwd act=%d%s" % (m, din, dout, act, " +pooled" if a[1] else "")
     if name == "kgcn_graphconv_fwd_f32":
         c = _csr(a[0]); din, dout = a[4], a[5]
         rows = c.num_graphs * c.rows
