@@ -14,10 +14,10 @@
 //   workgroup `half` of a pair:  dX[:, 128 half .. +128)  =  dpre . W^T[:, that column range]      (needs all of dpre: dY, a)
 //                                dW[128 half .. +128, :]  =  x[:, that column range]^T . dpre       (needs HALF of x)
 //   HBM: dY + a + x in, dX out (the pair's second read of dY and a hits L2 / the memory-side cache);  per workgroup W' is
-//   128 KB of registers and dW 128 KB of accumulators: 4 waves x 512 registers, one wave per SIMD.
+//   128 KB of registers and dW 128 KB of accumulators: 8 waves x 256 registers, two per SIMD, in two roles (below).
 //
-// One stage = 32 rows.  A wave (w = 0..3):
-//   staging    rows 8 w .. 8 w + 7 of the stage travel HBM -> registers as 1 KiB rows (lane = 4 consecutive columns; dY and the
+// One stage = 32 rows.  Waves 0..3 multiply for dX, waves 4..7 for dW (roles: see gemmb_kernel), all eight stage:
+//   staging    rows 4 w .. 4 w + 3 of the stage travel HBM -> registers as 1 KiB rows (lane = 4 consecutive columns; dY and the
 //              saved activation, one stage ahead), dpre = dY (.) act'(a) [+ the read-out's broadcast gradient], row maximum by a
 //              DPP wave reduction -> row exponent kr (scalar), pieces h = f16(dpre 2^kr), l = f16(dpre 2^kr - h) -> LDS ONCE,
 //              in an image that serves both products (below); dbias = column sums on the way.
@@ -51,9 +51,20 @@ constexpr int GB_PLANE = 20480;               // bytes of one piece plane
 constexpr int GB_BUF = 2 * GB_PLANE;          // h | l
 // k-steps of W' held in registers; the others live in LDS (below).  The form that adds the read-out's gradient to a row gradient
 // (BC = 1) keeps eight more staging registers alive through the multiplication: four k-steps fewer in registers there.
-__host__ __device__ constexpr int gb_wreg(int bc) { return bc == 1 ? 10 : 14; }
+__host__ __device__ constexpr int gb_wreg(int) { return 10; }
 __host__ __device__ constexpr size_t gb_lds(int bc) { return 2 * (size_t)GB_BUF + 2 * GB_R * 4 + 4 * (size_t)(16 - gb_wreg(bc)) * 2 * 1024; }
 constexpr int GB_ZERO_ROW_K = 120;            // row exponent of an all-zero dpre row: x 2^(K - 120) vanishes
+
+#ifdef KGCN_PROBE   // development: per-wave cycle sums per phase of gemmb_kernel (tools/gemmb_probe.py)
+__device__ long long* gb_probe = nullptr;
+#define GBP_DECL long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long pc_ = __builtin_readcyclecounter();
+#define GBP(k) { const long long n_ = __builtin_readcyclecounter(); pt_[k] += n_ - pc_; pc_ = n_; }
+#define GBP_FLUSH if (gb_probe && lane == 0) { for (int k_ = 0; k_ < 8; ++k_) gb_probe[((long)blockIdx.x * 8 + wave) * 8 + k_] = pt_[k_]; }
+#else
+#define GBP_DECL
+#define GBP(k)
+#define GBP_FLUSH
+#endif
 
 typedef short gb_i16x4 __attribute__((ext_vector_type(4)));
 #define GB_LDS_AS __attribute__((address_space(3)))
@@ -72,8 +83,22 @@ __device__ __forceinline__ u32x2 gb_ld_tr16(unsigned a) {
 // to (BC = 1) or standing for (BC = 2) the row gradient -- kgcn_dense_dx_dact_gather_f32's operand; BC = 0: none.  A template
 // parameter, not a uniform branch: the first build tested da.bc per row at run time -- two dozen extra basic blocks in the loop
 // body, registers live across all of them, 172 spilled VGPRs.
+//
+// EIGHT waves, two per SIMD, in two ROLES (wave w and w + 4 share a SIMD):
+//   waves 0..3 ("dX")  STAGE the rows (eight per wave and stage: dY / a rows -> dpre -> row exponent -> pieces -> LDS, requested a
+//                      stage ahead), keep W' (k-steps 0..9 in 80 accumulator-file registers, 10..15 in LDS) and multiply the
+//                      stage's 32 rows with their 32 dX columns: 48 MFMAs, epilogue, 16 stores per stage
+//   waves 4..7 ("dW")  keep the eight dW accumulator tiles of their 32 x columns (128 accumulator-file registers), load x in
+//                      fragment layout, counter-scale and split it, and multiply with the stage's dpre read transposed: 48 MFMAs
+// The first build of this kernel ran both roles in ONE wave per SIMD (4 waves x 512 registers): with nobody to fill its
+// issue slots a lone wave spent 6,400 cycles of every stage on ~900 non-MFMA instructions next to 3,400 cycles of MFMAs, one
+// after the other (tools/gemmb_probe.py, profiles/r05_gemmb_history.txt: 248 us at 200,000 rows).  Two waves of 256 registers
+// each hold HALF of the stationary data and fill each other's gaps.  Registers decide who stages: a wave has 128 VGPRs next to
+// its 128 accumulator-file registers; the dW role's accumulators fill its accumulator file, so its x fragments, their pieces and
+// the transposed fragments are all it has room for -- with four staged rows per wave on top the allocator spilled ACCUMULATORS to
+// scratch memory (181-413 spilled registers); the dX role leaves 32 accumulator-file registers free for the rows in flight.
 template <int DK, int BC>
-__global__ __launch_bounds__(256, 1) void gemmb_kernel(const float* __restrict__ g, long m, int kdim, long ld,
+__global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__ g, long m, int kdim, long ld,
                                                        const float* __restrict__ x, int ndim, long x_ld,
                                                        const u32x4* __restrict__ tab, float* __restrict__ dx, long dx_ld,
                                                        float* __restrict__ part_dw, float* __restrict__ part_db, GhDact da,
@@ -81,6 +106,7 @@ __global__ __launch_bounds__(256, 1) void gemmb_kernel(const float* __restrict__
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w4 = wave & 3;                                    // the wave's column tile inside its role
   // pair (q0, half): workgroups b and b + 8 land on the same XCD (round-robin dispatch), i.e. behind the same L2
   const int b = (int)blockIdx.x;
   const int half = (b >> 3) & 1;
@@ -88,80 +114,28 @@ __global__ __launch_bounds__(256, 1) void gemmb_kernel(const float* __restrict__
   const long G = gridDim.x >> 1;
   const unsigned lds0 = gb_lds_off(dsm);
   int* rowk_base = reinterpret_cast<int*>(dsm + 2 * (size_t)GB_BUF);          // [2][32] row exponents
+  GBP_DECL
 
-  // ---- dX side: this wave's 32 output columns of W' (the f16 table of W^T, wtable.hip), whole launch ----------------------
-  const int nt32 = gh_nt32(ndim), kse = gh_kse(kdim);
-  const int* kctab = reinterpret_cast<const int*>(tab + (long)kse * nt32 * 2 * 64);
-  const int nt = 4 * half + wave;
-  const int ntc = nt < nt32 ? nt : nt32 - 1;                 // clamped: the columns of such a wave are never stored
-  // Register files: the 8 + 1 accumulator tiles take 144 of the 256 AGPRs (hipcc gives every MFMA of a function its C / D in
-  // the accumulator file); W' is a B operand, which the matrix pipe reads from either file.  The fragments of k-steps 0..13 are
-  // pinned to the remaining 112 AGPRs (0..9 in the BC = 1 form) (an empty asm with an "a" constraint at the definition: the value's register class); left
-  // to itself the allocator kept W' in VGPRs, used the AGPRs as spill slots and copied every fragment back in front of its
-  // MFMAs (650 v_accvgpr_read + 50-94 scratch spills per loop body in the first build of this kernel).  The fragments of
-  // k-steps 14, 15 do not fit either file next to the staging registers: they wait in LDS (4 KB per wave, written once) and are
-  // read with the stage's other fragments -- in VGPRs they were spilled to scratch memory and reloaded INSIDE the loop, a vmcnt
-  // wait in front of the prefetch (lesson 4b).
-  constexpr int GB_WREG = gb_wreg(BC);
-  u32x4 Wh[GB_WREG], Wl[GB_WREG];
-  const unsigned wl_base = lds0 + (unsigned)(2 * GB_BUF + 2 * GB_R * 4 + wave * (16 - GB_WREG) * 2048 + lane * 16);
-  static_for<16>([&](auto kc) __attribute__((always_inline)) {
-    constexpr int ks = decltype(kc)::value;
-    const int kk = ks < kse ? ks : 0;
-    const u32x4* e = tab + ((long)(kk * nt32 + ntc) * 2) * 64 + lane;
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    const u32x4 h = ks < kse ? e[0] : z, l = ks < kse ? e[64] : z;
-    if constexpr (ks < GB_WREG) {
-      Wh[ks] = h;
-      Wl[ks] = l;
-      asm volatile("" : "+a"(Wh[ks]));
-      asm volatile("" : "+a"(Wl[ks]));
-    } else {
-      *(GB_LDS_AS u32x4*)(uintptr_t)(wl_base + (unsigned)((ks - GB_WREG) * 2048)) = h;
-      *(GB_LDS_AS u32x4*)(uintptr_t)(wl_base + (unsigned)((ks - GB_WREG) * 2048 + 1024)) = l;
-    }
-  });
-  const int col = 32 * nt + li;                              // dX column of this lane
-  const int ldy4 = (int)(dx_ld * 4);
-  const unsigned voff_y = 4u * (unsigned)(4 * hi * dx_ld + (col < ndim ? col : 0));
-  const int kcol = kctab[32 * ntc + li];
-
-  // ---- staging side --------------------------------------------------------------------------------------------------
+  // ---- staging (dX role): rows 8 w .. 8 w + 7 of a stage; lane = 4 consecutive columns --------------------------------------
   const int c4 = 4 * lane;
   const bool cok = c4 < kdim;
-  const unsigned voff_g = 16u * (unsigned)(cok ? lane : 0);
-  const int ld4 = (int)(ld * 4);
   unsigned wbase[2];                                          // LDS write bases of rows 8 w + 0..3 / 8 w + 4..7
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    const int Rr = 2 * wave + p;
+    const int Rr = 2 * w4 + p;
     wbase[p] = lds0 + (unsigned)(Rr * 2560 + (lane >> 3) * 320 + ((((lane >> 1) & 3) ^ (Rr & 3)) << 4) + 8 * (lane & 1));
   }
-  // A-operand rows of dX (row li): k-step even / odd
-  const unsigned abaseE = lds0 + (unsigned)((li >> 2) * 2560 + (li & 3) * 64 + ((hi ^ ((li >> 2) & 3)) << 4));
-  const unsigned abaseO = lds0 + (unsigned)((li >> 2) * 2560 + (li & 3) * 64 + (((2 + hi) ^ ((li >> 2) & 3)) << 4));
-  // transpose reads of dW's B operand: 16-lane group g16 = (hi, column half), lane i16 addresses row 4 t + (i16 >> 2) of its
-  // 8-row half, columns 16 half16 + 4 (i16 & 3) .. + 3
-  unsigned tbase[2];
-  {
-    const int g16 = lane >> 4, i16 = lane & 15, half16 = g16 & 1;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      tbase[t] = lds0 + (unsigned)(2 * hi * 2560 + (i16 >> 2) * 64 + ((((2 * half16) + ((i16 & 3) >> 1)) ^ (2 * hi + t)) << 4) +
-                                   8 * (i16 & 1));
-  }
-  // x in fragment layout: lane (li, hi) = x[row 16 q + 8 hi + j][i0 + li]
-  const int i0 = 128 * half + 32 * wave;
-  const int ca = i0 + li < ndim ? i0 + li : ndim - 1;        // clamped: what such a column contributes is never stored
-  const unsigned voff_x = 4u * (unsigned)(8 * hi * x_ld + ca);
-  const int xld4 = (int)(x_ld * 4);
-
   f32x4 raw[8], ya[DK != 0 ? 8 : 1];
   // rows 4 hl .. 4 hl + 3 of this wave's share of stage `st` (dY and the saved activation), requested as soon as the registers
   // of the same rows of the previous stage are free
+  // (buffer loads with a row-block descriptor: rows past the end read as 0.  global_load_dwordx4 with a uniform row pointer --
+  // ~3-7 cycles of issue in tools/issue_cost.hip against ~30 for a buffer load -- was measured in THIS kernel and lost: 243 us
+  // against 218 us at 200,000 rows with x, dY, a and dX all moved to global accesses, every phase slower; profiles/r05_gemmb_history.txt)
+  const unsigned voff_g = 16u * (unsigned)(cok ? lane : 0);
+  const int ld4 = (int)(ld * 4);
   auto load_ga = [&](long st, auto hlc) __attribute__((always_inline)) {
     constexpr int hl = decltype(hlc)::value;
-    const long r0 = st * GB_R + 8 * wave;
+    const long r0 = st * GB_R + 8 * w4;
     if constexpr (BC == 2) {                                  // the gradient is the read-out's broadcast alone
 #pragma unroll
       for (int i = 4 * hl; i < 4 * hl + 4; ++i) raw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -176,24 +150,14 @@ __global__ __launch_bounds__(256, 1) void gemmb_kernel(const float* __restrict__
       for (int i = 4 * hl; i < 4 * hl + 4; ++i) ya[i] = gh_ld4(ra, voff_g, i * ld4);
     }
   };
-  auto load_x = [&](long st, float (&xr)[2][8]) __attribute__((always_inline)) {
-    const __amdgpu_buffer_rsrc_t rx = gh_rows(x, st * GB_R, GB_R, m, x_ld);
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        xr[q][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)voff_x, (16 * q + j) * xld4, 0));
-  };
-
   // the read-out's gradient rows of the (at most two: bc_n >= 8) graphs this wave's eight rows of stage `st` belong to, and how
-  // many of the eight belong to the first one.  Requested with the x fragments of the stage, a whole multiplication ahead: read
-  // where they are needed they were the YOUNGEST loads in flight, and vmcnt -- which counts in order -- made each of them wait
-  // for everything requested before, the next stage's rows included.
+  // many of the eight belong to the first one.  Requested a whole multiplication ahead: read where they are needed they were
+  // the YOUNGEST loads in flight, and vmcnt -- which counts in order -- made each of them wait for everything requested before.
   f32x4 bcv[BC != 0 ? 2 : 1];
   int bc_first = 8;
   auto load_bc = [&](long st) __attribute__((always_inline)) {
     if constexpr (BC != 0) {
-      const long r0 = st * GB_R + 8 * wave;
+      const long r0 = st * GB_R + 8 * w4;
       const long gmax = (m - 1) / da.bc_n;                    // rows beyond m are zeroed in the staging; their address stays valid
       const long gq = r0 / da.bc_n;
       bc_first = da.bc_n - (int)(r0 - gq * da.bc_n);
@@ -206,10 +170,9 @@ __global__ __launch_bounds__(256, 1) void gemmb_kernel(const float* __restrict__
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   // stage `st` (in the registers) -> pieces in buffer `buf`; the rows of stage `st_next` are requested half by half into the
   // registers this stage's rows leave: they travel while the rest of this stage is split, through the barrier and under the
-  // whole multiplication of stage `st` -- requested at the head of the loop body (the first build) they had only the
-  // multiplication to arrive in, and every stage waited ~1 us for them (5.6 us per stage at 200,000 rows)
+  // whole multiplication of stage `st`
   auto stage_dpre = [&](long st, long st_next, int buf) __attribute__((always_inline)) {
-    const long r0 = st * GB_R + 8 * wave;
+    const long r0 = st * GB_R + 8 * w4;
     int* rowk = rowk_base + GB_R * buf;
     const unsigned boff = (unsigned)(buf * GB_BUF);
     static_for<2>([&](auto hlc) __attribute__((always_inline)) {
@@ -228,7 +191,8 @@ __global__ __launch_bounds__(256, 1) void gemmb_kernel(const float* __restrict__
             else v[e] = a > 0.f ? v[e] : 0.f;
           }
         }
-        if (!(cok && (DK == 0 || r0 + i < m))) v = f32x4{0.f, 0.f, 0.f, 0.f};      // (plain form: rows >= m were loaded as 0)
+        // (without a broadcast gradient rows >= m are zero already: dY was loaded as 0 through the descriptor)
+        if (!(cok && (BC == 0 || r0 + i < m))) v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) bsum[e] += v[e];
         float a;
@@ -267,203 +231,304 @@ __global__ __launch_bounds__(256, 1) void gemmb_kernel(const float* __restrict__
         const unsigned ad = wbase[hl] + boff + (unsigned)(u * 64);
         gb_st64(ad, h0, h1);
         gb_st64(ad + GB_PLANE, l0, l1);
-        rowk[8 * wave + i] = k;                                // same value from every lane
+        rowk[8 * w4 + i] = k;                                  // same value from every lane
       }
       __builtin_amdgcn_sched_barrier(0);
       load_ga(st_next, hlc);
       __builtin_amdgcn_sched_barrier(0);
+      GBP(3 + hl)
     });
   };
 
-  // ---- dW side: 8 accumulator tiles [32 x-columns x 32 dpre-columns], online column scale of x'' ---------------------------
-  f32x16 acc[8];
-#pragma unroll
-  for (int jt = 0; jt < 8; ++jt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
-  GhCol sx{0, 0.f, 0.f};
-  auto max8 = [&](const float (&v)[8]) __attribute__((always_inline)) {
-    float t;
-    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(t) : "v"(v[0]), "v"(v[1]), "v"(v[2]));
-    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(t) : "v"(t), "v"(v[3]), "v"(v[4]));
-    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(t) : "v"(t), "v"(v[5]), "v"(v[6]));
-    asm("v_max_f32 %0, %1, |%2|" : "=v"(t) : "v"(t), "v"(v[7]));
-    return t;
-  };
+  long t = q0;
 
-  struct Frags { u32x4 th, tl, ph, pl; };                    // dW B fragment of one column tile, dX A fragment of one k-step
-  float xr[2][8];                                             // x of the stage in flight, fragment layout
-  auto compute = [&](long st, long st_next, int buf) __attribute__((always_inline)) {
-    const int* rowk = rowk_base + GB_R * buf;
-    const unsigned boff = (unsigned)(buf * GB_BUF);
-    // ---- x'' = x 2^(K - kr[row]) in fragment layout, split once per stage ------------------------------------------------
-    u32x4 Xh[2], Xl[2];
-    {
-      float tv[2][8];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const u32x4 k0 = *reinterpret_cast<const u32x4*>(rowk + 16 * q + 8 * hi);
-        const u32x4 k1 = *reinterpret_cast<const u32x4*>(rowk + 16 * q + 8 * hi + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          tv[q][j] = __builtin_ldexpf(xr[q][j], -(int)k0[j]);
-          tv[q][4 + j] = __builtin_ldexpf(xr[q][4 + j], -(int)k1[j]);
-        }
+  if (wave < 4) {
+    // =============================== dX role ====================================================================
+    // Register files: hipcc gives every MFMA of a function its C / D in the accumulator file; W' is a B operand, which the
+    // matrix pipe reads from either file.  Its fragments are pinned to accumulator-file registers (an empty asm with an "a"
+    // constraint at the definition: the value's register class); left to itself the allocator kept W' in VGPRs, used the AGPRs
+    // as spill slots and copied every fragment back in front of its MFMAs.  The fragments of the last k-steps wait in LDS
+    // (4 KB per wave and k-step pair, written once) and are read with the stage's other fragments.
+    const int nt32 = gh_nt32(ndim), kse = gh_kse(kdim);
+    const int* kctab = reinterpret_cast<const int*>(tab + (long)kse * nt32 * 2 * 64);
+    const int nt = 4 * half + w4;
+    const int ntc = nt < nt32 ? nt : nt32 - 1;               // clamped: the columns of such a wave are never stored
+    constexpr int GB_WREG = gb_wreg(BC);
+    u32x4 Wh[GB_WREG], Wl[GB_WREG];
+    const unsigned wl_base = lds0 + (unsigned)(2 * GB_BUF + 2 * GB_R * 4 + w4 * (16 - GB_WREG) * 2048 + lane * 16);
+    static_for<16>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int ks = decltype(kc)::value;
+      const int kk = ks < kse ? ks : 0;
+      const u32x4* e = tab + ((long)(kk * nt32 + ntc) * 2) * 64 + lane;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      const u32x4 h = ks < kse ? e[0] : z, l = ks < kse ? e[64] : z;
+      if constexpr (ks < GB_WREG) {
+        Wh[ks] = h;
+        Wl[ks] = l;
+        asm volatile("" : "+a"(Wh[ks]));
+        asm volatile("" : "+a"(Wl[ks]));
+      } else {
+        *(GB_LDS_AS u32x4*)(uintptr_t)(wl_base + (unsigned)((ks - GB_WREG) * 2048)) = h;
+        *(GB_LDS_AS u32x4*)(uintptr_t)(wl_base + (unsigned)((ks - GB_WREG) * 2048 + 1024)) = l;
       }
-      __builtin_amdgcn_sched_barrier(0);
-      load_x(st_next, xr);                                    // the next stage's x: in flight behind this stage's arithmetic
+    });
+    const int col = 32 * nt + li;                            // dX column of this lane
+    const int ldy4 = (int)(dx_ld * 4);
+    const unsigned voff_y = 4u * (unsigned)(4 * hi * dx_ld + (col < ndim ? col : 0));
+    const int kcol = kctab[32 * ntc + li];
+    // A-operand rows of dX (row li): k-step even / odd
+    const unsigned abaseE = lds0 + (unsigned)((li >> 2) * 2560 + (li & 3) * 64 + ((hi ^ ((li >> 2) & 3)) << 4));
+    const unsigned abaseO = lds0 + (unsigned)((li >> 2) * 2560 + (li & 3) * 64 + (((2 + hi) ^ ((li >> 2) & 3)) << 4));
+
+    auto compute_dx = [&](long st, long st_next, int buf) __attribute__((always_inline)) {
+      const int* rowk = rowk_base + GB_R * buf;
+      const unsigned boff = (unsigned)(buf * GB_BUF);
+      const unsigned abE = abaseE + boff, abO = abaseO + boff;
       load_bc(st_next);
-      __builtin_amdgcn_sched_barrier(0);
-      const float cm = fmaxf(max8(tv[0]), max8(tv[1]));
-      if (__builtin_amdgcn_ballot_w64(cm > sx.lim) != 0) {    // wave-uniform, rare after the first stages
-        float mxc = fmaxf(cm, __shfl_xor(cm, 32, 64));        // both lane halves hold rows of the same column
-        mxc = fmaxf(sx.run, mxc);
-        sx.run = mxc;
-        int d = 0;
-        if (mxc > sx.lim) {                                   // (a column that has only seen zeros keeps (k, lim) = (0, 0))
-          const int kn = 13 - __builtin_amdgcn_frexp_expf(mxc);          // the maximum lands in [2^12, 2^13)
-          d = kn - sx.k;
-          sx.k = kn;
-          sx.lim = __builtin_ldexpf(0.99951171875f, 16 - kn);
+      // ONE accumulator chain: the wave's dependent MFMAs leave gaps on the matrix pipe that the SIMD's other wave (the dW
+      // role, eight independent tiles) fills -- a second chain would cost 16 of the 128 accumulator-file registers W' needs
+      f32x16 ax;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ax[r] = 0.f;
+      struct P { u32x4 ph, pl, wh, wl; };
+      auto read_p = [&](P& f, auto kc) __attribute__((always_inline)) {
+        constexpr int ks = decltype(kc)::value;
+        const unsigned ab = ((ks & 1) ? abO : abE) + (unsigned)((ks >> 1) * 320);
+        f.pl = gb_ld128(ab + GB_PLANE);
+        f.ph = gb_ld128(ab);
+        if constexpr (ks >= GB_WREG) {
+          f.wh = gb_ld128(wl_base + (unsigned)((ks - GB_WREG) * 2048));
+          f.wl = gb_ld128(wl_base + (unsigned)((ks - GB_WREG) * 2048 + 1024));
         }
+      };
+      P F[17];                                                // (SSA names: F[k] dies inside k-step k)
+      read_p(F[0], std::integral_constant<int, 0>{});
+      static_for<16>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int ks = decltype(kc)::value;
+        u32x4 wh, wl;
+        if constexpr (ks < GB_WREG) { wh = Wh[ks]; wl = Wl[ks]; } else { wh = F[ks].wh; wl = F[ks].wl; }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ks + 1 < 16) read_p(F[ks + 1], std::integral_constant<int, (ks + 1 < 16 ? ks + 1 : 0)>{});
+        __builtin_amdgcn_sched_barrier(0);
+        ax = mfma_f16(F[ks].pl, wh, ax);
+        ax = mfma_f16(F[ks].ph, wl, ax);
+        ax = mfma_f16(F[ks].ph, wh, ax);
+      });
+      GBP(1)
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- dX <- 2^-(kr + kc) ax -----------------------------------------------------------------------------------------
+      // (dword buffer stores, 2 rows x 128 bytes each.  The transposed form -- dX^T = W' dpre^T, a lane then owns 4 consecutive
+      // columns of a row and stores 16 bytes -- was measured with global_store_dwordx4 and lost together with the global loads)
+      if (col < ndim) {
+        const __amdgpu_buffer_rsrc_t ry = gh_rows(dx, st * GB_R, GB_R, m, dx_ld);        // rows >= m: dropped by the descriptor
 #pragma unroll
-        for (int r16 = 0; r16 < 16; ++r16) {
-          const int dr = __shfl(d, (r16 & 3) + 8 * (r16 >> 2) + 4 * hi, 64);        // the x column of this accumulator row
+        for (int rq = 0; rq < 4; ++rq) {
+          const u32x4 kr4 = *reinterpret_cast<const u32x4*>(rowk + 8 * rq + 4 * hi);
 #pragma unroll
-          for (int jt = 0; jt < 8; ++jt) acc[jt][r16] = __builtin_ldexpf(acc[jt][r16], dr);
-          // (scheduling scope = one accumulator row: left alone, the scheduler reads all 128 accumulator registers out of the
-          // accumulator file first -- a register-pressure peak in this COLD block that made the allocator spill W' fragments
-          // whose reloads then sit in the hot loop)
-          __builtin_amdgcn_sched_barrier(0);
+          for (int rj = 0; rj < 4; ++rj) {
+            const float v = __builtin_ldexpf(ax[4 * rq + rj], -((int)kr4[rj] + kcol));
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, (int)voff_y, (rj + 8 * rq) * ldy4, 0);
+          }
         }
       }
+      GBP(2)
+    };
+
+    load_ga(t, std::integral_constant<int, 0>{});
+    load_ga(t, std::integral_constant<int, 1>{});
+    load_bc(t);
+    stage_dpre(t, t + G, 0);
+    gh_barrier_lds();
+    for (int it = 0; it < niter; ++it) {
+      const int buf = it & 1;
+      compute_dx(t, t + G, buf);
+      stage_dpre(t + G, t + 2 * G, buf ^ 1);
+      gh_barrier_lds();
+      GBP(5)
+      t += G;
+    }
+  } else {
+    // =============================== dW role ====================================================================
+    // transpose reads of dW's B operand: 16-lane group g16 = (hi, column half), lane i16 addresses row 4 t + (i16 >> 2) of
+    // its 8-row half, columns 16 half16 + 4 (i16 & 3) .. + 3
+    unsigned tbase[2];
+    {
+      const int g16 = lane >> 4, i16 = lane & 15, half16 = g16 & 1;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+        tbase[tt] = lds0 + (unsigned)(2 * hi * 2560 + (i16 >> 2) * 64 + ((((2 * half16) + ((i16 & 3) >> 1)) ^ (2 * hi + tt)) << 4) +
+                                      8 * (i16 & 1));
+    }
+    // x in fragment layout: lane (li, hi) = x[row 16 q + 8 hi + j][i0 + li]
+    const int i0 = 128 * half + 32 * w4;
+    const int ca = i0 + li < ndim ? i0 + li : ndim - 1;      // clamped: what such a column contributes is never stored
+    float xr[2][8];                                           // x of the stage in flight, fragment layout
+    const unsigned voff_x = 4u * (unsigned)(8 * hi * x_ld + ca);
+    const int xld4 = (int)(x_ld * 4);
+    auto load_x = [&](long st) __attribute__((always_inline)) {
+      const __amdgpu_buffer_rsrc_t rx = gh_rows(x, st * GB_R, GB_R, m, x_ld);
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          unsigned h, l;
-          splith_pair(__builtin_ldexpf(tv[q][2 * e], sx.k), __builtin_ldexpf(tv[q][2 * e + 1], sx.k), h, l);
-          Xh[q][e] = h; Xl[q][e] = l;
-        }
-    }
-    // ---- 16 groups of 6 MFMAs: dW tile (q, jt) and dX k-step ks = 8 q + jt; fragments one group ahead ---------------------------
-    f32x16 ax;                                                // ONE dX chain: inside a group it alternates with the dW tile's
+        for (int j = 0; j < 8; ++j)
+          xr[q][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)voff_x, (16 * q + j) * xld4, 0));
+    };
+    f32x16 acc[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ax[r] = 0.f;
-    const unsigned tb0 = tbase[0] + boff, tb1 = tbase[1] + boff, abE = abaseE + boff, abO = abaseO + boff;
-    // fragment reads of group gi, one piece at a time (each is requested where the registers of the previous group's piece
-    // become free: ONE fragment set of 16 registers, refilled in place -- two sets were 16 registers too many, and the W'
-    // fragments the allocator then spilled were reloaded from scratch memory inside the loop: a vmcnt wait that drains the
-    // prefetch, lesson 4b)
-    auto read_th = [&](Frags& f, auto gc) __attribute__((always_inline)) {
-      constexpr int gi = decltype(gc)::value, q = gi >> 3, jt = gi & 7;
-      const u32x2 h0 = gb_ld_tr16(tb0 + (unsigned)((4 * q + 0) * 2560 + jt * 320));
-      const u32x2 h1 = gb_ld_tr16(tb1 + (unsigned)((4 * q + 1) * 2560 + jt * 320));
-      f.th = u32x4{h0[0], h0[1], h1[0], h1[1]};
-    };
-    auto read_tl = [&](Frags& f, auto gc) __attribute__((always_inline)) {
-      constexpr int gi = decltype(gc)::value, q = gi >> 3, jt = gi & 7;
-      const u32x2 l0 = gb_ld_tr16(tb0 + GB_PLANE + (unsigned)((4 * q + 0) * 2560 + jt * 320));
-      const u32x2 l1 = gb_ld_tr16(tb1 + GB_PLANE + (unsigned)((4 * q + 1) * 2560 + jt * 320));
-      f.tl = u32x4{l0[0], l0[1], l1[0], l1[1]};
-    };
-    auto read_ph = [&](Frags& f, auto gc) __attribute__((always_inline)) {
-      constexpr int ks = decltype(gc)::value;
-      f.ph = gb_ld128(((ks & 1) ? abO : abE) + (unsigned)((ks >> 1) * 320));
-    };
-    auto read_pl = [&](Frags& f, auto gc) __attribute__((always_inline)) {
-      constexpr int ks = decltype(gc)::value;
-      f.pl = gb_ld128(((ks & 1) ? abO : abE) + GB_PLANE + (unsigned)((ks >> 1) * 320));
-    };
-    Frags F[17];                                              // (SSA names: every F[g] dies inside group g; 16 registers live)
-    read_th(F[0], std::integral_constant<int, 0>{});
-    read_pl(F[0], std::integral_constant<int, 0>{});
-    read_tl(F[0], std::integral_constant<int, 0>{});
-    read_ph(F[0], std::integral_constant<int, 0>{});
-    static_for<16>([&](auto gc) __attribute__((always_inline)) {
-      constexpr int gi = decltype(gc)::value, q = gi >> 3, jt = gi & 7, ks = gi;
-      constexpr bool more = gi + 1 < 16;
-      using NX = std::integral_constant<int, more ? gi + 1 : 0>;
-      Frags& f = F[gi];
-      Frags& n = F[gi + 1];
-      u32x4 wh, wl;                                           // this k-step's slice of W': a register or the wave's LDS copy
-      if constexpr (ks < GB_WREG) { wh = Wh[ks]; wl = Wl[ks]; }
-      else {
-        wh = gb_ld128(wl_base + (unsigned)((ks - GB_WREG) * 2048));
-        wl = gb_ld128(wl_base + (unsigned)((ks - GB_WREG) * 2048 + 1024));
-      }
-      // l.H, h.H, h.L for the dW tile (q, jt), l.H, h.L, h.H for the dX k-step ks; the two accumulators alternate (a dependent
-      // MFMA waits for its predecessor's last pass)
-      __builtin_amdgcn_sched_barrier(0);
-      acc[jt] = mfma_f16(Xl[q], f.th, acc[jt]);
-      __builtin_amdgcn_sched_barrier(0);
-      ax = mfma_f16(f.pl, wh, ax);
-      if constexpr (more) read_pl(n, NX{});
-      __builtin_amdgcn_sched_barrier(0);
-      acc[jt] = mfma_f16(Xh[q], f.th, acc[jt]);
-      if constexpr (more) read_th(n, NX{});
-      __builtin_amdgcn_sched_barrier(0);
-      ax = mfma_f16(f.ph, wl, ax);
-      __builtin_amdgcn_sched_barrier(0);
-      acc[jt] = mfma_f16(Xh[q], f.tl, acc[jt]);
-      if constexpr (more) read_tl(n, NX{});
-      __builtin_amdgcn_sched_barrier(0);
-      ax = mfma_f16(f.ph, wh, ax);
-      if constexpr (more) read_ph(n, NX{});
-    });
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- dX <- 2^-(kr + kc) ax -------------------------------------------------------------------------------------------
-    if (col < ndim) {
-      const __amdgpu_buffer_rsrc_t ry = gh_rows(dx, st * GB_R, GB_R, m, dx_ld);          // rows >= m: dropped by the descriptor
+    for (int jt = 0; jt < 8; ++jt)
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const u32x4 kr4 = *reinterpret_cast<const u32x4*>(rowk + 8 * rq + 4 * hi);
-#pragma unroll
-        for (int rj = 0; rj < 4; ++rj) {
-          const float v = __builtin_ldexpf(ax[4 * rq + rj], -((int)kr4[rj] + kcol));
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, (int)voff_y, (rj + 8 * rq) * ldy4, 0);
-        }
-      }
-    }
-  };
+      for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+    GhCol sx{0, 0.f, 0.f};
+    auto max8 = [&](const float (&v)[8]) __attribute__((always_inline)) {
+      float tmx;
+      asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(tmx) : "v"(v[0]), "v"(v[1]), "v"(v[2]));
+      asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(tmx) : "v"(tmx), "v"(v[3]), "v"(v[4]));
+      asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(tmx) : "v"(tmx), "v"(v[5]), "v"(v[6]));
+      asm("v_max_f32 %0, %1, |%2|" : "=v"(tmx) : "v"(tmx), "v"(v[7]));
+      return tmx;
+    };
 
-  // ---- the stage loop: every workgroup runs `niter` stages q0, q0 + G, ...; stages past the end are empty (descriptors
-  // of zero rows: loads return 0, stores are dropped) -- no exit between a request and its use ----------------------------------
-  long t = q0;
-  load_ga(t, std::integral_constant<int, 0>{});
-  load_ga(t, std::integral_constant<int, 1>{});
-  load_x(t, xr);
-  load_bc(t);
-  stage_dpre(t, t + G, 0);
-  gh_barrier_lds();
-  for (int it = 0; it < niter; ++it) {
-    const int buf = it & 1;
-    compute(t, t + G, buf);
-    stage_dpre(t + G, t + 2 * G, buf ^ 1);
+    auto compute_dw = [&](long st, long st_next, int buf) __attribute__((always_inline)) {
+      const int* rowk = rowk_base + GB_R * buf;
+      const unsigned boff = (unsigned)(buf * GB_BUF);
+      // ---- x'' = x 2^(K - kr[row]) in fragment layout, split once per stage ----------------------------------------------
+      u32x4 Xh[2], Xl[2];
+      {
+        float tv[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const u32x4 k0 = *reinterpret_cast<const u32x4*>(rowk + 16 * q + 8 * hi);
+          const u32x4 k1 = *reinterpret_cast<const u32x4*>(rowk + 16 * q + 8 * hi + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            tv[q][j] = __builtin_ldexpf(xr[q][j], -(int)k0[j]);
+            tv[q][4 + j] = __builtin_ldexpf(xr[q][4 + j], -(int)k1[j]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_x(st_next);                                      // the next stage's x: in flight behind this stage's arithmetic
+        __builtin_amdgcn_sched_barrier(0);
+        const float cm = fmaxf(max8(tv[0]), max8(tv[1]));
+#ifndef GB_NO_RESCALE
+        if (__builtin_amdgcn_ballot_w64(cm > sx.lim) != 0) {  // wave-uniform, rare after the first stages
+          float mxc = fmaxf(cm, __shfl_xor(cm, 32, 64));      // both lane halves hold rows of the same column
+          mxc = fmaxf(sx.run, mxc);
+          sx.run = mxc;
+          int d = 0;
+          if (mxc > sx.lim) {                                 // (a column that has only seen zeros keeps (k, lim) = (0, 0))
+            const int kn = 13 - __builtin_amdgcn_frexp_expf(mxc);        // the maximum lands in [2^12, 2^13)
+            d = kn - sx.k;
+            sx.k = kn;
+            sx.lim = __builtin_ldexpf(0.99951171875f, 16 - kn);
+          }
+          int dr[16];                                         // the x column of accumulator row r16: its change of exponent
+#pragma unroll
+          for (int r16 = 0; r16 < 16; ++r16) dr[r16] = __shfl(d, (r16 & 3) + 8 * (r16 >> 2) + 4 * hi, 64);
+          // one accumulator tile at a time (scheduling scope = a tile: left alone, the scheduler reads all 128 accumulator
+          // registers out of the accumulator file first -- a register-pressure peak in this COLD block)
+          static_for<8>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int jt = decltype(jc)::value;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r16 = 0; r16 < 16; ++r16) {
+              // in place in the accumulator file (as C++ on the tile's elements the block cost 70-100 spilled registers: the
+              // allocator moved whole tiles through VGPRs and scratch memory to merge the rescaled and the untouched values)
+              float e = acc[jt][r16], tmp;
+              asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_ldexp_f32 %1, %1, %2\n\ts_nop 1\n\tv_accvgpr_write_b32 %0, %1"
+                           : "+a"(e), "=&v"(tmp) : "v"(dr[r16]));
+              acc[jt][r16] = e;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          });
+#ifdef GB_PIN_ACC
+#pragma unroll
+          for (int jt = 0; jt < 8; ++jt) asm volatile("" : "+a"(acc[jt]));
+#endif
+        }
+#endif
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            unsigned h, l;
+            splith_pair(__builtin_ldexpf(tv[q][2 * e], sx.k), __builtin_ldexpf(tv[q][2 * e + 1], sx.k), h, l);
+            Xh[q][e] = h; Xl[q][e] = l;
+          }
+      }
+      GBP(0)
+      // ---- 8 groups of 6 MFMAs over two tiles each ---------------------------------------------------------------------------
+      const unsigned tb0 = tbase[0] + boff, tb1 = tbase[1] + boff;
+      // fragments of tile (q, jt): requested one tile ahead; th is read twice (l.H first, h.H last)
+      struct T { u32x4 th, tl; };
+      auto read_t = [&](T& f, auto gc) __attribute__((always_inline)) {
+        constexpr int gi = decltype(gc)::value, q = gi >> 3, jt = gi & 7;
+        constexpr unsigned jo = (unsigned)(jt * 320);
+        const u32x2 h0 = gb_ld_tr16(tb0 + (unsigned)((4 * q + 0) * 2560) + jo);
+        const u32x2 h1 = gb_ld_tr16(tb1 + (unsigned)((4 * q + 1) * 2560) + jo);
+        const u32x2 l0 = gb_ld_tr16(tb0 + GB_PLANE + (unsigned)((4 * q + 0) * 2560) + jo);
+        const u32x2 l1 = gb_ld_tr16(tb1 + GB_PLANE + (unsigned)((4 * q + 1) * 2560) + jo);
+        f.th = u32x4{h0[0], h0[1], h1[0], h1[1]};
+        f.tl = u32x4{l0[0], l0[1], l1[0], l1[1]};
+      };
+      T F[17];
+      read_t(F[0], std::integral_constant<int, 0>{});
+      read_t(F[1], std::integral_constant<int, 1>{});
+      static_for<8>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int g0 = 2 * decltype(pc)::value, g1 = g0 + 1, q = g0 >> 3, j0 = g0 & 7, j1 = g1 & 7;
+        // product-major over two independent tiles
+        __builtin_amdgcn_sched_barrier(0);
+        acc[j0] = mfma_f16(Xl[q], F[g0].th, acc[j0]);
+        acc[j1] = mfma_f16(Xl[q], F[g1].th, acc[j1]);
+        acc[j0] = mfma_f16(Xh[q], F[g0].tl, acc[j0]);
+        acc[j1] = mfma_f16(Xh[q], F[g1].tl, acc[j1]);
+        acc[j0] = mfma_f16(Xh[q], F[g0].th, acc[j0]);
+        acc[j1] = mfma_f16(Xh[q], F[g1].th, acc[j1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g0 + 2 < 16) {
+          read_t(F[g0 + 2 < 16 ? g0 + 2 : 16], std::integral_constant<int, (g0 + 2 < 16 ? g0 + 2 : 0)>{});
+          read_t(F[g0 + 3 < 16 ? g0 + 3 : 16], std::integral_constant<int, (g0 + 3 < 16 ? g0 + 3 : 0)>{});
+        }
+      });
+      GBP(1)
+    };
+
+    load_x(t);
     gh_barrier_lds();
-    t += G;
-  }
-
-  // ---- the workgroup's partial dW rows [128 half + 32 w .. + 32) x all columns, unscaled; one partial per PAIR ------------------
-  float* pw = part_dw + q0 * (long)ndim * kdim;
+    for (int it = 0; it < niter; ++it) {
+      const int buf = it & 1;
+      compute_dw(t, t + G, buf);
+      GBP(2)
+      gh_barrier_lds();
+      GBP(5)
+      t += G;
+    }
+    // ---- the wave's partial dW rows [128 half + 32 w4 .. + 32) x all columns, unscaled; one partial per PAIR --------------------
+    float* pw = part_dw + q0 * (long)ndim * kdim;
 #pragma unroll
-  for (int r16 = 0; r16 < 16; ++r16) {
-    const int rr = (r16 & 3) + 8 * (r16 >> 2) + 4 * hi;
-    const int kr = __shfl(sx.k, rr, 64);
-    const int row = i0 + rr;
+    for (int r16 = 0; r16 < 16; ++r16) {
+      const int rr = (r16 & 3) + 8 * (r16 >> 2) + 4 * hi;
+      const int kr = __shfl(sx.k, rr, 64);
+      const int row = i0 + rr;
 #pragma unroll
-    for (int jt = 0; jt < 8; ++jt) {
-      const int cj = 32 * jt + li;
-      if (row < ndim && cj < kdim) pw[(long)row * kdim + cj] = __builtin_ldexpf(acc[jt][r16], -kr);
+      for (int jt = 0; jt < 8; ++jt) {
+        const int cj = 32 * jt + li;
+        if (row < ndim && cj < kdim) pw[(long)row * kdim + cj] = __builtin_ldexpf(acc[jt][r16], -kr);
+      }
     }
   }
+  GBP_FLUSH
   // dbias: column sums of dpre over the pair's rows (both workgroups hold the same sums; half 0 stores them)
   if (part_db && half == 0) {                                  // uniform
     float* red = reinterpret_cast<float*>(dsm);                // (every wave is behind the loop's last barrier: the image is free)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[wave * 256 + c4 + e] = bsum[e];
+    for (int e = 0; e < 4; ++e) red[wave * 256 + c4 + e] = bsum[e];       // (the dW waves staged nothing: zeros)
     __syncthreads();
-    if (tid < kdim) part_db[q0 * kdim + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+    if (tid < kdim) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 4; ++w8) sum += red[w8 * 256 + tid];
+      part_db[q0 * kdim + tid] = sum;
+    }
   }
 }
 
@@ -509,7 +574,7 @@ int launch_gemmb(const float* grad, const float* act_out, long m, int din, int d
                                 kLdsBytes);
       attr_set = true;
     }
-    hipLaunchKernelGGL((gemmb_kernel<DKc, BCc>), grid, dim3(256), gb_lds(BCc), s, base, m, dout, ld, x, din, x_ld, tab, dx, dx_ld, part_dw,
+    hipLaunchKernelGGL((gemmb_kernel<DKc, BCc>), grid, dim3(512), gb_lds(BCc), s, base, m, dout, ld, x, din, x_ld, tab, dx, dx_ld, part_dw,
                        part_db, da, niter);
   };
   using I0 = std::integral_constant<int, 0>;
@@ -523,3 +588,10 @@ int launch_gemmb(const float* grad, const float* act_out, long m, int din, int d
 }
 
 }  // namespace kgcn
+
+#ifdef KGCN_PROBE
+extern "C" int kgcn_gb_probe_set(void* buf) {
+  long long* p = static_cast<long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(kgcn::gb_probe), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
