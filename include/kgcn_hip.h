@@ -381,7 +381,7 @@ int kgcn_dense_dx_dact_gather_f32(const float* grad, const float* pooled_grad, i
  * passes over [m, 256] tensors instead of four).  grad may be NULL when pooled_grad is given (the layer output was only read out
  * by GraphGather); pooled_grad as in kgcn_dense_dx_dact_gather_f32, with n_nodes >= 8 (smaller graphs: the two-call route).
  * ld: row stride of grad and act_out.
- * kgcn_dense_bwd_supported(m, din, dout): 128 < din, dout <= 256, multiples of 4, m >= 16,384.  table / table_ready: the
+ * kgcn_dense_bwd_supported(m, din, dout): dout == 256, 128 < din <= 256 (a multiple of 4), m >= 16,384.  table / table_ready: the
  * fragment tables of w^T as for kgcn_dense_dx_dact_gather_f32 (kgcn_dense_fwd_workspace_bytes(dout, din) bytes); workspace >=
  * kgcn_dense_wgrad_workspace_bytes(m, din, dout) (128 partials, fixed-order second stage, deferrable: kgcn_reduce_defer).
  * Arithmetic: route 3 of "Conventions" (f16 x 2) with a row scale on dpre and a counter-scaled, per-column online scale on x. */

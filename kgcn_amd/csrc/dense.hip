@@ -829,7 +829,7 @@ int launch_reduce_pair(const float* part_dw, long n_dw, float* dw, const float* 
 }  // namespace kgcn
 
 extern "C" int kgcn_dense_bwd_supported(int64_t m, int32_t din, int32_t dout) {
-  return (din > 128 && din <= 256 && dout > 128 && dout <= 256 && din % 4 == 0 && dout % 4 == 0 && m >= (int64_t)kNumCU * 64) ? 1 : 0;
+  return (din > 128 && din <= 256 && dout == 256 && din % 4 == 0 && m >= (int64_t)kNumCU * 64) ? 1 : 0;
 }
 
 extern "C" int kgcn_dense_bwd_f32(const float* grad, const float* pooled_grad, int64_t pooled_ld, int32_t n_nodes,

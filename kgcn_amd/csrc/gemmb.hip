@@ -118,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
 
   // ---- staging (dX role): rows 8 w .. 8 w + 7 of a stage; lane = 4 consecutive columns --------------------------------------
   const int c4 = 4 * lane;
-  const bool cok = c4 < kdim;
+  constexpr bool cok = true;                                  // kdim == 256 (launch_gemmb): every lane holds four valid columns
   unsigned wbase[2];                                          // LDS write bases of rows 8 w + 0..3 / 8 w + 4..7
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
@@ -126,29 +126,19 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
     wbase[p] = lds0 + (unsigned)(Rr * 2560 + (lane >> 3) * 320 + ((((lane >> 1) & 3) ^ (Rr & 3)) << 4) + 8 * (lane & 1));
   }
   f32x4 raw[8], ya[DK != 0 ? 8 : 1];
-  // rows 4 hl .. 4 hl + 3 of this wave's share of stage `st` (dY and the saved activation), requested as soon as the registers
-  // of the same rows of the previous stage are free
+  // row i of this wave's share of stage `st` (dY and the saved activation), requested as soon as the registers of the same row
+  // of the previous stage are free
   // (buffer loads with a row-block descriptor: rows past the end read as 0.  global_load_dwordx4 with a uniform row pointer --
   // ~3-7 cycles of issue in tools/issue_cost.hip against ~30 for a buffer load -- was measured in THIS kernel and lost: 243 us
   // against 218 us at 200,000 rows with x, dY, a and dX all moved to global accesses, every phase slower; profiles/r05_gemmb_history.txt)
   const unsigned voff_g = 16u * (unsigned)(cok ? lane : 0);
   const int ld4 = (int)(ld * 4);
-  auto load_ga = [&](long st, auto hlc) __attribute__((always_inline)) {
-    constexpr int hl = decltype(hlc)::value;
+  auto load_ga_row = [&](long st, auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
     const long r0 = st * GB_R + 8 * w4;
-    if constexpr (BC == 2) {                                  // the gradient is the read-out's broadcast alone
-#pragma unroll
-      for (int i = 4 * hl; i < 4 * hl + 4; ++i) raw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    } else {
-      const __amdgpu_buffer_rsrc_t rg = gh_rows(g, r0, 8, m, ld);       // stages past the end: empty descriptor, zeros
-#pragma unroll
-      for (int i = 4 * hl; i < 4 * hl + 4; ++i) raw[i] = gh_ld4(rg, voff_g, i * ld4);
-    }
-    if constexpr (DK != 0) {
-      const __amdgpu_buffer_rsrc_t ra = gh_rows(g + da.ydiff, r0, 8, m, ld);
-#pragma unroll
-      for (int i = 4 * hl; i < 4 * hl + 4; ++i) ya[i] = gh_ld4(ra, voff_g, i * ld4);
-    }
+    if constexpr (BC == 2) raw[i] = f32x4{0.f, 0.f, 0.f, 0.f};          // the gradient is the read-out's broadcast alone
+    else raw[i] = gh_ld4(gh_rows(g, r0, 8, m, ld), voff_g, i * ld4);     // stages past the end: empty descriptor, zeros
+    if constexpr (DK != 0) ya[i] = gh_ld4(gh_rows(g + da.ydiff, r0, 8, m, ld), voff_g, i * ld4);
   };
   // the read-out's gradient rows of the (at most two: bc_n >= 8) graphs this wave's eight rows of stage `st` belong to, and how
   // many of the eight belong to the first one.  Requested a whole multiplication ahead: read where they are needed they were
@@ -168,76 +158,80 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
   };
 
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  // stage `st` (in the registers) -> pieces in buffer `buf`; the rows of stage `st_next` are requested half by half into the
-  // registers this stage's rows leave: they travel while the rest of this stage is split, through the barrier and under the
-  // whole multiplication of stage `st`
-  auto stage_dpre = [&](long st, long st_next, int buf) __attribute__((always_inline)) {
+  // Staging of ONE row of stage `st` (in the registers) into buffer `buf`, in two parts that the dX loop lays between the MFMAs of
+  // two consecutive k-steps (a wave's MFMAs leave its vector-ALU slots free: staged after the multiplication -- the second build --
+  // the eight rows were 3,700 cycles at the END of every stage with the dW waves idle at the barrier, tools/gemmb_probe.py):
+  //   part A  dpre = dY (.) act'(a) [+ read-out gradient], column sums for dbias, the row's largest magnitude (DPP wave reduction)
+  //   part B  row exponent, pieces -> LDS, and the request for the same row of stage `st_next` into the registers this one leaves
+  unsigned rmx = 0;
+  auto row_max = [&](unsigned v) __attribute__((always_inline)) {       // wave maximum of a non-negative float pattern -> scalar
+    asm volatile("s_nop 1\n"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1\n"
+                 : "+v"(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+  };
+  auto stage_row_a = [&](long st, auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
     const long r0 = st * GB_R + 8 * w4;
-    int* rowk = rowk_base + GB_R * buf;
-    const unsigned boff = (unsigned)(buf * GB_BUF);
-    static_for<2>([&](auto hlc) __attribute__((always_inline)) {
-      constexpr int hl = decltype(hlc)::value;
-      unsigned mx[4];
+    f32x4 v = raw[i];
+    if constexpr (DK != 0) {
+      if constexpr (BC != 0) v += i < bc_first ? bcv[0] : bcv[1];        // uniform select: the row's graph
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = 4 * hl + u;
-        f32x4 v = raw[i];
-        if constexpr (DK != 0) {
-          if constexpr (BC != 0) v += i < bc_first ? bcv[0] : bcv[1];      // uniform select: the row's graph
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float a = ya[i][e];
-            if constexpr (DK == 1) v[e] *= __builtin_fmaf(__builtin_fmaf(da.c2, a, da.c1), a, da.c0);
-            else v[e] = a > 0.f ? v[e] : 0.f;
-          }
-        }
-        // (without a broadcast gradient rows >= m are zero already: dY was loaded as 0 through the descriptor)
-        if (!(cok && (BC == 0 || r0 + i < m))) v = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bsum[e] += v[e];
-        float a;
-        asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(a) : "v"(v[0]), "v"(v[1]), "v"(v[2]));
-        asm("v_max_f32 %0, %1, |%2|" : "=v"(a) : "v"(a), "v"(v[3]));
-        mx[u] = __float_as_uint(a);
-        raw[i] = v;
+      for (int e = 0; e < 4; ++e) {
+        const float a = ya[i][e];
+        if constexpr (DK == 1) v[e] *= __builtin_fmaf(__builtin_fmaf(da.c2, a, da.c1), a, da.c0);
+        else v[e] = a > 0.f ? v[e] : 0.f;
       }
-      wave_umax4(mx[0], mx[1], mx[2], mx[3]);
-      // A row that holds +-inf / NaN: its exponent comes from its FINITE values, so that those keep their places in the weight
-      // gradient (dW[:, j] of a finite column j must not turn non-finite -- or lose the row -- because ANOTHER column of that
-      // row is; the non-finite element itself splits into non-finite pieces at any scale).  Cold, wave-uniform.
+    }
+    // Rows >= m need no mask: dY and a were loaded as 0 through the descriptors, so relu' (a > 0) and sigmoid' (a (1 - a)) make
+    // the row zero whatever the broadcast gradient added; only tanh' (1 - a^2 = 1) with a broadcast gradient keeps it alive
+    if constexpr (DK == 1 && BC != 0) {
+      if (r0 + i >= m) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (__builtin_expect(mx[u] >= 0x7f800000u, 0)) {
-          unsigned q = 0u;
+    for (int e = 0; e < 4; ++e) bsum[e] += v[e];
+    float a;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(a) : "v"(v[0]), "v"(v[1]), "v"(v[2]));
+    asm("v_max_f32 %0, %1, |%2|" : "=v"(a) : "v"(a), "v"(v[3]));
+    raw[i] = v;
+    rmx = row_max(__float_as_uint(a));
+    unsigned mxr = rmx;                                       // (part A ends with the one branch of a row's staging: part B is straight-line code between its MFMAs)
+    // A row that holds +-inf / NaN: its exponent comes from its FINITE values, so that those keep their places in the weight
+    // gradient (dW[:, j] of a finite column j must not turn non-finite -- or lose the row -- because ANOTHER column of that
+    // row is; the non-finite element itself splits into non-finite pieces at any scale).  Cold, wave-uniform.
+    if (__builtin_expect(mxr >= 0x7f800000u, 0)) {
+      unsigned q = 0u;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const unsigned av = __float_as_uint(raw[4 * hl + u][e]) & 0x7fffffffu;
-            q = (av < 0x7f800000u && av > q) ? av : q;
-          }
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) {
-            const unsigned v = (unsigned)__shfl_xor((int)q, o, 64);
-            q = v > q ? v : q;
-          }
-          mx[u] = (unsigned)__builtin_amdgcn_readfirstlane((int)q);
-        }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = 4 * hl + u;
-        const int k = mx[u] == 0u ? GB_ZERO_ROW_K : scale_exp(__uint_as_float(mx[u]));   // wave-uniform
-        unsigned h0, l0, h1, l1;
-        splith_pair(__builtin_ldexpf(raw[i][0], k), __builtin_ldexpf(raw[i][1], k), h0, l0);
-        splith_pair(__builtin_ldexpf(raw[i][2], k), __builtin_ldexpf(raw[i][3], k), h1, l1);
-        const unsigned ad = wbase[hl] + boff + (unsigned)(u * 64);
-        gb_st64(ad, h0, h1);
-        gb_st64(ad + GB_PLANE, l0, l1);
-        rowk[8 * w4 + i] = k;                                  // same value from every lane
+      for (int e = 0; e < 4; ++e) {
+        const unsigned av = __float_as_uint(raw[i][e]) & 0x7fffffffu;
+        q = (av < 0x7f800000u && av > q) ? av : q;
       }
-      __builtin_amdgcn_sched_barrier(0);
-      load_ga(st_next, hlc);
-      __builtin_amdgcn_sched_barrier(0);
-      GBP(3 + hl)
-    });
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned v = (unsigned)__shfl_xor((int)q, o, 64);
+        q = v > q ? v : q;
+      }
+      mxr = (unsigned)__builtin_amdgcn_readfirstlane((int)q);
+    }
+    rmx = mxr;
+  };
+  auto stage_row_b = [&](long st_next, int buf, auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    const unsigned mxr = rmx;
+    const int k = mxr == 0u ? GB_ZERO_ROW_K : scale_exp(__uint_as_float(mxr));          // wave-uniform
+    unsigned h0, l0, h1, l1;
+    splith_pair(__builtin_ldexpf(raw[i][0], k), __builtin_ldexpf(raw[i][1], k), h0, l0);
+    splith_pair(__builtin_ldexpf(raw[i][2], k), __builtin_ldexpf(raw[i][3], k), h1, l1);
+    const unsigned ad = wbase[i >> 2] + (unsigned)(buf * GB_BUF) + (unsigned)((i & 3) * 64);
+    gb_st64(ad, h0, h1);
+    gb_st64(ad + GB_PLANE, l0, l1);
+    (rowk_base + GB_R * buf)[8 * w4 + i] = k;                  // same value from every lane
+    load_ga_row(st_next, ic);
   };
 
   long t = q0;
@@ -280,11 +274,10 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
     const unsigned abaseE = lds0 + (unsigned)((li >> 2) * 2560 + (li & 3) * 64 + ((hi ^ ((li >> 2) & 3)) << 4));
     const unsigned abaseO = lds0 + (unsigned)((li >> 2) * 2560 + (li & 3) * 64 + (((2 + hi) ^ ((li >> 2) & 3)) << 4));
 
-    auto compute_dx = [&](long st, long st_next, int buf) __attribute__((always_inline)) {
+    auto compute_dx = [&](long st, long st_next, long st_load, int buf) __attribute__((always_inline)) {
       const int* rowk = rowk_base + GB_R * buf;
       const unsigned boff = (unsigned)(buf * GB_BUF);
       const unsigned abE = abaseE + boff, abO = abaseO + boff;
-      load_bc(st_next);
       // ONE accumulator chain: the wave's dependent MFMAs leave gaps on the matrix pipe that the SIMD's other wave (the dW
       // role, eight independent tiles) fills -- a second chain would cost 16 of the 128 accumulator-file registers W' needs
       f32x16 ax;
@@ -313,7 +306,20 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
         ax = mfma_f16(F[ks].pl, wh, ax);
         ax = mfma_f16(F[ks].ph, wl, ax);
         ax = mfma_f16(F[ks].ph, wh, ax);
+        // BETWEEN the k-step's MFMAs: half a row of the NEXT stage's staging (row ks / 2 -> the other buffer).  The three
+        // MFMAs form one dependent chain: issued back to back they hold the wave's issue port until the last one starts, and
+        // vector work placed behind them overlaps only that one (the first interleaved build: 6,200 cycles for the phase
+        // against 1,770 + 3,740 apart) -- the group barriers ask the scheduler for MFMA, 7 vector instructions, MFMA, ...
+        if constexpr ((ks & 1) == 0) stage_row_a(st_next, std::integral_constant<int, ks / 2>{});
+        else stage_row_b(st_load, buf ^ 1, std::integral_constant<int, ks / 2>{});
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
       });
+      load_bc(st_load);                                      // (the rows staged above used the previous request)
       GBP(1)
       __builtin_amdgcn_sched_barrier(0);
       // ---- dX <- 2^-(kr + kc) ax -----------------------------------------------------------------------------------------
@@ -334,15 +340,17 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
       GBP(2)
     };
 
-    load_ga(t, std::integral_constant<int, 0>{});
-    load_ga(t, std::integral_constant<int, 1>{});
+    static_for<8>([&](auto ic) __attribute__((always_inline)) { load_ga_row(t, ic); });
     load_bc(t);
-    stage_dpre(t, t + G, 0);
+    static_for<8>([&](auto ic) __attribute__((always_inline)) {          // the first stage: staged without a multiplication to hide in
+      stage_row_a(t, ic);
+      stage_row_b(t + G, 0, ic);
+    });
+    load_bc(t + G);
     gh_barrier_lds();
     for (int it = 0; it < niter; ++it) {
       const int buf = it & 1;
-      compute_dx(t, t + G, buf);
-      stage_dpre(t + G, t + 2 * G, buf ^ 1);
+      compute_dx(t, t + G, t + 2 * G, buf);
       gh_barrier_lds();
       GBP(5)
       t += G;
@@ -534,7 +542,7 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
 
 bool gemmb_ok(const float* g, const float* act_out, const float* x, long m, int din, int dout, long ld, long x_ld, long dx_ld,
               const float* dx) {
-  return din > 128 && din <= 256 && dout > 128 && dout <= 256 && din % 4 == 0 && dout % 4 == 0 && ld % 4 == 0 && x_ld >= din &&
+  return din > 128 && din <= 256 && dout == 256 && din % 4 == 0 && ld % 4 == 0 && x_ld >= din &&
          dx_ld >= din && (!g || aligned16(g)) && (!act_out || aligned16(act_out)) && m >= (long)kNumCU * 64 &&
          ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx)) & 3u) == 0;
 }

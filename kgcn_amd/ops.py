@@ -480,7 +480,7 @@ weight_tables = WeightTables()
 dense_bwd_fusion = True
 
 
-def _dense_bwd_fused_ok(x2d, w, gy, yact, gp=None, gp_ld=0, n_nodes=0):
+def _dense_bwd_fused_ok(x2d, w, gy, yact, gp=None, gp_ld=0, n_nodes=0, act_is_smooth=False):
     m, din = x2d.shape
     dout = w.shape[1]
     if not (dense_bwd_fusion and lib.kgcn_dense_bwd_supported(m, din, dout)):
@@ -488,7 +488,12 @@ def _dense_bwd_fused_ok(x2d, w, gy, yact, gp=None, gp_ld=0, n_nodes=0):
     ts = [t for t in (x2d, gy, yact) if t is not None]
     if not all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in ts):
         return False
-    return gp is None or (gp.data_ptr() % 16 == 0 and gp_ld % 4 == 0 and n_nodes >= 8)
+    if gp is None:
+        return True
+    # (a sigmoid / tanh layer that is read out AND handed on: that kernel form spills registers inside its loop -- two-call route)
+    if gy is not None and yact is not None and act_is_smooth:
+        return False
+    return gp.data_ptr() % 16 == 0 and gp_ld % 4 == 0 and n_nodes >= 8
 
 
 def _dense_bwd_fused(ctx, x2d, w, gy, yact, act, need_b, gp=None, gp_ld=0, n_nodes=0):
@@ -728,7 +733,7 @@ class _DenseGather(torch.autograd.Function):
         need_b = ctx.bias_shape is not None and ctx.needs_input_grad[2]
         if need_x and ctx.needs_input_grad[1] and (gp is None or (ctx.act and gp.dtype == torch.float32 and gp.dim() == 2 and
                                                                   gp.stride(1) == 1)) and \
-                _dense_bwd_fused_ok(x2d, w, gy, y if ctx.act else None, gp, gp_ld if gp is not None else 0, N):
+                _dense_bwd_fused_ok(x2d, w, gy, y if ctx.act else None, gp, gp_ld if gp is not None else 0, N, ctx.act in (1, 3)):
             # the whole backward in one pass: the read-out's gradient joins (or stands for) the row gradient while the rows are staged
             dx, dw, db = _dense_bwd_fused(ctx, x2d, w, gy, y, ctx.act, need_b, gp, gp_ld if gp is not None else 0, N)
             return dx, dw, db, None, None, None, None, None

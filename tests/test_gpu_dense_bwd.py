@@ -114,10 +114,10 @@ def _layer(rng, m, din, dout, act):
 
 @pytest.mark.parametrize("act", [None, "sigmoid", "relu", "tanh"])
 @pytest.mark.parametrize("m,din,dout,ld_pad", [(16500, 256, 256, 0), (16384 + 31, 256, 256, 4), (16500, 192, 256, 0),
-                                               (16500, 256, 132, 0), (40000, 256, 256, 0)])
+                                               (40000, 256, 256, 0)])
 def test_one_pass_backward_against_fp64(act, m, din, dout, ld_pad):
     """every activation code; ragged last stage (m % 32 != 0), fewer stages than two per workgroup pair, padded leading
-    dimensions (nothing outside the [m, din] block of dx may be touched), widths below 256 (clamped column tiles)."""
+    dimensions (nothing outside the [m, din] block of dx may be touched), an input width below 256 (clamped column tiles)."""
     rng = np.random.default_rng(m + din + dout + len(str(act)))
     x, g, a, w = _layer(rng, m, din, dout, act)
     got = _call(x, g, a, w, act, ld_pad=ld_pad)
@@ -205,7 +205,7 @@ def test_one_pass_backward_argument_checks():
     from kgcn_amd import _lib
     lib = _lib.lib
     assert lib.kgcn_dense_bwd_supported(16384, 256, 256) == 1 and lib.kgcn_dense_bwd_supported(16383, 256, 256) == 0
-    assert lib.kgcn_dense_bwd_supported(20000, 128, 256) == 0 and lib.kgcn_dense_bwd_supported(20000, 256, 258) == 0
+    assert lib.kgcn_dense_bwd_supported(20000, 128, 256) == 0 and lib.kgcn_dense_bwd_supported(20000, 256, 252) == 0
     z = ctypes.c_void_p(0)
     p = ctypes.c_void_p(4096)
     # unsupported shape, NULL operands, pooled gradient without an activation, dx aliasing an input: status + message, no launch

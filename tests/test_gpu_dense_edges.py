@@ -394,8 +394,8 @@ def test_read_outs_joined_in_one_buffer_equal_concatenation(act, T, N, d):
 def test_gin_dense_d_epsilon_inside_the_dx_gemm(act, T, N, d, dout):
     """ops.gin_dense = GINAggregate + activated GraphDense (model_gin.py:45-50).  With inputs that need no gradient d epsilon =
     <d out, x> (kgcn/layers.py:469) is accumulated by the dX GEMM (kgcn_dense_dx_dact_dot_f32: the product is never stored); the last
-    case is below the fused form's size and takes the two ops.  Checked against the two separate ops (same d pre-activation kernel:
-    dW / dbias bit-equal) and against fp64 for y and d epsilon."""
+    case is below the fused form's size and takes the two ops.  Checked against the two separate ops (y bit-equal, dW / dbias to
+    fp32 rounding) and against fp64 for y and d epsilon."""
     from kgcn_amd import ops
     from kgcn_amd.batched_csr import BatchedAdjacency
     from oracle import kgcn_oracle as K
@@ -415,7 +415,11 @@ def test_gin_dense_d_epsilon_inside_the_dx_gemm(act, T, N, d, dout):
         assert (y.grad_fn.name().startswith("_GinDense")) == (fused and T * N >= 16384)
         (y * t32(gy)).sum().backward()
         res.append((y.detach(), eps.grad.clone(), tw.grad.clone(), tb.grad.clone()))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])
+    assert torch.equal(res[0][0], res[1][0])
+    # (round 5: with inputs that need a gradient the wide cases take the ONE-PASS backward -- another weight-gradient kernel than the
+    # d-pre-activation route behind gin_dense: agreement to fp32 rounding instead of bit equality)
+    close(res[0][2], res[1][2].cpu().numpy(), atol=0, rel=4e-6, what="gin_dense dW: dot route vs separate ops")
+    close(res[0][3], res[1][3].cpu().numpy(), atol=0, rel=4e-6, what="gin_dense dbias: dot route vs separate ops")
     # fp64: y and d epsilon
     A = np.zeros((T, N, N))
     for t, chans in enumerate(adjs):

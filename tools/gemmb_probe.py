@@ -50,8 +50,7 @@ stages = -(-(-(-M // 32)) // 128)
 print("launch %.1f us (probed, incl. second stage), %.1f stages per workgroup; cycles per stage, mean over the role's waves (min .. max wave):"
       % (e0.elapsed_time(e1) * 1e3, stages))
 roles = (("dX role (waves 0-3: staging, dX)", pr[:, :4, :],
-          ["-", "16 k-steps: 48 MFMAs (waits: LDS fragments)", "dX epilogue + stores", "staging rows 0-3 (waits: dY, a) + next requests",
-           "staging rows 4-7 + next requests", "barrier"]),
+          ["-", "16 k-steps: 48 MFMAs + the next stage's staging", "dX epilogue + stores", "-", "-", "barrier"]),
          ("dW role (waves 4-7)", pr[:, 4:, :],
           ["x'' split (waits: x fragments, row exponents)", "16 tiles: 48 MFMAs (waits: LDS fragments)", "-", "-", "-", "barrier (incl. loop)"]))
 for title, v, names in roles:
