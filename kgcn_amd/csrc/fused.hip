@@ -1592,7 +1592,11 @@ extern "C" int64_t kgcn_graphconv_bwd_workspace_bytes(int32_t num_graphs, int32_
                                                       int32_t dout) {
   if (num_graphs <= 0 || din <= 0 || dout <= 0) return 0;
   // one partial per persistent workgroup (at most one workgroup per CU)
+#ifdef KGCN_DEV_KNOBS
+  return (int64_t)16 * kNumCU * ((int64_t)din * dout + dout) * 4;         // (room for the KGCN_BWD_GRID_MULT experiment)
+#else
   return (int64_t)kNumCU * ((int64_t)din * dout + dout) * 4;
+#endif
 }
 
 extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, const float* w,
@@ -1622,7 +1626,12 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
   const int pack = (full || is_full(at->rows, din, dout)) ? 1 : pack_factor(at->rows, at->max_nnz_per_graph, FD * FD * 4);
   const size_t per = full ? full_lds / BWD_FULL_WPB : bwd_slice(at->max_nnz_per_graph * pack);
   const int wpb = full ? BWD_FULL_WPB : fused_wpb(per, FD * FD * 4);
-  const int blocks = fused_grid((at->num_graphs + pack - 1) / pack, wpb);
+  int blocks = fused_grid((at->num_graphs + pack - 1) / pack, wpb);
+  // development (the non-persistent form, measured): KGCN_BWD_GRID_MULT = k launches k workgroups per CU slot,
+  // each walking 1 / k of the graphs with its own pipeline fill, W' split and dW partial (k x 256 partials in the second stage) --
+  // the form the kernel's LDS footprint (one 4-wave workgroup per CU) allows.  profiles/r05_headline_experiments.txt
+  static const char* gm = dev_knob("KGCN_BWD_GRID_MULT");
+  if (gm && atoi(gm) > 1 && atoi(gm) <= 16 && (long)blocks * atoi(gm) * wpb * 2 <= at->num_graphs) blocks *= atoi(gm);
   const int64_t need = (int64_t)blocks * ((int64_t)din * dout + dout) * 4;
   if (!workspace || workspace_bytes < need)
     return fail("kgcn_graphconv_bwd_f32: workspace %lld < %lld bytes", (long long)workspace_bytes,

@@ -228,6 +228,92 @@ __global__ __launch_bounds__(64 * NW) void spmm_tile_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// The 32-column slices of ONE graph as the waves of ONE workgroup (round 5).  Since round 3 a graph of
+// 17..32 nodes is aggregated in 32-column slices (the kernel lives off occupancy); as separate one-wave workgroups every
+// slice read the graph's CSR for itself: PMC traffic 1.920 GB for 1.7316 GB of algorithmic bytes (x1.11) on BASELINE config 2,
+// and scalar bookkeeping as heavy as the arithmetic (SQ_INSTS_SALU 7.1e7 against SQ_INSTS_VALU 7.8e7 per launch: the generic
+// kernel walks (row, vector) pairs with run-time strides).  Here wave w stages and aggregates slice w, the CSR slice is staged
+// ONCE by all waves, sizes are compile-time (ds = 32: a row of a slice = 8 lanes x 16 bytes, 8 rows per pass), and the
+// occupancy is unchanged (NS waves and NS tiles + one CSR copy per workgroup).  One channel; the activation epilogue, the
+// act' prologue and the GIN self term as in spmm_tile_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(64 * NS) void spmm_slices_kernel(const int* __restrict__ rowptr, const int2* __restrict__ cv, int max_nnz,
+                                                              const float* __restrict__ rhs, long rhs_ld, long rhs_gs,
+                                                              float* __restrict__ out, long out_ld, long out_gs, int M, int K,
+                                                              float beta, const float* __restrict__ self_scale, int act,
+                                                              const float* __restrict__ aout, int dact) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int DS = 32;                               // columns per slice
+  const int t = blockIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int tile_floats = K * DS;
+  float* tile = reinterpret_cast<float*>(smem) + wv * tile_floats;
+  int2* ecv = reinterpret_cast<int2*>(smem + (size_t)NS * tile_floats * 4);
+  int* rp = reinterpret_cast<int*>(ecv + max_nnz);
+  const int* grp = rowptr + (long)t * M;
+  const int base = grp[0];
+  const int cnt = grp[M] - base;
+  const int col0 = wv * DS;
+  // ---- this wave's slice of the rhs block: row i >> 3, 16-byte chunk i & 7 (128-byte row segments) ----------------------------
+  const float* rb = rhs + (long)t * rhs_gs + col0 + (lane >> 3) * rhs_ld + (lane & 7) * 4;
+  const int nv = K * 8;
+  if (dact == KGCN_ACT_NONE) {
+    for (int i = lane; i < nv; i += 256) {                  // four loads in flight per lane (K = 32: the whole tile)
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i + 64 * u < nv) v[u] = ld4(rb + (long)(8 * u + (i >> 3) - (lane >> 3)) * rhs_ld);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i + 64 * u < nv) st4(tile + (size_t)(i + 64 * u) * 4, v[u]);
+    }
+  } else {
+    const float* ab = aout + (long)t * rhs_gs + col0 + (lane >> 3) * rhs_ld + (lane & 7) * 4;     // same layout as the gradient
+    for (int i = lane; i < nv; i += 256) {
+      f32x4 v[4], a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i + 64 * u < nv) {
+          v[u] = ld4(rb + (long)(8 * u + (i >> 3) - (lane >> 3)) * rhs_ld);
+          a[u] = ld4(ab + (long)(8 * u + (i >> 3) - (lane >> 3)) * rhs_ld);
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i + 64 * u < nv) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[u][j] *= act_dout(a[u][j], dact);
+          st4(tile + (size_t)(i + 64 * u) * 4, v[u]);
+        }
+    }
+  }
+  // ---- the graph's CSR slice, once for all slices ---------------------------------------------------------------------------
+  for (int i = threadIdx.x; i < cnt; i += 64 * NS) ecv[i] = cv[base + i];
+  for (int i = threadIdx.x; i <= M; i += 64 * NS) rp[i] = grp[i] - base;
+  __syncthreads();
+  // ---- aggregate: 8 rows per pass, 8 lanes x float4 per row ----------------------------------------------------------------------
+  const int sub = lane >> 3, cl4 = (lane & 7) * 4;
+  const float sscale = self_scale ? self_scale[0] : 0.f;
+  float* ob = out + (long)t * out_gs + col0 + cl4;
+  for (int r = sub; r < M; r += 8) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int s0 = rp[r], e0 = rp[r + 1];
+    for (int k = s0; k < e0; ++k) {
+      const int2 p = ecv[k];
+      acc += __int_as_float(p.y) * ld4(tile + (size_t)p.x * DS + cl4);
+    }
+    if (self_scale) acc += sscale * ld4(tile + (size_t)r * DS + cl4);
+    float* o = ob + (long)r * out_ld;
+    if (beta != 0.f) acc += ld4(o);
+    if (act != KGCN_ACT_NONE) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = act_fwd(acc[j], act);
+    }
+    st4(o, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // row-chunk kernel: big matrices whose rhs block does not fit LDS -- the block-diagonal [sum N x sum N] batch of the
 // kgcn-sparse path (kgcn/data_util.py:698-845) and the ragged-compact batches (ragged.hip), VEC in {4, 2}.
 // The generic gather kernel below walks one row per lane group with THREE dependent loads per entry (rowptr -> cv ->
@@ -851,6 +937,20 @@ int launch_spmm_multi(const kgcn_csr_batch* a, int nch, const float* rhs, long r
                                   dotx != nullptr);      // the fused <rhs, dotx> needs a graph's whole rows in one workgroup
   if (plan.ok && (long)T * plan.slices <= 0x7fffffffL) {
     const int ds = d / plan.slices;
+#ifndef KGCN_SPMM_NO_SLICE_WAVES
+    if (nch == 1 && plan.vec == 4 && ds == 32 && plan.nw == 1 && (plan.slices == 2 || plan.slices == 4) && !dotx) {
+      // the slices of a graph as the waves of one workgroup: its CSR staged once (spmm_slices_kernel)
+      const size_t lds2 = (size_t)plan.slices * K * 32 * 4 + (size_t)a->max_nnz_per_graph * 8 + (size_t)(M + 1) * 4;
+      const int2* cvp = reinterpret_cast<const int2*>(a->cv);
+      if (plan.slices == 2)
+        hipLaunchKernelGGL(spmm_slices_kernel<2>, dim3((unsigned)T), dim3(128), lds2, stream, a->rowptr, cvp, a->max_nnz_per_graph, rhs,
+                           rhs_ld, rhs_gs, out, out_ld, out_gs, M, K, beta, self_scale, act, aout, dact);
+      else
+        hipLaunchKernelGGL(spmm_slices_kernel<4>, dim3((unsigned)T), dim3(256), lds2, stream, a->rowptr, cvp, a->max_nnz_per_graph, rhs,
+                           rhs_ld, rhs_gs, out, out_ld, out_gs, M, K, beta, self_scale, act, aout, dact);
+      return check_launch("spmm_slices_kernel");
+    }
+#endif
     size_t lds = 0;
     for (int c = 0; c < nch; ++c) lds += tile_chan_bytes(M, K, ds, a[c].max_nnz_per_graph);
     const int lanes = ds / plan.vec;
