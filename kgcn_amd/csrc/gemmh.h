@@ -63,6 +63,19 @@ __device__ __forceinline__ void wave_umax4(unsigned& a, unsigned& b, unsigned& c
 }
 
 
+// the same for ONE value per lane (a row's maximum where rows are staged one at a time between MFMAs: gemmb.hip, gemmh_fwd_kernel)
+__device__ __forceinline__ unsigned wave_umax1(unsigned v) {
+  asm volatile("s_nop 1\n"
+               "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n"
+               "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n"
+               "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n"
+               "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n"
+               "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n"
+               "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1\n"
+               : "+v"(v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // dot_part != nullptr (backward forms): the product is NOT stored; its inner product with `y` (read as an [m, dout] operand of the
 // same row stride) is accumulated instead, one partial per workgroup -- d epsilon of a GINAggregate whose input needs no gradient
 // (kgcn/layers.py:469: <d out, x>; the d out tensor then never exists in HBM).

@@ -55,6 +55,9 @@ __device__ long long* gh_probe = nullptr;
 #define GHP(k)
 #define GHP_FLUSH
 #endif
+#ifndef GH_INTERLEAVE
+#define GH_INTERLEAVE 1          // 0: the next tile staged AFTER the multiplication (rounds 4 form; build/variants A/B)
+#endif
 #ifndef GH_VARIANT
 #define GH_VARIANT 0             // development (tools/gemmh_variants.sh): 2 no y stores, 3 no x loads (forward); 5 no MFMAs, 6 no
 #endif                           // split, 7 no loads (gemmh_wgradl) -- what each part of the kernels costs
@@ -195,8 +198,28 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
       rowk[rr] = k;                                      // same value from every lane
     }
   };
+  // ONE row of the next tile (plain form): what `stage` does for the wave's eight rows at once, as a piece the multiplication
+  // lays between its MFMAs (round 5: staged after the multiplication the 8 rows were a vector-ALU phase with the matrix pipe idle,
+  // and the multiplication a matrix phase with the vector ALU idle -- 0.47 of the HBM floor at 65 / 107 us; gemmb.hip's history)
+  auto stage_row = [&](int buf, auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    if (!cok) raw[i] = f32x4{0.f, 0.f, 0.f, 0.f};              // (rows >= m were loaded as 0)
+    float a;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(a) : "v"(raw[i][0]), "v"(raw[i][1]), "v"(raw[i][2]));
+    asm("v_max_f32 %0, %1, |%2|" : "=v"(a) : "v"(a), "v"(raw[i][3]));
+    const int k = scale_exp(__uint_as_float(wave_umax1(__float_as_uint(a))));           // wave-uniform
+    const int rr = 8 * wave + i;
+    unsigned h0, l0, h1, l1;
+    splith_pair(__builtin_ldexpf(raw[i][0], k), __builtin_ldexpf(raw[i][1], k), h0, l0);
+    splith_pair(__builtin_ldexpf(raw[i][2], k), __builtin_ldexpf(raw[i][3], k), h1, l1);
+    unsigned char* e = dsm + (size_t)buf * GH_PIECES * 16 +
+                       ((size_t)(((rr >> 5) * 16 + wks) * 2) * 64 + gh_slot(rr & 31, wks, whi)) * 16 + 8 * wsub;
+    *reinterpret_cast<u32x2*>(e) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(e + 1024) = u32x2{l0, l1};
+    (rowk_base + 64 * buf)[rr] = k;                            // same value from every lane
+  };
   float dotacc = 0.f;
-  auto compute = [&](long tt, int buf) __attribute__((always_inline)) {
+  auto compute = [&](long tt, int buf, long tt_load = 0) __attribute__((always_inline)) {
     const u32x4* lds = reinterpret_cast<const u32x4*>(dsm) + (size_t)buf * GH_PIECES;
     const int* rowk = rowk_base + 64 * buf;
     f32x16 acc[2];
@@ -235,6 +258,24 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
       acc[1] = mfma_f16(A1[2], Bl[ks + 1], acc[1]);
       acc[0] = mfma_f16(A1[0], Bh[ks + 1], acc[0]);
       acc[1] = mfma_f16(A1[2], Bh[ks + 1], acc[1]);
+      if constexpr (DK == 0 && GH_INTERLEAVE != 0 && NKS == 16) {
+        // between these six MFMAs: row ks / 2 of the NEXT tile (already in the registers) -> the other buffer
+        stage_row(buf ^ 1, std::integral_constant<int, ks / 2>{});
+        // ... and its registers take the same row of the tile after that: a whole multiplication ahead of its use
+        raw[ks / 2] = gh_ld4(gh_rows(x, tt_load * GH_BM + 8 * wave, 8, m, x_ld), voff_x, (ks / 2) * ldx4);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+      }
     });
     __builtin_amdgcn_sched_barrier(0);
     // ---- y <- act(2^-(kr + kc) acc + bias) ---------------------------------------------------------------------------
@@ -288,20 +329,21 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
 
   load_tile(t);
   stage(t, 0);
+  if constexpr (DK == 0 && GH_INTERLEAVE != 0 && NKS == 16) load_tile(t + G);      // the rows the first multiplication stages
   gh_barrier_lds();
   // No exit between a request and its use (hipcc proves a requested tile dead on an exit path and sinks its loads behind
   // everything in between -- seen in the ISA of an earlier form): the tile after the last one clamps to the last row (cached)
   // and is staged into the buffer nobody reads.
   for (long i = 0; i < ntw; ++i) {
     const int buf = (int)(i & 1);
-    if constexpr (DK == 0) {
+    if constexpr (DK == 0 && !(GH_INTERLEAVE != 0 && NKS == 16)) {
       __builtin_amdgcn_sched_barrier(0);
       load_tile(t + G);                                  // on its way from HBM while this tile is multiplied
       __builtin_amdgcn_sched_barrier(0);
     }
-    compute(t, buf);
+    compute(t, buf, t + 2 * G);
     if constexpr (DK != 0) load_tile(t + G);             // backward form: gradient and saved output travel together below
-    stage(t + G, buf ^ 1);
+    if constexpr (!(DK == 0 && GH_INTERLEAVE != 0 && NKS == 16)) stage(t + G, buf ^ 1);
     gh_barrier_lds();
     t += G;
   }
