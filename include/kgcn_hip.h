@@ -390,6 +390,15 @@ int kgcn_dense_bwd_f32(const float* grad, const float* pooled_grad, int64_t pool
                        int32_t act, int64_t ld, const float* x, int64_t x_ld, int64_t m, int32_t din, int32_t dout,
                        const float* w, int64_t w_ld, float* dx, int64_t dx_ld, float* dw, float* dbias, void* table,
                        int64_t table_bytes, int32_t table_ready, void* workspace, int64_t workspace_bytes, void* stream);
+/* ... and its form for a layer whose d-input product is only needed for an inner product (kgcn_dense_dx_dact_dot_f32's case: the
+ * activated wide GraphDense behind a GINAggregate whose input needs no gradient, example_model/model_gin.py:45-50):
+ *   dot_out[0] = < dpre @ w^T , dotx >     dw = x^T @ dpre     dbias = colsum(dpre)        dpre = grad (.) act'(act_out)
+ * from one sweep over (grad, act_out, x, dotx); nothing of size [m, .] is written.  Shapes, table and workspace as for
+ * kgcn_dense_bwd_f32. */
+int kgcn_dense_bwd_dot_f32(const float* grad, const float* act_out, int32_t act, int64_t ld, const float* x, int64_t x_ld, int64_t m,
+                           int32_t din, int32_t dout, const float* w, int64_t w_ld, const float* dotx, int64_t dotx_ld, float* dw,
+                           float* dbias, float* dot_out, void* table, int64_t table_bytes, int32_t table_ready, void* workspace,
+                           int64_t workspace_bytes, void* stream);
 /* The same dX contraction where the product is only needed for an inner product (d epsilon of a GINAggregate, kgcn/layers.py:469
  * <d out, x>, in front of an activated wide layer whose input needs no gradient -- the first block of example_model/model_gin.py):
  *   dot_out[0] = < (grad (.) act'(act_out)) @ w^T , dotx >       dotx [m, din] (row stride dotx_ld, 16-byte aligned rows)

@@ -114,6 +114,8 @@ SIGNATURES = {
                                           c_f32p, c_f32p, c_i32, c_i64, ctypes.c_void_p]),
     "kgcn_dense_wgrad_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32]),
     "kgcn_dense_bwd_supported": (ctypes.c_int, [c_i64, c_i32, c_i32]),
+    "kgcn_dense_bwd_dot_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i32, c_i64, c_f32p, c_i64, c_i64, c_i32, c_i32, c_f32p, c_i64, c_f32p, c_i64,
+                                              c_f32p, c_f32p, c_f32p, ctypes.c_void_p, c_i64, c_i32, ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_dense_bwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i64, c_i32, c_f32p, c_i32, c_i64, c_f32p, c_i64, c_i64, c_i32, c_i32,
                                           c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, ctypes.c_void_p, c_i64, c_i32,
                                           ctypes.c_void_p, c_i64, ctypes.c_void_p]),

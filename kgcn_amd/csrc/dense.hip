@@ -823,7 +823,7 @@ extern "C" int kgcn_dense_dx_dact_dot_f32(const float* grad, const float* act_ou
 namespace kgcn {
 int launch_gemmb(const float* grad, const float* act_out, long m, int din, int dout, long ld, const float* x, long x_ld,
                  const void* tabh, float* dx, long dx_ld, float* part_dw, float* part_db, int dact, const float* pooled_grad,
-                 int n_nodes, long pooled_ld, hipStream_t s);
+                 int n_nodes, long pooled_ld, hipStream_t s, float* dot_part);
 int launch_reduce_pair(const float* part_dw, long n_dw, float* dw, const float* part_db, long n_db, float* dbias, int nparts,
                        hipStream_t s);
 }  // namespace kgcn
@@ -859,9 +859,41 @@ extern "C" int kgcn_dense_bwd_f32(const float* grad, const float* pooled_grad, i
   float* part_db = part_dw + (long)pairs * din * dout;
   const int rc = launch_gemmb(grad, act_out, (long)m, din, dout, (long)ld, x, (long)x_ld,
                               static_cast<const char*>(table) + wtable_bf16_bytes(dout, din), dx, (long)dx_ld, part_dw,
-                              dbias ? part_db : nullptr, act, pooled_grad, n_nodes, (long)pooled_ld, s);
+                              dbias ? part_db : nullptr, act, pooled_grad, n_nodes, (long)pooled_ld, s, nullptr);
   if (rc == -1) return fail("kgcn_dense_bwd_f32: operands must be 16-byte aligned with ld %% 4 == 0");
   if (rc < 0) return 1;
+  return launch_reduce_pair(part_dw, (long)din * dout, dw, part_db, dout, dbias, rc, s);
+}
+
+// the one-pass backward where the d-input product is only needed for an inner product (kgcn_dense_dx_dact_dot_f32's case): dW, dbias
+// and dot_out[0] = <dpre @ w^T, dotx> from ONE sweep; neither d pre-activation nor the [m, din] product is ever written
+extern "C" int kgcn_dense_bwd_dot_f32(const float* grad, const float* act_out, int32_t act, int64_t ld, const float* x, int64_t x_ld,
+                                      int64_t m, int32_t din, int32_t dout, const float* w, int64_t w_ld, const float* dotx,
+                                      int64_t dotx_ld, float* dw, float* dbias, float* dot_out, void* table, int64_t table_bytes,
+                                      int32_t table_ready, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (act <= KGCN_ACT_NONE || act > KGCN_ACT_TANH) return fail("kgcn_dense_bwd_dot_f32: activation code %d", act);
+  if (!kgcn_dense_bwd_supported(m, din, dout))
+    return fail("kgcn_dense_bwd_dot_f32: shape m=%lld %d -> %d has no one-pass form (kgcn_dense_dx_dact_dot_f32 + kgcn_dense_wgrad_f32)",
+                (long long)m, din, dout);
+  if (!grad || !act_out || !x || !w || !dotx || !dw || !dot_out) return fail("kgcn_dense_bwd_dot_f32: NULL operand");
+  if (ld < dout || x_ld < din || dotx_ld < din || w_ld < dout) return fail("kgcn_dense_bwd_dot_f32: leading dimension too small");
+  if (!table || table_bytes < wtable_bytes(dout, din)) return fail("kgcn_dense_bwd_dot_f32: table / workspace too small");
+  const int pairs = kNumCU / 2;
+  const int64_t need = kgcn_dense_wgrad_workspace_bytes(m, din, dout);
+  if (!workspace || workspace_bytes < need || need < (int64_t)(pairs * ((int64_t)din * dout + dout) + kNumCU) * 4)
+    return fail("kgcn_dense_bwd_dot_f32: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+  hipStream_t s = as_stream(stream);
+  if (!table_ready) launch_wtable_split(w, (long)w_ld, 1, dout, din, table, s);
+  float* part_dw = static_cast<float*>(workspace);
+  float* part_db = part_dw + (long)pairs * din * dout;
+  float* part_dot = part_db + (long)pairs * dout;                // one partial per workgroup: kNumCU floats
+  const int rc = launch_gemmb(grad, act_out, (long)m, din, dout, (long)ld, x, (long)x_ld,
+                              static_cast<const char*>(table) + wtable_bf16_bytes(dout, din), const_cast<float*>(dotx), (long)dotx_ld,
+                              part_dw, dbias ? part_db : nullptr, act, nullptr, 0, 0, s, part_dot);
+  if (rc == -1) return fail("kgcn_dense_bwd_dot_f32: operands must be 16-byte aligned with ld %% 4 == 0");
+  if (rc < 0) return 1;
+  hipLaunchKernelGGL(dx_dot_final_kernel, dim3(1), dim3(256), 0, s, part_dot, kNumCU, dot_out);
+  if (int rc2 = check_launch("dx_dot_final_kernel")) return rc2;
   return launch_reduce_pair(part_dw, (long)din * dout, dw, part_db, dout, dbias, rc, s);
 }
 

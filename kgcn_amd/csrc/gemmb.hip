@@ -83,6 +83,8 @@ __device__ __forceinline__ u32x2 gb_ld_tr16(unsigned a) {
 // to (BC = 1) or standing for (BC = 2) the row gradient -- kgcn_dense_dx_dact_gather_f32's operand; BC = 0: none.  A template
 // parameter, not a uniform branch: the first build tested da.bc per row at run time -- two dozen extra basic blocks in the loop
 // body, registers live across all of them, 172 spilled VGPRs.
+// DOT: the dX product is not stored; its inner product with `dx` (READ as an [m, ndim] operand) goes to da.dot_part, one partial per
+// workgroup -- d epsilon of a GINAggregate whose input needs no gradient (kgcn/layers.py:469), as in gemmh_fwd_kernel's dot form.
 //
 // EIGHT waves, two per SIMD, in two ROLES (wave w and w + 4 share a SIMD):
 //   waves 0..3 ("dX")  STAGE the rows (eight per wave and stage: dY / a rows -> dpre -> row exponent -> pieces -> LDS, requested a
@@ -97,7 +99,7 @@ __device__ __forceinline__ u32x2 gb_ld_tr16(unsigned a) {
 // its 128 accumulator-file registers; the dW role's accumulators fill its accumulator file, so its x fragments, their pieces and
 // the transposed fragments are all it has room for -- with four staged rows per wave on top the allocator spilled ACCUMULATORS to
 // scratch memory (181-413 spilled registers); the dX role leaves 32 accumulator-file registers free for the rows in flight.
-template <int DK, int BC>
+template <int DK, int BC, bool DOT>
 __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__ g, long m, int kdim, long ld,
                                                        const float* __restrict__ x, int ndim, long x_ld,
                                                        const u32x4* __restrict__ tab, float* __restrict__ dx, long dx_ld,
@@ -270,6 +272,7 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
     const int ldy4 = (int)(dx_ld * 4);
     const unsigned voff_y = 4u * (unsigned)(4 * hi * dx_ld + (col < ndim ? col : 0));
     const int kcol = kctab[32 * ntc + li];
+    float dotacc = 0.f;
     // A-operand rows of dX (row li): k-step even / odd
     const unsigned abaseE = lds0 + (unsigned)((li >> 2) * 2560 + (li & 3) * 64 + ((hi ^ ((li >> 2) & 3)) << 4));
     const unsigned abaseO = lds0 + (unsigned)((li >> 2) * 2560 + (li & 3) * 64 + (((2 + hi) ^ ((li >> 2) & 3)) << 4));
@@ -278,6 +281,7 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
       const int* rowk = rowk_base + GB_R * buf;
       const unsigned boff = (unsigned)(buf * GB_BUF);
       const unsigned abE = abaseE + boff, abO = abaseO + boff;
+      float zz[DOT ? 16 : 1];                                 // dot form: this stage's elements of the dot operand
       // ONE accumulator chain: the wave's dependent MFMAs leave gaps on the matrix pipe that the SIMD's other wave (the dW
       // role, eight independent tiles) fills -- a second chain would cost 16 of the 128 accumulator-file registers W' needs
       f32x16 ax;
@@ -302,6 +306,14 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
         if constexpr (ks < GB_WREG) { wh = Wh[ks]; wl = Wl[ks]; } else { wh = F[ks].wh; wl = F[ks].wl; }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (ks + 1 < 16) read_p(F[ks + 1], std::integral_constant<int, (ks + 1 < 16 ? ks + 1 : 0)>{});
+        if constexpr (DOT && ks == 5) {
+          // requested here, ten k-steps ahead of the epilogue: at the head of the stage the sixteen values were sixteen more
+          // registers alive through the whole multiplication (18 spilled, reloaded from scratch memory inside the loop)
+          const __amdgpu_buffer_rsrc_t rz = gh_rows(dx, st * GB_R, GB_R, m, dx_ld);
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            zz[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rz, (int)voff_y, ((r & 3) + 8 * (r >> 2)) * ldy4, 0));
+        }
         __builtin_amdgcn_sched_barrier(0);
         ax = mfma_f16(F[ks].pl, wh, ax);
         ax = mfma_f16(F[ks].ph, wl, ax);
@@ -326,14 +338,15 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
       // (dword buffer stores, 2 rows x 128 bytes each.  The transposed form -- dX^T = W' dpre^T, a lane then owns 4 consecutive
       // columns of a row and stores 16 bytes -- was measured with global_store_dwordx4 and lost together with the global loads)
       if (col < ndim) {
-        const __amdgpu_buffer_rsrc_t ry = gh_rows(dx, st * GB_R, GB_R, m, dx_ld);        // rows >= m: dropped by the descriptor
+        const __amdgpu_buffer_rsrc_t ry = gh_rows(dx, st * GB_R, GB_R, m, dx_ld);        // rows >= m: dropped / read as 0
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
           const u32x4 kr4 = *reinterpret_cast<const u32x4*>(rowk + 8 * rq + 4 * hi);
 #pragma unroll
           for (int rj = 0; rj < 4; ++rj) {
             const float v = __builtin_ldexpf(ax[4 * rq + rj], -((int)kr4[rj] + kcol));
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, (int)voff_y, (rj + 8 * rq) * ldy4, 0);
+            if constexpr (DOT) dotacc = __builtin_fmaf(v, zz[4 * rq + rj], dotacc);
+            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, (int)voff_y, (rj + 8 * rq) * ldy4, 0);
           }
         }
       }
@@ -354,6 +367,11 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
       gh_barrier_lds();
       GBP(5)
       t += G;
+    }
+    if constexpr (DOT) {                                      // fixed order: lanes (butterfly), then the four dX waves (below)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) dotacc += __shfl_xor(dotacc, o, 64);
+      if (lane == 0) reinterpret_cast<float*>(dsm + 2 * (size_t)GB_BUF)[wave] = dotacc;       // (the row exponents are done with)
     }
   } else {
     // =============================== dW role ====================================================================
@@ -525,6 +543,14 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
     }
   }
   GBP_FLUSH
+  if constexpr (DOT) {
+    __syncthreads();
+    if (tid == 0) {
+      const float* red = reinterpret_cast<const float*>(dsm + 2 * (size_t)GB_BUF);
+      da.dot_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+    __syncthreads();
+  }
   // dbias: column sums of dpre over the pair's rows (both workgroups hold the same sums; half 0 stores them)
   if (part_db && half == 0) {                                  // uniform
     float* red = reinterpret_cast<float*>(dsm);                // (every wave is behind the loop's last barrier: the image is free)
@@ -552,10 +578,11 @@ bool gemmb_ok(const float* g, const float* act_out, const float* x, long m, int 
 // tabh: the f16 table of W^T (contraction over dout).  Returns the number of partials (> 0) or -1 when the operands do not fit.
 int launch_gemmb(const float* grad, const float* act_out, long m, int din, int dout, long ld, const float* x, long x_ld,
                  const void* tabh, float* dx, long dx_ld, float* part_dw, float* part_db, int dact, const float* pooled_grad,
-                 int n_nodes, long pooled_ld, hipStream_t s) {
+                 int n_nodes, long pooled_ld, hipStream_t s, float* dot_part) {
+  // dot_part != nullptr: `dx` is READ ([m, din], row stride dx_ld) and <dpre W^T, dx> goes to dot_part[workgroups] (256 floats)
   const float* base = grad ? grad : act_out;
   if (!base || !gemmb_ok(grad, act_out, x, m, din, dout, ld, x_ld, dx_ld, dx) || !tabh || (!grad && !pooled_grad) ||
-      (dact != KGCN_ACT_NONE && !act_out) || (dact == KGCN_ACT_NONE && pooled_grad) ||
+      (dact != KGCN_ACT_NONE && !act_out) || (dact == KGCN_ACT_NONE && pooled_grad) || (dot_part && (pooled_grad || dact == KGCN_ACT_NONE)) ||
       (pooled_grad && !(aligned16(pooled_grad) && n_nodes >= 8 && pooled_ld % 4 == 0)))     // (eight rows of a wave: <= 2 graphs)
     return -1;
   GhDact da{};
@@ -567,6 +594,7 @@ int launch_gemmb(const float* grad, const float* act_out, long m, int din, int d
   da.c0 = dact == KGCN_ACT_TANH ? 1.f : 0.f;
   da.c1 = dact == KGCN_ACT_SIGMOID ? 1.f : 0.f;
   da.c2 = -1.f;
+  da.dot_part = dot_part;
   const int pairs = kNumCU / 2;
   const long stages = (m + GB_R - 1) / GB_R;
   const int niter = (int)((stages + pairs - 1) / pairs);
@@ -574,23 +602,27 @@ int launch_gemmb(const float* grad, const float* act_out, long m, int din, int d
   const u32x4* tab = static_cast<const u32x4*>(tabh);
   const int bc = pooled_grad ? (grad ? 1 : 2) : 0;
   const int dk = dact == KGCN_ACT_NONE ? 0 : (dact == KGCN_ACT_RELU ? 2 : 1);
-  auto go = [&](auto dkc, auto bcc) {
+  auto go = [&](auto dkc, auto bcc, auto dotc) {
     constexpr int DKc = decltype(dkc)::value, BCc = decltype(bcc)::value;
+    constexpr bool DOTc = decltype(dotc)::value;
     static thread_local bool attr_set = false;                 // (one flag per instantiation of this lambda)
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemmb_kernel<DKc, BCc>), hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemmb_kernel<DKc, BCc, DOTc>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kLdsBytes);
       attr_set = true;
     }
-    hipLaunchKernelGGL((gemmb_kernel<DKc, BCc>), grid, dim3(512), gb_lds(BCc), s, base, m, dout, ld, x, din, x_ld, tab, dx, dx_ld, part_dw,
-                       part_db, da, niter);
+    hipLaunchKernelGGL((gemmb_kernel<DKc, BCc, DOTc>), grid, dim3(512), gb_lds(BCc), s, base, m, dout, ld, x, din, x_ld, tab, dx, dx_ld,
+                       part_dw, part_db, da, niter);
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
-  if (dk == 0) go(I0{}, I0{});
-  else if (dk == 1) { if (bc == 0) go(I1{}, I0{}); else if (bc == 1) go(I1{}, I1{}); else go(I1{}, I2{}); }
-  else { if (bc == 0) go(I2{}, I0{}); else if (bc == 1) go(I2{}, I1{}); else go(I2{}, I2{}); }
+  using F = std::false_type;
+  using Tt = std::true_type;
+  if (dot_part) { if (dk == 1) go(I1{}, I0{}, Tt{}); else go(I2{}, I0{}, Tt{}); }
+  else if (dk == 0) go(I0{}, I0{}, F{});
+  else if (dk == 1) { if (bc == 0) go(I1{}, I0{}, F{}); else if (bc == 1) go(I1{}, I1{}, F{}); else go(I1{}, I2{}, F{}); }
+  else { if (bc == 0) go(I2{}, I0{}, F{}); else if (bc == 1) go(I2{}, I1{}, F{}); else go(I2{}, I2{}, F{}); }
   if (check_launch("gemmb_kernel")) return -2;
   return pairs;
 }

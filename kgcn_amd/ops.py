@@ -969,20 +969,34 @@ class _GinDense(torch.autograd.Function):
         m, din = agg.shape
         dout = w.shape[1]
         gy = _f32c(gy.reshape(m, dout), "grad")
-        dpre = torch.empty_like(gy)
         deps = torch.empty((1,), device=gy.device, dtype=torch.float32)
         tab, tb = weight_tables.lookup(w, 1)
         ready = 1
         if tab is None:
             tb, tab = _dense_ws(dout, din, gy.device)
             ready = 0
+        need_w = ctx.needs_input_grad[3]
+        need_b = ctx.bias_shape is not None and ctx.needs_input_grad[4]
+        if need_w and _dense_bwd_fused_ok(agg, w, gy, y):
+            # ONE pass: d eps, dW and dbias from a single sweep over (gy, y, agg, x) -- no d pre-activation tensor either
+            dw = torch.empty_like(w)
+            db = torch.empty((dout,), device=gy.device, dtype=torch.float32) if need_b else None
+            with _no_deferral_unless(getattr(ctx, "defer_ok", False) and _single_use(*ctx.defer_ids)):
+                wsb = lib.kgcn_dense_wgrad_workspace_bytes(m, din, dout)
+                wsp = torch.empty((max(wsb, 4) // 4,), device=gy.device, dtype=torch.float32)
+                check(lib.kgcn_dense_bwd_dot_f32(ptr(gy), ptr(y), ctx.act, dout, ptr(agg), din, m, din, dout, ptr(w), dout, ptr(x), din,
+                                                 ptr(dw), ptr(db), ptr(deps), ptr(tab), tb, ready, ptr(wsp), wsb, current_stream()),
+                      "kgcn_dense_bwd_dot_f32")
+                _keep_until_flush(wsp)
+            if db is not None:
+                db = db.reshape(ctx.bias_shape)
+            return None, (deps.reshape(ctx.eps_shape) if ctx.needs_input_grad[1] else None), None, dw, db, None
+        dpre = torch.empty_like(gy)
         wsb = lib.kgcn_dense_dx_dact_dot_workspace_bytes(m, din)
         wsp = torch.empty((max(wsb, 4) // 4,), device=gy.device, dtype=torch.float32)
         check(lib.kgcn_dense_dx_dact_dot_f32(ptr(gy), ptr(y), m, dout, dout, ptr(w), dout, din, ptr(x), din, ctx.act, ptr(dpre),
                                              ptr(tab), tb, ready, ptr(deps), ptr(wsp), wsb, current_stream()),
               "kgcn_dense_dx_dact_dot_f32")
-        need_w = ctx.needs_input_grad[3]
-        need_b = ctx.bias_shape is not None and ctx.needs_input_grad[4]
         dw = db = None
         if need_w or need_b:
             dw, db = _Dense._wgrad(ctx, agg, w, dpre, y, m, din, dout, need_w, need_b, False)
