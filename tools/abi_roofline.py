@@ -26,7 +26,7 @@ HBM = 8.0e12
 F32_MFMA = 157.3e12
 F16_MFMA = 2.5e15              # dense f16 / bf16 matrix rate (MI355X_MICROARCH.md)
 NOMINAL = ("kgcn_reduce_flush", "kgcn_wtable_split_multi")
-REPEATABLE = ("kgcn_dense_fwd", "kgcn_dense_dx_dact", "kgcn_dense_wgrad", "kgcn_dense_bwd_f32", "kgcn_bspmm", "kgcn_gin_aggregate", "kgcn_graphconv_")
+REPEATABLE = ("kgcn_dense_fwd", "kgcn_dense_dx_dact", "kgcn_dense_wgrad", "kgcn_dense_bwd_f32", "kgcn_dense_bwd_dot_f32", "kgcn_bspmm", "kgcn_gin_aggregate", "kgcn_graphconv_")
 
 
 def _products(name, a):
@@ -40,7 +40,7 @@ def _products(name, a):
         return q(1, a[2], a[3], a[7])
     if name == "kgcn_dense_wgrad_f32":
         return q(2, a[4], a[5], a[6])
-    if name == "kgcn_dense_bwd_f32":
+    if name in ("kgcn_dense_bwd_f32", "kgcn_dense_bwd_dot_f32"):
         return 3                                   # gemmb.hip: f16 two-piece products for both contractions
     if name == "kgcn_dense_wgrad_dact_f32":
         return q(2, a[6], a[7], a[8])
@@ -161,6 +161,10 @@ def _cost(name, a):
         extra = 4 * d * c.num_graphs * c.rows if a[7] is not None else 0          # x read once more for d eps
         return b + extra, f * a[1] + (2 * d * c.num_graphs * c.rows if a[7] is not None else 0), \
             "C=%d T=%d N=%d d=%d%s" % (a[1], c.num_graphs, c.rows, d, " +deps" if a[7] is not None else "")
+    if name == "kgcn_dense_bwd_dot_f32":
+        # ONE pass: reads grad, act_out, x and the dot operand; dW / dbias leave as 128 partials, the [m, din] product is not stored
+        m, din, dout, act = a[6], a[7], a[8], a[2]
+        return 4 * (2 * m * dout + 2 * m * din + 2 * din * dout), 4 * m * din * dout, "m=%d %d<->%d one-pass bwd act=%d dot" % (m, din, dout, act)
     if name == "kgcn_dense_wgrad_dact_f32":
         m, din, dout = a[6], a[7], a[8]
         return 4 * (m * din + 2 * m * dout + din * dout), 2 * m * din * dout, "m=%d %dx%d dact=%d" % (m, din, dout, a[5])
