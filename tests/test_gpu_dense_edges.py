@@ -466,7 +466,6 @@ def test_f16_two_piece_rows_spanning_2_to_16_stay_within_fp32_arithmetic():
         e_hip = float((np.abs(got - ref) / scale).max())
         e_np = float((np.abs(np32.astype(np.float64) - ref) / scale).max())
         import conftest
-        # (the weight gradient sums 16,500 products per output in another order than numpy's BLAS: 4 x there)
-        factor = 4 if name == "dW" else 2
+        factor = 2                                  # (measured, profiles/r05_accuracy.json: 0.67 / 0.68 / 0.58 of numpy's own error)
         conftest.record_accuracy("span 2^16 %s: err / sum|x||w| (tolerance = %d x numpy float32's)" % (name, factor), e_hip, factor * e_np, 1.0)
         assert e_hip <= factor * e_np, (name, e_hip, e_np)

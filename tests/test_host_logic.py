@@ -211,3 +211,16 @@ def test_batch_statistics_under_data_parallel_ranks_are_refused(monkeypatch):
     with pytest.raises(RuntimeError, match="data-parallel ranks"):
         bn(torch.zeros(3, 4, 5))
     assert layers.allow_local_batch_statistics is False
+
+
+def test_gemmb_lds_image_serves_row_reads_and_transpose_reads():
+    """tools/gemmb_layout_check.py: the LDS image of kgcn_amd/csrc/gemmb.hip (one-pass dense backward) emulated on the CPU -- the
+    address functions the kernel uses (lane base + immediate), the lane exchange of ds_read_b64_tr_b16 and the bank rules of
+    MI355X_MICROARCH.md: injective, both reads deliver exactly the MFMA fragments, all three access patterns conflict-free."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gemmb_layout_check", os.path.join(root, "tools", "gemmb_layout_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main()
