@@ -531,13 +531,14 @@ class Cfg2:
         if spmm is not None:
             sb = 2 * 4 * N_NODES * FEAT + ab["csr"]
             sf, sa = stats(spmm[0]), stats(spmm[1])
-            spmm_entry = {"kernel": "spmm_tile_kernel (kgcn_bspmm_f32: Bspmm / Bspmdt / Bconv)", "bound": "hbm",
+            spmm_entry = {"kernel": "spmm_slices_kernel<2> (kgcn_bspmm_f32: Bspmm / Bspmdt / Bconv; the two 32-column slices of a graph "
+                                    "as waves of one workgroup)", "bound": "hbm",
                           "algorithmic_bytes_per_graph": sb, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "forward": dict(sf, achieved=sb * T / (sf["median_ms"] * 1e-3) / 1e9,
                                           frac=sb * T / (sf["median_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS),
                           "adjoint": dict(sa, achieved=sb * T / (sa["median_ms"] * 1e-3) / 1e9,
                                           frac=sb * T / (sa["median_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS),
-                          "traffic": traffic.get("spmm_tile_kernel")}
+                          "traffic": traffic.get("spmm_slices_kernel", traffic.get("spmm_tile_kernel"))}
         config = {"workload": "cfg2: %d random 32-node graphs per GPU (tree+3 edges+self loops, nnz=100), 64-dim "
                               "features, 1 adjacency channel, GraphConv fwd+bwd (dX,dW,dbias)%s"
                               % (T, ", unfused kernels" if args.unfused else ""),
@@ -587,7 +588,7 @@ def abi_roofline_of(step_fn):
 
 # kernel behind the dominant call (for `traffic`): (entry prefix, matrix-pipe products) -> kernel name prefix in profiles/traffic_<cfg>.json
 _KERNEL_OF = {("kgcn_dense_fwd", 3): "gemmh_fwd_kernel<0", ("kgcn_dense_dx_dact", 3): "gemmh_fwd_kernel<1",
-              ("kgcn_dense_wgrad", 3): "gemmh_wgradl_kernel", ("kgcn_dense_fwd", 6): "gemm3_fwd_kernel",
+              ("kgcn_dense_wgrad", 3): "gemmh_wgradl_kernel", ("kgcn_dense_bwd", 3): "gemmb_kernel", ("kgcn_dense_fwd", 6): "gemm3_fwd_kernel",
               ("kgcn_dense_wgrad", 6): "gemm3_wgrad_kernel", ("kgcn_bspmm", 0): "spmm_", ("kgcn_bconv", 0): "spmm_",
               ("kgcn_gin_aggregate", 0): "spmm_tile_kernel"}
 

@@ -18,7 +18,7 @@ import sys
 src = sys.argv[1]
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 short = lambda n: re.sub(r"\(.*$", "", n).replace("kgcn::", "").replace("void ", "")[:44]
-HOT = ("graphconv", "spmm_tile", "reduce_partials")
+HOT = ("graphconv", "spmm_tile", "spmm_slices", "reduce_partials")
 dur, pmc, meta = {}, {}, {}
 for db in sorted(glob.glob(os.path.join(src, "*", "*.db"))):
     sub = os.path.basename(os.path.dirname(db))
@@ -83,7 +83,7 @@ if bench:
                 " (+ reduce_partials, in the event bracket)" if extra else "", 100 * (prof / (ms["median_ms"] * 1e3) - 1)))
     sp = r.get("spmm_kernel")
     if sp:
-        print("spmm_tile_kernel: forward %.1f us = %.4f of HBM peak, adjoint %.1f us = %.4f (HIP events, median)" % (
+        print("batched SpMM (spmm_slices_kernel): forward %.1f us = %.4f of HBM peak, adjoint %.1f us = %.4f (HIP events, median)" % (
             sp["forward"]["median_ms"] * 1e3, sp["forward"]["frac"], sp["adjoint"]["median_ms"] * 1e3, sp["adjoint"]["frac"]))
 # the kernel sources these byte counts were measured on: bench.py flags the figures as stale when they change
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
