@@ -340,8 +340,11 @@ typedef struct kgcn_wtable_job {
   const float* w;
   int64_t w_ld;
   int32_t trans_w, k, n;
-  int32_t reserved_;
+  int32_t k_w;               /* stacked operand (extra_row != NULL, trans_w = 0): rows 0 .. k_w - 1 come from w */
   void* table;
+  const float* extra_row;    /* NULL: plain operand.  Else the operand is [w (k_w rows); extra_row (1 row, n floats); zeros] of k rows:
+                                [W; bias; 0] of an aggregate-first GraphConv -- A (X W + 1 b) = (A [X | 1]) [W; b], kgcn/layers.py:112-113 --
+                                split without a concatenation pass (ABI version 2) */
 } kgcn_wtable_job;
 int kgcn_wtable_split_multi(const kgcn_wtable_job* jobs, int32_t num_jobs, void* stream);
 int kgcn_dense_fwd_tab_f32(const float* x, int64_t m, int32_t din, int64_t x_ld, const float* w, int64_t w_ld,

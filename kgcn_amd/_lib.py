@@ -76,8 +76,8 @@ class AdamSegment(ctypes.Structure):
 
 class WtableJob(ctypes.Structure):
     """struct kgcn_wtable_job (include/kgcn_hip.h)."""
-    _fields_ = [("w", ctypes.c_void_p), ("w_ld", c_i64), ("trans_w", c_i32), ("k", c_i32), ("n", c_i32), ("reserved_", c_i32),
-                ("table", ctypes.c_void_p)]
+    _fields_ = [("w", ctypes.c_void_p), ("w_ld", c_i64), ("trans_w", c_i32), ("k", c_i32), ("n", c_i32), ("k_w", c_i32),
+                ("table", ctypes.c_void_p), ("extra_row", ctypes.c_void_p)]
 
 
 ASSEMBLE_MAX_CSR, ASSEMBLE_MAX_TABLES = 4, 6

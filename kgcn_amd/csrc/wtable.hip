@@ -27,14 +27,17 @@ __host__ __device__ inline long wtable_entries(int din, int dout) {
 // trip).  Every one of them computes the column maxima over all k itself -- the 32 KB column block comes from L2, and the launch
 // is latency: with one workgroup per tile (four sequential k-step trips behind the maxima) it took 17 us of a training step.
 constexpr int WTH_SPLIT = 4;
+// kw / extra (stacked operand, trans_w == 0): rows k < kw come from w, row kw from extra[n], rows beyond are zero -- the
+// operand [W; bias; 0] of an aggregate-first GraphConv (kgcn_amd/layers.py) without a concatenation pass; extra == nullptr: plain
 __device__ __forceinline__ void wtableh_tile(const float* __restrict__ w, long w_ld, int trans_w, int din, int dout, int job,
-                                             unsigned char* __restrict__ sec) {
+                                             unsigned char* __restrict__ sec, int kw = 0, const float* __restrict__ extra = nullptr) {
   __shared__ float red[8][32];
   const int nt = job / WTH_SPLIT, part_ks = job % WTH_SPLIT;
   const int tid = threadIdx.x, li = tid & 31, part = tid >> 5;
   const int nt32 = gh_nt32(dout), kse = gh_kse(din);
   const int n = 32 * nt + li;
   auto at = [&](int k) __attribute__((always_inline)) {
+    if (extra) return (n < dout && k <= kw) ? (k < kw ? w[(long)k * w_ld + n] : extra[n]) : 0.f;
     return (n < dout && k < din) ? (trans_w ? w[(long)n * w_ld + k] : w[(long)k * w_ld + n]) : 0.f;
   };
   // column maxima: 8 independent loads in flight per thread
@@ -107,6 +110,8 @@ struct WtJobs {
   u32x4* table[KGCN_WTABLE_MAX_JOBS];
   long w_ld[KGCN_WTABLE_MAX_JOBS];
   int trans[KGCN_WTABLE_MAX_JOBS], din[KGCN_WTABLE_MAX_JOBS], dout[KGCN_WTABLE_MAX_JOBS];
+  const float* extra[KGCN_WTABLE_MAX_JOBS];
+  int kw[KGCN_WTABLE_MAX_JOBS];
 };
 
 __global__ __launch_bounds__(256) void wtable_split_multi_kernel(WtJobs jb, int nb3) {
@@ -118,7 +123,8 @@ __global__ __launch_bounds__(256) void wtable_split_multi_kernel(WtJobs jb, int 
   if ((int)blockIdx.x >= nb3) {                 // the f16 section: one workgroup per 32-column tile of this job
     const int nt = (int)blockIdx.x - nb3;
     if (nt < WTH_SPLIT * gh_nt32(dout))
-      wtableh_tile(w, w_ld, trans_w, din, dout, nt, reinterpret_cast<unsigned char*>(table) + wtable_entries(din, dout) * 16);
+      wtableh_tile(w, w_ld, trans_w, din, dout, nt, reinterpret_cast<unsigned char*>(table) + wtable_entries(din, dout) * 16, jb.kw[q],
+                   jb.extra[q]);
     return;
   }
   const int ntiles = ((dout + WT_BN - 1) / WT_BN) * (WT_BN / 32);
@@ -133,7 +139,8 @@ __global__ __launch_bounds__(256) void wtable_split_multi_kernel(WtJobs jb, int 
     for (int j = 0; j < 8; ++j) {
       const int k = k0 + j;
       float x = 0.f;
-      if (n < dout && k < din) x = trans_w ? w[(long)n * w_ld + k] : w[(long)k * w_ld + n];
+      if (jb.extra[q]) { if (n < dout && k <= jb.kw[q]) x = k < jb.kw[q] ? w[(long)k * w_ld + n] : jb.extra[q][n]; }
+      else if (n < dout && k < din) x = trans_w ? w[(long)n * w_ld + k] : w[(long)k * w_ld + n];
       v[j] = x;
     }
     Frag3 f;
@@ -170,6 +177,9 @@ extern "C" int kgcn_wtable_split_multi(const kgcn_wtable_job* jobs, int32_t num_
       if (j.w_ld < (j.trans_w ? j.k : j.n)) return fail("kgcn_wtable_split_multi: job %d: w_ld too small", base + q);
       jb.w[q] = j.w; jb.table[q] = static_cast<u32x4*>(j.table); jb.w_ld[q] = (long)j.w_ld;
       jb.trans[q] = j.trans_w; jb.din[q] = j.k; jb.dout[q] = j.n;
+      jb.extra[q] = j.extra_row; jb.kw[q] = j.k_w;
+      if (j.extra_row && (j.trans_w || j.k_w < 0 || j.k_w >= j.k))
+        return fail("kgcn_wtable_split_multi: job %d: a stacked operand needs trans_w = 0 and 0 <= k_w < k", base + q);
       const long threads = wtable_entries(j.k, j.n) / 3;
       if (threads > most) most = threads;
       if (gh_nt32(j.n) > most_nt) most_nt = gh_nt32(j.n);

@@ -151,6 +151,9 @@ class GraphConv(nn.Module):
                     self._agg_pad.device != inputs.device:
                 self._agg_pad = self.w[0].new_zeros((dp - din - 1, dout))          # constant: allocated and zeroed once
             pad = self._agg_pad
+            if C == 1 and not z[0].requires_grad:
+                # [W; b; 0] is never assembled: its fragment table is split from the two parameters by the step's one table launch
+                return ops.dense_stacked(z[0], self.w[0], self.bias[0], activation=act).reshape(B, N, dout)
             wa = ops.stack_rows(self.w[0], self.bias[0], pad) if C == 1 else \
                 torch.cat([t for c in range(C) for t in (self.w[c], self.bias[c], pad)], dim=0)
             return ops.dense(z[0] if C == 1 else torch.cat(z, dim=1), wa, None, activation=act).reshape(B, N, dout)

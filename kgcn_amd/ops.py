@@ -401,7 +401,7 @@ class WeightTables:
         self.entries = {}          # (data_ptr, shape) -> entry
 
     class _Entry:
-        __slots__ = ("ref", "tables", "epoch", "version", "used")
+        __slots__ = ("ref", "tables", "epoch", "version", "used", "ref2", "rows")
 
     def _entry(self, w, create):
         import weakref
@@ -440,15 +440,59 @@ class WeightTables:
             return None, 0
         return e.tables[trans], e.tables[trans].numel() * 4
 
+    # ---- stacked operands [w; bias; 0] of the aggregate-first GraphConv (layers.py): split straight from the two parameters by a
+    # table job with an extra row -- no torch.cat per step, no table split of its own in front of the layer's GEMM
+    def _stacked_key(self, w, bias, rows):
+        return ("stacked", w.data_ptr(), bias.data_ptr(), int(rows), tuple(w.shape))
+
+    def register_stacked(self, w, bias, rows):
+        if not (enabled_weight_tables and isinstance(w, torch.nn.Parameter) and isinstance(bias, torch.nn.Parameter) and w.is_cuda and
+                w.is_contiguous() and bias.is_contiguous() and bias.numel() == w.shape[1] and rows > w.shape[0]):
+            return
+        key = self._stacked_key(w, bias, rows)
+        e = self.entries.get(key)
+        if e is None or e.ref() is None or e.ref2() is None:
+            import weakref
+            b = int(lib.kgcn_dense_fwd_workspace_bytes(rows, w.shape[1]))
+            if b <= 0:
+                return
+            e = WeightTables._Entry()
+            e.ref, e.ref2 = weakref.ref(w), weakref.ref(bias)
+            e.tables = [torch.empty((b // 4,), device=w.device, dtype=torch.float32), None]
+            e.epoch, e.version, e.used, e.rows = -1, (-1, -1), False, int(rows)
+            self.entries[key] = e
+        e.used = True
+
+    def lookup_stacked(self, w, bias, rows):
+        """-> (table tensor, bytes) of [w; bias; 0] with `rows` rows, refreshed in this epoch for these parameter versions, or (None, 0)."""
+        if not enabled_weight_tables:
+            return None, 0
+        e = self.entries.get(self._stacked_key(w, bias, rows))
+        if e is None or e.epoch != self.epoch:
+            return None, 0
+        p, q = e.ref(), e.ref2()
+        if p is None or q is None or (p._version, q._version) != e.version:
+            return None, 0
+        e.used = True
+        return e.tables[0], e.tables[0].numel() * 4
+
     def invalidate(self):
         self.epoch += 1
 
     def refresh(self):
         import ctypes
         _param_uses.clear()                            # a training step begins here (kgcn_amd.train calls refresh() first)
-        live = []
+        live, stacked = [], []
         for key, e in list(self.entries.items()):
             p = e.ref()
+            if key[0] == "stacked":
+                q = e.ref2()
+                if p is None or q is None or p.data_ptr() != key[1] or q.data_ptr() != key[2]:
+                    del self.entries[key]
+                elif e.used:
+                    e.used = False
+                    stacked.append((p, q, e))
+                continue
             if p is None or p.data_ptr() != key[0]:
                 del self.entries[key]
                 continue
@@ -456,10 +500,14 @@ class WeightTables:
                 continue                          # no dense() call touched this weight since the last refresh (another model's)
             e.used = False
             live.append((p, e))
-        if not live or not enabled_weight_tables:
+        if not (live or stacked) or not enabled_weight_tables:
             return
-        jobs = (_lib.WtableJob * (2 * len(live)))()
+        jobs = (_lib.WtableJob * (2 * len(live) + len(stacked)))()
         n = 0
+        for p, q, e in stacked:
+            din, dout = p.shape
+            jobs[n] = _lib.WtableJob(p.data_ptr(), dout, 0, e.rows, dout, din, e.tables[0].data_ptr(), q.data_ptr())
+            n += 1
         for p, e in live:
             din, dout = p.shape
             for trans, (k, nn) in enumerate(((din, dout), (dout, din))):
@@ -469,6 +517,8 @@ class WeightTables:
         check(lib.kgcn_wtable_split_multi(ctypes.cast(jobs, ctypes.c_void_p), n, current_stream()), "kgcn_wtable_split_multi")
         for p, e in live:
             e.epoch, e.version = self.epoch, p._version
+        for p, q, e in stacked:
+            e.epoch, e.version = self.epoch, (p._version, q._version)
 
 
 enabled_weight_tables = True
@@ -658,6 +708,64 @@ def stack_rows(w, bias, pad):
     out._kgcn_defer_params = (w, bias)         # _Dense counts / checks THESE: `out` is a new tensor on every call
     _count_use(w, bias)
     return out
+
+
+class _DenseStacked(torch.autograd.Function):
+    """y = act(x2d @ [w; bias; 0]) for an input that needs NO gradient (the first layer's aggregate-first form, layers.py): the operand
+    is never assembled -- the forward reads its fragment table (split from w and bias by the step's one table launch), the backward is ONE
+    weight-gradient GEMM over x2d whose row blocks ARE d w and d bias (views: nothing reads them inside the pass, so the second stage
+    waits for the step's one reduction launch like a leaf parameter's)."""
+
+    @staticmethod
+    def forward(ctx, x2d, w, bias, act, tab, tb):
+        m, rows = x2d.shape
+        dout = w.shape[1]
+        y = torch.empty((m, dout), device=x2d.device, dtype=torch.float32)
+        check(lib.kgcn_dense_fwd_tab_f32(ptr(x2d), m, rows, rows, ptr(w), dout, 0, None, ptr(y), dout, dout, int(act), ptr(tab), tb,
+                                         current_stream()), "kgcn_dense_fwd_tab_f32")
+        ctx.act = int(act)
+        ctx.save_for_backward(x2d, w, bias, y)
+        ctx.defer_ok = bool(w.is_leaf and bias.is_leaf)
+        ctx.defer_ids = (w, bias)
+        _count_use(w, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2d, w, bias, y = ctx.saved_tensors
+        gy = _f32c(gy, "grad")
+        m, rows = x2d.shape
+        din, dout = w.shape
+        fuse_dact = bool(ctx.act) and wgrad_dact_fusion and bool(lib.kgcn_dense_wgrad_dact_supported(rows, dout))
+        if ctx.act and not fuse_dact:
+            gy = activation_backward(y, gy, ctx.act)
+        with _no_deferral_unless(ctx.defer_ok and _single_use(*ctx.defer_ids)):
+            wsb = lib.kgcn_dense_wgrad_workspace_bytes(m, rows, dout)
+            wsp = torch.empty((max(wsb, 4) // 4,), device=gy.device, dtype=torch.float32)
+            dwa = torch.empty((rows, dout), device=gy.device, dtype=torch.float32)
+            if fuse_dact:
+                check(lib.kgcn_dense_wgrad_dact_f32(ptr(x2d), rows, ptr(gy), ptr(y), dout, ctx.act, m, rows, dout, ptr(dwa), None,
+                                                    ptr(wsp), wsb, current_stream()), "kgcn_dense_wgrad_dact_f32")
+            else:
+                check(lib.kgcn_dense_wgrad_f32(ptr(x2d), rows, ptr(gy), dout, m, rows, dout, ptr(dwa), None, ptr(wsp), wsb,
+                                               current_stream()), "kgcn_dense_wgrad_f32")
+            _keep_until_flush(wsp)
+        return None, dwa[:din], dwa[din:din + 1].reshape(bias.shape), None, None, None
+
+
+def dense_stacked(x2d, w, bias, activation=None):
+    """act(x2d @ [w; bias; 0]) with x2d [m, rows >= din + 1] -- the GEMM of an aggregate-first GraphConv (A [X | 1 | 0]) [W; b; 0].
+    Without a concatenation when the operand's table is ready (inside a training step) and x2d needs no gradient; else stack_rows + dense."""
+    rows = x2d.shape[1]
+    weight_tables.register_stacked(w, bias, rows)
+    # (>= 1,024 rows: below that the dense entry point does not take the table route and would read `rows` rows of w itself)
+    if not x2d.requires_grad and x2d.dtype == torch.float32 and x2d.is_contiguous() and bias.dim() == 2 and bias.shape[0] == 1 and \
+            x2d.shape[0] >= 1024:
+        tab, tb = weight_tables.lookup_stacked(w, bias, rows)
+        if tab is not None:
+            return _DenseStacked.apply(x2d, w, bias, act_code(activation), tab, tb)
+    pad = w.new_zeros((rows - w.shape[0] - 1, w.shape[1]))
+    return dense(x2d, stack_rows(w, bias, pad), None, activation=activation)
 
 
 def dense(x2d, w, bias=None, activation=None):
