@@ -1060,7 +1060,14 @@ static int dense_wgrad_impl(const float* x, int64_t x_ld, const float* dy, int64
     const int tiles = ((din + 127) / 128) * ((dout + 255) / 256);
     long nb = kNumCU / tiles;
     if (nb < 1) nb = 1;
-    const long chunks = (m + 31) / 32;
+    // at least 64 rows per row range: a range's partial is a whole [din x dout] block (256 KB at 256 x 256) -- with one 32-row
+    // chunk per workgroup sparse.py's 4,457 rows wrote 128 partials = 32 MB per layer and the step's reduction launch read 119 MB
+    // (profiles/r05_h_cfg3_rocprof.txt).  A/B on one box, cfg3 whole step: 32 rows 0.308 ms, 64 rows 0.301, 128 rows 0.318 (too few
+    // workgroups), 256 rows 0.364
+#ifndef KGCN_WGRAD_MIN_ROWS
+#define KGCN_WGRAD_MIN_ROWS 64
+#endif
+    const long chunks = (m + KGCN_WGRAD_MIN_ROWS - 1) / KGCN_WGRAD_MIN_ROWS;
     if (nb > chunks) nb = chunks;
     float* part_dw = static_cast<float*>(workspace);
     float* part_db = part_dw + nb * din * dout;
