@@ -92,6 +92,7 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: row indices stay on the SALU
   int* rowk_base = reinterpret_cast<int*>(dsm + 2 * (size_t)GH_PIECES * 16);     // [2][64] row exponents
+  GHP_DECL                                                 // (development: tools/gemmh_fwd_probe.py)
   const long ntiles = (m + GH_BM - 1) / GH_BM;
   const long G = gridDim.x;
   long t = blockIdx.x;
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
         __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
       }
     });
+    GHP(1)
     __builtin_amdgcn_sched_barrier(0);
     // ---- y <- act(2^-(kr + kc) acc + bias) ---------------------------------------------------------------------------
     const long row0 = tt * GH_BM;
@@ -300,6 +302,7 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
     else if (act == KGCN_ACT_RELU) apply(std::integral_constant<int, KGCN_ACT_RELU>{});
     else if (act == KGCN_ACT_TANH) apply(std::integral_constant<int, KGCN_ACT_TANH>{});
     if (GH_VARIANT == 2 && acc[0][0] != 1.2345e-30f) return;
+    GHP(2)
     if (DK != 0 && da.dot_part) {                        // uniform: <product, y operand> instead of the stores
       if (col < dout) {
         const __amdgpu_buffer_rsrc_t rz = gh_rows(y, row0, GH_BM, m, y_ld);   // rows >= m: read as 0
@@ -341,12 +344,16 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
       load_tile(t + G);                                  // on its way from HBM while this tile is multiplied
       __builtin_amdgcn_sched_barrier(0);
     }
+    GHP(0)
     compute(t, buf, t + 2 * G);
+    GHP(3)
     if constexpr (DK != 0) load_tile(t + G);             // backward form: gradient and saved output travel together below
     if constexpr (!(DK == 0 && GH_INTERLEAVE != 0 && NKS == 16)) stage(t + G, buf ^ 1);
     gh_barrier_lds();
+    GHP(4)
     t += G;
   }
+  GHP_FLUSH
   if constexpr (DK != 0) {
     if (da.dot_part) {                                   // uniform.  Fixed order: lanes (butterfly), then the eight waves
 #pragma unroll
