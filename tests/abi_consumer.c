@@ -39,6 +39,9 @@ static int layout(void) {
   printf("offsetof_block_ptr %zu\n", offsetof(kgcn_csr_batch, block_ptr));
   printf("offsetof_num_blocks %zu\n", offsetof(kgcn_csr_batch, num_blocks));
   printf("offsetof_block_rows_max %zu\n", offsetof(kgcn_csr_batch, block_rows_max));
+  printf("sizeof_wtable_job %zu\n", sizeof(kgcn_wtable_job));
+  printf("offsetof_wtable_job_table %zu\n", offsetof(kgcn_wtable_job, table));
+  printf("offsetof_wtable_job_extra_row %zu\n", offsetof(kgcn_wtable_job, extra_row));
   CHECK(kgcn_abi_version() == KGCN_HIP_ABI_VERSION, "library and header ABI versions differ");
   CHECK(kgcn_csr_batch_size() == (int64_t)sizeof(kgcn_csr_batch), "kgcn_csr_batch size differs between header and library");
   CHECK(strcmp(kgcn_build_arch(), "gfx950") == 0, "build arch");

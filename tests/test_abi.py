@@ -55,6 +55,9 @@ def test_c_consumer_sees_the_layout_the_binding_mirrors():
     assert int(facts["sizeof_csr_batch"]) == int(facts["library_csr_batch_size"]) == ctypes.sizeof(_lib.CsrBatch)
     for field in ("nnz", "rowptr", "cv", "slots", "graph_ptr", "block_ptr", "num_blocks", "block_rows_max"):
         assert int(facts["offsetof_" + field]) == getattr(_lib.CsrBatch, field).offset, field
+    assert int(facts["sizeof_wtable_job"]) == ctypes.sizeof(_lib.WtableJob)
+    assert int(facts["offsetof_wtable_job_table"]) == _lib.WtableJob.table.offset
+    assert int(facts["offsetof_wtable_job_extra_row"]) == _lib.WtableJob.extra_row.offset
     assert "NULL" in facts["last_error"]
 
 
