@@ -53,6 +53,9 @@ constexpr int GB_BUF = 2 * GB_PLANE;          // h | l
 // (BC = 1) keeps eight more staging registers alive through the multiplication: four k-steps fewer in registers there.
 __host__ __device__ constexpr int gb_wreg(int) { return 10; }
 __host__ __device__ constexpr size_t gb_lds(int bc) { return 2 * (size_t)GB_BUF + 2 * GB_R * 4 + 4 * (size_t)(16 - gb_wreg(bc)) * 2 * 1024; }
+#ifndef GB_DW_ROWS
+#define GB_DW_ROWS 0                            // rows (of a wave quarter's eight per stage) staged by the dW wave
+#endif
 constexpr int GB_ZERO_ROW_K = 120;            // row exponent of an all-zero dpre row: x 2^(K - 120) vanishes
 
 #ifdef KGCN_PROBE   // development: per-wave cycle sums per phase of gemmb_kernel (tools/gemmb_probe.py)
@@ -76,6 +79,23 @@ __device__ __forceinline__ void gb_st64(unsigned a, unsigned lo, unsigned hi) {
 }
 __device__ __forceinline__ u32x2 gb_ld_tr16(unsigned a) {
   return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((GB_LDS_AS gb_i16x4*)(uintptr_t)a));
+}
+
+// wave maximum of the FINITE magnitudes of a row (cold path of the staging: a row that holds +-inf / NaN).  Out of line: inlined into
+// each of the eight rows of a stage it was ~150 instructions of never-taken code per row inside the loop body.
+__device__ __attribute__((noinline)) unsigned gb_finite_row_max(f32x4 v) {
+  unsigned q = 0u;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned av = __float_as_uint(v[e]) & 0x7fffffffu;
+    q = (av < 0x7f800000u && av > q) ? av : q;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned u = (unsigned)__shfl_xor((int)q, o, 64);
+    q = u > q ? u : q;
+  }
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)q);
 }
 
 // DK: 0 plain (dpre = the incoming gradient); 1 dpre = g (.) (c0 + c1 a + c2 a^2) (sigmoid / tanh derivative in the layer
@@ -206,20 +226,7 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
     // A row that holds +-inf / NaN: its exponent comes from its FINITE values, so that those keep their places in the weight
     // gradient (dW[:, j] of a finite column j must not turn non-finite -- or lose the row -- because ANOTHER column of that
     // row is; the non-finite element itself splits into non-finite pieces at any scale).  Cold, wave-uniform.
-    if (__builtin_expect(mxr >= 0x7f800000u, 0)) {
-      unsigned q = 0u;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const unsigned av = __float_as_uint(raw[i][e]) & 0x7fffffffu;
-        q = (av < 0x7f800000u && av > q) ? av : q;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const unsigned v = (unsigned)__shfl_xor((int)q, o, 64);
-        q = v > q ? v : q;
-      }
-      mxr = (unsigned)__builtin_amdgcn_readfirstlane((int)q);
-    }
+    if (__builtin_expect(mxr >= 0x7f800000u, 0)) mxr = gb_finite_row_max(raw[i]);
     rmx = mxr;
   };
   auto stage_row_b = [&](long st_next, int buf, auto ic) __attribute__((always_inline)) {
@@ -237,6 +244,9 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
   };
 
   long t = q0;
+  // Rows 0 .. GB_DX_ROWS-1 of a wave quarter's eight are staged by its dX wave, the rest by its dW wave (same w4): the dX waves are
+  // the stage's critical path, the dW waves waited ~1,400 cycles at its barrier (tools/gemmb_probe.py)
+  constexpr int GB_DX_ROWS = 8 - GB_DW_ROWS;
 
   if (wave < 4) {
     // =============================== dX role ====================================================================
@@ -322,8 +332,10 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
         // MFMAs form one dependent chain: issued back to back they hold the wave's issue port until the last one starts, and
         // vector work placed behind them overlaps only that one (the first interleaved build: 6,200 cycles for the phase
         // against 1,770 + 3,740 apart) -- the group barriers ask the scheduler for MFMA, 7 vector instructions, MFMA, ...
-        if constexpr ((ks & 1) == 0) stage_row_a(st_next, std::integral_constant<int, ks / 2>{});
-        else stage_row_b(st_load, buf ^ 1, std::integral_constant<int, ks / 2>{});
+        if constexpr (ks / 2 < GB_DX_ROWS) {
+          if constexpr ((ks & 1) == 0) stage_row_a(st_next, std::integral_constant<int, ks / 2>{});
+          else stage_row_b(st_load, buf ^ 1, std::integral_constant<int, ks / 2>{});
+        }
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -353,9 +365,9 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
       GBP(2)
     };
 
-    static_for<8>([&](auto ic) __attribute__((always_inline)) { load_ga_row(t, ic); });
+    static_for<GB_DX_ROWS>([&](auto ic) __attribute__((always_inline)) { load_ga_row(t, ic); });
     load_bc(t);
-    static_for<8>([&](auto ic) __attribute__((always_inline)) {          // the first stage: staged without a multiplication to hide in
+    static_for<GB_DX_ROWS>([&](auto ic) __attribute__((always_inline)) {          // the first stage: staged without a multiplication to hide in
       stage_row_a(t, ic);
       stage_row_b(t + G, 0, ic);
     });
@@ -414,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
       return tmx;
     };
 
-    auto compute_dw = [&](long st, long st_next, int buf) __attribute__((always_inline)) {
+    auto compute_dw = [&](long st, long st_next, long st_load, int buf) __attribute__((always_inline)) {
       const int* rowk = rowk_base + GB_R * buf;
       const unsigned boff = (unsigned)(buf * GB_BUF);
       // ---- x'' = x 2^(K - kr[row]) in fragment layout, split once per stage ----------------------------------------------
@@ -514,15 +526,33 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
           read_t(F[g0 + 2 < 16 ? g0 + 2 : 16], std::integral_constant<int, (g0 + 2 < 16 ? g0 + 2 : 0)>{});
           read_t(F[g0 + 3 < 16 ? g0 + 3 : 16], std::integral_constant<int, (g0 + 3 < 16 ? g0 + 3 : 0)>{});
         }
+        // this wave's share of the NEXT stage's staging: a row's two parts behind two consecutive groups
+        if constexpr (GB_DW_ROWS > 0) {
+          constexpr int pp = decltype(pc)::value, sp = 8 / (GB_DW_ROWS > 0 ? GB_DW_ROWS : 1), jr = pp / sp;
+          if constexpr (pp % sp == 0) stage_row_a(st_next, std::integral_constant<int, GB_DX_ROWS + jr>{});
+          else if constexpr (pp % sp == 1) stage_row_b(st_load, buf ^ 1, std::integral_constant<int, GB_DX_ROWS + jr>{});
+        }
       });
+      if constexpr (GB_DW_ROWS > 0) load_bc(st_load);
       GBP(1)
     };
 
     load_x(t);
+    if constexpr (GB_DW_ROWS > 0) {
+      static_for<GB_DW_ROWS>([&](auto ic) __attribute__((always_inline)) {
+        load_ga_row(t, std::integral_constant<int, GB_DX_ROWS + decltype(ic)::value>{});
+      });
+      load_bc(t);
+      static_for<GB_DW_ROWS>([&](auto ic) __attribute__((always_inline)) {
+        stage_row_a(t, std::integral_constant<int, GB_DX_ROWS + decltype(ic)::value>{});
+        stage_row_b(t + G, 0, std::integral_constant<int, GB_DX_ROWS + decltype(ic)::value>{});
+      });
+      load_bc(t + G);
+    }
     gh_barrier_lds();
     for (int it = 0; it < niter; ++it) {
       const int buf = it & 1;
-      compute_dw(t, t + G, buf);
+      compute_dw(t, t + G, t + 2 * G, buf);
       GBP(2)
       gh_barrier_lds();
       GBP(5)
@@ -555,12 +585,12 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
   if (part_db && half == 0) {                                  // uniform
     float* red = reinterpret_cast<float*>(dsm);                // (every wave is behind the loop's last barrier: the image is free)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[wave * 256 + c4 + e] = bsum[e];       // (the dW waves staged nothing: zeros)
+    for (int e = 0; e < 4; ++e) red[wave * 256 + c4 + e] = bsum[e];
     __syncthreads();
     if (tid < kdim) {
       float sum = 0.f;
 #pragma unroll
-      for (int w8 = 0; w8 < 4; ++w8) sum += red[w8 * 256 + tid];
+      for (int w8 = 0; w8 < (GB_DW_ROWS > 0 ? 8 : 4); ++w8) sum += red[w8 * 256 + tid];
       part_db[q0 * kdim + tid] = sum;
     }
   }
