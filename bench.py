@@ -729,7 +729,8 @@ class Cfg4(_ModelStep):
         self.sizes_d = torch.from_numpy(sizes.astype(np.int32)).to(dev)
         torch.manual_seed(0)                                                    # the same initial weights on every rank
         model = models.MultitaskGCN(1, TASKS, ragged=not args.padded).to(dev)
-        sb = self.ds.static_batch(B) if args.padded else self.ds.static_ragged_batch(B)
+        sb = self.ds.static_batch(B) if args.padded else \
+            self.ds.static_ragged_batch(B, augmented_features=models.wants_augmented_features(model, F))
         # labels / label mask / true sizes of the batch come out of the same device-side assembly as its adjacency and features
         self.lab_s, self.ml_s, self.en_s = sb.add_table(self.lab_d), sb.add_table(self.ml_d), sb.add_table(self.sizes_d)
         sb.load(np.arange(B))

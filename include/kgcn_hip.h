@@ -512,6 +512,11 @@ int kgcn_ragged_blocks(const int32_t* graph_ptr, int32_t num_sel, int32_t capaci
  * rows >= R. */
 int kgcn_ragged_compact_rows_f32(const float* src, const int32_t* sel, int32_t num_sel, int32_t n_nodes, int32_t d,
                                  const int32_t* graph_ptr, int32_t capacity_rows, float* dst, void* stream);
+/* The same rows as [x | 1 | 0 ...]: dst [capacity_rows, dst_ld], dst_ld >= d + 1; column d of EVERY row <- 1, columns d + 1 .. <- 0
+ * (= kgcn_ragged_compact_rows_f32 followed by kgcn_augment_ones_f32 in one pass: the operand of the aggregate-first GraphConv,
+ * A (X W + 1 b) = (A [X | 1]) [W ; b], kgcn/layers.py:99-113).  n_nodes * dst_ld < 2^22. */
+int kgcn_ragged_compact_rows_aug_f32(const float* src, const int32_t* sel, int32_t num_sel, int32_t n_nodes, int32_t d,
+                                     const int32_t* graph_ptr, int32_t capacity_rows, float* dst, int32_t dst_ld, void* stream);
 /* back to the padded layout: dst [num_graphs, n_nodes, d]; padded rows <- row fill_row of src (the padding representative)
  * or zeros (fill_row < 0). */
 int kgcn_ragged_expand_rows_f32(const float* src, int32_t num_graphs, int32_t n_nodes, int32_t d,

@@ -210,6 +210,8 @@ SIGNATURES = {
     "kgcn_ragged_blocks": (ctypes.c_int, [c_i32p, c_i32, c_i32, c_i32p, ctypes.c_void_p]),
     "kgcn_ragged_compact_rows_f32": (ctypes.c_int, [c_f32p, c_i32p, c_i32, c_i32, c_i32, c_i32p, c_i32, c_f32p,
                                                     ctypes.c_void_p]),
+    "kgcn_ragged_compact_rows_aug_f32": (ctypes.c_int, [c_f32p, c_i32p, c_i32, c_i32, c_i32, c_i32p, c_i32, c_f32p, c_i32,
+                                                        ctypes.c_void_p]),
     "kgcn_ragged_expand_rows_f32": (ctypes.c_int, [c_f32p, c_i32, c_i32, c_i32, c_i32p, c_i32, c_f32p, ctypes.c_void_p]),
     "kgcn_ragged_gather_fwd_f32": (ctypes.c_int, [c_f32p, c_i32p, c_i64, c_i32, c_i32, c_i32, c_f32p, ctypes.c_void_p]),
     "kgcn_ragged_gather_bwd_workspace_bytes": (c_i64, [c_i32]),

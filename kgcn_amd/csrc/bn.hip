@@ -17,6 +17,8 @@ namespace kgcn {
 int launch_reduce_partials(const float* part, int nparts, long n, float* out, hipStream_t s);
 int launch_reduce_pair_now(const float* part_a, long n_a, float* out_a, const float* part_b, long n_b, float* out_b, int nparts,
                        hipStream_t s);
+int launch_reduce_pair(const float* part_a, long n_a, float* out_a, const float* part_b, long n_b, float* out_b, int nparts,
+                       hipStream_t s);            // (dense.hip: queued inside a deferral scope, kgcn_reduce_defer)
 
 constexpr int BN_BLOCKS = 1024;    // partial rows of the first reduction stage
 
@@ -341,7 +343,8 @@ static int bn_bwd_impl(const float* x, const float* grad, const float* aout, int
     // inference phase: dx does not depend on the reductions -> one pass over x and g
     hipLaunchKernelGGL(bn_colreduce_kernel<3>, dim3(nb), dim3(256), 0, s, x, grad, rows, n_nodes, d, enabled, mean, var, eps,
                        part0, part1, gamma, dx, aout, dact);
-    return launch_reduce_pair_now(part0, d, dbeta, part1, d, dgamma, nb, s);
+    // (nothing in this call reads d gamma / d beta back: their second stage may wait for the step's one reduction launch)
+    return launch_reduce_pair(part0, d, dbeta, part1, d, dgamma, nb, s);
   }
   hipLaunchKernelGGL(bn_colreduce_kernel<2>, dim3(nb), dim3(256), 0, s, x, grad, rows, n_nodes, d, enabled, mean, var, eps,
                      part0, part1, nullptr, nullptr, aout, dact);

@@ -184,6 +184,45 @@ __global__ __launch_bounds__(256) void ragged_rows_kernel(const float* __restric
   }
 }
 
+// the same copy into rows of dp >= d + 1 floats that end in [1 | 0 ...]: the [x | 1 | 0] operand of the aggregate-first GraphConv
+// (layers.py; kgcn_augment_ones_f32 was a pass of its own over the compact rows: 17.9 us and 83 MB per step of BASELINE config 4,
+// profiles/r05_h_cfg4_rocprof.txt).  A graph's n_t x dp destination floats are still ONE contiguous run.
+__global__ __launch_bounds__(256) void ragged_rows_aug_kernel(const float* __restrict__ src, const int* __restrict__ sel, int T,
+                                                              int M, int d, int dp, const int* __restrict__ graph_ptr,
+                                                              int capacity_rows, float* __restrict__ dst) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long nthreads = (long)gridDim.x * 256;
+  const int R = graph_ptr[T];
+  const float inv = 1.0f / (float)dp;
+  // (j + 0.5) / dp in fp32: j < 2^22 keeps the quotient's error far below the 0.5 / dp that separates two rows
+  auto split = [&](long j, int& row, int& c) __attribute__((always_inline)) {
+    row = (int)(((float)j + 0.5f) * inv);
+    c = (int)(j - (long)row * dp);
+  };
+  const long tail0 = (long)R * dp, tail1 = (long)capacity_rows * dp;
+  for (long i = tail0 + gtid; i < tail1; i += nthreads) dst[i] = (int)(i % dp) == d ? 1.f : 0.f;
+  for (long t = gtid / kWave; t < T; t += nthreads / kWave) {
+    const int g = sel ? sel[t] : (int)t;
+    if (g < 0) continue;
+    const int r0 = graph_ptr[t];
+    const long len = (long)(graph_ptr[t + 1] - r0) * dp;
+    const float* s = src + (long)g * M * d;
+    float* o = dst + (long)r0 * dp;
+    auto value = [&](long j) __attribute__((always_inline)) {
+      int row, c;
+      split(j, row, c);
+      return c < d ? s[(long)row * d + c] : (c == d ? 1.f : 0.f);
+    };
+    long i = lane;
+    for (; i + 3 * kWave < len; i += 4 * kWave) {
+      const float a0 = value(i), a1 = value(i + kWave), a2 = value(i + 2 * kWave), a3 = value(i + 3 * kWave);
+      o[i] = a0; o[i + kWave] = a1; o[i + 2 * kWave] = a2; o[i + 3 * kWave] = a3;
+    }
+    for (; i < len; i += kWave) o[i] = value(i);
+  }
+}
+
 // inverse of ragged_rows_kernel for results that are wanted in the padded layout: padded[t, r, :] = compact[graph_ptr[t]+r]
 // for r < n_t, `fill` (the padding representative row, or zeros when fill_row < 0) elsewhere
 __global__ __launch_bounds__(256) void ragged_expand_kernel(const float* __restrict__ src, int T, int M, int d,
@@ -419,6 +458,20 @@ extern "C" int kgcn_ragged_compact_rows_f32(const float* src, const int32_t* sel
   hipLaunchKernelGGL(ragged_rows_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, sel, num_sel, n_nodes, d,
                      graph_ptr, capacity_rows, dst);
   return check_launch("ragged_rows_kernel");
+}
+
+extern "C" int kgcn_ragged_compact_rows_aug_f32(const float* src, const int32_t* sel, int32_t num_sel, int32_t n_nodes,
+                                                int32_t d, const int32_t* graph_ptr, int32_t capacity_rows, float* dst,
+                                                int32_t dst_ld, void* stream) {
+  if (num_sel < 0 || n_nodes < 0 || d < 0 || capacity_rows < 0) return fail("kgcn_ragged_compact_rows_aug_f32: negative size");
+  if (dst_ld < d + 1) return fail("kgcn_ragged_compact_rows_aug_f32: dst_ld %d leaves no room for the ones column behind %d features", dst_ld, d);
+  if ((long)n_nodes * dst_ld >= (1L << 22)) return fail("kgcn_ragged_compact_rows_aug_f32: n_nodes * dst_ld = %ld >= 2^22", (long)n_nodes * dst_ld);
+  if (capacity_rows == 0) return 0;
+  if (!graph_ptr || !dst || (!src && num_sel > 0 && d > 0)) return fail("kgcn_ragged_compact_rows_aug_f32: NULL operand");
+  const unsigned blocks = grid_cap((long)(num_sel > 0 ? num_sel : 1) * kWave, (long)kNumCU * 32);
+  hipLaunchKernelGGL(ragged_rows_aug_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, sel, num_sel, n_nodes, d, dst_ld,
+                     graph_ptr, capacity_rows, dst);
+  return check_launch("ragged_rows_aug_kernel");
 }
 
 extern "C" int kgcn_ragged_expand_rows_f32(const float* src, int32_t num_graphs, int32_t n_nodes, int32_t d,

@@ -262,10 +262,11 @@ class DeviceGraphDataset:
         """Fixed-address batch buffers for hipGraph replay (kgcn_amd.train.GraphedTrainStep)."""
         return StaticBatch(self, batch_size, fused)
 
-    def static_ragged_batch(self, batch_size, capacity=None):
-        """Fixed-address, fixed-capacity batch buffers in the ragged-compact layout (valid node rows only)."""
+    def static_ragged_batch(self, batch_size, capacity=None, augmented_features=False):
+        """Fixed-address, fixed-capacity batch buffers in the ragged-compact layout (valid node rows only).
+        augmented_features: see kgcn_amd.ragged.StaticRaggedBatch (models.wants_augmented_features(model, F) says when it pays)."""
         from .ragged import StaticRaggedBatch
-        return StaticRaggedBatch(self, batch_size, capacity)
+        return StaticRaggedBatch(self, batch_size, capacity, augmented_features=augmented_features)
 
     def ragged_batch(self, batch_idx, batch_size=None):
         """One mini-batch assembled on the device directly in the ragged-compact layout (exact capacity R + 1)."""

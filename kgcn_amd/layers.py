@@ -145,7 +145,9 @@ class GraphConv(nn.Module):
             # aggregation (dW, db come out of ONE weight-gradient GEMM over [A X | rowsum(A)]; d inputs -- when asked for --
             # is a dp-wide adjoint).  Per channel the operand is aggregated with that channel's adjacency; the channels are
             # concatenated along the contraction axis.
-            xa = ops.augment_ones(x2d, dp)
+            xa = getattr(inputs, "_kgcn_aug", None)     # rows assembled as [x | 1 | 0] already (ragged.StaticRaggedBatch)
+            if xa is None or tuple(xa.shape) != (B * N, dp) or inputs.requires_grad or xa.data_ptr() != inputs.data_ptr():
+                xa = ops.augment_ones(x2d, dp)
             z = [ops.bspmm(a.channels[c], xa) for c in range(C)]
             if getattr(self, "_agg_pad", None) is None or tuple(self._agg_pad.shape) != (dp - din - 1, dout) or \
                     self._agg_pad.device != inputs.device:

@@ -162,6 +162,18 @@ class MultitaskGCN(nn.Module):
         return self.out(layer)                      # prediction = sigmoid(logits)
 
 
+def wants_augmented_features(model, n_features):
+    """True when `model`'s first layer is a one-kernel-per-step consumer of [x | 1 | 0] feature rows: a GraphConv that takes the
+    aggregate-first route (layers.py: din + 1 padded to 4 below its width), so that a static ragged batch should assemble its rows
+    in that form (data_util.DeviceGraphDataset.static_ragged_batch(augmented_features=True))."""
+    first = next((m for m in model.children() if isinstance(m, (layers.GraphConv, layers.GraphDense, layers.GINAggregate))), None)
+    if not isinstance(first, layers.GraphConv) or not getattr(model, "ragged", False):
+        return False
+    dp = (int(n_features) + 1 + 3) // 4 * 4
+    return bool(layers.aggregate_first and dp < first.output_dim and not (layers.enabled_bconv or layers.enabled_bspmm or
+                                                                          layers.enabled_batched))
+
+
 class SparseGCN(nn.Module):
     """example_model/sparse.py:45-134 (params of build(): out_dims [256,256,256], dense_dim 256,
     batch_normalize False, max_pool False; both optional layers are available as flags)."""

@@ -1601,7 +1601,7 @@ class _SparseCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dlog,) = ctx.saved_tensors
-        return dlog * g, None
+        return _loss_grad(dlog, None, g, 1), None          # dlog * g in the library's launch (no ATen kernel in the step)
 
 
 def sparse_softmax_ce_sum(logits, label_idx):
@@ -1647,6 +1647,10 @@ class _GraphBN(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, mean, var, enabled, eps, training, act=0):
         x = _f32c(x, "inputs")
         T, N, D = x.shape
+        # learning phase 0: d gamma / d beta are not read inside the backward call (the C side queues their second stage in a deferral scope)
+        ctx.defer_ok = bool(not training and gamma.is_leaf and beta.is_leaf)
+        ctx.defer_ids = (gamma, beta)
+        _count_use(gamma, beta)
         gamma, beta = _f32c(gamma, "gamma"), _f32c(beta, "beta")
         y = torch.empty_like(x)
         check(lib.kgcn_graph_bn_apply_act_f32(ptr(x), T, N, D, ptr(enabled), ptr(mean), ptr(var), ptr(gamma), ptr(beta),
@@ -1665,10 +1669,12 @@ class _GraphBN(torch.autograd.Function):
         dbeta = torch.empty_like(dgamma)
         wsb = lib.kgcn_graph_bn_workspace_bytes(D)
         wsp = torch.empty((wsb // 4 + 1,), device=x.device, dtype=torch.float32)
-        check(lib.kgcn_graph_bn_bwd_dact_f32(ptr(x), ptr(g), ptr(yact) if ctx.act else None, ctx.act, T, N, D,
-                                             ptr(ctx.enabled), ptr(mean), ptr(var), ptr(gamma), ctx.eps, int(ctx.training),
-                                             ptr(dx), ptr(dgamma), ptr(dbeta), ptr(wsp), wsb, current_stream()),
-              "kgcn_graph_bn_bwd_dact_f32")
+        with _no_deferral_unless(ctx.defer_ok and dx is not None and _single_use(*ctx.defer_ids)):
+            check(lib.kgcn_graph_bn_bwd_dact_f32(ptr(x), ptr(g), ptr(yact) if ctx.act else None, ctx.act, T, N, D,
+                                                 ptr(ctx.enabled), ptr(mean), ptr(var), ptr(gamma), ctx.eps, int(ctx.training),
+                                                 ptr(dx), ptr(dgamma), ptr(dbeta), ptr(wsp), wsb, current_stream()),
+                  "kgcn_graph_bn_bwd_dact_f32")
+            _keep_until_flush(wsp)
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 

@@ -225,7 +225,11 @@ class StaticRaggedBatch:
     hipGraph (kgcn_amd.train.GraphedTrainStep) keep reading the same pointers whatever R the new batch has.
     .features / .adjacency are what the model takes (adjacency = the RaggedBatch)."""
 
-    def __init__(self, dataset, batch_size, capacity=None):
+    def __init__(self, dataset, batch_size, capacity=None, augmented_features=False):
+        """augmented_features: the feature rows are assembled as [x | 1 | 0 ...] rows of (F + 1 rounded up to 4) floats -- the
+        operand of an aggregate-first GraphConv as the model's first layer (layers.GraphConv reads it where it lies instead of
+        running ops.augment_ones over the compact rows every step).  `.features` is then a [1, capacity, F] VIEW of that
+        buffer (row stride > F): anything else that reads it makes its own contiguous copy."""
         import torch
         if dataset.sizes is None:
             raise ValueError("the dataset was built without `sizes` (true node counts per graph)")
@@ -254,7 +258,15 @@ class StaticRaggedBatch:
             self._chan.append((src, src.transpose(), entry_ptr, pair))
             chans.append(pair[0])
         f = dataset.features
-        feat = None if f is None else f.new_zeros((1, cap, f.shape[2]))
+        self._feat_aug = None
+        if f is not None and augmented_features:
+            F = int(f.shape[2])
+            self._feat_aug = f.new_zeros((cap, (F + 1 + 3) // 4 * 4))
+            self._feat_aug[:, F] = 1.0
+            feat = self._feat_aug[:, :F].unsqueeze(0)
+            feat._kgcn_aug = self._feat_aug          # (a Python attribute of THIS tensor object: the model receives the same object)
+        else:
+            feat = None if f is None else f.new_zeros((1, cap, f.shape[2]))
         self.ragged = RaggedBatch(BatchedAdjacency(chans), feat, self._graph_ptr, B, N, cap)
         self.features = feat
         self.adjacency = self.ragged
@@ -294,10 +306,16 @@ class StaticRaggedBatch:
                 _compact_csr(s, self._sel_dev, B, self._graph_ptr, entry_ptr, self.capacity, c.rowptr, c.cv, self.status)
         if self.features is not None:
             f = ds.features
-            _lib.check(_lib.lib.kgcn_ragged_compact_rows_f32(_lib.ptr(f), _lib.ptr(self._sel_dev), B, f.shape[1], f.shape[2],
-                                                             _lib.ptr(self._graph_ptr), self.capacity,
-                                                             _lib.ptr(self.features), _lib.current_stream()),
-                       "kgcn_ragged_compact_rows_f32")
+            if self._feat_aug is not None:
+                _lib.check(_lib.lib.kgcn_ragged_compact_rows_aug_f32(_lib.ptr(f), _lib.ptr(self._sel_dev), B, f.shape[1], f.shape[2],
+                                                                     _lib.ptr(self._graph_ptr), self.capacity,
+                                                                     _lib.ptr(self._feat_aug), self._feat_aug.shape[1],
+                                                                     _lib.current_stream()), "kgcn_ragged_compact_rows_aug_f32")
+            else:
+                _lib.check(_lib.lib.kgcn_ragged_compact_rows_f32(_lib.ptr(f), _lib.ptr(self._sel_dev), B, f.shape[1], f.shape[2],
+                                                                 _lib.ptr(self._graph_ptr), self.capacity,
+                                                                 _lib.ptr(self.features), _lib.current_stream()),
+                           "kgcn_ragged_compact_rows_f32")
         if self._tables:
             import torch
             plan = _lib.AssemblePlan()

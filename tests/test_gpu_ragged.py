@@ -203,6 +203,72 @@ def test_static_ragged_batch_equals_compact_and_replays():
         close(pg, pe.detach().cpu().numpy(), atol=2e-5, rel=1e-4, what="parameters after 4 steps: captured ragged vs eager")
 
 
+def test_static_ragged_batch_with_augmented_feature_rows():
+    """StaticRaggedBatch(augmented_features=True): the rows are assembled as [x | 1 | 0] (kgcn_ragged_compact_rows_aug_f32) -- bit for
+    bit what kgcn_ragged_compact_rows_f32 + kgcn_augment_ones_f32 write --, `.features` is a view of them, an aggregate-first GraphConv
+    reads the buffer where it lies (no augment_ones pass) and the captured train step lands on the SAME parameters, bit for bit, as the
+    one on the plain batch."""
+    from kgcn_amd import data_util as D, models, ops, train
+    rng = np.random.default_rng(19)
+    G, N, F, T, B = 400, 20, 7, 3, 160
+    x, adjs, labels, mask, mask_label, sizes = tox21_like_batch(rng, B=G, N=N, F=F, T=T)
+    sizes = np.maximum(sizes, 1)
+    flat = D.FlatAdjacency.from_coo_list([a[0] for a in adjs], n_nodes=N)
+    ds = D.DeviceGraphDataset([flat], x.astype(np.float32), device=dev(), sizes=sizes)
+    plain, aug = ds.static_ragged_batch(B), ds.static_ragged_batch(B, augmented_features=True)
+    assert aug.capacity == plain.capacity and tuple(aug.features.shape) == tuple(plain.features.shape)
+    assert aug.features._kgcn_aug.shape == (aug.capacity, 8) and aug.features._kgcn_aug.data_ptr() == aug.features.data_ptr()
+    for trial in range(3):
+        idx = rng.permutation(G)[:B - (trial == 2) * 9]            # the last one is a short batch (dummy graphs)
+        plain.load(idx); aug.load(idx)
+        assert np.array_equal(aug.features.cpu().numpy(), plain.features.cpu().numpy())
+        want = ops.augment_ones(plain.features[0], 8).cpu().numpy()
+        assert np.array_equal(aug.features._kgcn_aug.cpu().numpy(), want)
+    assert not models.wants_augmented_features(models.GIN(2), F)
+    lab_d, ml_d = t32(labels), t32(mask_label)
+    batches = [rng.permutation(G)[:B] for _ in range(3)]
+    ones = torch.ones(B, device=dev())
+    out = []
+    seen = {"augment": 0}
+    real = ops.augment_ones
+    for sb in (plain, aug):
+        torch.manual_seed(3)
+        m = models.MultitaskGCN(1, T, ragged=True).to(dev())
+        m.conv1 = type(m.conv1)(64, 1, activation="sigmoid")     # 7 + 1 -> 8 < 64: aggregate-first (>= 1,024 rows)
+        assert sb.capacity >= 1024
+        assert models.wants_augmented_features(m, F)
+        sb.load(batches[0])
+        en_s = sb.add_table(torch.as_tensor(sizes.astype(np.int32), device=dev()))
+        sb.load(batches[0])
+        m(sb.features, sb.adjacency, enabled_node_nums=en_s)
+        opt = train.TFAdam(m.parameters(), lr=1e-2, capturable=True)
+        lab_s, ml_s = torch.zeros((B, T), device=dev()), torch.zeros((B, T), device=dev())
+
+        def counting(x2d, width):
+            seen["augment"] += int(width == 8)       # (conv2, 64 -> 256, is aggregate-first too: its operand is made by augment_ones)
+            return real(x2d, width)
+        ops.augment_ones = counting
+        try:
+            step = train.GraphedTrainStep(m, opt, lambda lg, lb, mk: models.masked_sigmoid_ce(lg, lb, mk, ml_s), sb, lab_s, ones,
+                                          enabled_node_nums=en_s)
+        finally:
+            ops.augment_ones = real
+        if sb is aug:
+            assert seen["augment"] == 0, "the augmented rows were not read where they lie"
+        else:
+            assert seen["augment"] > 0
+            seen["augment"] = 0
+        for b in batches:
+            it = torch.as_tensor(b, device=dev())
+            sb.load(b); lab_s.copy_(lab_d[it]); ml_s.copy_(ml_d[it])
+            step.replay()
+        torch.cuda.synchronize()
+        out.append([p_.detach().cpu().numpy().copy() for p_ in m.parameters()])
+        del step
+    for a, b in zip(*out):
+        assert np.array_equal(a, b), "parameters after 3 captured steps differ between the plain and the augmented batch"
+
+
 @pytest.mark.parametrize("B,N,din,dout,C,act", [(40, 50, 81, 256, 1, "sigmoid"), (64, 20, 6, 40, 2, None), (30, 40, 30, 50, 1, "relu"),
                                                 (64, 20, 7, 64, 6, "tanh")])
 def test_graphconv_aggregate_first_equals_contract_first(B, N, din, dout, C, act):
