@@ -501,6 +501,11 @@ int kgcn_ragged_plan(const kgcn_csr_batch* src, const int32_t* sizes, const int3
 int kgcn_ragged_compact_csr(const kgcn_csr_batch* src, const int32_t* sel, int32_t num_sel, const int32_t* graph_ptr,
                             const int32_t* entry_ptr, int32_t capacity_rows, int32_t* dst_rowptr, int32_t* dst_cv,
                             int64_t dst_cv_capacity, int32_t* status, void* stream);
+/* The same for a channel's A and A^T (one plan, two destination containers) in ONE launch. */
+int kgcn_ragged_compact_csr_pair(const kgcn_csr_batch* src, const kgcn_csr_batch* src_t, const int32_t* sel, int32_t num_sel,
+                                 const int32_t* graph_ptr, const int32_t* entry_ptr, int32_t capacity_rows, int32_t* dst_rowptr,
+                                 int32_t* dst_cv, int64_t dst_cv_capacity, int32_t* dst_t_rowptr, int32_t* dst_t_cv,
+                                 int64_t dst_t_cv_capacity, int32_t* status, void* stream);
 /* The row blocks of a ragged-compact batch (kgcn_csr_batch.block_ptr): block_ptr [kgcn_ragged_num_blocks(capacity_rows) + 1]
  * from the plan's graph_ptr [num_sel + 1]; blocks past the valid rows cover the padding rows in steps of
  * KGCN_RAGGED_BLOCK_ROWS.  Every block holds at most KGCN_RAGGED_BLOCK_ROWS + n_nodes - 1 rows. */

@@ -205,6 +205,8 @@ SIGNATURES = {
                                         ctypes.c_void_p]),
     "kgcn_ragged_compact_csr": (ctypes.c_int, [_CSRP, c_i32p, c_i32, c_i32p, c_i32p, c_i32, c_i32p, c_i32p, c_i64, c_i32p,
                                                ctypes.c_void_p]),
+    "kgcn_ragged_compact_csr_pair": (ctypes.c_int, [_CSRP, _CSRP, c_i32p, c_i32, c_i32p, c_i32p, c_i32, c_i32p, c_i32p, c_i64, c_i32p,
+                                                    c_i32p, c_i64, c_i32p, ctypes.c_void_p]),
     "kgcn_ragged_block_rows": (c_i32, []),
     "kgcn_ragged_num_blocks": (c_i32, [c_i32]),
     "kgcn_ragged_blocks": (ctypes.c_int, [c_i32p, c_i32, c_i32, c_i32p, ctypes.c_void_p]),

@@ -106,13 +106,51 @@ __global__ __launch_bounds__(kRScan) void ragged_plan_finish_kernel(const int2* 
   }
 }
 
+// stages 2 + 3 in one launch (<= 1,024 count blocks): every workgroup adds up the totals of the count blocks in front of it itself
+// (<= 4 int2 per thread, one LDS reduction) -- the one-workgroup scan between two grid launches was a 4.6 us launch of its own per
+// step of BASELINE config 4 (profiles/r05_k_cfg4_rocprof.txt).  block_sums stays as the count stage wrote it.
+__global__ __launch_bounds__(kRScan) void ragged_plan_finish2_kernel(const int2* __restrict__ block_sums, int nb, int T,
+                                                                     int* __restrict__ graph_ptr, int* __restrict__ entry_ptr) {
+  __shared__ int red[4][kRScan];
+  int px = 0, py = 0, tx = 0, ty = 0;
+  for (int i = threadIdx.x; i < nb; i += kRScan) {
+    const int2 v = block_sums[i];
+    tx += v.x; ty += v.y;
+    if (i < (int)blockIdx.x) { px += v.x; py += v.y; }
+  }
+  red[0][threadIdx.x] = px; red[1][threadIdx.x] = py; red[2][threadIdx.x] = tx; red[3][threadIdx.x] = ty;
+  __syncthreads();
+  for (int o = kRScan / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  const int t = blockIdx.x * kRScan + threadIdx.x;
+  if (t < T) {
+    graph_ptr[t] += red[0][0];
+    entry_ptr[t] += red[1][0];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { graph_ptr[T] = red[2][0]; entry_ptr[T] = red[3][0]; }
+}
+
 // block-diagonal CSR of the valid blocks.  One wave per graph; the tail rows [R, capacity] are filled by the same grid.
 // status[0] += entries of the selected graphs that lie outside their valid n_t x n_t block (rows >= n_t that store
 // entries, columns >= n_t, or a count that disagrees with the plan): they have no place in the compact layout.
+struct RaggedCsrJob {          // one container of a launch (blockIdx.y): A, A^T of a channel share the plan
+  const int* src_rowptr; const int2* src_cv; long cv_capacity; int* dst_rowptr; int2* dst_cv;
+};
+struct RaggedCsrJobs { RaggedCsrJob j[2]; };
 __global__ __launch_bounds__(256) void ragged_csr_kernel(
-    const int* __restrict__ src_rowptr, const int2* __restrict__ src_cv, const int* __restrict__ sel, int T, int M,
-    const int* __restrict__ graph_ptr, const int* __restrict__ entry_ptr, int capacity_rows, long cv_capacity,
-    int* __restrict__ dst_rowptr, int2* __restrict__ dst_cv, int* __restrict__ status) {
+    RaggedCsrJobs jobs, const int* __restrict__ sel, int T, int M,
+    const int* __restrict__ graph_ptr, const int* __restrict__ entry_ptr, int capacity_rows, int* __restrict__ status) {
+  const RaggedCsrJob& jb = jobs.j[blockIdx.y];
+  const int* __restrict__ src_rowptr = jb.src_rowptr;
+  const int2* __restrict__ src_cv = jb.src_cv;
+  const long cv_capacity = jb.cv_capacity;
+  int* __restrict__ dst_rowptr = jb.dst_rowptr;
+  int2* __restrict__ dst_cv = jb.dst_cv;
   const int lane = threadIdx.x & (kWave - 1);
   const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
   const long nthreads = (long)gridDim.x * 256;
@@ -387,6 +425,10 @@ extern "C" int kgcn_ragged_plan(const kgcn_csr_batch* src, const int32_t* sizes,
   hipLaunchKernelGGL(ragged_plan_count_kernel, dim3(nb), dim3(kRScan), 0, s, src->rowptr, sizes, sel, num_sel, src->rows,
                      graph_ptr, entry_ptr, bs);
   if (int rc = check_launch("ragged_plan_count_kernel")) return rc;
+  if (nb <= 1024) {
+    hipLaunchKernelGGL(ragged_plan_finish2_kernel, dim3(nb), dim3(kRScan), 0, s, bs, nb, num_sel, graph_ptr, entry_ptr);
+    return check_launch("ragged_plan_finish2_kernel");
+  }
   hipLaunchKernelGGL(ragged_plan_scan_kernel, dim3(1), dim3(kRScan), 0, s, bs, nb, graph_ptr + num_sel, entry_ptr + num_sel);
   if (int rc = check_launch("ragged_plan_scan_kernel")) return rc;
   if (nb > 1) {
@@ -408,9 +450,37 @@ extern "C" int kgcn_ragged_compact_csr(const kgcn_csr_batch* src, const int32_t*
   if (dst_cv_capacity < 0 || (dst_cv_capacity > 0 && !dst_cv)) return fail("kgcn_ragged_compact_csr: dst_cv is NULL");
   const long waves_needed = num_sel > 0 ? num_sel : 1;
   const unsigned blocks = grid_cap(waves_needed * kWave, (long)kNumCU * 32);
-  hipLaunchKernelGGL(ragged_csr_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src->rowptr,
-                     reinterpret_cast<const int2*>(src->cv), sel, num_sel, src->rows, graph_ptr, entry_ptr, capacity_rows,
-                     (long)dst_cv_capacity, dst_rowptr, reinterpret_cast<int2*>(dst_cv), status);
+  RaggedCsrJobs jobs{};
+  jobs.j[0] = RaggedCsrJob{src->rowptr, reinterpret_cast<const int2*>(src->cv), (long)dst_cv_capacity, dst_rowptr,
+                           reinterpret_cast<int2*>(dst_cv)};
+  hipLaunchKernelGGL(ragged_csr_kernel, dim3(blocks, 1), dim3(256), 0, as_stream(stream), jobs, sel, num_sel, src->rows, graph_ptr,
+                     entry_ptr, capacity_rows, status);
+  return check_launch("ragged_csr_kernel");
+}
+
+extern "C" int kgcn_ragged_compact_csr_pair(const kgcn_csr_batch* src, const kgcn_csr_batch* src_t, const int32_t* sel,
+                                            int32_t num_sel, const int32_t* graph_ptr, const int32_t* entry_ptr,
+                                            int32_t capacity_rows, int32_t* dst_rowptr, int32_t* dst_cv, int64_t dst_cv_capacity,
+                                            int32_t* dst_t_rowptr, int32_t* dst_t_cv, int64_t dst_t_cv_capacity, int32_t* status,
+                                            void* stream) {
+  if (int rc = validate_csr(src, "kgcn_ragged_compact_csr_pair")) return rc;
+  if (int rc = validate_csr(src_t, "kgcn_ragged_compact_csr_pair")) return rc;
+  if (num_sel < 0 || capacity_rows < 0) return fail("kgcn_ragged_compact_csr_pair: negative size");
+  if (!graph_ptr || !entry_ptr || !dst_rowptr || !dst_t_rowptr) return fail("kgcn_ragged_compact_csr_pair: NULL operand");
+  if (src->rows != src->cols || src_t->rows != src->rows || src_t->cols != src->cols || src_t->num_graphs != src->num_graphs)
+    return fail("kgcn_ragged_compact_csr_pair: the two containers must be square and of one shape");
+  if (!sel && num_sel != src->num_graphs) return fail("kgcn_ragged_compact_csr_pair: sel is NULL but num_sel != graphs");
+  if (dst_cv_capacity < 0 || (dst_cv_capacity > 0 && !dst_cv) || dst_t_cv_capacity < 0 || (dst_t_cv_capacity > 0 && !dst_t_cv))
+    return fail("kgcn_ragged_compact_csr_pair: dst_cv is NULL");
+  const long waves_needed = num_sel > 0 ? num_sel : 1;
+  const unsigned blocks = grid_cap(waves_needed * kWave, (long)kNumCU * 16);
+  RaggedCsrJobs jobs{};
+  jobs.j[0] = RaggedCsrJob{src->rowptr, reinterpret_cast<const int2*>(src->cv), (long)dst_cv_capacity, dst_rowptr,
+                           reinterpret_cast<int2*>(dst_cv)};
+  jobs.j[1] = RaggedCsrJob{src_t->rowptr, reinterpret_cast<const int2*>(src_t->cv), (long)dst_t_cv_capacity, dst_t_rowptr,
+                           reinterpret_cast<int2*>(dst_t_cv)};
+  hipLaunchKernelGGL(ragged_csr_kernel, dim3(blocks, 2), dim3(256), 0, as_stream(stream), jobs, sel, num_sel, src->rows, graph_ptr,
+                     entry_ptr, capacity_rows, status);
   return check_launch("ragged_csr_kernel");
 }
 

@@ -302,8 +302,12 @@ class StaticRaggedBatch:
             _plan(src, ds.sizes_dev, self._sel_dev, B, self._graph_ptr, entry_ptr, self._ws)
             if ic == 0:
                 _blocks(self._graph_ptr, B, self.capacity, self._block_ptr)
-            for s, c in ((src, pair[0]), (src_t, pair[1])):
-                _compact_csr(s, self._sel_dev, B, self._graph_ptr, entry_ptr, self.capacity, c.rowptr, c.cv, self.status)
+            a, t = pair
+            _lib.check(_lib.lib.kgcn_ragged_compact_csr_pair(
+                src.desc(), src_t.desc(), _lib.ptr(self._sel_dev), B, _lib.ptr(self._graph_ptr), _lib.ptr(entry_ptr), self.capacity,
+                _lib.ptr(a.rowptr), a.cv.data_ptr() if a.cv.shape[0] else 0, a.cv.shape[0],
+                _lib.ptr(t.rowptr), t.cv.data_ptr() if t.cv.shape[0] else 0, t.cv.shape[0], _lib.ptr(self.status),
+                _lib.current_stream()), "kgcn_ragged_compact_csr_pair")       # A and A^T of the channel: one launch
         if self.features is not None:
             f = ds.features
             if self._feat_aug is not None:

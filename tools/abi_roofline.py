@@ -193,6 +193,10 @@ def _cost(name, a):
         return 4 * 7 * a[4], 10 * a[4], "n=%d" % a[4]
     if name == "kgcn_ragged_compact_rows_f32":
         return 8 * a[6] * a[4], 0, "capacity=%d d=%d" % (a[6], a[4])
+    if name == "kgcn_ragged_compact_rows_aug_f32":        # rows in (d floats), rows out (dst_ld floats: [x | 1 | 0])
+        return 4 * a[6] * (a[4] + a[8]), 0, "capacity=%d d=%d -> %d" % (a[6], a[4], a[8])
+    if name == "kgcn_ragged_compact_csr_pair":            # A and A^T: twice kgcn_ragged_compact_csr's bytes
+        return 16 * (a[9] + a[12]) // 4 + 16 * a[6], 0, "sel=%d capacity=%d (A and A^T)" % (a[3], a[6])
     if name == "kgcn_ragged_compact_csr":
         c = _csr(a[0])
         return 16 * a[8] // 4 + 8 * a[5], 0, "sel=%d capacity=%d" % (a[2], a[5])
