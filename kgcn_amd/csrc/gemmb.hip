@@ -51,8 +51,18 @@ constexpr int GB_PLANE = 20480;               // bytes of one piece plane
 constexpr int GB_BUF = 2 * GB_PLANE;          // h | l
 // k-steps of W' held in registers; the others live in LDS (below).  The form that adds the read-out's gradient to a row gradient
 // (BC = 1) keeps eight more staging registers alive through the multiplication: four k-steps fewer in registers there.
-__host__ __device__ constexpr int gb_wreg(int) { return 10; }
-__host__ __device__ constexpr size_t gb_lds(int bc) { return 2 * (size_t)GB_BUF + 2 * GB_R * 4 + 4 * (size_t)(16 - gb_wreg(bc)) * 2 * 1024; }
+#ifndef GB_DOT_WREG
+#define GB_DOT_WREG 8
+#endif
+#ifndef GB_DOT_KS
+#define GB_DOT_KS 0                             // the k-step of a stage at which the dot form requests its dot operand
+#endif
+// W' k-steps a dX wave keeps in registers (the rest wait in LDS).  The dot form gives two more of them to LDS: its sixteen values of
+// the dot operand are requested at the HEAD of a stage -- a whole multiplication ahead of the epilogue that uses them -- and live in
+// the registers that frees (requested at k-step 5 they were ~1,500 cycles ahead of their use, under the loaded HBM latency:
+// 248 us per launch at 200,000 rows against 196 us of the plain form that moves the same bytes, profiles/r05_p_cfg5_rocprof.txt)
+__host__ __device__ constexpr int gb_wreg(bool dot) { return dot ? GB_DOT_WREG : 10; }
+__host__ __device__ constexpr size_t gb_lds(bool dot) { return 2 * (size_t)GB_BUF + 2 * GB_R * 4 + 4 * (size_t)(16 - gb_wreg(dot)) * 2 * 1024; }
 #ifndef GB_DW_ROWS
 #define GB_DW_ROWS 0                            // rows (of a wave quarter's eight per stage) staged by the dW wave
 #endif
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
     const int* kctab = reinterpret_cast<const int*>(tab + (long)kse * nt32 * 2 * 64);
     const int nt = 4 * half + w4;
     const int ntc = nt < nt32 ? nt : nt32 - 1;               // clamped: the columns of such a wave are never stored
-    constexpr int GB_WREG = gb_wreg(BC);
+    constexpr int GB_WREG = gb_wreg(DOT);
     u32x4 Wh[GB_WREG], Wl[GB_WREG];
     const unsigned wl_base = lds0 + (unsigned)(2 * GB_BUF + 2 * GB_R * 4 + w4 * (16 - GB_WREG) * 2048 + lane * 16);
     static_for<16>([&](auto kc) __attribute__((always_inline)) {
@@ -316,9 +326,9 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
         if constexpr (ks < GB_WREG) { wh = Wh[ks]; wl = Wl[ks]; } else { wh = F[ks].wh; wl = F[ks].wl; }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (ks + 1 < 16) read_p(F[ks + 1], std::integral_constant<int, (ks + 1 < 16 ? ks + 1 : 0)>{});
-        if constexpr (DOT && ks == 5) {
-          // requested here, ten k-steps ahead of the epilogue: at the head of the stage the sixteen values were sixteen more
-          // registers alive through the whole multiplication (18 spilled, reloaded from scratch memory inside the loop)
+        if constexpr (DOT && ks == GB_DOT_KS) {
+          // (with ten k-steps of W' in registers these sixteen values, requested at the head of the stage, were sixteen more registers
+          // alive through the whole multiplication: 18 spilled, reloaded from scratch memory inside the loop -- see gb_wreg)
           const __amdgpu_buffer_rsrc_t rz = gh_rows(dx, st * GB_R, GB_R, m, dx_ld);
 #pragma unroll
           for (int r = 0; r < 16; ++r)
@@ -641,7 +651,7 @@ int launch_gemmb(const float* grad, const float* act_out, long m, int din, int d
                                 kLdsBytes);
       attr_set = true;
     }
-    hipLaunchKernelGGL((gemmb_kernel<DKc, BCc, DOTc>), grid, dim3(512), gb_lds(BCc), s, base, m, dout, ld, x, din, x_ld, tab, dx, dx_ld,
+    hipLaunchKernelGGL((gemmb_kernel<DKc, BCc, DOTc>), grid, dim3(512), gb_lds(DOTc), s, base, m, dout, ld, x, din, x_ld, tab, dx, dx_ld,
                        part_dw, part_db, da, niter);
   };
   using I0 = std::integral_constant<int, 0>;
