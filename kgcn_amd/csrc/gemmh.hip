@@ -58,6 +58,9 @@ __device__ long long* gh_probe = nullptr;
 #ifndef GH_INTERLEAVE
 #define GH_INTERLEAVE 1          // 0: the next tile staged AFTER the multiplication (rounds 4 form; build/variants A/B)
 #endif
+#ifndef GH_TWO_PHASES
+#define GH_TWO_PHASES 1          // 1: waves 0-3 and 4-7 (one of each per SIMD) run half a tile apart (see the forward kernel's main loop)
+#endif
 #ifndef GH_VARIANT
 #define GH_VARIANT 0             // development (tools/gemmh_variants.sh): 2 no y stores, 3 no x loads (forward); 5 no MFMAs, 6 no
 #endif                           // split, 7 no loads (gemmh_wgradl) -- what each part of the kernels costs
@@ -83,7 +86,7 @@ __device__ __forceinline__ int gh_slot(int rr32, int ks, int hi) { return (rr32 
 // pointer per access (32 y pointers next to 128 registers of W' were the spill source of the first build), and rows beyond m
 // need no clamps or masks: loads outside the descriptor return 0, stores outside it are dropped.
 constexpr int GH_PIECES = 2 * 16 * 2 * 64;     // u32x4 entries of one LDS tile buffer: (m-tile, k-step, piece, slot)
-constexpr size_t GH_LDS = 2 * (size_t)GH_PIECES * 16 + 2 * 64 * 4;
+constexpr size_t GH_LDS = 2 * (size_t)GH_PIECES * 16 + 4 * 64 * 4;     // two piece buffers + (up to three) sets of row exponents
 template <int DK, int NKS>
 __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restrict__ x, long m, int din, long x_ld,
                                                            const u32x4* __restrict__ tab, const float* __restrict__ bias,
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: row indices stay on the SALU
-  int* rowk_base = reinterpret_cast<int*>(dsm + 2 * (size_t)GH_PIECES * 16);     // [2][64] row exponents
+  int* rowk_base = reinterpret_cast<int*>(dsm + 2 * (size_t)GH_PIECES * 16);     // [2 or 3][64] row exponents
   GHP_DECL                                                 // (development: tools/gemmh_fwd_probe.py)
   const long ntiles = (m + GH_BM - 1) / GH_BM;
   const long G = gridDim.x;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
   // ONE row of the next tile (plain form): what `stage` does for the wave's eight rows at once, as a piece the multiplication
   // lays between its MFMAs (round 5: staged after the multiplication the 8 rows were a vector-ALU phase with the matrix pipe idle,
   // and the multiplication a matrix phase with the vector ALU idle -- 0.47 of the HBM floor at 65 / 107 us; gemmb.hip's history)
-  auto stage_row = [&](int buf, auto ic) __attribute__((always_inline)) {
+  auto stage_row = [&](int buf, int kslot, auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     if (!cok) raw[i] = f32x4{0.f, 0.f, 0.f, 0.f};              // (rows >= m were loaded as 0)
     float a;
@@ -217,12 +220,14 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
                        ((size_t)(((rr >> 5) * 16 + wks) * 2) * 64 + gh_slot(rr & 31, wks, whi)) * 16 + 8 * wsub;
     *reinterpret_cast<u32x2*>(e) = u32x2{h0, h1};
     *reinterpret_cast<u32x2*>(e + 1024) = u32x2{l0, l1};
-    (rowk_base + 64 * buf)[rr] = k;                            // same value from every lane
+    (rowk_base + 64 * kslot)[rr] = k;                          // same value from every lane
   };
   float dotacc = 0.f;
-  auto compute = [&](long tt, int buf, long tt_load = 0) __attribute__((always_inline)) {
+  // kslot / kslot_next: where the row exponents of this tile lie / those of the tile staged meanwhile go (== buf / buf ^ 1 but for the
+  // two-phase schedule, whose group B reads a tile's exponents while group A already stages the tile after the next one: three sets)
+  auto compute = [&](long tt, int buf, long tt_load, int kslot, int kslot_next) __attribute__((always_inline)) {
     const u32x4* lds = reinterpret_cast<const u32x4*>(dsm) + (size_t)buf * GH_PIECES;
-    const int* rowk = rowk_base + 64 * buf;
+    const int* rowk = rowk_base + 64 * kslot;
     f32x16 acc[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
       acc[1] = mfma_f16(A1[2], Bh[ks + 1], acc[1]);
       if constexpr (DK == 0 && GH_INTERLEAVE != 0 && NKS == 16) {
         // between these six MFMAs: row ks / 2 of the NEXT tile (already in the registers) -> the other buffer
-        stage_row(buf ^ 1, std::integral_constant<int, ks / 2>{});
+        stage_row(buf ^ 1, kslot_next, std::integral_constant<int, ks / 2>{});
         // ... and its registers take the same row of the tile after that: a whole multiplication ahead of its use
         raw[ks / 2] = gh_ld4(gh_rows(x, tt_load * GH_BM + 8 * wave, 8, m, x_ld), voff_x, (ks / 2) * ldx4);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -280,6 +285,10 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
     });
     GHP(1)
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DK == 0 && GH_INTERLEAVE != 0 && NKS == 16 && GH_TWO_PHASES != 0) {
+      gh_barrier_lds();                                  // (the other group's multiplication starts / has ended here: see the main loop)
+      GHP(4)
+    }
     // ---- y <- act(2^-(kr + kc) acc + bias) ---------------------------------------------------------------------------
     const long row0 = tt * GH_BM;
 #pragma unroll
@@ -337,19 +346,37 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
   // No exit between a request and its use (hipcc proves a requested tile dead on an exit path and sinks its loads behind
   // everything in between -- seen in the ISA of an earlier form): the tile after the last one clamps to the last row (cached)
   // and is staged into the buffer nobody reads.
+  // TWO PHASES (plain form): a tile's 16 k-steps keep the matrix pipe busy only while BOTH waves of a SIMD are inside them -- 6,421 of
+  // the 13,095 cycles of a tile with the eight waves in lock-step; head, scaling, activation, stores and the barrier (51 %) left it idle
+  // (tools/gemmh_fwd_probe.py).  Waves 0-3 (group A) and 4-7 (group B) now alternate: every wave passes TWO barriers per tile, one
+  // behind its k-steps and one in front of them, and the instances pair up as  X: A has multiplied tile t, B starts to;  Y: B has, A
+  // starts on tile t + 1 -- one group's epilogue and loop head run under the other group's MFMAs.  Who stages what and which buffer is
+  // free when is unchanged: a group's rows of tile t + 1 are staged during ITS k-steps of tile t, both before either group reads them.
+  constexpr bool kTwoPhases = DK == 0 && GH_INTERLEAVE != 0 && NKS == 16 && GH_TWO_PHASES != 0;
+  const bool group_b = wave >= 4;                          // uniform
+  int k3 = 0;                                              // the tile's set of row exponents (two phases: one of three)
   for (long i = 0; i < ntw; ++i) {
     const int buf = (int)(i & 1);
+    if constexpr (kTwoPhases) {
+      if (group_b) gh_barrier_lds();                     // X: group A's k-steps of this tile are done
+    }
     if constexpr (DK == 0 && !(GH_INTERLEAVE != 0 && NKS == 16)) {
       __builtin_amdgcn_sched_barrier(0);
       load_tile(t + G);                                  // on its way from HBM while this tile is multiplied
       __builtin_amdgcn_sched_barrier(0);
     }
     GHP(0)
-    compute(t, buf, t + 2 * G);
+    const int kslot = kTwoPhases ? k3 : buf;
+    if constexpr (kTwoPhases) k3 = k3 == 2 ? 0 : k3 + 1;
+    compute(t, buf, t + 2 * G, kslot, kTwoPhases ? k3 : (buf ^ 1));
     GHP(3)
     if constexpr (DK != 0) load_tile(t + G);             // backward form: gradient and saved output travel together below
     if constexpr (!(DK == 0 && GH_INTERLEAVE != 0 && NKS == 16)) stage(t + G, buf ^ 1);
-    gh_barrier_lds();
+    if constexpr (kTwoPhases) {
+      if (!group_b) gh_barrier_lds();                    // Y: group B's k-steps of this tile are done
+    } else {
+      gh_barrier_lds();
+    }
     GHP(4)
     t += G;
   }
