@@ -353,7 +353,10 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
   // starts on tile t + 1 -- one group's epilogue and loop head run under the other group's MFMAs.  Who stages what and which buffer is
   // free when is unchanged: a group's rows of tile t + 1 are staged during ITS k-steps of tile t, both before either group reads them.
   constexpr bool kTwoPhases = DK == 0 && GH_INTERLEAVE != 0 && NKS == 16 && GH_TWO_PHASES != 0;
-  const bool group_b = wave >= 4;                          // uniform
+#ifndef GH_GROUP_SHIFT
+#define GH_GROUP_SHIFT 2
+#endif
+  const bool group_b = ((wave >> GH_GROUP_SHIFT) & 1) != 0;    // uniform; waves w and w + 4 share a SIMD
   int k3 = 0;                                              // the tile's set of row exponents (two phases: one of three)
   for (long i = 0; i < ntw; ++i) {
     const int buf = (int)(i & 1);
