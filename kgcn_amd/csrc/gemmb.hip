@@ -60,7 +60,7 @@ constexpr int GB_BUF = 2 * GB_PLANE;          // h | l
 // W' k-steps a dX wave keeps in registers (the rest wait in LDS).  The dot form gives two more of them to LDS: its sixteen values of
 // the dot operand are requested at the HEAD of a stage -- a whole multiplication ahead of the epilogue that uses them -- and live in
 // the registers that frees (requested at k-step 5 they were ~1,500 cycles ahead of their use, under the loaded HBM latency:
-// 248 us per launch at 200,000 rows against 196 us of the plain form that moves the same bytes, profiles/r05_w_cfg5_rocprof.txt)
+// 248 us per launch at 200,000 rows against 196 us of the plain form that moves the same bytes, profiles/r05_p_cfg5_rocprof.txt)
 __host__ __device__ constexpr int gb_wreg(bool dot) { return dot ? GB_DOT_WREG : 10; }
 __host__ __device__ constexpr size_t gb_lds(bool dot) { return 2 * (size_t)GB_BUF + 2 * GB_R * 4 + 4 * (size_t)(16 - gb_wreg(dot)) * 2 * 1024; }
 #ifndef GB_DW_ROWS
