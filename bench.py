@@ -208,6 +208,173 @@ def stats(ms):
 
 
 # ---------------------------------------------------------------------------------------------
+# The state of the box: what the shader clock, the package power and the HBM were during the
+# kind of load the timed region puts on the GPU -- so that a reader of the ONE line can tell a slow box from a regression.
+# ---------------------------------------------------------------------------------------------
+class BoxSensors:
+    """Shader clock / memory clock / socket power of one GPU, read from the amdgpu hwmon files (a few microseconds per read)
+    or, where they are absent, through amdsmi.  Every failure ends in `source = None` with the reason kept: never raises."""
+
+    def __init__(self, device_index=0):
+        self.source, self.why, self._files, self._smi = None, [], {}, None
+        try:
+            self._find_hwmon(device_index)
+        except Exception as e:                                    # noqa: BLE001
+            self.why.append("hwmon: %r" % (e,))
+        if self.source is None:
+            try:
+                self._find_amdsmi(device_index)
+            except Exception as e:                                # noqa: BLE001
+                self.why.append("amdsmi: %r" % (e,))
+
+    def _find_hwmon(self, device_index):
+        import glob
+        bus = None
+        try:
+            import torch
+            p = torch.cuda.get_device_properties(device_index)
+            bus = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        except Exception:                                         # noqa: BLE001
+            pass
+        cands = []
+        for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+            dev = os.path.realpath(os.path.join(card, "device"))
+            for hw in glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
+                if os.path.exists(os.path.join(hw, "freq1_input")):
+                    cands.append((dev, hw))
+        if not cands:
+            self.why.append("hwmon: no card with freq1_input under /sys/class/drm")
+            return
+        pick = [c for c in cands if bus and os.path.basename(c[0]).startswith(bus)] or cands[device_index:device_index + 1] or cands[:1]
+        dev, hw = pick[0]
+        files = {"sclk_mhz": (os.path.join(hw, "freq1_input"), 1e-6), "mclk_mhz": (os.path.join(hw, "freq2_input"), 1e-6)}
+        for name in ("power1_average", "power1_input"):
+            if os.path.exists(os.path.join(hw, name)):
+                files["power_w"] = (os.path.join(hw, name), 1e-6)
+                break
+        self._files = {k: v for k, v in files.items() if os.path.exists(v[0])}
+        float(open(self._files["sclk_mhz"][0]).read())            # must be readable now
+        self.source = "hwmon:" + os.path.basename(dev)
+
+    def _find_amdsmi(self, device_index):
+        import amdsmi
+        amdsmi.amdsmi_init()
+        hs = amdsmi.amdsmi_get_processor_handles()
+        h = hs[device_index if device_index < len(hs) else 0]
+        self._smi = (amdsmi, h)
+        if self._read_amdsmi().get("sclk_mhz") is None:
+            self._smi = None
+            self.why.append("amdsmi: no gfx clock")
+            return
+        self.source = "amdsmi"
+
+    def _read_amdsmi(self):
+        amdsmi, h = self._smi
+        out = {}
+        try:
+            c = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)
+            v = c.get("clk", c.get("cur_clk"))
+            out["sclk_mhz"] = float(v) if isinstance(v, (int, float)) else None
+        except Exception:                                         # noqa: BLE001
+            out["sclk_mhz"] = None
+        try:
+            c = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.MEM)
+            v = c.get("clk", c.get("cur_clk"))
+            out["mclk_mhz"] = float(v) if isinstance(v, (int, float)) else None
+        except Exception:                                         # noqa: BLE001
+            pass
+        try:
+            pw = amdsmi.amdsmi_get_power_info(h)
+            for k in ("current_socket_power", "average_socket_power"):
+                if isinstance(pw.get(k), (int, float)):
+                    out["power_w"] = float(pw[k])
+                    break
+        except Exception:                                         # noqa: BLE001
+            pass
+        return out
+
+    def read(self):
+        if self.source is None:
+            return {}
+        if self._smi is not None:
+            return self._read_amdsmi()
+        out = {}
+        for k, (path, scale) in self._files.items():
+            try:
+                out[k] = float(open(path).read()) * scale
+            except (OSError, ValueError):
+                pass
+        return out
+
+
+def _summ(vals):
+    vals = sorted(v for v in vals if v is not None)
+    if not vals:
+        return None
+    return {"median": vals[len(vals) // 2], "min": vals[0], "max": vals[-1], "samples": len(vals)}
+
+
+def box_state(wl, ctx, ms_per_step, want_ms=250.0):
+    """-> dict for `roofline.box`.  (1) The same step queued for ~want_ms more (the clocks and the power of the timed region's
+    load, which itself lasts only tens of milliseconds: too short for the sensors' own averaging) while the host polls the
+    sensors until the last step's event completes; (2) right after it, grid-stride float4 streams of 512 MiB operands through
+    kgcn_hbm_probe in the read : write mixes of the priced kernels (2 : 1 fused backward, 1 : 1 SpMM, read only)."""
+    import torch
+    from kgcn_amd import _lib
+    out = {}
+    try:
+        sensors = BoxSensors(ctx.device.index or 0)
+        n = int(min(2000, max(20, want_ms / max(ms_per_step, 1e-3))))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        samples = []
+        e0.record()
+        for i in range(n):
+            wl.step()
+            if i % 8 == 7 and sensors.source:                     # the launch queue is ahead of the device: the GPU is under load here
+                samples.append(sensors.read())
+        e1.record()
+        while sensors.source and not e1.query():
+            samples.append(sensors.read())
+            time.sleep(0.002)
+        torch.cuda.synchronize()
+        out["sustained"] = {"steps": n, "ms_per_step": e0.elapsed_time(e1) / n,
+                            "sclk_mhz": _summ([x.get("sclk_mhz") for x in samples]),
+                            "mclk_mhz": _summ([x.get("mclk_mhz") for x in samples]),
+                            "power_w": _summ([x.get("power_w") for x in samples]),
+                            "sensors": sensors.source, "sensors_unavailable": None if sensors.source else sensors.why}
+    except Exception as e:                                        # noqa: BLE001  (a measurement aid never fails the bench line)
+        out["sustained"] = {"error": repr(e)}
+    try:
+        nbytes = 512 << 20
+        a = torch.empty(nbytes // 4, device=ctx.device).fill_(1.0)
+        a2 = torch.empty_like(a).fill_(2.0)
+        b = torch.empty_like(a)
+        moved = {0: 2 * nbytes, 1: 3 * nbytes, 2: nbytes}
+        names = {0: "copy_1r1w", 1: "add_2r1w", 2: "read_only"}
+        probe = {}
+        for mix in (1, 0, 2):
+            call = lambda: _lib.check(_lib.lib.kgcn_hbm_probe(mix, _lib.ptr(a), _lib.ptr(a2), _lib.ptr(b), nbytes,
+                                                               _lib.current_stream()), "kgcn_hbm_probe")
+            for _ in range(3):
+                call()
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(41)]
+            evs[0].record()
+            for k in range(40):
+                call()
+                evs[k + 1].record()
+            torch.cuda.synchronize()
+            ms = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(40))
+            probe[names[mix]] = {"GB/s": moved[mix] / (ms[20] * 1e-3) / 1e9, "median_ms": ms[20],
+                                 "frac_of_peak": moved[mix] / (ms[20] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        probe["note"] = "kgcn_hbm_probe, 512 MiB per operand (beyond the 256 MiB last-level cache), 40 launches each, right after the sustained loop"
+        out["hbm_probe"] = probe
+        del a, a2, b
+    except Exception as e:                                        # noqa: BLE001
+        out["hbm_probe"] = {"error": repr(e)}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
 # CPU baseline: the C restatement (oracle/kgcn_ref.c) on the host cores -- reported, never shipped
 # ---------------------------------------------------------------------------------------------
 def cpu_baseline(wl, budget_s=12.0, sample=20000):
@@ -1093,6 +1260,10 @@ def main(argv=None):
     elapsed = ctx.max_over_ranks(local_elapsed)
     per_rank = ctx.gather_over_ranks(local_elapsed / args.steps * 1e3)
 
+    box = None
+    if ctx.rank == 0 and ctx.on_gpu and not args.dry and not args.profile:
+        box = box_state(wl, ctx, elapsed / args.steps * 1e3)      # first thing after the timed region: same load, same clocks
+
     hipgraph = None
     if args.graph and ctx.on_gpu and args.config == "cfg2" and not args.dry:
         hipgraph = wl.hipgraph_replay(args.steps, args.warmup)
@@ -1118,6 +1289,17 @@ def main(argv=None):
                                "target for this path"}}
     if ctx.rank == 0:
         config, roofline, extra = wl.report(ev)
+        if box is not None:
+            roofline["box"] = box
+            pr = box.get("hbm_probe", {})
+            mix = "add_2r1w" if args.config == "cfg2" and not args.unfused else "copy_1r1w"
+            if roofline.get("achieved") and isinstance(pr.get(mix), dict):
+                roofline["frac_of_probe_rate"] = {"value": roofline["achieved"] / pr[mix]["GB/s"], "probe": mix,
+                                                  "note": "achieved / what this box's HBM streamed in the kernel's read : write mix"}
+            sp = roofline.get("spmm_kernel")
+            if sp and isinstance(pr.get("copy_1r1w"), dict):
+                sp["forward"]["frac_of_probe_rate"] = sp["forward"]["achieved"] / pr["copy_1r1w"]["GB/s"]
+                sp["adjoint"]["frac_of_probe_rate"] = sp["adjoint"]["achieved"] / pr["copy_1r1w"]["GB/s"]
         config["parallelism"] = "dp%d" % ctx.world
         config["collective"] = None if not ctx.dist_on else \
             "one %s all-reduce of the flat gradient bucket (%d floats) per step over %d ranks" \

@@ -632,6 +632,9 @@ int kgcn_gcn_stack_bwd_f32(const kgcn_csr_batch* at, const float* x, const int32
  * kgcn_reduce_defer(1) (PROCESS-wide -- frameworks run backward nodes on worker threads --; returns the previous setting) makes those calls QUEUE that second stage instead: dw /
  * dbias are then NOT valid, and the workspaces must stay untouched, until kgcn_reduce_flush(stream) has added all queued
  * partials in ONE launch (same order of additions: bit-identical results).  kgcn_reduce_pending(): queued second stages.
+ * Deferring entry points: kgcn_dense_wgrad*_f32, kgcn_dense_bwd*_f32, kgcn_graphconv_bwd_f32 and -- with training == 0 only
+ * (learning phase 0: d gamma / d beta are not read inside the call) -- kgcn_graph_bn_bwd_f32 / kgcn_graph_bn_bwd_dact_f32, whose
+ * dgamma / dbeta buffers must likewise stay allocated until the flush.
  * The reference has no counterpart (TF sums gradients inside its executor, core.py:124); used by kgcn_amd.train. */
 int kgcn_reduce_defer(int32_t on);
 int kgcn_reduce_pending(void);
@@ -643,6 +646,12 @@ int kgcn_reduce_flush(void* stream);
  * wgradn / wgradx, 2.5 PF / 6), 1: v_mfma_f32_32x32x2_f32 kernels (157.3 TF), 0: no matrix pipe (read-out layers).
  * kind 0: y = act(x W + b) / dx = dy W^T (din = contraction width), 1: dx with the activation derivative, 2: weight gradient. */
 int kgcn_dense_mfma_products(int32_t kind, int64_t m, int32_t din, int32_t dout);
+
+/* Measurement aid (bench.py: `roofline.hbm_probe`, SURVEY 8(d) "report both nominal and achievable"): one grid-stride float4
+ * stream over `bytes` bytes per operand in the read : write mix of the kernel being priced, so that a bench line carries what
+ * THIS box's HBM delivers right after the timed region.  mix 0: b = a (1 : 1, the batched SpMM's mix); 1: b = a + a2 (2 : 1, the
+ * fused backward's mix); 2: read a only (b receives at most 16 bytes); 3: write b only.  No reference counterpart. */
+int kgcn_hbm_probe(int32_t mix, const void* a, const void* a2, void* b, int64_t bytes, void* stream);
 
 /* dW, dbias of act(x W + b) when the layer INPUT needs no gradient (first layer of a model): d pre-activation = dy * act'(act_out)
  * is formed while the weight-gradient GEMM stages the gradient rows, so it never exists in HBM.  Wide layers only

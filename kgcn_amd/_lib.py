@@ -220,6 +220,7 @@ SIGNATURES = {
     "kgcn_ragged_gather_bwd_f32": (ctypes.c_int, [c_f32p, c_i32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32p,
                                                   ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_dense_mfma_products": (ctypes.c_int, [c_i32, c_i64, c_i32, c_i32]),
+    "kgcn_hbm_probe": (ctypes.c_int, [c_i32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_reduce_defer": (ctypes.c_int, [c_i32]),
     "kgcn_reduce_pending": (ctypes.c_int, []),
     "kgcn_reduce_flush": (ctypes.c_int, [ctypes.c_void_p]),

@@ -156,9 +156,46 @@ static unsigned grid_for(long total_threads) {
   return (unsigned)blocks;
 }
 
+// Streaming probe of the box's HBM (measurement aid of bench.py: "slow box" vs "regression"): grid-stride float4 streams in the
+// read : write mix of the priced kernel.  mix 0: b = a (1 : 1, the SpMM's mix); 1: b = a + a2 (2 : 1, the fused backward's mix);
+// 2: read only; 3: write only.
+template <int MIX>
+__global__ __launch_bounds__(256) void hbm_probe_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ a2,
+                                                         f32x4* __restrict__ b, size_t n) {
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 one = {1.f, 2.f, 3.f, 4.f};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    if constexpr (MIX == 0) b[i] = a[i];
+    else if constexpr (MIX == 1) b[i] = a[i] + a2[i];
+    else if constexpr (MIX == 2) s += a[i];
+    else b[i] = one;
+  }
+  if constexpr (MIX == 2) {
+    if (s[0] + s[1] + s[2] + s[3] == 123.456f) b[0] = s;
+  }
+}
+
 }  // namespace kgcn
 
 using namespace kgcn;
+
+extern "C" int kgcn_hbm_probe(int32_t mix, const void* a, const void* a2, void* b, int64_t bytes, void* stream) {
+  if (mix < 0 || mix > 3) return fail("kgcn_hbm_probe: mix %d", mix);
+  if (bytes <= 0 || (bytes & 15)) return fail("kgcn_hbm_probe: bytes=%lld (a positive multiple of 16)", (long long)bytes);
+  if (!b || (mix != 3 && !a) || (mix == 1 && !a2)) return fail("kgcn_hbm_probe: NULL operand");
+  if (!aligned16(a) || !aligned16(a2) || !aligned16(b)) return fail("kgcn_hbm_probe: operands must be 16-byte aligned");
+  const size_t n = (size_t)bytes / 16;
+  const dim3 grid((unsigned)kNumCU * 32), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const f32x4* pa = static_cast<const f32x4*>(a);
+  const f32x4* pa2 = static_cast<const f32x4*>(a2);
+  f32x4* pb = static_cast<f32x4*>(b);
+  if (mix == 0) hipLaunchKernelGGL(hbm_probe_kernel<0>, grid, block, 0, s, pa, pa2, pb, n);
+  else if (mix == 1) hipLaunchKernelGGL(hbm_probe_kernel<1>, grid, block, 0, s, pa, pa2, pb, n);
+  else if (mix == 2) hipLaunchKernelGGL(hbm_probe_kernel<2>, grid, block, 0, s, pa, pa2, pb, n);
+  else hipLaunchKernelGGL(hbm_probe_kernel<3>, grid, block, 0, s, pa, pa2, pb, n);
+  return check_launch("hbm_probe_kernel");
+}
 
 extern "C" int kgcn_abi_version(void) { return KGCN_HIP_ABI_VERSION; }
 extern "C" int64_t kgcn_csr_batch_size(void) { return (int64_t)sizeof(kgcn_csr_batch); }

@@ -942,6 +942,9 @@ int launch_spmm_multi(const kgcn_csr_batch* a, int nch, const float* rhs, long r
       // the slices of a graph as the waves of one workgroup: its CSR staged once (spmm_slices_kernel)
       const size_t lds2 = (size_t)plan.slices * K * 32 * 4 + (size_t)a->max_nnz_per_graph * 8 + (size_t)(M + 1) * 4;
       const int2* cvp = reinterpret_cast<const int2*>(a->cv);
+      // the tile plan budgets its LDS per SLICE workgroup; this kernel holds all slices of the graph in one: beyond the
+      // 64 KiB a launch gets without an attribute (K around 121..150 at d = 128) the slice-per-workgroup kernel runs instead
+      if (lds2 > 64 * 1024) goto tile_route;
       if (plan.slices == 2)
         hipLaunchKernelGGL(spmm_slices_kernel<2>, dim3((unsigned)T), dim3(128), lds2, stream, a->rowptr, cvp, a->max_nnz_per_graph, rhs,
                            rhs_ld, rhs_gs, out, out_ld, out_gs, M, K, beta, self_scale, act, aout, dact);
@@ -950,6 +953,7 @@ int launch_spmm_multi(const kgcn_csr_batch* a, int nch, const float* rhs, long r
                            rhs_ld, rhs_gs, out, out_ld, out_gs, M, K, beta, self_scale, act, aout, dact);
       return check_launch("spmm_slices_kernel");
     }
+  tile_route:
 #endif
     size_t lds = 0;
     for (int c = 0; c < nch; ++c) lds += tile_chan_bytes(M, K, ds, a[c].max_nnz_per_graph);

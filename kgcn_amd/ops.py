@@ -1669,12 +1669,19 @@ class _GraphBN(torch.autograd.Function):
         dbeta = torch.empty_like(dgamma)
         wsb = lib.kgcn_graph_bn_workspace_bytes(D)
         wsp = torch.empty((wsb // 4 + 1,), device=x.device, dtype=torch.float32)
-        with _no_deferral_unless(ctx.defer_ok and dx is not None and _single_use(*ctx.defer_ids)):
+        # d gamma / d beta receive their second stage at the flush: both must still be alive then.  autograd drops the
+        # gradient of an input that does not require one as soon as backward returns (frozen affine parameters, a
+        # detached gamma of the inference call), so deferral needs BOTH to be wanted -- and the two results are kept
+        # until the flush next to the workspace either way.
+        want_affine = bool(ctx.needs_input_grad[1] and ctx.needs_input_grad[2])
+        with _no_deferral_unless(ctx.defer_ok and want_affine and dx is not None and _single_use(*ctx.defer_ids)):
             check(lib.kgcn_graph_bn_bwd_dact_f32(ptr(x), ptr(g), ptr(yact) if ctx.act else None, ctx.act, T, N, D,
                                                  ptr(ctx.enabled), ptr(mean), ptr(var), ptr(gamma), ctx.eps, int(ctx.training),
                                                  ptr(dx), ptr(dgamma), ptr(dbeta), ptr(wsp), wsb, current_stream()),
                   "kgcn_graph_bn_bwd_dact_f32")
             _keep_until_flush(wsp)
+            _keep_until_flush(dgamma)
+            _keep_until_flush(dbeta)
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 

@@ -85,17 +85,55 @@ def record_accuracy(what, err, tol, mag, written_tol=None):
 # (fixed-order reductions, seeded inputs), so the measured errors reproduce; a comparison the table does not know (a new test,
 # a new parametrisation) runs on its written tolerance until the table is regenerated.
 _BOUNDS = None
+_RATCHET = {"applied": 0, "unratcheted": 0, "state": "off"}
+
+
+def fingerprint():
+    """what the measured errors depend on beside the sources: the torch build (RNG / initialisers), the HIP runtime the
+    library was compiled against, the device and its CU count (route choices and partial counts follow kNumCU)."""
+    import torch
+    fp = {"torch": torch.__version__, "hip": str(getattr(torch.version, "hip", None))}
+    if torch.cuda.is_available():
+        p = torch.cuda.get_device_properties(0)
+        fp["device"] = p.name
+        fp["compute_units"] = int(p.multi_processor_count)
+        fp["arch"] = str(getattr(p, "gcnArchName", "")).split(":")[0]
+    return fp
+
+
+def _load_bounds():
+    global _BOUNDS
+    import json
+    path = os.path.join(GOLDEN, "accuracy_bounds.json")
+    _BOUNDS = {}
+    if os.environ.get("KGCN_NO_RATCHET") or not os.path.exists(path):
+        return
+    table = json.load(open(path))
+    made_on = table.get("fingerprint")
+    here = fingerprint()
+    if made_on is not None and made_on != here:
+        # another torch / ROCm / device: the recorded errors are not this box's; the written tolerances decide alone
+        _RATCHET["state"] = "fingerprint mismatch (table %s, here %s): written tolerances only" % (made_on, here)
+        import warnings
+        warnings.warn("accuracy ratchet not applied: " + _RATCHET["state"])
+        return
+    _RATCHET["state"] = "applied (fingerprint %s)" % ("matches" if made_on is not None else "not recorded in the table")
+    _BOUNDS = table["bounds"]
 
 
 def accuracy_bound(what, mag):
     """-> absolute bound for this comparison from the ratchet table, or None."""
-    global _BOUNDS
     if _BOUNDS is None:
-        import json
-        path = os.path.join(GOLDEN, "accuracy_bounds.json")
-        _BOUNDS = json.load(open(path))["bounds"] if os.path.exists(path) and not os.environ.get("KGCN_NO_RATCHET") else {}
+        _load_bounds()
     rel = _BOUNDS.get(current_test(), {}).get(what or "-")
+    _RATCHET["applied" if rel is not None else "unratcheted"] += 1
     return None if rel is None else rel * max(1.0, mag)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if _RATCHET["applied"] + _RATCHET["unratcheted"]:
+        terminalreporter.write_line("accuracy ratchet: %s; %d close() comparisons bounded by the table, %d ran on their written "
+                                    "tolerance alone (no table entry)" % (_RATCHET["state"], _RATCHET["applied"], _RATCHET["unratcheted"]))
 
 
 def pytest_sessionfinish(session, exitstatus):
@@ -106,5 +144,7 @@ def pytest_sessionfinish(session, exitstatus):
     try:
         os.makedirs(out, exist_ok=True)
         json.dump(ACCURACY, open(os.path.join(out, "accuracy_tests.json"), "w"), indent=1, sort_keys=True)
+        json.dump({"fingerprint": fingerprint(), "ratchet": _RATCHET}, open(os.path.join(out, "accuracy_fingerprint.json"), "w"),
+                  indent=1, sort_keys=True)
     except OSError:
         pass

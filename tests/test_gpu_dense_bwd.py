@@ -114,18 +114,19 @@ def _layer(rng, m, din, dout, act):
 
 @pytest.mark.parametrize("act", [None, "sigmoid", "relu", "tanh"])
 @pytest.mark.parametrize("m,din,dout,ld_pad", [(16500, 256, 256, 0), (16384 + 31, 256, 256, 4), (16500, 192, 256, 0),
-                                               (40000, 256, 256, 0)])
+                                               (40000, 256, 256, 0), (16500, 132, 256, 0), (16411, 200, 256, 4)])
 def test_one_pass_backward_against_fp64(act, m, din, dout, ld_pad):
     """every activation code; ragged last stage (m % 32 != 0), fewer stages than two per workgroup pair, padded leading
-    dimensions (nothing outside the [m, din] block of dx may be touched), an input width below 256 (clamped column tiles)."""
+    dimensions (nothing outside the [m, din] block of dx may be touched), input widths below 256 (clamped column tiles; 132
+    and 200 are what the aggregate-first route passes: F + 1 rounded up to a multiple of 4, partial last column tile)."""
     rng = np.random.default_rng(m + din + dout + len(str(act)))
     x, g, a, w = _layer(rng, m, din, dout, act)
     got = _call(x, g, a, w, act, ld_pad=ld_pad)
     _check(x, g, a, w, act, got, what="one-pass %s %d %d->%d" % (act, m, din, dout))
 
 
-@pytest.mark.parametrize("act", ["relu", "sigmoid"])
-@pytest.mark.parametrize("with_rows", [True, False])
+@pytest.mark.parametrize("act,with_rows", [("relu", True), ("relu", False), ("sigmoid", True), ("sigmoid", False),
+                                           ("tanh", False)])
 def test_one_pass_backward_with_the_read_out_gradient(act, with_rows):
     """the layer output was read out by GraphGather (example_model/model_gin.py:45-60): the gradient of node row r is
     grad[r] + d pooled[r / N] -- or the broadcast alone when the output was not passed on (grad = NULL)."""

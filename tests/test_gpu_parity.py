@@ -741,6 +741,58 @@ def test_graph_batch_normalization_fused_activation(act, phase):
     close(layer.beta.grad, dbeta, rel=1e-5, atol=1e-4, what="dbeta")
 
 
+@pytest.mark.parametrize("frozen", ["gamma", "both"])
+def test_inference_bn_backward_with_frozen_affine_inside_a_deferral_scope(frozen):
+    """with learning phase 0 the BN backward queues the second stage of d gamma / d beta.  When gamma or
+    beta does not require a gradient autograd drops that result as soon as backward() returns, and the flush would add D floats
+    into whatever the caching allocator put there next.  The call must not defer then: a canary tensor allocated right after
+    the backward (same size class as the dropped gradient) stays untouched by the flush, and dx / the wanted gradient are the
+    ones of the plain call."""
+    from kgcn_amd import layers, ops
+    rng = np.random.default_rng(77)
+    T, N, D = 64, 10, 50
+    x = rng.standard_normal((T, N, D)).astype(np.float32)
+    g = rng.standard_normal((T, N, D)).astype(np.float32)
+    en = rng.integers(0, N + 1, T).astype(np.int32)
+    layer = layers.GraphBatchNormalization(learning_phase=0)
+    layer.build(x.shape, dev())
+    with torch.no_grad():
+        layer.gamma.copy_(t32(rng.uniform(0.5, 1.5, D).astype(np.float32)))
+        layer.moving_variance.copy_(t32(rng.uniform(0.5, 2.0, D).astype(np.float32)))
+    layer.gamma.requires_grad_(False)
+    if frozen == "both":
+        layer.beta.requires_grad_(False)
+    ten = torch.from_numpy(en).to(dev())
+
+    def run(defer):
+        layer.beta.grad = None
+        tx = t32(x).requires_grad_(True)
+        y = layer(tx, enabled_node_nums=ten)
+        cost = (y * t32(g)).sum()
+        if defer:
+            with ops.deferred_reductions(root=cost):
+                cost.backward()
+                canaries = [torch.full((D,), 7.0, device=dev()) for _ in range(8)]
+                assert ops.lib.kgcn_reduce_pending() == 0, "the BN backward deferred a gradient nobody keeps"
+            torch.cuda.synchronize()
+            for c in canaries:
+                assert bool((c == 7.0).all())
+        else:
+            cost.backward()
+        torch.cuda.synchronize()
+        return tx.grad.clone(), None if layer.beta.grad is None else layer.beta.grad.clone()
+
+    dx0, db0 = run(False)
+    dx1, db1 = run(True)
+    assert torch.equal(dx0, dx1)
+    assert (db0 is None) == (db1 is None) == (frozen == "both")
+    if db0 is not None:
+        assert torch.equal(db0, db1)
+    gam = layer.gamma.detach().cpu().numpy()
+    ref_dx = K.graph_bn_bwd(x, gam, layer.moving_mean.cpu().numpy(), layer.moving_variance.cpu().numpy(), g, en, training=False)[0]
+    close(dx1, ref_dx, rel=1e-5, what="dx")
+
+
 @pytest.mark.parametrize("channels,D", [("plain", 3), ("split", 50), ("norm", 64)])
 def test_graph_maxpooling(channels, D):
     """kgcn/layers.py:122-153 (row N3): values on a coarse grid so that ties -- between entries and

@@ -35,7 +35,9 @@ def main():
                 loose_after += 1
             worst.append((new_tol / mag1, test, what, e["max_abs_err"], new_tol, e["ref_max_abs"]))
     worst.sort(reverse=True)
-    out = {"made_from": os.path.basename(sys.argv[1]), "tests_with_comparisons": len(rec), "comparisons": checks,
+    fpath = os.path.join(os.path.dirname(os.path.abspath(sys.argv[1])), "accuracy_fingerprint.json")
+    fp = json.load(open(fpath))["fingerprint"] if os.path.exists(fpath) else None     # tests/conftest.py applies the table only on a match
+    out = {"made_from": os.path.basename(sys.argv[1]), "fingerprint": fp, "tests_with_comparisons": len(rec), "comparisons": checks,
            "rule": "relative bound = max(10 x max err / max(1, |ref|), 2^-22); close() uses min(written tolerance, bound x max(1, |ref|))",
            "bounds": bounds}
     json.dump(out, open(os.path.join(ROOT, "tests", "golden", "accuracy_bounds.json"), "w"), indent=0, sort_keys=True)

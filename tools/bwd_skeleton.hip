@@ -1,22 +1,23 @@
-// Memory skeleton of the fused GraphConv backward (development tool, GPU box only): persistent waves that move
-// exactly the HBM bytes of graphconv_bwd_full_kernel -- per graph two [32 x 64] fp32 tiles in (x, g), a CSR
-// slice in, one [32 x 64] tile out -- with NO contraction / aggregation work, so what it reaches is the
-// ceiling the memory system gives this access pattern (2:1 read:write, 8 KiB tiles, T graphs strided over the
-// waves).  The store pattern is the variable:
-//   0  32 x global_store_dword   (MFMA C layout of dX = dFW W^T: lane = column, 2 x 128 B per instruction)
-//   1   8 x global_store_dwordx4 (whole rows: 1 KiB contiguous per instruction)
-//   2   8 x global_store_dwordx4 (C layout of dX^T = W dFW^T: lane = row, 32 B segments at 256 B stride)
-//   3   as 1, nontemporal
-//   4   no stores (read side alone)
-// usage: bwd_skeleton [graphs] [waves per CU: 4 or 8]
+// Memory skeleton of the fused GraphConv backward (development tool, GPU box only): kernels that move exactly the HBM bytes of
+// graphconv_bwd_planes_kernel -- per graph two [32 x 64] fp32 tiles in (x, g), a CSR slice in, one [32 x 64] tile out -- with NO
+// contraction / aggregation work, so what they reach is the ceiling the memory system gives this byte pattern (2 : 1 read : write,
+// 8 KiB tiles).  Round 2 measured the persistent form at 4 and 8 waves per CU (profiles/r02_microbench_bwd_memory_skeleton.txt:
+// 0.472-0.484 ms whatever the occupancy); round 6 adds the questions the two-wave-roles kernel raises:
+//   P   persistent waves, one graph per wave, prefetch depth 1 / 2, 4 / 8 / 12 waves per CU           (the shipped structure)
+//   PX  as P with x loaded in the dW A-fragment layout of the shipped kernel (16 x 8-byte loads, two 256-byte rows each)
+//   H   persistent PAIRS: two waves share a graph (wave A: g + CSR in, dX out; wave B: x in), 8 waves per CU   (the two-role form)
+//   N   non-persistent, one wave per graph, no prefetch, as many waves per CU as registers allow       (the SpMM's structure)
+// usage: bwd_skeleton [graphs]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
+// MODE 0: x as 8 x dwordx4 rows;  1: x in the fragment layout (16 x dwordx2)
 template <int MODE, int DEPTH>
-__global__ __launch_bounds__(256) void skel(const float* __restrict__ x, const float* __restrict__ g,
-                                            const f4* __restrict__ cv, float* __restrict__ dx, int T) {
+__global__ __launch_bounds__(256) void skel_p(const float* __restrict__ x, const float* __restrict__ g,
+                                              const f4* __restrict__ cv, float* __restrict__ dx, int T) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nw = gridDim.x * (blockDim.x >> 6);
   const int t0 = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -26,10 +27,22 @@ __global__ __launch_bounds__(256) void skel(const float* __restrict__ x, const f
   f4 xr[DEPTH][8], gr[DEPTH][8], cr[DEPTH][2];
   auto issue = [&](int k, int slot) {
     const int t = t0 + (k < cnt ? k : cnt - 1) * nw;
-    const f4* xs = reinterpret_cast<const f4*>(x + (long)t * 2048);
     const f4* gs = reinterpret_cast<const f4*>(g + (long)t * 2048);
+    if constexpr (MODE == 0) {
+      const f4* xs = reinterpret_cast<const f4*>(x + (long)t * 2048);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { xr[slot][q] = xs[lane + 64 * q]; gr[slot][q] = gs[lane + 64 * q]; }
+      for (int q = 0; q < 8; ++q) xr[slot][q] = xs[lane + 64 * q];
+    } else {
+      const float* xb = x + (long)t * 2048 + (8 * hi) * 64 + 2 * li;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const f2 v = *reinterpret_cast<const f2*>((q >> 3 ? xb + 16 * 64 : xb) + (q & 7) * 64);
+        xr[slot][q >> 1][2 * (q & 1)] = v[0];
+        xr[slot][q >> 1][2 * (q & 1) + 1] = v[1];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) gr[slot][q] = gs[lane + 64 * q];
     cr[slot][0] = cv[(long)t * 80 + lane];
     cr[slot][1] = lane < 16 ? cv[(long)t * 80 + 64 + lane] : f4{0, 0, 0, 0};
   };
@@ -45,64 +58,130 @@ __global__ __launch_bounds__(256) void skel(const float* __restrict__ x, const f
       for (int q = 0; q < 8; ++q) o[q] = xr[d][q] * gr[d][q] + cr[d][q & 1];
       issue(i + d + DEPTH, d);
       float* dst = dx + (long)t * 2048;
-      if constexpr (MODE == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-          dst[row * 64 + li] = o[r >> 2][r & 3];
-          dst[row * 64 + 32 + li] = o[4 + (r >> 2)][r & 3];
-        }
-      } else if constexpr (MODE == 1) {
+      for (int q = 0; q < 8; ++q)          // the C layout of dX^T = W dFW^T: lane = row, 32-byte segments at 256-byte stride
+        *reinterpret_cast<f4*>(dst + li * 64 + (q >> 2) * 32 + 8 * (q & 3) + 4 * hi) = o[q];
+    }
+  }
+}
+
+// pairs: wave 2p moves g + CSR in and dX out, wave 2p+1 moves x in (and hands a checksum over through LDS so that nothing is dead)
+template <int DEPTH>
+__global__ __launch_bounds__(512) void skel_h(const float* __restrict__ x, const float* __restrict__ g,
+                                              const f4* __restrict__ cv, float* __restrict__ dx, int T) {
+  __shared__ float hand[8][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pair = wave >> 1, role = wave & 1;
+  const int npairs = gridDim.x * 4;
+  const int t0 = blockIdx.x * 4 + pair;
+  const int cnt_max = (T - 1) / npairs + 1;
+  const int cnt = t0 < T ? (T - 1 - t0) / npairs + 1 : 0;
+  const int li = lane & 31, hi = lane >> 5;
+  f4 r[DEPTH][8], cr[DEPTH][2];
+  auto issue = [&](int k, int slot) {
+    const int kk = k < cnt ? k : (cnt > 0 ? cnt - 1 : 0);
+    const int t = cnt > 0 ? t0 + kk * npairs : 0;
+    const f4* s = reinterpret_cast<const f4*>((role ? x : g) + (long)t * 2048);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) reinterpret_cast<f4*>(dst)[lane + 64 * q] = o[q];
-      } else if constexpr (MODE == 2) {
+    for (int q = 0; q < 8; ++q) r[slot][q] = s[lane + 64 * q];
+    if (!role) {
+      cr[slot][0] = cv[(long)t * 80 + lane];
+      cr[slot][1] = lane < 16 ? cv[(long)t * 80 + 64 + lane] : f4{0, 0, 0, 0};
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) issue(d, d);
+  for (int i = 0; i < cnt_max; i += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const bool live = i + d < cnt;
+      f4 o[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = r[d][q];
+      if (role) {
+        f4 s = o[0] + o[1] + o[2] + o[3] + o[4] + o[5] + o[6] + o[7];
+        hand[wave][lane] = s[0] + s[1] + s[2] + s[3];
+      }
+      issue(i + d + DEPTH, d);
+      __syncthreads();                       // one workgroup barrier per graph, as the two-role kernel would pay
+      if (!role && live) {
+        const float hv = hand[wave + 1][lane];
+        float* dst = dx + (long)(t0 + (i + d) * npairs) * 2048;
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-          *reinterpret_cast<f4*>(dst + li * 64 + (q >> 2) * 32 + 8 * (q & 3) + 4 * hi) = o[q];
-      } else if constexpr (MODE == 3) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) __builtin_nontemporal_store(o[q], reinterpret_cast<f4*>(dst) + lane + 64 * q);
-      } else {
-        f4 s = o[0] + o[1] + o[2] + o[3] + o[4] + o[5] + o[6] + o[7];
-        if (s[0] + s[1] + s[2] + s[3] == 123.456f) dst[lane] = 1.f;
+          *reinterpret_cast<f4*>(dst + li * 64 + (q >> 2) * 32 + 8 * (q & 3) + 4 * hi) = o[q] * hv + cr[d][q & 1];
       }
     }
   }
 }
 
-template <int MODE, int DEPTH>
-static float run(const float* x, const float* g, const f4* cv, float* dx, int T, int wpc) {
+// non-persistent: one wave per graph, everything requested at once
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void skel_n(const float* __restrict__ x, const float* __restrict__ g,
+                                                   const f4* __restrict__ cv, float* __restrict__ dx, int T) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.x * WPB + wave;
+  if (t >= T) return;
+  const int li = lane & 31, hi = lane >> 5;
+  const f4* xs = reinterpret_cast<const f4*>(x + (long)t * 2048);
+  const f4* gs = reinterpret_cast<const f4*>(g + (long)t * 2048);
+  f4 xr[8], gr[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { xr[q] = xs[lane + 64 * q]; gr[q] = gs[lane + 64 * q]; }
+  const f4 c0 = cv[(long)t * 80 + lane];
+  const f4 c1 = lane < 16 ? cv[(long)t * 80 + 64 + lane] : f4{0, 0, 0, 0};
+  float* dst = dx + (long)t * 2048;
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    *reinterpret_cast<f4*>(dst + li * 64 + (q >> 2) * 32 + 8 * (q & 3) + 4 * hi) = xr[q] * gr[q] + ((q & 1) ? c1 : c0);
+}
+
+static float* X; static float* G; static float* DX; static f4* CV; static int T;
+template <typename L>
+static float timeit(L launch) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  const int blocks = 256 * wpc / 4;
-  for (int w = 0; w < 5; ++w) hipLaunchKernelGGL((skel<MODE, DEPTH>), dim3(blocks), dim3(256), 0, 0, x, g, cv, dx, T);
+  for (int w = 0; w < 5; ++w) launch();
   hipEventRecord(e0);
-  for (int r = 0; r < 20; ++r) hipLaunchKernelGGL((skel<MODE, DEPTH>), dim3(blocks), dim3(256), 0, 0, x, g, cv, dx, T);
+  for (int r = 0; r < 20; ++r) launch();
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   return ms / 20;
 }
+static void line(const char* name, float ms) {
+  const double bytes = (double)T * (8192 * 3 + 932);           // the kernel's ALGORITHMIC bytes (the skeleton reads 1,280 B of CSR)
+  printf("  %-64s %.3f ms  %.0f GB/s  %.3f of 8 TB/s\n", name, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0);
+  fflush(stdout);
+}
 
 int main(int argc, char** argv) {
-  const int T = argc > 1 ? atoi(argv[1]) : 100000;
-  float *x, *g, *dx; f4* cv;
+  T = argc > 1 ? atoi(argv[1]) : 100000;
   const size_t tb = (size_t)T * 8192;
-  hipMalloc(&x, tb); hipMalloc(&g, tb); hipMalloc(&dx, tb); hipMalloc(&cv, (size_t)T * 1280);
-  hipMemset(x, 0x11, tb); hipMemset(g, 0x22, tb); hipMemset(cv, 0, (size_t)T * 1280);
-  const double rd = (double)T * (8192 * 2 + 1280), wr = (double)T * 8192;
-  const char* names[5] = {"32 x dword (C layout)", "8 x dwordx4 rows (1 KiB)", "8 x dwordx4, 32 B segments",
-                          "8 x dwordx4 rows, nontemporal", "no stores"};
-  for (int wpc : {4, 8}) {
-    printf("waves per CU = %d, graphs = %d\n", wpc, T);
-    float ms[5] = {run<0, 2>(x, g, cv, dx, T, wpc), run<1, 2>(x, g, cv, dx, T, wpc), run<2, 2>(x, g, cv, dx, T, wpc),
-                   run<3, 2>(x, g, cv, dx, T, wpc), run<4, 2>(x, g, cv, dx, T, wpc)};
-    for (int m = 0; m < 5; ++m)
-      printf("  depth 2  %-34s %.3f ms  %.0f GB/s\n", names[m], ms[m], (rd + (m == 4 ? 0 : wr)) / ms[m] / 1e6);
-    float m1[2] = {run<1, 1>(x, g, cv, dx, T, wpc), run<0, 1>(x, g, cv, dx, T, wpc)};
-    printf("  depth 1  %-34s %.3f ms  %.0f GB/s\n", names[1], m1[0], (rd + wr) / m1[0] / 1e6);
-    printf("  depth 1  %-34s %.3f ms  %.0f GB/s\n", names[0], m1[1], (rd + wr) / m1[1] / 1e6);
+  hipMalloc(&X, tb); hipMalloc(&G, tb); hipMalloc(&DX, tb); hipMalloc(&CV, (size_t)T * 1280);
+  hipMemset(X, 0x11, tb); hipMemset(G, 0x22, tb); hipMemset(CV, 0, (size_t)T * 1280);
+  printf("graphs = %d, algorithmic bytes per graph 25,508\n", T);
+  char nm[128];
+  for (int rep = 0; rep < 2; ++rep) {
+    for (int wpc : {4, 8, 12}) {
+      const int blocks = 256 * wpc / 4;
+      snprintf(nm, sizeof nm, "P  persistent, depth 2, %2d waves/CU", wpc);
+      line(nm, timeit([&] { hipLaunchKernelGGL((skel_p<0, 2>), dim3(blocks), dim3(256), 0, 0, X, G, CV, DX, T); }));
+      snprintf(nm, sizeof nm, "P  persistent, depth 1, %2d waves/CU", wpc);
+      line(nm, timeit([&] { hipLaunchKernelGGL((skel_p<0, 1>), dim3(blocks), dim3(256), 0, 0, X, G, CV, DX, T); }));
+      snprintf(nm, sizeof nm, "PX persistent, depth 1, x in fragment layout, %2d waves/CU", wpc);
+      line(nm, timeit([&] { hipLaunchKernelGGL((skel_p<1, 1>), dim3(blocks), dim3(256), 0, 0, X, G, CV, DX, T); }));
+    }
+    line("H  pairs (g+CSR+dX | x), depth 1, 8 waves/CU, barrier per graph",
+         timeit([&] { hipLaunchKernelGGL((skel_h<1>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("H  pairs (g+CSR+dX | x), depth 2, 8 waves/CU, barrier per graph",
+         timeit([&] { hipLaunchKernelGGL((skel_h<2>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("H  pairs, depth 2, 16 waves/CU",
+         timeit([&] { hipLaunchKernelGGL((skel_h<2>), dim3(512), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("N  one wave per graph, 64-thread workgroups",
+         timeit([&] { hipLaunchKernelGGL((skel_n<1>), dim3(T), dim3(64), 0, 0, X, G, CV, DX, T); }));
+    line("N  one wave per graph, 256-thread workgroups",
+         timeit([&] { hipLaunchKernelGGL((skel_n<4>), dim3((T + 3) / 4), dim3(256), 0, 0, X, G, CV, DX, T); }));
   }
   return 0;
 }
