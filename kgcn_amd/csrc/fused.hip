@@ -1461,6 +1461,420 @@ __global__ __launch_bounds__(256, 1) void graphconv_bwd_planes_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward, FULL shape, "pairs" version (round 6): TWO waves share one graph slot -- the planes kernel's LDS
+// (plane buffers, gather tile, CSR slices: ~36 KB per graph in flight) now serves a PAIR, eight waves per CU, two per SIMD, 256
+// registers each, in two roles:
+//   wave A ("dX")  g + CSR in (one iteration ahead), the adjoint aggregation dFW(i+1) = A^T g(i+1) -> three bf16 planes + dbias,
+//                  dX(i)^T = W dFW(i)^T (48 MFMAs: W p1 resident, p2 / p3 from the workgroup's table), the dX stores
+//   wave B ("dW")  x in (fragment layout, one iteration ahead), its 3-way split into resident fragments, dW += x(i)^T dFW(i)
+//                  (48 MFMAs against the planes read transposed), the four dW accumulator tiles
+// and ONE workgroup barrier per graph (s_waitcnt lgkmcnt(0) + s_barrier: vector-memory operations stay in flight across it): at the
+// barrier that ends iteration i, planes[(i+1)&1] hold dFW(i+1) for both roles and nobody reads planes[i&1] any more.
+// Why (tools/bwd_skeleton.hip, profiles/r06_microbench_bwd_memory_skeleton.txt): the memory system streams this byte pattern at
+// 0.71 of 8 TB/s when the two read streams come from different waves that meet at a barrier (H: 0.447 ms per 100,000 graphs),
+// at 0.66-0.685 when every wave moves its graph alone (P / PX: 0.466-0.48 ms, the planes kernel's structure, whatever the
+// occupancy) -- and a lone wave per SIMD has nobody to fill its issue slots (SQ_WAIT_INST_ANY 0.33 of the wave cycles).
+// With two instruction streams per SIMD the phases are NOT interleaved by hand any more: A aggregates (vector ALU + LDS) while
+// B multiplies, A multiplies while B splits x.
+// Iteration counts are uniform (every wave passes the same barriers): the launcher takes this kernel for T >= 2 pairs-in-flight
+// graphs only, so a pair owns cnt_max or cnt_max - 1 >= 2 graphs; the one iteration a short pair lacks is skipped under uniform
+// branches that hold no vector-memory instruction.
+// ------------------------------------------------------------------------------------------------
+constexpr int BP_PAIRS = 4;
+#ifndef KGCN_BWD_PAIRS
+#define KGCN_BWD_PAIRS 1        // 0: the one-wave-per-graph planes kernel for every batch
+#endif
+#ifndef KGCN_BP_ROLE_BIT
+#define KGCN_BP_ROLE_BIT 2      // 2: pair = wave & 3, role = wave >> 2 (the two roles of a pair share a SIMD); 0: pair = wave >> 1, role = wave & 1
+#endif
+__device__ __forceinline__ void bp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
+    const int* __restrict__ slots_t, const int* __restrict__ gptr_t, const int2* __restrict__ cv_t,
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ g,
+    float* __restrict__ dx, float* __restrict__ part_dw, float* __restrict__ part_db, int T,
+    int max_nnz) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int N = FN, D = FD;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int pair = KGCN_BP_ROLE_BIT == 2 ? (wave & 3) : (wave >> 1);
+  const int role = KGCN_BP_ROLE_BIT == 2 ? (wave >> 2) : (wave & 1);
+  const int li = lane & 31, hi = lane >> 5;
+  const int sub = lane >> 4, cl = lane & 15;
+  static_assert(BWD_WPB_ == BP_PAIRS, "one graph slot of the planes layout per pair");
+  unsigned char* sl = smem + (size_t)pair * 2 * DFWP_BYTES;
+  const unsigned pl0 = lds_off(sl);                               // dFW planes, buffer 0 (buffer 1: + DFWP_BYTES)
+  if (pl0 & 4095u) __builtin_trap();                              // XOR addressing needs 4 KiB aligned plane buffers
+  const unsigned wtab = lds_off(smem + PLANES_ALL) + (unsigned)lane * 16;
+  float* gt = reinterpret_cast<float*>(smem + PLANES_ALL + WTAB_BYTES +
+                                       (size_t)pair * bwd_planes_wave_bytes(max_nnz));   // [FN+1][FD], row FN stays zero
+  int2* ecv0 = reinterpret_cast<int2*>(gt + (FN + 1) * FD);
+  const size_t ecv_stride = ecv_bytes(max_nnz) / 8;
+  int* tab0 = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(ecv0) + 2 * ecv_bytes(max_nnz));
+
+  const int npairs = gridDim.x * BP_PAIRS;
+  const int t0 = blockIdx.x * BP_PAIRS + pair;
+  const int cnt_max = (T - 1) / npairs + 1;                       // iterations (= barriers) of EVERY wave; >= 2 (launcher)
+  const int cntw = (T - 1 - t0) / npairs + 1;                     // graphs of this pair: cnt_max or cnt_max - 1
+  const int tl = t0 + (cntw - 1) * npairs;                        // its last graph
+  const bool whole = cntw == cnt_max;                             // uniform
+  auto gidx = [&](int k) { const int t = t0 + k * npairs; return t < tl ? t : tl; };  // clamped
+  PROBE_DECL
+
+  f32x16 dw00, dw01, dw10, dw11;                                  // role B
+  f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};                             // role A
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dw00[r] = 0.f; dw01[r] = 0.f; dw10[r] = 0.f; dw11[r] = 0.f; }
+
+  if (role == 0) {
+    // =========================================== role A ===========================================================
+    for (int i = lane; i < D; i += 64) gt[FN * FD + i] = 0.f;
+    const unsigned h_e = (unsigned)cl >> 3;
+    const unsigned lanexor = (h_e << 8) | (h_e << 6) | ((((unsigned)cl & 7) >> 1) << 4) | (((unsigned)cl & 1) << 3);
+    unsigned LB[4];                                               // row reads: lane (li, hi): features 16 ks + 8 hi .. + 7 of node li
+    {
+      const unsigned R = (unsigned)li >> 2, a = (unsigned)li & 3;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        LB[ks] = pl0 + ((R << 9) | ((a ^ (unsigned)(ks >> 1)) << 6) |
+                        (((2 * (unsigned)(ks & 1) + (unsigned)hi) ^ (R & 3)) << 4));
+    }
+    // A fragments of dX^T = W dFW^T (as in the planes kernel): p1 resident, p2 / p3 in the workgroup's table
+    u32x4 WF1[2][4];
+    static_for<8>([&](auto c) __attribute__((always_inline)) {
+      constexpr int nt = decltype(c)::value >> 2, ks = decltype(c)::value & 3;
+      const float* src = w + (32 * nt + li) * D + 16 * ks + 8 * hi;
+      const f32x4 lo = ldv4(src), hi4 = ldv4(src + 4);
+      const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+      Frag3 f;
+      split8(v, f);
+      WF1[nt][ks] = f.p1;
+      if (pair == (decltype(c)::value >> 1)) {
+        *(KGCN_LDS u32x4*)(uintptr_t)(wtab + (0 * 8 + nt * 4 + ks) * 1024) = f.p2;
+        *(KGCN_LDS u32x4*)(uintptr_t)(wtab + (1 * 8 + nt * 4 + ks) * 1024) = f.p3;
+      }
+    });
+    __syncthreads();                                              // barrier 0: the W table
+
+    const float* srcl = gt + cl * 4;
+    TileRegs gpf;
+    CsrRegs cpf;
+    MetaRegs m_a, m_b;   // m_a: graph whose g / CSR are in flight; m_b: the one after it
+    auto emit_to = [&](unsigned lx, const PlaneSteps& q, bool live) __attribute__((always_inline)) {
+      unsigned q1, q2, q3, r1, r2, r3;
+      split_pair(q.a[0], q.a[1], q1, q2, q3);
+      split_pair(q.a[2], q.a[3], r1, r2, r3);
+      const unsigned ad = q.rw ^ lx;
+      lds_st64(ad, q1, r1);
+      lds_st64(ad + PL_BYTES, q2, r2);
+      lds_st64(ad + 2 * PL_BYTES, q3, r3);
+      if (live) add4(dbacc, q.a);                                 // (uniform)
+    };
+    // adjoint aggregation of the graph in the gather tile -> planes at `plane_off`, two passes in flight
+    auto aggregate = [&](const int2* ecv, const int* tab, unsigned plane_off, bool live) __attribute__((always_inline)) {
+      const unsigned lx = lanexor | (pl0 + plane_off);
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        PlaneSteps qa, qb;
+        qa.slot(tab, 8 * gq + sub);
+        qb.slot(tab, 8 * gq + 4 + sub);
+        qa.q0 = *reinterpret_cast<const i32x4*>(ecv + qa.s);
+        qa.q1 = *reinterpret_cast<const i32x4*>(ecv + qa.s + 2);
+        qb.q0 = *reinterpret_cast<const i32x4*>(ecv + qb.s);
+        qb.q1 = *reinterpret_cast<const i32x4*>(ecv + qb.s + 2);
+        qa.x0 = ldv4(srcl + qa.q0.x * FD); qa.x1 = ldv4(srcl + qa.q0.z * FD);
+        qa.x2 = ldv4(srcl + qa.q1.x * FD); qa.x3 = ldv4(srcl + qa.q1.z * FD);
+        qb.x0 = ldv4(srcl + qb.q0.x * FD); qb.x1 = ldv4(srcl + qb.q0.z * FD);
+        qb.x2 = ldv4(srcl + qb.q1.x * FD); qb.x3 = ldv4(srcl + qb.q1.z * FD);
+        {
+          const float v = __int_as_float(qa.q0.y);
+          qa.a[0] = v * qa.x0[0]; qa.a[1] = v * qa.x0[1]; qa.a[2] = v * qa.x0[2]; qa.a[3] = v * qa.x0[3];
+          fma4(qa.a, __int_as_float(qa.q0.w), qa.x1);
+          fma4(qa.a, __int_as_float(qa.q1.y), qa.x2);
+          fma4(qa.a, __int_as_float(qa.q1.w), qa.x3);
+        }
+        {
+          const float v = __int_as_float(qb.q0.y);
+          qb.a[0] = v * qb.x0[0]; qb.a[1] = v * qb.x0[1]; qb.a[2] = v * qb.x0[2]; qb.a[3] = v * qb.x0[3];
+          fma4(qb.a, __int_as_float(qb.q0.w), qb.x1);
+          fma4(qb.a, __int_as_float(qb.q1.y), qb.x2);
+          fma4(qb.a, __int_as_float(qb.q1.w), qb.x3);
+        }
+        qa.tail(ecv, srcl);
+        qb.tail(ecv, srcl);
+        emit_to(lx, qa, live);
+        emit_to(lx, qb, live);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    // ---- prologue: graph 0 aggregated into planes 0; g(1), CSR(1) in LDS; g(2), CSR(2) in flight ---------------
+    issue_meta(m_a, slots_t, gptr_t, gidx(0), N, lane);
+    int base_a = meta_base(m_a), cnt_a = meta_cnt(m_a);
+    issue_tile<true>(gpf, g + (long)gidx(0) * N * D, 512, lane);
+    issue_cv(cpf, cv_t, base_a, cnt_a, lane);
+    issue_meta(m_b, slots_t, gptr_t, gidx(1), N, lane);
+    land_tile<true>(gpf, gt, FD, 512, 16, lane);
+    land_csr(cpf, ecv0, tab0, cv_t, slot_plane_word(m_a.slot), base_a, cnt_a, N, lane);
+    wave_sync();
+    m_a = m_b;
+    base_a = meta_base(m_a);
+    cnt_a = meta_cnt(m_a);
+    issue_tile<true>(gpf, g + (long)gidx(1) * N * D, 512, lane);
+    issue_cv(cpf, cv_t, base_a, cnt_a, lane);
+    issue_meta(m_b, slots_t, gptr_t, gidx(2), N, lane);
+    aggregate(ecv0, tab0, 0u, true);
+    wave_sync();
+    land_tile<true>(gpf, gt, FD, 512, 16, lane);
+    land_csr(cpf, ecv0 + ecv_stride, tab0 + (FN + 4), cv_t, slot_plane_word(m_a.slot), base_a, cnt_a, N, lane);
+    m_a = m_b;
+    base_a = meta_base(m_a);
+    cnt_a = meta_cnt(m_a);
+    issue_tile<true>(gpf, g + (long)gidx(2) * N * D, 512, lane);
+    issue_cv(cpf, cv_t, base_a, cnt_a, lane);
+    issue_meta(m_b, slots_t, gptr_t, gidx(3), N, lane);
+    bp_barrier();                                                 // barrier 1: dFW(0) in planes 0
+
+    f32x16 c0, c1;
+    // g(i+2), CSR(i+2): registers -> LDS (the aggregation of graph i+1 has read the gather tile: same wave, in order);
+    // g(i+3), CSR(i+3), slots(i+4) requested -- a whole iteration ahead of their landing
+    auto land_and_prefetch = [&](int i, int cur) __attribute__((always_inline)) {
+      const float* gsrc = g + (long)gidx(i + 3) * N * D + 4 * lane;
+      int2* ecv_c = ecv0 + cur * ecv_stride;                      // CSR(i) is dead: receives CSR(i+2)
+      int* tab_c = tab0 + cur * (FN + 4);
+      static_for<8>([&](auto qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value;
+        stv4(gt + 4 * lane + q * 256, gpf.v[q]);
+        gpf.v[q] = ldv4((q >> 2 ? gsrc + 1024 : gsrc) + (q & 3) * 256);
+      });
+      land_csr(cpf, ecv_c, tab_c, cv_t, slot_plane_word(m_a.slot), base_a, cnt_a, N, lane);
+      const int base_n = meta_base(m_b), cnt_n = meta_cnt(m_b);
+      issue_cv(cpf, cv_t, base_n, cnt_n, lane);
+      // a REAL register move (see the planes kernel: a plain `m_a = m_b` becomes a phi whose copy lands behind the new load)
+      asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+                   : "=&v"(m_a.slot), "=&v"(m_a.gp) : "v"(m_b.slot), "v"(m_b.gp));
+      issue_meta(m_b, slots_t, gptr_t, gidx(i + 4), N, lane);
+      base_a = base_n;
+      cnt_a = cnt_n;
+    };
+    // dX(i)^T = W dFW(i)^T out of planes `cur`, then its 16-byte stores
+    auto dx_of = [&](int i, int cur) __attribute__((always_inline)) {
+      const unsigned cur_off = cur ? (unsigned)DFWP_BYTES : 0u;
+      u32x4 FA[4][3];            // dFW(i) fragments [k-step][piece]
+      u32x4 WL[4][2][2];         // W p2 / p3 fragments [k-step][piece - 1][tile]
+      auto read_fa = [&](auto ksc) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ksc)::value;
+        static_for<3>([&](auto pc) __attribute__((always_inline)) {
+          constexpr int p = decltype(pc)::value;
+          FA[ks][p] = lds_ld128(LB[ks] + cur_off + ((ks >> 1) << 8) + p * PL_BYTES);
+        });
+        static_for<4>([&](auto vc) __attribute__((always_inline)) {
+          constexpr int pc = decltype(vc)::value >> 1, nt = decltype(vc)::value & 1;
+          WL[ks][pc][nt] = lds_ld128(wtab + (pc * 8 + nt * 4 + ks) * 1024);
+        });
+      };
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+      read_fa(std::integral_constant<int, 0>{});
+      static_for<48>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value, ks = m / 12, pr = (m % 12) >> 1, nt = m & 1;
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+        constexpr int wl = PB[pr] == 0 ? 0 : PB[pr] - 1;
+        const u32x4 wv = PB[pr] == 0 ? WF1[nt][ks] : WL[ks][wl][nt];
+        if constexpr (nt == 0) c0 = mfma_bf16(wv, FA[ks][PA[pr]], c0);
+        else c1 = mfma_bf16(wv, FA[ks][PA[pr]], c1);
+        if constexpr (m % 12 == 1 && ks < 3) {                     // one k-step ahead
+          read_fa(std::integral_constant<int, ks + 1>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      float* dxp = dx + (long)gidx(i) * N * D + li * D + 4 * hi;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v0 = {c0[4 * q], c0[4 * q + 1], c0[4 * q + 2], c0[4 * q + 3]};
+        const f32x4 v1 = {c1[4 * q], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]};
+        stv4(dxp + 8 * q, v0);
+        stv4(dxp + 32 + 8 * q, v1);
+      }
+    };
+
+    int cur = 0;
+    PROBE(0)
+    for (int i = 0; i < cnt_max - 2; ++i) {                       // graphs i and i + 1 exist for every pair
+      aggregate(ecv0 + (cur ^ 1) * ecv_stride, tab0 + (cur ^ 1) * (FN + 4), cur ? 0u : (unsigned)DFWP_BYTES, true);
+      PROBE(1)
+      wave_sync();
+      land_and_prefetch(i, cur);
+      PROBE(2)
+      dx_of(i, cur);
+      PROBE(3)
+      bp_barrier();
+      PROBE(4)
+      cur ^= 1;
+    }
+    // iteration cnt_max - 2: graph cnt_max - 1 exists for a whole pair only
+    if (whole) aggregate(ecv0 + (cur ^ 1) * ecv_stride, tab0 + (cur ^ 1) * (FN + 4), cur ? 0u : (unsigned)DFWP_BYTES, true);
+    wave_sync();
+    dx_of(cnt_max - 2, cur);
+    bp_barrier();
+    cur ^= 1;
+    // iteration cnt_max - 1
+    if (whole) dx_of(cnt_max - 1, cur);
+    PROBE(5)
+  } else {
+    // =========================================== role B ===========================================================
+    // transpose reads: lane l addresses 4 features (16 nb + 4 a4 ..) of node 16 ks + 8 hi + 4 rd + jj
+    const unsigned nb = ((unsigned)lane >> 4) & 1, jj = ((unsigned)lane >> 2) & 3, a4 = (unsigned)lane & 3;
+    unsigned TRB[2][2];                                            // [feature half nt][read rd]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int rd = 0; rd < 2; ++rd)
+        TRB[nt][rd] = pl0 + (((unsigned)hi << 10) | ((jj ^ (unsigned)nt) << 6) |
+                             (((2 * nb + (a4 >> 1)) ^ (2 * (unsigned)hi + (unsigned)rd)) << 4) | ((a4 & 1) << 3));
+    const int xlane = (8 * hi) * D + 2 * li;                      // lane share of the x fragment addresses (floats)
+    f32x2 xr[16];        // x tile in flight in the A-fragment layout of dW (see the planes kernel)
+    float sr0[16], ss0[16], sr1[16], sv0[16], sv1[16];
+    u32x4 XF[2][2][3];   // x(i) fragments [k-step][feature half mt][piece]
+    auto load_x = [&](const float* xb, auto qc) __attribute__((always_inline)) {
+      constexpr int q = decltype(qc)::value;
+      xr[q] = *reinterpret_cast<const f32x2*>((q >> 3 ? xb + 16 * D : xb) + (q & 7) * D);
+    };
+    auto split_x_half = [&](auto uc, auto hc) __attribute__((always_inline)) {
+      constexpr int u = decltype(uc)::value, hh = decltype(hc)::value, P = u >> 1, mt = u & 1, ks = P >> 2, J = P & 3;
+      const unsigned msk = 0xffff0000u;
+      if constexpr (hh == 0) {
+        float v0, v1;                                             // (the tile in flight lives in the accumulator file: planes kernel)
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v0) : "a"(xr[8 * ks + 2 * J][mt]));
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v1) : "a"(xr[8 * ks + 2 * J + 1][mt]));
+        sv0[u] = v0; sv1[u] = v1;
+        const float h0 = __uint_as_float(__float_as_uint(v0) & msk), h1 = __uint_as_float(__float_as_uint(v1) & msk);
+        sr0[u] = v0 - h0;
+        sr1[u] = v1 - h1;
+        ss0[u] = sr0[u] - __uint_as_float(__float_as_uint(sr0[u]) & msk);
+      } else {
+        const float v0 = sv0[u], v1 = sv1[u];
+        const float s1 = sr1[u] - __uint_as_float(__float_as_uint(sr1[u]) & msk);
+        XF[ks][mt][0][J] = __builtin_amdgcn_perm(__float_as_uint(v1), __float_as_uint(v0), 0x07060302u);
+        XF[ks][mt][1][J] = __builtin_amdgcn_perm(__float_as_uint(sr1[u]), __float_as_uint(sr0[u]), 0x07060302u);
+        XF[ks][mt][2][J] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(ss0[u]), 0x07060302u);
+      }
+    };
+    // x(k) -> fragments; every node pair's two registers take x(k + 1) as soon as both of their tiles are split
+    auto split_and_reload = [&](int knext) __attribute__((always_inline)) {
+      const float* xb = x + (long)gidx(knext) * N * D + xlane;
+      static_for<8>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int P = decltype(pc)::value, ks = P >> 2, J = P & 3;
+        split_x_half(std::integral_constant<int, 2 * P>{}, std::integral_constant<int, 0>{});
+        split_x_half(std::integral_constant<int, 2 * P + 1>{}, std::integral_constant<int, 0>{});
+        split_x_half(std::integral_constant<int, 2 * P>{}, std::integral_constant<int, 1>{});
+        split_x_half(std::integral_constant<int, 2 * P + 1>{}, std::integral_constant<int, 1>{});
+        load_x(xb, std::integral_constant<int, 8 * ks + 2 * J>{});
+        load_x(xb, std::integral_constant<int, 8 * ks + 2 * J + 1>{});
+      });
+    };
+    auto read_bf = [&](u32x4 (&BF)[2][3], auto ksc, auto ntc, auto pcc, unsigned buf_off) __attribute__((always_inline)) {
+      constexpr int ks = decltype(ksc)::value, nt = decltype(ntc)::value, pc = decltype(pcc)::value;
+      const u32x2 r0 = lds_ld_tr16(TRB[nt][0] + buf_off + (ks << 11) + (nt << 8) + pc * PL_BYTES);
+      const u32x2 r1 = lds_ld_tr16(TRB[nt][1] + buf_off + (ks << 11) + (1 << 9) + (nt << 8) + pc * PL_BYTES);
+      BF[nt][pc][0] = r0[0]; BF[nt][pc][1] = r0[1]; BF[nt][pc][2] = r1[0]; BF[nt][pc][3] = r1[1];
+    };
+    // dW += x(i)^T dFW(i) out of planes `cur`
+    auto dw_of = [&](int cur) __attribute__((always_inline)) {
+      const unsigned cur_off = cur ? (unsigned)DFWP_BYTES : 0u;
+      u32x4 BF0[2][3], BF1[2][3];
+      static_for<6>([&](auto c) __attribute__((always_inline)) {
+        constexpr int v = decltype(c)::value;
+        read_bf(BF0, std::integral_constant<int, 0>{}, std::integral_constant<int, v / 3>{},
+                std::integral_constant<int, v % 3>{}, cur_off);
+      });
+      static_for<2>([&](auto ksc) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ksc)::value;
+        static_for<24>([&](auto mc) __attribute__((always_inline)) {
+          constexpr int m = decltype(mc)::value, pr = m >> 2, tile = m & 3;
+          constexpr int PA0[6] = {2, 1, 0, 1, 0, 0}, PB0[6] = {0, 1, 2, 0, 1, 0};
+          constexpr int PA1[6] = {0, 1, 2, 0, 1, 0}, PB1[6] = {2, 1, 0, 1, 0, 0};
+          constexpr int pa = ks == 0 ? PA0[pr] : PA1[pr], pb = ks == 0 ? PB0[pr] : PB1[pr];
+          const u32x4 av = XF[ks][tile >> 1][pa];
+          const u32x4 bv = ks == 0 ? BF0[tile & 1][pb] : BF1[tile & 1][pb];
+          if constexpr (tile == 0) dw00 = mfma_bf16(av, bv, dw00);
+          else if constexpr (tile == 1) dw01 = mfma_bf16(av, bv, dw01);
+          else if constexpr (tile == 2) dw10 = mfma_bf16(av, bv, dw10);
+          else dw11 = mfma_bf16(av, bv, dw11);
+          if constexpr (ks == 0 && (m == 12 || m == 13 || m == 20 || m == 21 || m == 22 || m == 23)) {
+            constexpr int pc = m < 14 ? 2 : m < 22 ? 1 : 0;   // fragments of k-step 1: p3, p2, p1 (one tile per MFMA)
+            read_bf(BF1, std::integral_constant<int, 1>{}, std::integral_constant<int, (m & 1)>{},
+                    std::integral_constant<int, pc>{}, cur_off);
+          }
+        });
+      });
+    };
+
+    __syncthreads();                                              // barrier 0: the W table (role A)
+    // ---- prologue: x(0) -> fragments, x(1) in flight ---------------------------------------------------------------
+    {
+      const float* xb = x + (long)gidx(0) * N * D + xlane;
+      static_for<16>([&](auto qc) __attribute__((always_inline)) { load_x(xb, qc); });
+    }
+    split_and_reload(1);
+    bp_barrier();                                                 // barrier 1: dFW(0) in planes 0
+
+    int cur = 0;
+    PROBE(0)
+    for (int i = 0; i < cnt_max - 1; ++i) {                       // graph i exists for every pair
+      dw_of(cur);
+      PROBE(1)
+      split_and_reload(i + 2);                                    // x(i+1) -> fragments, x(i+2) requested
+      PROBE(2)
+      bp_barrier();
+      PROBE(4)
+      cur ^= 1;
+    }
+    if (whole) dw_of(cur);                                        // iteration cnt_max - 1
+    PROBE(5)
+  }
+  PROBE_FLUSH(blockIdx.x * 8 + wave)
+
+  // ---- reduce the workgroup's pairs through LDS; one partial per workgroup ---------------------
+  __syncthreads();
+  float* park = reinterpret_cast<float*>(sl);   // the pair's plane buffers: 24,576 B >= (4096 + 64) floats
+  if (role == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      park[(2 * row) * FD + li] = dw00[r];            // row `row` of M tile mt is input feature 2 row + mt
+      park[(2 * row) * FD + 32 + li] = dw01[r];
+      park[(2 * row + 1) * FD + li] = dw10[r];
+      park[(2 * row + 1) * FD + 32 + li] = dw11[r];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = dbacc[j];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      dbacc[j] = v;
+    }
+    if (lane < 16) stv4(park + FD * FD + lane * 4, dbacc);
+  }
+  __syncthreads();
+  const size_t slice_f = 2 * DFWP_BYTES / 4;
+  const float* slice0 = reinterpret_cast<const float*>(smem);
+  float* pw = part_dw + (long)blockIdx.x * D * D;
+  for (int i = tid; i < D * D; i += blockDim.x) {
+    float s = 0.f;
+    for (int wv = 0; wv < BP_PAIRS; ++wv) s += slice0[wv * slice_f + i];
+    pw[i] = s;
+  }
+  if (tid < D) {
+    float s = 0.f;
+    for (int wv = 0; wv < BP_PAIRS; ++wv) s += slice0[wv * slice_f + D * D + tid];
+    part_db[(long)blockIdx.x * D + tid] = s;
+  }
+}
+
 // waves per block that fit the LDS budget (0 = does not fit at all)
 static int fused_wpb(size_t per_wave, size_t shared_bytes) {
   long fit = ((long)kLdsBytes - (long)shared_bytes) / (long)per_wave;
@@ -1627,6 +2041,8 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
   const size_t per = full ? full_lds / BWD_FULL_WPB : bwd_slice(at->max_nnz_per_graph * pack);
   const int wpb = full ? BWD_FULL_WPB : fused_wpb(per, FD * FD * 4);
   int blocks = fused_grid((at->num_graphs + pack - 1) / pack, wpb);
+  // two waves per graph slot (graphconv_bwd_pairs_kernel): every pair must own at least two graphs (uniform barrier counts)
+  const bool pairs = KGCN_BWD_PAIRS != 0 && full && at->num_graphs >= 2 * BP_PAIRS * blocks;
   // development (the non-persistent form, measured): KGCN_BWD_GRID_MULT = k launches k workgroups per CU slot,
   // each walking 1 / k of the graphs with its own pipeline fill, W' split and dW partial (k x 256 partials in the second stage) --
   // the form the kernel's LDS footprint (one 4-wave workgroup per CU) allows.  profiles/r05_headline_experiments.txt
@@ -1642,13 +2058,18 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
   static thread_local bool attr_set = false;
   if (!attr_set) {
     allow_big_lds(graphconv_bwd_planes_kernel);
+    allow_big_lds(graphconv_bwd_pairs_kernel);
     allow_big_lds(graphconv_bwd_kernel<2>);
     allow_big_lds(graphconv_bwd_kernel<1>);
     allow_big_lds(graphconv_bwd_kernel<0>);
     attr_set = true;
   }
   const int2* cv = reinterpret_cast<const int2*>(at->cv);
-  if (full)
+  if (pairs)
+    hipLaunchKernelGGL(graphconv_bwd_pairs_kernel, dim3(blocks), dim3(512), lds, s, at->slots,
+                       at->graph_ptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
+                       at->max_nnz_per_graph);
+  else if (full)
     hipLaunchKernelGGL(graphconv_bwd_planes_kernel, dim3(blocks), dim3(64 * wpb), lds, s, at->slots,
                        at->graph_ptr, cv, x, w, dout_grad, dx, part_dw, part_db, at->num_graphs,
                        at->max_nnz_per_graph);

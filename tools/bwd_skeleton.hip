@@ -15,18 +15,19 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 // MODE 0: x as 8 x dwordx4 rows;  1: x in the fragment layout (16 x dwordx2)
-template <int MODE, int DEPTH>
-__global__ __launch_bounds__(256) void skel_p(const float* __restrict__ x, const float* __restrict__ g,
+template <int MODE, int DEPTH, int BAR = 0, int NT = 256>
+__global__ __launch_bounds__(NT) void skel_p(const float* __restrict__ x, const float* __restrict__ g,
                                               const f4* __restrict__ cv, float* __restrict__ dx, int T) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nw = gridDim.x * (blockDim.x >> 6);
   const int t0 = blockIdx.x * (blockDim.x >> 6) + wave;
-  if (t0 >= T) return;
-  const int cnt = (T - 1 - t0) / nw + 1;
+  if (BAR == 0 && t0 >= T) return;
+  const int cnt = t0 < T ? (T - 1 - t0) / nw + 1 : 0;
+  const int cnt_max = BAR ? (T - 1) / nw + 1 : cnt;
   const int li = lane & 31, hi = lane >> 5;
   f4 xr[DEPTH][8], gr[DEPTH][8], cr[DEPTH][2];
   auto issue = [&](int k, int slot) {
-    const int t = t0 + (k < cnt ? k : cnt - 1) * nw;
+    const int t = cnt > 0 ? t0 + (k < cnt ? k : cnt - 1) * nw : 0;
     const f4* gs = reinterpret_cast<const f4*>(g + (long)t * 2048);
     if constexpr (MODE == 0) {
       const f4* xs = reinterpret_cast<const f4*>(x + (long)t * 2048);
@@ -48,25 +49,28 @@ __global__ __launch_bounds__(256) void skel_p(const float* __restrict__ x, const
   };
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) issue(d, d);
-  for (int i = 0; i < cnt; i += DEPTH) {
+  for (int i = 0; i < cnt_max; i += DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-      if (i + d >= cnt) break;
+      if (BAR == 0 && i + d >= cnt) break;
       const int t = t0 + (i + d) * nw;
       f4 o[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) o[q] = xr[d][q] * gr[d][q] + cr[d][q & 1];
       issue(i + d + DEPTH, d);
+      if constexpr (BAR != 0) __syncthreads();
       float* dst = dx + (long)t * 2048;
+      if (i + d < cnt) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q)          // the C layout of dX^T = W dFW^T: lane = row, 32-byte segments at 256-byte stride
-        *reinterpret_cast<f4*>(dst + li * 64 + (q >> 2) * 32 + 8 * (q & 3) + 4 * hi) = o[q];
+        for (int q = 0; q < 8; ++q)          // the C layout of dX^T = W dFW^T: lane = row, 32-byte segments at 256-byte stride
+          *reinterpret_cast<f4*>(dst + li * 64 + (q >> 2) * 32 + 8 * (q & 3) + 4 * hi) = o[q];
+      }
     }
   }
 }
 
 // pairs: wave 2p moves g + CSR in and dX out, wave 2p+1 moves x in (and hands a checksum over through LDS so that nothing is dead)
-template <int DEPTH>
+template <int DEPTH, int BAR = 1>
 __global__ __launch_bounds__(512) void skel_h(const float* __restrict__ x, const float* __restrict__ g,
                                               const f4* __restrict__ cv, float* __restrict__ dx, int T) {
   __shared__ float hand[8][64];
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(512) void skel_h(const float* __restrict__ x, const
         hand[wave][lane] = s[0] + s[1] + s[2] + s[3];
       }
       issue(i + d + DEPTH, d);
-      __syncthreads();                       // one workgroup barrier per graph, as the two-role kernel would pay
+      if constexpr (BAR != 0) __syncthreads();   // one workgroup barrier per graph, as the two-role kernel would pay
       if (!role && live) {
         const float hv = hand[wave + 1][lane];
         float* dst = dx + (long)(t0 + (i + d) * npairs) * 2048;
@@ -135,6 +139,59 @@ __global__ __launch_bounds__(64 * WPB) void skel_n(const float* __restrict__ x, 
     *reinterpret_cast<f4*>(dst + li * 64 + (q >> 2) * 32 + 8 * (q & 3) + 4 * hi) = xr[q] * gr[q] + ((q & 1) ? c1 : c0);
 }
 
+// forward: x + CSR in, out tile out (17,316 algorithmic bytes per graph).  ROLE 0: every wave reads and writes its graph;
+// ROLE 1: pairs -- wave A reads x + CSR, wave B writes the tile (handed over through LDS), one barrier per graph
+template <int ROLE, int BAR, int NT>
+__global__ __launch_bounds__(NT) void skel_f(const float* __restrict__ x, const f4* __restrict__ cv, float* __restrict__ out, int T) {
+  __shared__ f4 tile[NT / 64][8][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int units = ROLE ? NT / 128 : NT / 64, unit = ROLE ? wave >> 1 : wave, role = ROLE ? wave & 1 : 0;
+  const int nu = gridDim.x * units;
+  const int t0 = blockIdx.x * units + unit;
+  const int cnt = t0 < T ? (T - 1 - t0) / nu + 1 : 0;
+  const int cnt_max = (T - 1) / nu + 1;
+  f4 r[8], c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+  auto issue = [&](int k) {
+    const int t = cnt > 0 ? t0 + (k < cnt ? k : cnt - 1) * nu : 0;
+    if (ROLE == 0 || role == 0) {
+      const f4* s = reinterpret_cast<const f4*>(x + (long)t * 2048);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) r[q] = s[lane + 64 * q];
+      c0 = cv[(long)t * 80 + lane];
+      c1 = lane < 16 ? cv[(long)t * 80 + 64 + lane] : f4{0, 0, 0, 0};
+    }
+  };
+  issue(0);
+  for (int i = 0; i < (BAR || ROLE ? cnt_max : cnt); ++i) {
+    f4 o[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = r[q] + ((q & 1) ? c1 : c0);
+    if constexpr (ROLE != 0) {
+      if (role == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tile[wave][q][lane] = o[q];
+      }
+    }
+    issue(i + 1);
+    if constexpr (BAR != 0 || ROLE != 0) __syncthreads();
+    if (i < cnt) {
+      f4* dst = reinterpret_cast<f4*>(out + (long)(t0 + i * nu) * 2048);
+      if constexpr (ROLE != 0) {
+        if (role == 1) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) dst[lane + 64 * q] = tile[wave - 1][q][lane];
+        }
+        __syncthreads();
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dst[lane + 64 * q] = o[q];
+      }
+    } else if (ROLE != 0) {
+      __syncthreads();
+    }
+  }
+}
+
 static float* X; static float* G; static float* DX; static f4* CV; static int T;
 template <typename L>
 static float timeit(L launch) {
@@ -148,6 +205,11 @@ static float timeit(L launch) {
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   return ms / 20;
+}
+static void linef(const char* name, float ms) {
+  const double bytes = (double)T * (8192 * 2 + 932);
+  printf("  %-64s %.3f ms  %.0f GB/s  %.3f of 8 TB/s\n", name, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0);
+  fflush(stdout);
 }
 static void line(const char* name, float ms) {
   const double bytes = (double)T * (8192 * 3 + 932);           // the kernel's ALGORITHMIC bytes (the skeleton reads 1,280 B of CSR)
@@ -178,6 +240,28 @@ int main(int argc, char** argv) {
          timeit([&] { hipLaunchKernelGGL((skel_h<2>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
     line("H  pairs, depth 2, 16 waves/CU",
          timeit([&] { hipLaunchKernelGGL((skel_h<2>), dim3(512), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("H  pairs, depth 1, 8 waves/CU, NO barrier",
+         timeit([&] { hipLaunchKernelGGL((skel_h<1, 0>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("PB persistent, depth 1, 4 waves/CU, barrier per graph",
+         timeit([&] { hipLaunchKernelGGL((skel_p<0, 1, 1, 256>), dim3(256), dim3(256), 0, 0, X, G, CV, DX, T); }));
+    line("PB persistent, depth 1, x in fragment layout, 4 waves/CU, barrier per graph",
+         timeit([&] { hipLaunchKernelGGL((skel_p<1, 1, 1, 256>), dim3(256), dim3(256), 0, 0, X, G, CV, DX, T); }));
+    line("PB persistent, depth 1, 8 waves/CU as ONE 512-thread workgroup, barrier per graph",
+         timeit([&] { hipLaunchKernelGGL((skel_p<0, 1, 1, 512>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("P  persistent, depth 1, 8 waves/CU as ONE 512-thread workgroup, no barrier",
+         timeit([&] { hipLaunchKernelGGL((skel_p<0, 1, 0, 512>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    linef("F  forward: persistent, 8 waves/CU (512-thread workgroup), no barrier",
+          timeit([&] { hipLaunchKernelGGL((skel_f<0, 0, 512>), dim3(256), dim3(512), 0, 0, X, CV, DX, T); }));
+    linef("F  forward: persistent, 8 waves/CU (2 x 256-thread workgroups), no barrier",
+          timeit([&] { hipLaunchKernelGGL((skel_f<0, 0, 256>), dim3(512), dim3(256), 0, 0, X, CV, DX, T); }));
+    linef("FB forward: persistent, 8 waves/CU (512-thread workgroup), barrier per graph",
+          timeit([&] { hipLaunchKernelGGL((skel_f<0, 1, 512>), dim3(256), dim3(512), 0, 0, X, CV, DX, T); }));
+    linef("FB forward: persistent, 4 waves/CU, barrier per graph",
+          timeit([&] { hipLaunchKernelGGL((skel_f<0, 1, 256>), dim3(256), dim3(256), 0, 0, X, CV, DX, T); }));
+    linef("FH forward: pairs (x + CSR in | tile out via LDS), 8 waves/CU",
+          timeit([&] { hipLaunchKernelGGL((skel_f<1, 1, 512>), dim3(256), dim3(512), 0, 0, X, CV, DX, T); }));
+    linef("FH forward: pairs, 16 waves/CU",
+          timeit([&] { hipLaunchKernelGGL((skel_f<1, 1, 512>), dim3(512), dim3(512), 0, 0, X, CV, DX, T); }));
     line("N  one wave per graph, 64-thread workgroups",
          timeit([&] { hipLaunchKernelGGL((skel_n<1>), dim3(T), dim3(64), 0, 0, X, G, CV, DX, T); }));
     line("N  one wave per graph, 256-thread workgroups",

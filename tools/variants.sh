@@ -13,7 +13,7 @@ if [ "$mode" = build ]; then
   while [ $# -gt 0 ]; do
     name=$1; flags=$2; shift 2
     objs=""
-    for o in misc spmm dense gemm3 wtable gemmn wgradn narrow fused pack coopack gat bn; do
+    for o in misc ragged train stack stack_tile skinny spmm dense gemm3 gemmh gemmb wtable gemmn wgradn wgradx narrow fused pack coopack gat bn; do
       if [ $o = $VSRC ]; then objs="$objs $REPO/build/variants/${VSRC}_$name.o"; else objs="$objs $CS/$o.o"; fi
     done
     ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast $SLP $flags \
