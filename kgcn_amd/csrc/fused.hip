@@ -1485,6 +1485,15 @@ constexpr int BP_PAIRS = 4;
 #ifndef KGCN_BWD_PAIRS
 #define KGCN_BWD_PAIRS 1        // 0: the one-wave-per-graph planes kernel for every batch
 #endif
+#ifndef KGCN_BP_SPLIT_AGG
+#define KGCN_BP_SPLIT_AGG 2     // row groups (of four, eight rows each, longest rows first) of a graph that role B aggregates; role A the rest
+#endif
+#ifndef KGCN_BP_A_ORDER
+#define KGCN_BP_A_ORDER 1       // role A: 0 aggregate, multiply, land; 1 multiply, aggregate, land
+#endif
+#ifndef KGCN_BP_B_ORDER
+#define KGCN_BP_B_ORDER 1       // role B: 0 multiply, aggregate, split; 1 aggregate, multiply, split
+#endif
 #ifndef KGCN_BP_ROLE_BIT
 #define KGCN_BP_ROLE_BIT 2      // 2: pair = wave & 3, role = wave >> 2 (the two roles of a pair share a SIMD); 0: pair = wave >> 1, role = wave & 1
 #endif
@@ -1520,19 +1529,81 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
   const int cntw = (T - 1 - t0) / npairs + 1;                     // graphs of this pair: cnt_max or cnt_max - 1
   const int tl = t0 + (cntw - 1) * npairs;                        // its last graph
   const bool whole = cntw == cnt_max;                             // uniform
+#ifdef KGCN_ABL_HOT                                                 // development: two graphs per pair, cache resident -- the kernel without HBM
+  auto gidx = [&](int k) { const int t = t0 + (k & 1) * npairs; return t < tl ? t : tl; };
+#else
   auto gidx = [&](int k) { const int t = t0 + k * npairs; return t < tl ? t : tl; };  // clamped
+#endif
   PROBE_DECL
 
   f32x16 dw00, dw01, dw10, dw11;                                  // role B
-  f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};                             // role A
+  f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};                             // both roles (each aggregates half of a graph's rows)
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dw00[r] = 0.f; dw01[r] = 0.f; dw10[r] = 0.f; dw11[r] = 0.f; }
+
+  // ---- the adjoint aggregation, shared by the roles: role B takes the row groups {0, 2} of graph i + 1 (the longest rows: the slot
+  //      table is ordered by decreasing length), role A {1, 3}; both write the planes of buffer (i + 1) & 1 ----------------------
+  const unsigned h_e = (unsigned)cl >> 3;
+  const unsigned lanexor = (h_e << 8) | (h_e << 6) | ((((unsigned)cl & 7) >> 1) << 4) | (((unsigned)cl & 1) << 3);
+  const float* srcl = gt + cl * 4;
+  auto emit_to = [&](unsigned lx, const PlaneSteps& q) __attribute__((always_inline)) {
+    unsigned q1, q2, q3, r1, r2, r3;
+    split_pair(q.a[0], q.a[1], q1, q2, q3);
+    split_pair(q.a[2], q.a[3], r1, r2, r3);
+    const unsigned ad = q.rw ^ lx;
+    lds_st64(ad, q1, r1);
+    lds_st64(ad + PL_BYTES, q2, r2);
+    lds_st64(ad + 2 * PL_BYTES, q3, r3);
+    add4(dbacc, q.a);
+  };
+  // row groups gq = G0 .. G1 - 1 of the graph in the gather tile -> planes at `plane_off`, two passes in flight
+  auto aggregate = [&](auto g0c, auto g1c, const int2* ecv, const int* tab, unsigned plane_off) __attribute__((always_inline)) {
+    const unsigned lx = lanexor | (pl0 + plane_off);
+#pragma unroll
+    for (int gq = decltype(g0c)::value; gq < decltype(g1c)::value; ++gq) {
+      PlaneSteps qa, qb;
+      qa.slot(tab, 8 * gq + sub);
+      qb.slot(tab, 8 * gq + 4 + sub);
+      qa.q0 = *reinterpret_cast<const i32x4*>(ecv + qa.s);
+      qa.q1 = *reinterpret_cast<const i32x4*>(ecv + qa.s + 2);
+      qb.q0 = *reinterpret_cast<const i32x4*>(ecv + qb.s);
+      qb.q1 = *reinterpret_cast<const i32x4*>(ecv + qb.s + 2);
+      qa.x0 = ldv4(srcl + qa.q0.x * FD); qa.x1 = ldv4(srcl + qa.q0.z * FD);
+      qa.x2 = ldv4(srcl + qa.q1.x * FD); qa.x3 = ldv4(srcl + qa.q1.z * FD);
+      qb.x0 = ldv4(srcl + qb.q0.x * FD); qb.x1 = ldv4(srcl + qb.q0.z * FD);
+      qb.x2 = ldv4(srcl + qb.q1.x * FD); qb.x3 = ldv4(srcl + qb.q1.z * FD);
+      {
+        const float v = __int_as_float(qa.q0.y);
+        qa.a[0] = v * qa.x0[0]; qa.a[1] = v * qa.x0[1]; qa.a[2] = v * qa.x0[2]; qa.a[3] = v * qa.x0[3];
+        fma4(qa.a, __int_as_float(qa.q0.w), qa.x1);
+        fma4(qa.a, __int_as_float(qa.q1.y), qa.x2);
+        fma4(qa.a, __int_as_float(qa.q1.w), qa.x3);
+      }
+      {
+        const float v = __int_as_float(qb.q0.y);
+        qb.a[0] = v * qb.x0[0]; qb.a[1] = v * qb.x0[1]; qb.a[2] = v * qb.x0[2]; qb.a[3] = v * qb.x0[3];
+        fma4(qb.a, __int_as_float(qb.q0.w), qb.x1);
+        fma4(qb.a, __int_as_float(qb.q1.y), qb.x2);
+        fma4(qb.a, __int_as_float(qb.q1.w), qb.x3);
+      }
+      qa.tail(ecv, srcl);
+      qb.tail(ecv, srcl);
+      emit_to(lx, qa);
+      emit_to(lx, qb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I4 = std::integral_constant<int, 4>;
+  using INB = std::integral_constant<int, KGCN_BP_SPLIT_AGG>;
+  constexpr int NB = KGCN_BP_SPLIT_AGG;                                         // row groups [0, NB) are role B's, [NB, 4) role A's
+  // hand-over inside the pair: role B has finished READING the gather tile for graph i + 1 (flag = i + 1) before role A lands
+  // g(i + 2) in it.  LDS executes a wave's operations in order, so the flag write follows B's last gather read.
+  KGCN_LDS volatile int* const agg_flag = (KGCN_LDS volatile int*)(uintptr_t)lds_off(tab0 + FN + 2);
 
   if (role == 0) {
     // =========================================== role A ===========================================================
     for (int i = lane; i < D; i += 64) gt[FN * FD + i] = 0.f;
-    const unsigned h_e = (unsigned)cl >> 3;
-    const unsigned lanexor = (h_e << 8) | (h_e << 6) | ((((unsigned)cl & 7) >> 1) << 4) | (((unsigned)cl & 1) << 3);
     unsigned LB[4];                                               // row reads: lane (li, hi): features 16 ks + 8 hi .. + 7 of node li
     {
       const unsigned R = (unsigned)li >> 2, a = (unsigned)li & 3;
@@ -1558,58 +1629,9 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
     });
     __syncthreads();                                              // barrier 0: the W table
 
-    const float* srcl = gt + cl * 4;
     TileRegs gpf;
     CsrRegs cpf;
     MetaRegs m_a, m_b;   // m_a: graph whose g / CSR are in flight; m_b: the one after it
-    auto emit_to = [&](unsigned lx, const PlaneSteps& q, bool live) __attribute__((always_inline)) {
-      unsigned q1, q2, q3, r1, r2, r3;
-      split_pair(q.a[0], q.a[1], q1, q2, q3);
-      split_pair(q.a[2], q.a[3], r1, r2, r3);
-      const unsigned ad = q.rw ^ lx;
-      lds_st64(ad, q1, r1);
-      lds_st64(ad + PL_BYTES, q2, r2);
-      lds_st64(ad + 2 * PL_BYTES, q3, r3);
-      if (live) add4(dbacc, q.a);                                 // (uniform)
-    };
-    // adjoint aggregation of the graph in the gather tile -> planes at `plane_off`, two passes in flight
-    auto aggregate = [&](const int2* ecv, const int* tab, unsigned plane_off, bool live) __attribute__((always_inline)) {
-      const unsigned lx = lanexor | (pl0 + plane_off);
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        PlaneSteps qa, qb;
-        qa.slot(tab, 8 * gq + sub);
-        qb.slot(tab, 8 * gq + 4 + sub);
-        qa.q0 = *reinterpret_cast<const i32x4*>(ecv + qa.s);
-        qa.q1 = *reinterpret_cast<const i32x4*>(ecv + qa.s + 2);
-        qb.q0 = *reinterpret_cast<const i32x4*>(ecv + qb.s);
-        qb.q1 = *reinterpret_cast<const i32x4*>(ecv + qb.s + 2);
-        qa.x0 = ldv4(srcl + qa.q0.x * FD); qa.x1 = ldv4(srcl + qa.q0.z * FD);
-        qa.x2 = ldv4(srcl + qa.q1.x * FD); qa.x3 = ldv4(srcl + qa.q1.z * FD);
-        qb.x0 = ldv4(srcl + qb.q0.x * FD); qb.x1 = ldv4(srcl + qb.q0.z * FD);
-        qb.x2 = ldv4(srcl + qb.q1.x * FD); qb.x3 = ldv4(srcl + qb.q1.z * FD);
-        {
-          const float v = __int_as_float(qa.q0.y);
-          qa.a[0] = v * qa.x0[0]; qa.a[1] = v * qa.x0[1]; qa.a[2] = v * qa.x0[2]; qa.a[3] = v * qa.x0[3];
-          fma4(qa.a, __int_as_float(qa.q0.w), qa.x1);
-          fma4(qa.a, __int_as_float(qa.q1.y), qa.x2);
-          fma4(qa.a, __int_as_float(qa.q1.w), qa.x3);
-        }
-        {
-          const float v = __int_as_float(qb.q0.y);
-          qb.a[0] = v * qb.x0[0]; qb.a[1] = v * qb.x0[1]; qb.a[2] = v * qb.x0[2]; qb.a[3] = v * qb.x0[3];
-          fma4(qb.a, __int_as_float(qb.q0.w), qb.x1);
-          fma4(qb.a, __int_as_float(qb.q1.y), qb.x2);
-          fma4(qb.a, __int_as_float(qb.q1.w), qb.x3);
-        }
-        qa.tail(ecv, srcl);
-        qb.tail(ecv, srcl);
-        emit_to(lx, qa, live);
-        emit_to(lx, qb, live);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-
     // ---- prologue: graph 0 aggregated into planes 0; g(1), CSR(1) in LDS; g(2), CSR(2) in flight ---------------
     issue_meta(m_a, slots_t, gptr_t, gidx(0), N, lane);
     int base_a = meta_base(m_a), cnt_a = meta_cnt(m_a);
@@ -1625,7 +1647,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
     issue_tile<true>(gpf, g + (long)gidx(1) * N * D, 512, lane);
     issue_cv(cpf, cv_t, base_a, cnt_a, lane);
     issue_meta(m_b, slots_t, gptr_t, gidx(2), N, lane);
-    aggregate(ecv0, tab0, 0u, true);
+    aggregate(I0{}, I4{}, ecv0, tab0, 0u);                        // graph 0: all four row groups
     wave_sync();
     land_tile<true>(gpf, gt, FD, 512, 16, lane);
     land_csr(cpf, ecv0 + ecv_stride, tab0 + (FN + 4), cv_t, slot_plane_word(m_a.slot), base_a, cnt_a, N, lane);
@@ -1703,19 +1725,34 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
     int cur = 0;
     PROBE(0)
     for (int i = 0; i < cnt_max - 2; ++i) {                       // graphs i and i + 1 exist for every pair
-      aggregate(ecv0 + (cur ^ 1) * ecv_stride, tab0 + (cur ^ 1) * (FN + 4), cur ? 0u : (unsigned)DFWP_BYTES, true);
-      PROBE(1)
+      if constexpr (KGCN_BP_A_ORDER == 0) {
+        if constexpr (NB < 4)
+          aggregate(INB{}, I4{}, ecv0 + (cur ^ 1) * ecv_stride, tab0 + (cur ^ 1) * (FN + 4), cur ? 0u : (unsigned)DFWP_BYTES);
+        PROBE(1)
+        dx_of(i, cur);
+        PROBE(3)
+      } else {                                                    // the multiplications of both roles first
+        dx_of(i, cur);
+        PROBE(3)
+        if constexpr (NB < 4)
+          aggregate(INB{}, I4{}, ecv0 + (cur ^ 1) * ecv_stride, tab0 + (cur ^ 1) * (FN + 4), cur ? 0u : (unsigned)DFWP_BYTES);
+        PROBE(1)
+      }
+      if constexpr (NB != 0) {
+        while (*agg_flag < i + 1) __builtin_amdgcn_s_sleep(1);    // role B is through with the gather tile (normally long ago)
+      }
       wave_sync();
+      PROBE(6)
       land_and_prefetch(i, cur);
       PROBE(2)
-      dx_of(i, cur);
-      PROBE(3)
       bp_barrier();
       PROBE(4)
       cur ^= 1;
     }
     // iteration cnt_max - 2: graph cnt_max - 1 exists for a whole pair only
-    if (whole) aggregate(ecv0 + (cur ^ 1) * ecv_stride, tab0 + (cur ^ 1) * (FN + 4), cur ? 0u : (unsigned)DFWP_BYTES, true);
+    if constexpr (NB < 4) {
+      if (whole) aggregate(INB{}, I4{}, ecv0 + (cur ^ 1) * ecv_stride, tab0 + (cur ^ 1) * (FN + 4), cur ? 0u : (unsigned)DFWP_BYTES);
+    }
     wave_sync();
     dx_of(cnt_max - 2, cur);
     bp_barrier();
@@ -1819,13 +1856,26 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
       static_for<16>([&](auto qc) __attribute__((always_inline)) { load_x(xb, qc); });
     }
     split_and_reload(1);
+    if (lane == 0) *agg_flag = 0;
     bp_barrier();                                                 // barrier 1: dFW(0) in planes 0
 
     int cur = 0;
     PROBE(0)
     for (int i = 0; i < cnt_max - 1; ++i) {                       // graph i exists for every pair
-      dw_of(cur);
-      PROBE(1)
+      if constexpr (KGCN_BP_B_ORDER == 0) {
+        dw_of(cur);                                               // (matrix pipe) while role A aggregates (vector ALU)
+        PROBE(1)
+      }
+      if (NB != 0 && (i < cnt_max - 2 || whole)) {                // uniform; no vector-memory instruction inside
+        aggregate(I0{}, INB{}, ecv0 + (cur ^ 1) * ecv_stride, tab0 + (cur ^ 1) * (FN + 4), cur ? 0u : (unsigned)DFWP_BYTES);
+        wave_sync();
+        if (lane == 0) *agg_flag = i + 1;
+      }
+      PROBE(3)
+      if constexpr (KGCN_BP_B_ORDER != 0) {
+        dw_of(cur);
+        PROBE(1)
+      }
       split_and_reload(i + 2);                                    // x(i+1) -> fragments, x(i+2) requested
       PROBE(2)
       bp_barrier();
@@ -1839,7 +1889,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
 
   // ---- reduce the workgroup's pairs through LDS; one partial per workgroup ---------------------
   __syncthreads();
-  float* park = reinterpret_cast<float*>(sl);   // the pair's plane buffers: 24,576 B >= (4096 + 64) floats
+  float* park = reinterpret_cast<float*>(sl);   // the pair's plane buffers: 24,576 B >= (4096 + 128) floats
   if (role == 1) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1849,16 +1899,15 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
       park[(2 * row + 1) * FD + li] = dw10[r];
       park[(2 * row + 1) * FD + 32 + li] = dw11[r];
     }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v = dbacc[j];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      dbacc[j] = v;
-    }
-    if (lane < 16) stv4(park + FD * FD + lane * 4, dbacc);
   }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float v = dbacc[j];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    dbacc[j] = v;
+  }
+  if (lane < 16) stv4(park + FD * FD + role * FD + lane * 4, dbacc);      // [role A's rows | role B's rows]
   __syncthreads();
   const size_t slice_f = 2 * DFWP_BYTES / 4;
   const float* slice0 = reinterpret_cast<const float*>(smem);
@@ -1870,7 +1919,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
   }
   if (tid < D) {
     float s = 0.f;
-    for (int wv = 0; wv < BP_PAIRS; ++wv) s += slice0[wv * slice_f + D * D + tid];
+    for (int wv = 0; wv < BP_PAIRS; ++wv) s += slice0[wv * slice_f + D * D + tid] + slice0[wv * slice_f + D * D + D + tid];
     part_db[(long)blockIdx.x * D + tid] = s;
   }
 }

@@ -70,7 +70,11 @@ __global__ __launch_bounds__(NT) void skel_p(const float* __restrict__ x, const 
 }
 
 // pairs: wave 2p moves g + CSR in and dX out, wave 2p+1 moves x in (and hands a checksum over through LDS so that nothing is dead)
-template <int DEPTH, int BAR = 1>
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+// LOAD: synthetic arithmetic per wave and graph next to the memory streams (no LDS traffic, no dependence on the loaded data beyond a
+// final select): 1 = 48 v_mfma_f32_32x32x16_bf16 (the kernel's 96 per graph over the pair), 2 = those + 400 v_fma_f32, 3 = 400 v_fma_f32 only
+template <int DEPTH, int BAR = 1, int LOAD = 0>
 __global__ __launch_bounds__(512) void skel_h(const float* __restrict__ x, const float* __restrict__ g,
                                               const f4* __restrict__ cv, float* __restrict__ dx, int T) {
   __shared__ float hand[8][64];
@@ -81,6 +85,12 @@ __global__ __launch_bounds__(512) void skel_h(const float* __restrict__ x, const
   const int cnt = t0 < T ? (T - 1 - t0) / npairs + 1 : 0;
   const int li = lane & 31, hi = lane >> 5;
   f4 r[DEPTH][8], cr[DEPTH][2];
+  f16v acc0 = {}, acc1 = {}, acc2 = {}, acc3 = {};
+  bf8 fa, fb;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { fa[e] = (__bf16)(0.001f * (lane + e)); fb[e] = (__bf16)(0.002f * (lane - e)); }
+  float va[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
+  const float vm = 0.999f + 1e-9f * lane, vb = 1e-7f * lane;
   auto issue = [&](int k, int slot) {
     const int kk = k < cnt ? k : (cnt > 0 ? cnt - 1 : 0);
     const int t = cnt > 0 ? t0 + kk * npairs : 0;
@@ -106,6 +116,22 @@ __global__ __launch_bounds__(512) void skel_h(const float* __restrict__ x, const
         hand[wave][lane] = s[0] + s[1] + s[2] + s[3];
       }
       issue(i + d + DEPTH, d);
+      if constexpr (LOAD == 1 || LOAD == 2) {
+#pragma unroll
+        for (int m = 0; m < 12; ++m) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc2, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc3, 0, 0, 0);
+        }
+      }
+      if constexpr (LOAD >= 2) {
+#pragma unroll
+        for (int m = 0; m < 50; ++m) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) va[e] = __builtin_fmaf(va[e], vm, vb);
+        }
+      }
       if constexpr (BAR != 0) __syncthreads();   // one workgroup barrier per graph, as the two-role kernel would pay
       if (!role && live) {
         const float hv = hand[wave + 1][lane];
@@ -115,6 +141,12 @@ __global__ __launch_bounds__(512) void skel_h(const float* __restrict__ x, const
           *reinterpret_cast<f4*>(dst + li * 64 + (q >> 2) * 32 + 8 * (q & 3) + 4 * hi) = o[q] * hv + cr[d][q & 1];
       }
     }
+  }
+  if constexpr (LOAD != 0) {
+    float z = va[0] + va[1] + va[2] + va[3] + va[4] + va[5] + va[6] + va[7];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z += acc0[e] + acc1[e] + acc2[e] + acc3[e];
+    if (z == 123.456f) dx[lane] = z;
   }
 }
 
@@ -240,6 +272,12 @@ int main(int argc, char** argv) {
          timeit([&] { hipLaunchKernelGGL((skel_h<2>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
     line("H  pairs, depth 2, 16 waves/CU",
          timeit([&] { hipLaunchKernelGGL((skel_h<2>), dim3(512), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("H  pairs + 48 bf16 MFMAs per wave and graph",
+         timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 1>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("H  pairs + 48 bf16 MFMAs + 400 v_fma_f32 per wave and graph",
+         timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 2>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("H  pairs + 400 v_fma_f32 per wave and graph",
+         timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 3>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
     line("H  pairs, depth 1, 8 waves/CU, NO barrier",
          timeit([&] { hipLaunchKernelGGL((skel_h<1, 0>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
     line("PB persistent, depth 1, 4 waves/CU, barrier per graph",

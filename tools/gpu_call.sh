@@ -1,5 +1,4 @@
 #!/bin/bash
-# scratch script of the CURRENT gpurun call (rewritten per call)
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO
-for rep in 1 2; do timeout 900 bash tools/variants.sh run planes pairs2 pairs0; done
-tail -5 gpurun_out/variants/*.err
+KGCN_PROBE_LIB=build/variants/libkgcn_probe.so timeout 300 python tools/pairs_probe.py 100000 2 2>&1 | tail -21
+KGCN_PROBE_LIB=build/variants/libkgcn_probehot.so timeout 300 python tools/pairs_probe.py 100000 2 2>&1 | tail -21

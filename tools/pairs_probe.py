@@ -47,8 +47,9 @@ wave = np.arange(2048) % 8
 role = (wave >> 2) if role_bit == 2 else (wave & 1)
 iters = T / 1024.0
 print("%.1f us/launch (probe build); %.1f iterations per pair; cycles per iteration (s_memtime ticks)" % (e0.elapsed_time(e1) * 1e3, iters))
-names = {0: ["prologue", "aggregate(i+1) -> planes", "land g(i+2) / CSR, request (i+3)", "dX(i) MFMAs + stores", "barrier wait", "tail"],
-         1: ["prologue", "dW(i) MFMAs", "split x(i+1), request x(i+2)", "-", "barrier wait", "tail"]}
+names = {0: ["prologue", "aggregate half of (i+1) -> planes", "land g(i+2) / CSR, request (i+3)", "dX(i) MFMAs + stores", "barrier wait", "tail",
+             "wait for role B's flag", "-"],
+         1: ["prologue", "dW(i) MFMAs", "split x(i+1), request x(i+2)", "aggregate half of (i+1) -> planes, flag", "barrier wait", "tail", "-", "-"]}
 for r in (0, 1):
     sel = pr[role == r]
     tot = sel.sum(1).mean() / iters
