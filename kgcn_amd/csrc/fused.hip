@@ -1485,8 +1485,11 @@ constexpr int BP_PAIRS = 4;
 #ifndef KGCN_BWD_PAIRS
 #define KGCN_BWD_PAIRS 1        // 0: the one-wave-per-graph planes kernel for every batch
 #endif
-#ifndef KGCN_BP_SPLIT_AGG
-#define KGCN_BP_SPLIT_AGG 2     // row groups (of four, eight rows each, longest rows first) of a graph that role B aggregates; role A the rest
+#ifndef KGCN_BP_B_GROUPS
+#define KGCN_BP_B_GROUPS 5      // bit mask of the row groups (four of eight rows each, longest rows first) role B aggregates; role A the others
+#endif
+#ifndef KGCN_BP_AGG_SCOPE
+#define KGCN_BP_AGG_SCOPE 0     // 0: one scheduling scope per row group (two passes in flight); 1: a role's groups in ONE scope
 #endif
 #ifndef KGCN_BP_A_ORDER
 #define KGCN_BP_A_ORDER 1       // role A: 0 aggregate, multiply, land; 1 multiply, aggregate, land
@@ -1557,10 +1560,11 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
     add4(dbacc, q.a);
   };
   // row groups gq = G0 .. G1 - 1 of the graph in the gather tile -> planes at `plane_off`, two passes in flight
-  auto aggregate = [&](auto g0c, auto g1c, const int2* ecv, const int* tab, unsigned plane_off) __attribute__((always_inline)) {
+  auto aggregate = [&](auto maskc, const int2* ecv, const int* tab, unsigned plane_off) __attribute__((always_inline)) {
     const unsigned lx = lanexor | (pl0 + plane_off);
-#pragma unroll
-    for (int gq = decltype(g0c)::value; gq < decltype(g1c)::value; ++gq) {
+    static_for<4>([&](auto gqc) __attribute__((always_inline)) {
+      constexpr int gq = decltype(gqc)::value;
+      if constexpr (((decltype(maskc)::value >> gq) & 1) != 0) {
       PlaneSteps qa, qb;
       qa.slot(tab, 8 * gq + sub);
       qb.slot(tab, 8 * gq + 4 + sub);
@@ -1590,13 +1594,16 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
       qb.tail(ecv, srcl);
       emit_to(lx, qa);
       emit_to(lx, qb);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+      if constexpr (KGCN_BP_AGG_SCOPE == 0) __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+    if constexpr (KGCN_BP_AGG_SCOPE != 0) __builtin_amdgcn_sched_barrier(0);
   };
-  using I0 = std::integral_constant<int, 0>;
-  using I4 = std::integral_constant<int, 4>;
-  using INB = std::integral_constant<int, KGCN_BP_SPLIT_AGG>;
-  constexpr int NB = KGCN_BP_SPLIT_AGG;                                         // row groups [0, NB) are role B's, [NB, 4) role A's
+  using MALL = std::integral_constant<int, 15>;
+  using MB = std::integral_constant<int, KGCN_BP_B_GROUPS>;                  // role B's row groups (bit mask), role A's: the others
+  using MA = std::integral_constant<int, 15 & ~KGCN_BP_B_GROUPS>;
+  constexpr int NB = KGCN_BP_B_GROUPS;                                          // (0: role A aggregates alone)
+  constexpr int NA = 15 & ~KGCN_BP_B_GROUPS;
   // hand-over inside the pair: role B has finished READING the gather tile for graph i + 1 (flag = i + 1) before role A lands
   // g(i + 2) in it.  LDS executes a wave's operations in order, so the flag write follows B's last gather read.
   KGCN_LDS volatile int* const agg_flag = (KGCN_LDS volatile int*)(uintptr_t)lds_off(tab0 + FN + 2);
@@ -1647,7 +1654,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
     issue_tile<true>(gpf, g + (long)gidx(1) * N * D, 512, lane);
     issue_cv(cpf, cv_t, base_a, cnt_a, lane);
     issue_meta(m_b, slots_t, gptr_t, gidx(2), N, lane);
-    aggregate(I0{}, I4{}, ecv0, tab0, 0u);                        // graph 0: all four row groups
+    aggregate(MALL{}, ecv0, tab0, 0u);                        // graph 0: all four row groups
     wave_sync();
     land_tile<true>(gpf, gt, FD, 512, 16, lane);
     land_csr(cpf, ecv0 + ecv_stride, tab0 + (FN + 4), cv_t, slot_plane_word(m_a.slot), base_a, cnt_a, N, lane);
@@ -1697,15 +1704,16 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
           WL[ks][pc][nt] = lds_ld128(wtab + (pc * 8 + nt * 4 + ks) * 1024);
         });
       };
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+      const f32x16 zero16 = {};                                   // (the first product of a chain takes the inline constant 0 as its C operand)
       read_fa(std::integral_constant<int, 0>{});
       static_for<48>([&](auto mc) __attribute__((always_inline)) {
         constexpr int m = decltype(mc)::value, ks = m / 12, pr = (m % 12) >> 1, nt = m & 1;
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
         constexpr int wl = PB[pr] == 0 ? 0 : PB[pr] - 1;
         const u32x4 wv = PB[pr] == 0 ? WF1[nt][ks] : WL[ks][wl][nt];
-        if constexpr (nt == 0) c0 = mfma_bf16(wv, FA[ks][PA[pr]], c0);
+        if constexpr (m == 0) c0 = mfma_bf16(wv, FA[ks][PA[pr]], zero16);
+        else if constexpr (m == 1) c1 = mfma_bf16(wv, FA[ks][PA[pr]], zero16);
+        else if constexpr (nt == 0) c0 = mfma_bf16(wv, FA[ks][PA[pr]], c0);
         else c1 = mfma_bf16(wv, FA[ks][PA[pr]], c1);
         if constexpr (m % 12 == 1 && ks < 3) {                     // one k-step ahead
           read_fa(std::integral_constant<int, ks + 1>{});
@@ -1726,16 +1734,16 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
     PROBE(0)
     for (int i = 0; i < cnt_max - 2; ++i) {                       // graphs i and i + 1 exist for every pair
       if constexpr (KGCN_BP_A_ORDER == 0) {
-        if constexpr (NB < 4)
-          aggregate(INB{}, I4{}, ecv0 + (cur ^ 1) * ecv_stride, tab0 + (cur ^ 1) * (FN + 4), cur ? 0u : (unsigned)DFWP_BYTES);
+        if constexpr (NA != 0)
+          aggregate(MA{}, ecv0 + (cur ^ 1) * ecv_stride, tab0 + (cur ^ 1) * (FN + 4), cur ? 0u : (unsigned)DFWP_BYTES);
         PROBE(1)
         dx_of(i, cur);
         PROBE(3)
       } else {                                                    // the multiplications of both roles first
         dx_of(i, cur);
         PROBE(3)
-        if constexpr (NB < 4)
-          aggregate(INB{}, I4{}, ecv0 + (cur ^ 1) * ecv_stride, tab0 + (cur ^ 1) * (FN + 4), cur ? 0u : (unsigned)DFWP_BYTES);
+        if constexpr (NA != 0)
+          aggregate(MA{}, ecv0 + (cur ^ 1) * ecv_stride, tab0 + (cur ^ 1) * (FN + 4), cur ? 0u : (unsigned)DFWP_BYTES);
         PROBE(1)
       }
       if constexpr (NB != 0) {
@@ -1750,8 +1758,8 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
       cur ^= 1;
     }
     // iteration cnt_max - 2: graph cnt_max - 1 exists for a whole pair only
-    if constexpr (NB < 4) {
-      if (whole) aggregate(INB{}, I4{}, ecv0 + (cur ^ 1) * ecv_stride, tab0 + (cur ^ 1) * (FN + 4), cur ? 0u : (unsigned)DFWP_BYTES);
+    if constexpr (NA != 0) {
+      if (whole) aggregate(MA{}, ecv0 + (cur ^ 1) * ecv_stride, tab0 + (cur ^ 1) * (FN + 4), cur ? 0u : (unsigned)DFWP_BYTES);
     }
     wave_sync();
     dx_of(cnt_max - 2, cur);
@@ -1867,7 +1875,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
         PROBE(1)
       }
       if (NB != 0 && (i < cnt_max - 2 || whole)) {                // uniform; no vector-memory instruction inside
-        aggregate(I0{}, INB{}, ecv0 + (cur ^ 1) * ecv_stride, tab0 + (cur ^ 1) * (FN + 4), cur ? 0u : (unsigned)DFWP_BYTES);
+        aggregate(MB{}, ecv0 + (cur ^ 1) * ecv_stride, tab0 + (cur ^ 1) * (FN + 4), cur ? 0u : (unsigned)DFWP_BYTES);
         wave_sync();
         if (lane == 0) *agg_flag = i + 1;
       }
