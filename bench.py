@@ -713,9 +713,11 @@ class Cfg2:
                   "nnz_per_graph": wl["nnz_per_graph"], "adjacency_values": "kipf" if args.normalize else "ones"}
         roofline = {"bound": "hbm",
                     "kernel": "dense_wgrad+bspmm (unfused)" if args.unfused else
+                              "graphconv_bwd_pairs_kernel (two waves per graph slot; +1 reduce_partials launch, ~5 us, in the event "
+                              "bracket)" if T >= 2048 else
                               "graphconv_bwd_planes_kernel (+1 reduce_partials launch, ~5 us, in the event bracket)",
                     "achieved": bwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": bwd_gbs / HBM_PEAK_GBS, "traffic": traffic.get("graphconv_bwd_planes_kernel"),
+                    "frac": bwd_gbs / HBM_PEAK_GBS, "traffic": traffic.get("graphconv_bwd_pairs_kernel" if T >= 2048 else "graphconv_bwd_planes_kernel"),
                     "launch_ms": bwd_st,
                     "traffic_note": "HBM bytes per launch, rocprofv3 PMC (profiles/traffic_cfg2.json); "
                                     "algorithmic bytes per launch = %d" % int(ab["bwd"] * T),

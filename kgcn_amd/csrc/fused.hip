@@ -572,6 +572,12 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
   const int nwaves = gridDim.x * wpb;
   int t = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
   if (t >= T) return;   // no workgroup barrier below: idle waves may leave
+#ifdef KGCN_ABL_HOT       // development: every wave re-reads (and re-writes) its first two graphs -- the kernel without HBM traffic
+  const int t_first = t;
+  auto hot = [&](int tt) { return t_first + (((tt - t_first) / nwaves) & 1) * nwaves < T ? t_first + (((tt - t_first) / nwaves) & 1) * nwaves : t_first; };
+#else
+  auto hot = [&](int tt) { return tt; };
+#endif
 
   for (int i = lane; i < D; i += 64) ws.b[FN * FD + i] = 0.f;   // zero row for padding entries
   const float b0 = bias ? bias[li] : 0.f;
@@ -581,19 +587,19 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
   TileRegs fx;
   CsrRegs fc;
   MetaRegs m_cur, m_nxt;
-  issue_meta(m_cur, slots, gptr, t, N, lane);
+  issue_meta(m_cur, slots, gptr, hot(t), N, lane);
   int base = meta_base(m_cur), cnt = meta_cnt(m_cur);
-  issue_tile<true>(fx, x + (long)t * N * D, 512, lane);
+  issue_tile<true>(fx, x + (long)hot(t) * N * D, 512, lane);
   issue_cv(fc, cv, base, cnt, lane);
   int tn = t + nwaves;
-  issue_meta(m_nxt, slots, gptr, tn < T ? tn : t, N, lane);
+  issue_meta(m_nxt, slots, gptr, hot(tn < T ? tn : t), N, lane);
   wave_sync();
 
   int t_prev = t;      // graph whose FW sits in the gather tile (valid from the second step on)
   bool has_next = true;
   PROBE_DECL
   auto aggregate_prev = [&]() __attribute__((always_inline)) {
-    float* ot = out + (long)t_prev * N * D;
+    float* ot = out + (long)hot(t_prev) * N * D;
     aggregate_rows<true>(ws.ecv, ws.rp, ws.b, N, D, lane, [&](int r, int c4, f32x4 v) {
       stv4(ot + r * D + c4 * 4, v);
     });
@@ -607,7 +613,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
     land_tile<true>(fx, ws.a, ALD, 512, 16, lane);
     has_next = tn < T;
     const int tp = has_next ? tn : t;
-    issue_tile<true>(fx, x + (long)tp * N * D, 512, lane);
+    issue_tile<true>(fx, x + (long)hot(tp) * N * D, 512, lane);
     wave_sync();
     PROBE(1)
 
@@ -626,7 +632,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
                  : "=&v"(m_cur.slot), "=&v"(m_cur.gp) : "v"(m_nxt.slot), "v"(m_nxt.gp));
     {
       const int tnn = tn + nwaves;
-      issue_meta(m_nxt, slots, gptr, tnn < T ? tnn : tp, N, lane);
+      issue_meta(m_nxt, slots, gptr, hot(tnn < T ? tnn : tp), N, lane);
     }
 
     // ---- 4. FW(t) = X(t) W + b: per k-step 8 values of row li (k = 16 ks + 8 hi + j) are split, then

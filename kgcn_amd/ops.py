@@ -1671,8 +1671,10 @@ class _GraphBN(torch.autograd.Function):
         wsp = torch.empty((wsb // 4 + 1,), device=x.device, dtype=torch.float32)
         # d gamma / d beta receive their second stage at the flush: both must still be alive then.  autograd drops the
         # gradient of an input that does not require one as soon as backward returns (frozen affine parameters, a
-        # detached gamma of the inference call), so deferral needs BOTH to be wanted -- and the two results are kept
-        # until the flush next to the workspace either way.
+        # detached gamma of the inference call), so deferral needs BOTH to be wanted: AccumulateGrad then takes the two
+        # tensors themselves as .grad (deferred_reductions excludes parameters whose .grad exists or that carry hooks).
+        # They must NOT be referenced from here as well: a second reference makes AccumulateGrad clone them -- before the
+        # flush has written them (and costs two copy launches per step).
         want_affine = bool(ctx.needs_input_grad[1] and ctx.needs_input_grad[2])
         with _no_deferral_unless(ctx.defer_ok and want_affine and dx is not None and _single_use(*ctx.defer_ids)):
             check(lib.kgcn_graph_bn_bwd_dact_f32(ptr(x), ptr(g), ptr(yact) if ctx.act else None, ctx.act, T, N, D,
@@ -1680,8 +1682,6 @@ class _GraphBN(torch.autograd.Function):
                                                  ptr(dx), ptr(dgamma), ptr(dbeta), ptr(wsp), wsb, current_stream()),
                   "kgcn_graph_bn_bwd_dact_f32")
             _keep_until_flush(wsp)
-            _keep_until_flush(dgamma)
-            _keep_until_flush(dbeta)
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 

@@ -10,12 +10,19 @@ import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 import bench
 
-args = bench.build_parser().parse_args(sys.argv[1:] + ["--eager", "--no-cpu-baseline"])
+GRAPHED = "--graphed" in sys.argv        # the step as GraphedTrainStep captures it (its _eager body, run once more outside a capture)
+argv = [a for a in sys.argv[1:] if a != "--graphed"]
+args = bench.build_parser().parse_args(argv + ([] if GRAPHED else ["--eager"]) + ["--no-cpu-baseline"])
 ctx = bench.Ctx(args)
 wl = {"cfg1": bench.Cfg1, "cfg3": bench.Cfg3, "cfg4": bench.Cfg4, "cfg5": bench.Cfg5}[args.config](args, ctx)
 for _ in range(3):
     wl.step()
 torch.cuda.synchronize()
+step = wl.step
+if GRAPHED:
+    gs = getattr(wl, "graph_step", None) or getattr(wl, "gstep", None)
+    assert gs is not None, "this configuration has no captured step"
+    step = gs._eager
 seen = collections.OrderedDict()
 SKIP = ("aten.view", "aten._unsafe_view", "aten.reshape", "aten.detach", "aten.alias", "aten.t.", "aten.select", "aten.slice",
         "aten.as_strided", "aten.unsqueeze", "aten.squeeze", "aten.expand", "aten.empty", "aten.transpose", "aten._local_scalar",
@@ -34,8 +41,23 @@ class Log(TorchDispatchMode):
         return func(*a, **(kw or {}))
 
 
+fired = []
+if "--who" in sys.argv or os.environ.get("ATEN_WHO"):
+    # which parameter's AccumulateGrad made a copy: the copy_ happens just before that parameter's post-accumulate hook fires
+    model = wl.model.model if hasattr(wl.model, "model") else wl.model
+    for n_, p_ in model.named_parameters():
+        p_.register_post_accumulate_grad_hook(lambda t, n_=n_: fired.append((n_, tuple(t.shape))))
+    _orig = Log.__torch_dispatch__
+
+    def _td(self, func, types, a=(), kw=None):
+        if str(func).startswith("aten.copy_"):
+            fired.append(("<copy_>", [tuple(t.shape) for t in a if torch.is_tensor(t)][:1]))
+        return _orig(self, func, types, a, kw)
+    Log.__torch_dispatch__ = _td
 with Log():
-    wl.step()
+    step()
+if fired:
+    print("order of parameter accumulations and copies:", fired)
 torch.cuda.synchronize()
 for (name, where, shapes), n in seen.items():
     print("%2d x %-34s %-40s <- %s" % (n, name, shapes, where))

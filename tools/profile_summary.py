@@ -74,7 +74,8 @@ if bench:
     print("== bench line (un-profiled run): value %.4g %s, %.4f ms/step, roofline.frac %.4f" % (
         bench["value"], bench["unit"], bench["ms_per_step"], r["frac"]))
     st = dur.get("stats", {})
-    for name, ms in (("graphconv_bwd_planes_kernel", r["launch_ms"]), ("graphconv_fwd_full_kernel", r["fwd_kernel"]["launch_ms"])):
+    for name, ms in (("graphconv_bwd_pairs_kernel", r["launch_ms"]), ("graphconv_bwd_planes_kernel", r["launch_ms"]),
+                     ("graphconv_fwd_full_kernel", r["fwd_kernel"]["launch_ms"])):
         if name in st:
             extra = avg(st["reduce_partials_kernel"]) if name.startswith("graphconv_bwd") and "reduce_partials_kernel" in st else 0.0
             prof = avg(st[name]) + extra
