@@ -675,6 +675,12 @@ __global__ __launch_bounds__(512, 2) void graphconv_fwd_full_kernel(
     cnt = cnt_n;
   };
 
+#ifdef KGCN_FWD_STAGGER                          // development: the SIMD's second wave starts half a step late
+  if (wave >= wpb / 2) {
+#pragma unroll 1
+    for (int k = 0; k < KGCN_FWD_STAGGER; ++k) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
   step(std::false_type{});                       // first graph: nothing to aggregate yet
   while (has_next) step(std::true_type{});
   aggregate_prev();                              // epilogue: the last graph

@@ -36,33 +36,48 @@ def short(n):
     return n[:64]
 
 
-def timed(rows):
-    """rows: list in start order -> (dispatches per step, the dispatches of the timed steps).  A kernel that ran fewer
-    than PASSES / 2 times in the whole run belongs to set-up (model build, data generation, graph capture warm-up), not to
-    the steady-state step: per_step = 0."""
-    per_step = round(len(rows) / PASSES)
-    if per_step < 1:
-        return 0, []
-    return per_step, rows[-per_step * STEPS:]
+def load(db):
+    """-> {kernel: [(start, duration us)]} and the per-dispatch PMC rows {(kernel, counter): [(start, value)]} of one pass"""
+    cur = sqlite3.connect(db).cursor()
+    per, rows = {}, {}
+    for name, start, d, vg, ag, lds in cur.execute("select name, start, duration, vgpr_count, accum_vgpr_count, lds_size "
+                                                    "from kernels order by start"):
+        per.setdefault(short(name), []).append((start, d / 1e3))
+        meta[short(name)] = (vg, ag, lds)
+    try:
+        for k, c, start, v in cur.execute("select kernel_name, counter_name, start, value from counters_collection order by start"):
+            rows.setdefault((short(k), c), []).append((start, v))
+    except sqlite3.OperationalError:
+        pass
+    return per, rows
+
+
+def timed_start(per):
+    """Start time of the TIMED region of a pass: the timed steps are the end of the run, so the kernel with the largest total time
+    (one of the step's own) ran (its dispatches // passes) times per step, and the region begins with the first of its last
+    (per step x STEPS) dispatches.  Everything that started earlier -- set-up, warm-up, graph capture, and the torch fill / copy
+    kernels of model construction, which an earlier form of this script spread over the steps as "1 per step" -- is not counted."""
+    name = max(per, key=lambda k: sum(d for _, d in per[k]))
+    n = max(1, round(len(per[name]) / PASSES))
+    return per[name][-min(len(per[name]), n * STEPS)][0]
 
 
 dur, meta, pmc = {}, {}, {}
 for db in sorted(glob.glob(os.path.join(src, "*", "*.db"))):
     sub = os.path.basename(os.path.dirname(db))
-    cur = sqlite3.connect(db).cursor()
-    per = {}
-    for name, start, d, vg, ag, lds in cur.execute("select name, start, duration, vgpr_count, accum_vgpr_count, lds_size "
-                                                    "from kernels order by start"):
-        per.setdefault(short(name), []).append(d / 1e3)
-        meta[short(name)] = (vg, ag, lds)
-    dur[sub] = {k: timed(v) for k, v in per.items() if timed(v)[0] > 0}
+    per, rows = load(db)
+    if not per:
+        continue
+    t0 = timed_start(per)
+    dur[sub] = {}
+    for k, v in per.items():
+        t = [d for s_, d in v if s_ >= t0]
+        if t:
+            dur[sub][k] = (len(t) / STEPS, t)
     if sub != "stats":
-        rows = {}
-        for k, c, start, v in cur.execute("select kernel_name, counter_name, start, value from counters_collection order by start"):
-            rows.setdefault((short(k), c), []).append(v)
         for (k, c), vs in rows.items():
-            ps, t = timed(vs)
-            if ps > 0:
+            t = [v for s_, v in vs if s_ >= t0]
+            if t:
                 pmc.setdefault(k, {})[c] = sum(t) / len(t)
 
 avg = lambda xs: sum(xs) / len(xs)
