@@ -1503,6 +1503,9 @@ constexpr int BP_PAIRS = 4;
 #ifndef KGCN_BP_AGG_SCOPE
 #define KGCN_BP_AGG_SCOPE 0     // 0: one scheduling scope per row group (two passes in flight); 1: a role's groups in ONE scope
 #endif
+#ifndef KGCN_BP_PAIR_SYNC
+#define KGCN_BP_PAIR_SYNC 0     // 1 (development): pair-local rendezvous instead of the workgroup barrier per graph
+#endif
 #ifndef KGCN_BP_A_ORDER
 #define KGCN_BP_A_ORDER 1       // role A: 0 aggregate, multiply, land; 1 multiply, aggregate, land
 #endif
@@ -1619,6 +1622,20 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
   // hand-over inside the pair: role B has finished READING the gather tile for graph i + 1 (flag = i + 1) before role A lands
   // g(i + 2) in it.  LDS executes a wave's operations in order, so the flag write follows B's last gather read.
   KGCN_LDS volatile int* const agg_flag = (KGCN_LDS volatile int*)(uintptr_t)lds_off(tab0 + FN + 2);
+  // development (KGCN_BP_PAIR_SYNC): the end-of-iteration rendezvous between the TWO waves of a pair only (arrival counters in LDS)
+  // instead of the workgroup barrier that also ties the four pairs together
+  KGCN_LDS volatile int* const arrive_mine = (KGCN_LDS volatile int*)(uintptr_t)lds_off(tab0 + (FN + 4) + FN + 2 + role);
+  KGCN_LDS volatile int* const arrive_other = (KGCN_LDS volatile int*)(uintptr_t)lds_off(tab0 + (FN + 4) + FN + 2 + (role ^ 1));
+  auto iter_sync = [&](int i) __attribute__((always_inline)) {
+    if constexpr (KGCN_BP_PAIR_SYNC != 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) *arrive_mine = i + 1;
+      while (*arrive_other < i + 1) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+    } else {
+      bp_barrier();
+    }
+  };
 
   if (role == 0) {
     // =========================================== role A ===========================================================
@@ -1676,6 +1693,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
     issue_tile<true>(gpf, g + (long)gidx(2) * N * D, 512, lane);
     issue_cv(cpf, cv_t, base_a, cnt_a, lane);
     issue_meta(m_b, slots_t, gptr_t, gidx(3), N, lane);
+    if (lane == 0) *arrive_mine = 0;
     bp_barrier();                                                 // barrier 1: dFW(0) in planes 0
 
     f32x16 c0, c1;
@@ -1765,7 +1783,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
       PROBE(6)
       land_and_prefetch(i, cur);
       PROBE(2)
-      bp_barrier();
+      iter_sync(i);
       PROBE(4)
       cur ^= 1;
     }
@@ -1775,7 +1793,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
     }
     wave_sync();
     dx_of(cnt_max - 2, cur);
-    bp_barrier();
+    iter_sync(cnt_max - 2);
     cur ^= 1;
     // iteration cnt_max - 1
     if (whole) dx_of(cnt_max - 1, cur);
@@ -1876,7 +1894,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
       static_for<16>([&](auto qc) __attribute__((always_inline)) { load_x(xb, qc); });
     }
     split_and_reload(1);
-    if (lane == 0) *agg_flag = 0;
+    if (lane == 0) { *agg_flag = 0; *arrive_mine = 0; }
     bp_barrier();                                                 // barrier 1: dFW(0) in planes 0
 
     int cur = 0;
@@ -1898,7 +1916,7 @@ __global__ __launch_bounds__(512, 2) void graphconv_bwd_pairs_kernel(
       }
       split_and_reload(i + 2);                                    // x(i+1) -> fragments, x(i+2) requested
       PROBE(2)
-      bp_barrier();
+      iter_sync(i);
       PROBE(4)
       cur ^= 1;
     }

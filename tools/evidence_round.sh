@@ -35,3 +35,12 @@ for f in ("cfg2_normalize","cfg2_graphs4096","cfg2_forcedist","cfg4_forcedist","
         print(f, round(d["value"]), round(d["ms_per_step"],4), d.get("hipgraph_replay",{}).get("ms_per_step"), (json.dumps(c)[:300] if c else None))
     except Exception as e: print(f,"ERR",e)
 PY
+# ---- round 6 additions: the backward's two forms on THIS box, the memory skeleton, the per-role probe, multi-channel Bconv, sweeps ----
+if [ -d build/variants ]; then
+  { for rep in 1 2; do VB_TIMING_ONLY=1 bash tools/variants.sh run planes pairs pairs_hot planes_hot 2>&1 | cut -c1-900; done; } > $OUT/backward_forms.txt 2>&1
+  { KGCN_PROBE_LIB=build/variants/libkgcn_probe.so timeout 300 python tools/pairs_probe.py 100000 2; KGCN_PROBE_LIB=build/variants/libkgcn_probehot.so timeout 300 python tools/pairs_probe.py 100000 2; } > $OUT/pairs_probe.txt 2>&1
+fi
+[ -x build/bwd_skeleton ] && timeout 300 build/bwd_skeleton > $OUT/skeleton.txt 2>&1
+timeout 600 python tools/bconv_bench.py > $OUT/bconv_c6.jsonl 2> $OUT/bconv.err
+timeout 900 python tools/fuzz_gpu.py 300 606 > $OUT/fuzz_gpu.txt 2>&1; tail -3 $OUT/fuzz_gpu.txt
+timeout 900 python tools/fuzz_gemmh.py 200 606 > $OUT/fuzz_gemmh.txt 2>&1; tail -2 $OUT/fuzz_gemmh.txt

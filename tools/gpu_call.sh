@@ -1,4 +1,4 @@
 #!/bin/bash
-REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO; OUT=gpurun_out/r06f; mkdir -p $OUT
-timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; echo "pytest rc $?" >> $OUT/pytest.log; tail -15 $OUT/pytest.log
-cp gpurun_out/accuracy_tests.json gpurun_out/accuracy_fingerprint.json $OUT/
+REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO
+timeout 600 bash tools/variants.sh run psync 2>&1 | cut -c1-500
+for rep in 1 2; do VB_TIMING_ONLY=1 timeout 900 bash tools/variants.sh run head psync 2>&1 | cut -c1-1500; done
