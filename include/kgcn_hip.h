@@ -313,6 +313,15 @@ int kgcn_dot_f32(const float* a, const float* b, int64_t n, float* out, void* wo
 int kgcn_bconv_act_f32(const kgcn_csr_batch* a_ch, int32_t num_channels, const float* rhs, int64_t rhs_ld,
                        int64_t rhs_graph_stride, int64_t rhs_channel_stride, int32_t d, float* out, int64_t out_ld,
                        int64_t out_graph_stride, int32_t act, void* stream);
+
+/* The adjoint of Bconv for ALL channels from one read of the gradient (kgcn/bconv_call.py:45-53: addn_grad fans the incoming
+ * gradient out to every channel):   out_c[t] = A_c[t]^T (grad[t] (.) act'(act_out[t]))   for c = 0 .. num_channels - 1,
+ * out_c = out + c * out_channel_stride.  at_ch: the TRANSPOSED containers (A_c^T) of one batch shape; act / act_out as in
+ * kgcn_bspmm_dact_f32 (act = KGCN_ACT_NONE: act_out may be NULL).  Equivalent to num_channels calls of kgcn_bspmm_dact_f32 with
+ * beta = 0 (bit for bit: the same sums in the same order). */
+int kgcn_bconv_fanout_f32(const kgcn_csr_batch* at_ch, int32_t num_channels, const float* grad, const float* act_out, int64_t ld,
+                          int64_t graph_stride, int32_t d, int32_t act, float* out, int64_t out_ld, int64_t out_graph_stride,
+                          int64_t out_channel_stride, void* stream);
 /* backward of that layer through one channel (pass the A^T container):
  *   out[t] = beta*out[t] + A[t] @ ( grad[t] (.) act'(act_out[t]) )      grad, act_out: same layout (ld, graph stride) */
 int kgcn_bspmm_dact_f32(const kgcn_csr_batch* a, const float* grad, const float* act_out, int64_t ld,

@@ -155,6 +155,8 @@ SIGNATURES = {
     "kgcn_graph_gather_fwd_ld_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i32, c_f32p, c_i64, ctypes.c_void_p]),
     "kgcn_graph_gather_bwd_f32": (ctypes.c_int, [c_f32p, c_i64, c_i32, c_i32, c_f32p,
                                                  ctypes.c_void_p]),
+    "kgcn_bconv_fanout_f32": (ctypes.c_int, [_CSRP, c_i32, c_f32p, c_f32p, c_i64, c_i64, c_i32, c_i32, c_f32p, c_i64, c_i64, c_i64,
+                                             ctypes.c_void_p]),
     "kgcn_bconv_act_f32": (ctypes.c_int, [_CSRP, c_i32, c_f32p, c_i64, c_i64, c_i64, c_i32, c_f32p, c_i64, c_i64, c_i32,
                                           ctypes.c_void_p]),
     "kgcn_bspmm_dact_f32": (ctypes.c_int, [_CSRP, c_f32p, c_f32p, c_i64, c_i64, c_i32, c_i32, c_f32p, c_i64, c_i64,

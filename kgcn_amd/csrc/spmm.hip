@@ -822,6 +822,207 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Multi-channel aggregation with a CHANNEL LOOP (round 6; kgcn/bconv_call.py:11-23, the split_adj_flag case of
+// kgcn/data_util.py:76-122 -- one adjacency channel per bond type):   out[t] = act(beta out[t] + sum_c A_c[t] rhs_c[t]).
+// spmm_tile_kernel stages ALL channels of a graph before it aggregates: with C = 6 channels of a 32 x 64 operand that is a 48 KB
+// tile, three 4-wave workgroups per CU, 0.33 of the HBM peak (10 x 50: 0.23; tools/bconv_bench.py).  Here a ONE-wave workgroup
+// stages one channel's [K x ds] block at a time -- the next channel's block and CSR slice are already on their way in registers --
+// and the rows' sums stay in registers across the channels: lane (sub, cl) owns columns cl VEC .. of the rows p RPW + sub.  LDS per
+// workgroup = one block + one CSR slice (8-10 KB: the occupancy of the single-channel kernel).
+// bconv_fanout_kernel is the adjoint: out_c[t] = A_c[t] (g[t] (.) act'(aout[t])) for every channel c from ONE staging of g (the
+// reference's addn_grad fans the gradient out to every channel, bconv_call.py:45-53; until now: one launch per channel, each of them
+// reading g again).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sp_wave_sync() {     // LDS hand-over inside ONE wave: program order is enough (see fused.hip)
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int VEC, int NVL, int NP>
+__global__ __launch_bounds__(64) void bconv_loop_kernel(
+    SpmmChannels ch, const float* __restrict__ rhs, long rhs_ld, long rhs_gs, float* __restrict__ out, long out_ld, long out_gs,
+    int M, int K, int ds, int nslices, float beta, int act) {
+  using V = typename SpVec<VEC>::T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = blockIdx.x / nslices;
+  const int col0 = (blockIdx.x - t * nslices) * ds;
+  const int lane = threadIdx.x;
+  const int dv = ds / VEC, nv = K * dv;
+  const int step_r = 64 / dv, step_c = 64 - step_r * dv;
+  const int rpw = 64 / dv;                                   // rows per pass
+  const int sub = lane / dv, cl = lane - sub * dv;
+  const bool active = sub < rpw;
+  int max_nnz = 0;
+  for (int c = 0; c < ch.n; ++c) max_nnz = ch.max_nnz[c] > max_nnz ? ch.max_nnz[c] : max_nnz;
+  float* tile = reinterpret_cast<float*>(smem);
+  int2* ecv = reinterpret_cast<int2*>(smem + (((size_t)K * ds * 4 + 15) & ~(size_t)15));
+  int* rp = reinterpret_cast<int*>(ecv + max_nnz);
+  auto ldv = [](const float* p) { return *reinterpret_cast<const V*>(p); };
+
+  V pre[NVL];                 // the next channel's block in flight
+  int2 pe0, pe1;              // ... its first 128 CSR entries
+  int prp, pbase, pcnt;       // ... its row pointers (lane <= M), first entry, entry count
+  auto issue = [&](int c) __attribute__((always_inline)) {
+    const float* rb = rhs + c * ch.rhs_cs + (long)t * rhs_gs + col0;
+    int r = lane / dv, cc = lane - r * dv;
+#pragma unroll
+    for (int u = 0; u < NVL; ++u) {
+      const bool ok = lane + 64 * u < nv;
+      const int rr = ok ? r : 0, c2 = ok ? cc : 0;           // clamped: always a valid address
+      pre[u] = ldv(rb + (long)rr * rhs_ld + c2 * VEC);
+      r += step_r; cc += step_c;
+      if (cc >= dv) { cc -= dv; ++r; }
+    }
+    const int* grp = ch.rowptr[c] + (long)t * M;
+    pbase = grp[0];
+    pcnt = grp[M] - pbase;
+    prp = grp[lane <= M ? lane : M] - pbase;
+    const int2 z = {0, 0};
+    pe0 = lane < pcnt ? ch.cv[c][pbase + lane] : z;
+    pe1 = 64 + lane < pcnt ? ch.cv[c][pbase + 64 + lane] : z;
+  };
+  V acc[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[p][j] = 0.f;
+
+  issue(0);
+  for (int c = 0; c < ch.n; ++c) {
+    // ---- registers -> LDS (the aggregation of channel c - 1 is through with the block: same wave, program order) ----
+#pragma unroll
+    for (int u = 0; u < NVL; ++u)
+      if (lane + 64 * u < nv) *reinterpret_cast<V*>(tile + (size_t)(lane + 64 * u) * VEC) = pre[u];
+    const int cnt = pcnt, base = pbase;
+    if (lane < cnt) ecv[lane] = pe0;
+    if (64 + lane < cnt) ecv[64 + lane] = pe1;
+    for (int i = 128 + lane; i < cnt; i += 64) ecv[i] = ch.cv[c][base + i];      // rare: more than 128 entries in one channel
+    if (lane <= M) rp[lane] = prp;
+    if (M >= 64 && lane == 0) rp[M] = cnt;
+    if (c + 1 < ch.n) issue(c + 1);                          // uniform
+    sp_wave_sync();
+    // ---- aggregate channel c into the rows' sums ----
+    if (active) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int r = p * rpw + sub;
+        if (r < M) {
+          const int s0 = rp[r], e0 = rp[r + 1];
+          for (int k = s0; k < e0; ++k) {
+            const int2 q = ecv[k];
+            acc[p] += __int_as_float(q.y) * ldv(tile + (size_t)q.x * ds + cl * VEC);
+          }
+        }
+      }
+    }
+    sp_wave_sync();
+  }
+  if (active) {
+    float* ob = out + (long)t * out_gs + col0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int r = p * rpw + sub;
+      if (r < M) {
+        float* o = ob + (long)r * out_ld + cl * VEC;
+        V a = acc[p];
+        if (beta != 0.f) a += ldv(o);
+        if (act != KGCN_ACT_NONE) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) a[j] = act_fwd(a[j], act);
+        }
+        *reinterpret_cast<V*>(o) = a;
+      }
+    }
+  }
+}
+
+// ch: the TRANSPOSED containers (rows of A_c^T = columns of A_c); M = their rows, K = their columns (= rows of g's block)
+template <int VEC, int NVL>
+__global__ __launch_bounds__(64) void bconv_fanout_kernel(
+    SpmmChannels ch, const float* __restrict__ g, long g_ld, long g_gs, const float* __restrict__ aout, int dact,
+    float* __restrict__ out, long out_ld, long out_gs, long out_cs, int M, int K, int ds, int nslices) {
+  using V = typename SpVec<VEC>::T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = blockIdx.x / nslices;
+  const int col0 = (blockIdx.x - t * nslices) * ds;
+  const int lane = threadIdx.x;
+  const int dv = ds / VEC, nv = K * dv;
+  const int step_r = 64 / dv, step_c = 64 - step_r * dv;
+  const int rpw = 64 / dv;
+  const int sub = lane / dv, cl = lane - sub * dv;
+  const bool active = sub < rpw;
+  int max_nnz = 0;
+  for (int c = 0; c < ch.n; ++c) max_nnz = ch.max_nnz[c] > max_nnz ? ch.max_nnz[c] : max_nnz;
+  float* tile = reinterpret_cast<float*>(smem);
+  int2* ecv = reinterpret_cast<int2*>(smem + (((size_t)K * ds * 4 + 15) & ~(size_t)15));
+  int* rp = reinterpret_cast<int*>(ecv + max_nnz);
+  auto ldv = [](const float* p) { return *reinterpret_cast<const V*>(p); };
+
+  int2 pe0, pe1;
+  int prp, pbase, pcnt;
+  auto issue_csr = [&](int c) __attribute__((always_inline)) {
+    const int* grp = ch.rowptr[c] + (long)t * M;
+    pbase = grp[0];
+    pcnt = grp[M] - pbase;
+    prp = grp[lane <= M ? lane : M] - pbase;
+    const int2 z = {0, 0};
+    pe0 = lane < pcnt ? ch.cv[c][pbase + lane] : z;
+    pe1 = 64 + lane < pcnt ? ch.cv[c][pbase + 64 + lane] : z;
+  };
+  issue_csr(0);
+  {                                                          // the gradient block, once (times act'(aout) in an activated layer)
+    const float* gb = g + (long)t * g_gs + col0;
+    const float* ab = aout ? aout + (long)t * g_gs + col0 : nullptr;
+    V v[NVL], a[NVL];
+    int r = lane / dv, cc = lane - r * dv;
+#pragma unroll
+    for (int u = 0; u < NVL; ++u) {
+      const bool ok = lane + 64 * u < nv;
+      const int rr = ok ? r : 0, c2 = ok ? cc : 0;
+      v[u] = ldv(gb + (long)rr * g_ld + c2 * VEC);
+      if (dact != KGCN_ACT_NONE) a[u] = ldv(ab + (long)rr * g_ld + c2 * VEC);
+      r += step_r; cc += step_c;
+      if (cc >= dv) { cc -= dv; ++r; }
+    }
+#pragma unroll
+    for (int u = 0; u < NVL; ++u) {
+      if (dact != KGCN_ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[u][j] *= act_dout(a[u][j], dact);
+      }
+      if (lane + 64 * u < nv) *reinterpret_cast<V*>(tile + (size_t)(lane + 64 * u) * VEC) = v[u];
+    }
+  }
+  for (int c = 0; c < ch.n; ++c) {
+    const int cnt = pcnt, base = pbase;
+    if (lane < cnt) ecv[lane] = pe0;
+    if (64 + lane < cnt) ecv[64 + lane] = pe1;
+    for (int i = 128 + lane; i < cnt; i += 64) ecv[i] = ch.cv[c][base + i];
+    if (lane <= M) rp[lane] = prp;
+    if (M >= 64 && lane == 0) rp[M] = cnt;
+    if (c + 1 < ch.n) issue_csr(c + 1);
+    sp_wave_sync();
+    if (active) {
+      float* ob = out + c * out_cs + (long)t * out_gs + col0;
+      for (int r = sub; r < M; r += rpw) {
+        V acc;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+        const int s0 = rp[r], e0 = rp[r + 1];
+        for (int k = s0; k < e0; ++k) {
+          const int2 q = ecv[k];
+          acc += __int_as_float(q.y) * ldv(tile + (size_t)q.x * ds + cl * VEC);
+        }
+        *reinterpret_cast<V*>(ob + (long)r * out_ld + cl * VEC) = acc;
+      }
+    }
+    sp_wave_sync();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------
@@ -865,6 +1066,32 @@ static TilePlan tile_plan(const kgcn_csr_batch* a, int nch, const float* rhs, lo
   return p;
 }
 
+// Channel-loop kernels (bconv_loop_kernel / bconv_fanout_kernel): vec and the column slice ds of one wave (<= 64 vectors per row,
+// the block of ONE channel within 16 KiB, <= 16 block vectors and <= 16 row passes per lane); 0 = not this route.
+struct LoopPlan { int vec, ds, nvl, np; size_t lds; };
+static LoopPlan loop_plan(const kgcn_csr_batch* a, int nch, long ld_all, uintptr_t ptrs, int d) {
+  LoopPlan p = {0, 0, 0, 0, 0};
+  const int M = a->rows, K = a->cols;
+  if (M <= 0 || K <= 0 || M > 64 || K > 64 || d <= 0) return p;
+  const int vec = (ld_all % 4 == 0 && ptrs % 16 == 0) ? 4 : (ld_all % 2 == 0 && ptrs % 8 == 0) ? 2 : 0;
+  if (!vec) return p;
+  int ds = d;
+  while (ds / vec > 64 || (long)K * ds * 4 > 16 * 1024) {     // halve while the halves stay whole vectors of >= 32 columns
+    if (ds % 2 != 0 || (ds / 2) % vec != 0 || ds / 2 < 32) return p;
+    ds /= 2;
+  }
+  if (d % ds != 0) return p;
+  const int dv = ds / vec, nv = K * dv, rpw = 64 / dv;
+  const int nvl = (nv + 63) / 64, np = (M + rpw - 1) / rpw;
+  if (nvl > 16 || np > 16) return p;
+  int max_nnz = 0;
+  for (int c = 0; c < nch; ++c) max_nnz = a[c].max_nnz_per_graph > max_nnz ? a[c].max_nnz_per_graph : max_nnz;
+  p.vec = vec; p.ds = ds; p.nvl = nvl <= 8 ? 8 : 16; p.np = np <= 8 ? 8 : 16;
+  p.lds = (((size_t)K * ds * 4 + 15) & ~(size_t)15) + (size_t)max_nnz * 8 + (size_t)(M + 2) * 4;
+  if (p.lds > 40 * 1024) p.vec = 0;
+  return p;
+}
+
 // out[t] = act(beta*out[t] + sum_c A_c[t] @ (rhs_c[t] (.) act'(aout[t])));  a: nch channel descriptors of one batch shape
 int launch_spmm_multi(const kgcn_csr_batch* a, int nch, const float* rhs, long rhs_ld, long rhs_gs, long rhs_cs, int d,
                       float* out, long out_ld, long out_gs, float beta, const float* self_scale, int act,
@@ -891,6 +1118,29 @@ int launch_spmm_multi(const kgcn_csr_batch* a, int nch, const float* rhs, long r
     ch.cv[c] = reinterpret_cast<const int2*>(a[c].cv);
     ch.max_nnz[c] = a[c].max_nnz_per_graph;
   }
+#ifndef KGCN_BCONV_NO_LOOP
+  if (nch >= 2 && dact == KGCN_ACT_NONE && !self_scale && !dotx) {
+    // several channels: one channel's block in LDS at a time, the sums in registers (bconv_loop_kernel)
+    const LoopPlan lp = loop_plan(a, nch, rhs_ld | rhs_gs | out_ld | out_gs | rhs_cs | d,
+                                  reinterpret_cast<uintptr_t>(rhs) | reinterpret_cast<uintptr_t>(out), d);
+    if (lp.vec && (long)T * (d / lp.ds) <= 0x7fffffffL) {
+      const int nsl = d / lp.ds;
+      const dim3 grid((unsigned)(T * nsl));
+#define KGCN_LOOP(VEC, NVL, NP)                                                                                            \
+  hipLaunchKernelGGL((bconv_loop_kernel<VEC, NVL, NP>), grid, dim3(64), lp.lds, stream, ch, rhs, rhs_ld, rhs_gs, out, out_ld, \
+                     out_gs, M, K, lp.ds, nsl, beta, act)
+      if (lp.vec == 4) {
+        if (lp.nvl == 8 && lp.np == 8) KGCN_LOOP(4, 8, 8); else if (lp.nvl == 8) KGCN_LOOP(4, 8, 16);
+        else if (lp.np == 8) KGCN_LOOP(4, 16, 8); else KGCN_LOOP(4, 16, 16);
+      } else {
+        if (lp.nvl == 8 && lp.np == 8) KGCN_LOOP(2, 8, 8); else if (lp.nvl == 8) KGCN_LOOP(2, 8, 16);
+        else if (lp.np == 8) KGCN_LOOP(2, 16, 8); else KGCN_LOOP(2, 16, 16);
+      }
+#undef KGCN_LOOP
+      return check_launch("bconv_loop_kernel");
+    }
+  }
+#endif
   // ragged-compact batches with their block structure: every rhs row staged once (spmm_block_kernel)
   if (nch == 1 && T == 1 && a->block_ptr && a->num_blocks > 0 && a->block_rows_max > 0 && !dotx) {
     const long all = rhs_ld | out_ld | d;
@@ -1121,6 +1371,56 @@ extern "C" int kgcn_bconv_f32(const kgcn_csr_batch* a_ch, int32_t num_channels, 
 
 static int check_act(const char* who, int act) {
   if (act < KGCN_ACT_NONE || act > KGCN_ACT_TANH) return fail("%s: unknown activation code %d", who, act);
+  return 0;
+}
+
+extern "C" int kgcn_bconv_fanout_f32(const kgcn_csr_batch* at_ch, int32_t num_channels, const float* grad, const float* act_out,
+                                     int64_t ld, int64_t graph_stride, int32_t d, int32_t act, float* out, int64_t out_ld,
+                                     int64_t out_graph_stride, int64_t out_channel_stride, void* stream) {
+  if (num_channels <= 0) return fail("kgcn_bconv_fanout_f32: num_channels=%d", num_channels);
+  if (!at_ch) return fail("kgcn_bconv_fanout_f32: at_ch is NULL");
+  if (int rc = check_act("kgcn_bconv_fanout_f32", act)) return rc;
+  for (int c = 0; c < num_channels; ++c) {
+    if (int rc = validate_csr(at_ch + c, "kgcn_bconv_fanout_f32")) return rc;
+    if (at_ch[c].num_graphs != at_ch[0].num_graphs || at_ch[c].rows != at_ch[0].rows || at_ch[c].cols != at_ch[0].cols)
+      return fail("kgcn_bconv_fanout_f32: channel %d has a different batch shape", c);
+  }
+  if (d < 0) return fail("kgcn_bconv_fanout_f32: d=%d < 0", d);
+  const int T = at_ch[0].num_graphs, M = at_ch[0].rows, K = at_ch[0].cols;
+  if (T == 0 || M == 0 || d == 0) return 0;
+  if (!grad || !out || (act != KGCN_ACT_NONE && !act_out)) return fail("kgcn_bconv_fanout_f32: NULL operand");
+  if (ld < d || out_ld < d) return fail("kgcn_bconv_fanout_f32: leading dimension smaller than d");
+  hipStream_t s = as_stream(stream);
+  const uintptr_t ptrs = reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(out) |
+                         (act != KGCN_ACT_NONE ? reinterpret_cast<uintptr_t>(act_out) : 0);
+  const LoopPlan lp = num_channels <= MAX_CH
+      ? loop_plan(at_ch, num_channels, ld | graph_stride | out_ld | out_graph_stride | out_channel_stride | d, ptrs, d)
+      : LoopPlan{0, 0, 0, 0, 0};
+  if (lp.vec && (long)T * (d / lp.ds) <= 0x7fffffffL) {
+    SpmmChannels ch;
+    ch.n = num_channels;
+    ch.rhs_cs = 0;
+    for (int c = 0; c < num_channels; ++c) {
+      ch.rowptr[c] = at_ch[c].rowptr;
+      ch.cv[c] = reinterpret_cast<const int2*>(at_ch[c].cv);
+      ch.max_nnz[c] = at_ch[c].max_nnz_per_graph;
+    }
+    const int nsl = d / lp.ds;
+    const dim3 grid((unsigned)(T * nsl));
+    const float* ao = act != KGCN_ACT_NONE ? act_out : nullptr;
+#define KGCN_FAN(VEC, NVL)                                                                                                 \
+  hipLaunchKernelGGL((bconv_fanout_kernel<VEC, NVL>), grid, dim3(64), lp.lds, s, ch, grad, (long)ld, (long)graph_stride, ao, \
+                     (int)act, out, (long)out_ld, (long)out_graph_stride, (long)out_channel_stride, M, K, lp.ds, nsl)
+    if (lp.vec == 4) { if (lp.nvl == 8) KGCN_FAN(4, 8); else KGCN_FAN(4, 16); }
+    else { if (lp.nvl == 8) KGCN_FAN(2, 8); else KGCN_FAN(2, 16); }
+#undef KGCN_FAN
+    return check_launch("bconv_fanout_kernel");
+  }
+  for (int c = 0; c < num_channels; ++c) {                  // shapes the channel-loop kernel does not take: one launch per channel
+    int rc = launch_spmm_multi(at_ch + c, 1, grad, ld, graph_stride, 0, d, out + c * out_channel_stride, out_ld, out_graph_stride,
+                               0.f, nullptr, KGCN_ACT_NONE, act_out, act, s);
+    if (rc) return rc;
+  }
   return 0;
 }
 

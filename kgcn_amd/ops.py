@@ -301,13 +301,10 @@ class _BConv(torch.autograd.Function):
         d_rhs = None
         if ctx.needs_input_grad[0]:
             d_rhs = torch.empty((T * K, C * d), device=g.device, dtype=torch.float32)
-            for c, ch in enumerate(adj.channels):        # addn_grad: g fans out to every channel
-                if act:                                  # d pre-activation = g * act'(out), formed while it is gathered
-                    check(lib.kgcn_bspmm_dact_f32(ch.transpose().desc(), ptr(g), ptr(aout), d, M * d, d, act,
-                                                  d_rhs.data_ptr() + 4 * c * d, C * d, K * C * d, 0.0, current_stream()),
-                          "kgcn_bspmm_dact_f32")
-                else:
-                    bspmm_raw(ch.transpose(), g, d, d_rhs, out_ld=C * d, out_gs=K * C * d, out_col=c * d)
+            # addn_grad: g fans out to every channel -- ONE launch reads it once and writes every channel's column block
+            # (d pre-activation = g * act'(out) is formed while the block is staged)
+            check(lib.kgcn_bconv_fanout_f32(adj.desc_array(True), C, ptr(g), ptr(aout) if act else None, d, M * d, d, int(act),
+                                            ptr(d_rhs), C * d, K * C * d, d, current_stream()), "kgcn_bconv_fanout_f32")
         if act and ctx.nvalues and any(ctx.needs_input_grad[4:]):
             g = activation_backward(aout, g, act)        # d values needs d pre-activation as a tensor
         d_vals = []

@@ -1,20 +1,10 @@
 #!/bin/bash
-REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/mc -o mc -- python $REPO/bench.py --config cfg1 --profile --steps 20 --warmup 3 > /tmp/mc.log 2>&1
-python - <<'PY'
-import glob, sqlite3, collections
-for db in glob.glob('/tmp/mc/**/*.db', recursive=True):
-    con = sqlite3.connect(db); cur = con.cursor()
-    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
-    print([t for t in tabs if 'cop' in t.lower() or 'mem' in t.lower()][:20])
-    for t in tabs:
-        if 'memory_cop' in t.lower() and 'rocpd_' not in t:
-            cols = [r[1] for r in cur.execute("pragma table_info(%s)" % t)]
-            print(t, cols)
-            rows = list(cur.execute("select * from %s order by start" % t))
-            print(len(rows), "copies; last 12:")
-            for r in rows[-12:]: print(r)
-    ks = list(cur.execute("select name, start, duration from kernels order by start"))
-    print("last 40 kernels:")
-    for n, s, d in ks[-40:]: print(s, d, n[:60])
+REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO; OUT=gpurun_out/r06g; mkdir -p $OUT
+timeout 900 python -m pytest tests/test_gpu_bconv_loop.py -m gpu -q -x > $OUT/pytest_loop.log 2>&1; tail -15 $OUT/pytest_loop.log
+timeout 900 python -m pytest tests -m gpu -q -x -k "bconv or split or gat or maxpool or deferred or GCN" > $OUT/pytest_rel.log 2>&1; tail -4 $OUT/pytest_rel.log
+timeout 600 python tools/bconv_bench.py > $OUT/bconv_c6.jsonl 2> $OUT/bconv.err; python - <<'PY'
+import json
+for l in open('gpurun_out/r06g/bconv_c6.jsonl'):
+    d=json.loads(l); print(d['shape'], d['layer_fwd_bwd_ms']['median'], d['graphs_per_s'], d['bconv_forward'], d['bconv_adjoint'])
 PY
+tail -3 $OUT/bconv.err

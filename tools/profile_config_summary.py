@@ -53,13 +53,20 @@ def load(db):
 
 
 def timed_start(per):
-    """Start time of the TIMED region of a pass: the timed steps are the end of the run, so the kernel with the largest total time
-    (one of the step's own) ran (its dispatches // passes) times per step, and the region begins with the first of its last
-    (per step x STEPS) dispatches.  Everything that started earlier -- set-up, warm-up, graph capture, and the torch fill / copy
-    kernels of model construction, which an earlier form of this script spread over the steps as "1 per step" -- is not counted."""
-    name = max(per, key=lambda k: sum(d for _, d in per[k]))
-    n = max(1, round(len(per[name]) / PASSES))
-    return per[name][-min(len(per[name]), n * STEPS)][0]
+    """Start time of the TIMED region of a pass.  The timed steps are the end of the run; a kernel of the step itself is launched by
+    EVERY pass of the step function (set-up + warm-up + timed), i.e. (per step) x PASSES times, and its last (per step) x STEPS
+    dispatches are the timed ones: the region starts with the earliest of those over all such kernels.  Kernels with fewer
+    dispatches than that -- model construction, data generation, graph capture: the torch fill / copy kernels an earlier form of
+    this script spread over the steps as "1 per step" -- do not define the region, and what they launched before it is not counted."""
+    t0 = None
+    for name, rows in per.items():
+        n = round(len(rows) / PASSES)
+        if n >= 1 and len(rows) >= n * (PASSES - 2):
+            s0 = rows[-min(len(rows), n * STEPS)][0]
+            t0 = s0 if t0 is None else min(t0, s0)
+    if t0 is None:                                           # (no kernel ran once per pass: count everything)
+        t0 = min(r[0][0] for r in per.values())
+    return t0
 
 
 dur, meta, pmc = {}, {}, {}
@@ -101,7 +108,7 @@ for k, (ps, v) in sorted(st.items(), key=lambda kv: -kv[1][0] * avg(kv[1][1])):
     if ps * a < 0.002 * tot:
         continue
     c = pmc.get(k, {})
-    line = "%-64s %5d %9.1f %9.1f %5.1f%% |" % (k, ps, a, ps * a, 100 * ps * a / tot)
+    line = "%-64s %5s %9.1f %9.1f %5.1f%% |" % (k, ("%d" % round(ps)) if abs(ps - round(ps)) < 0.02 else ("%.2f" % ps), a, ps * a, 100 * ps * a / tot)
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         b = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
         line += " %10.2f %8.0f %6.3f |" % (b / 1e6, b / a / 1e3, b / a / 1e3 / 8000.0)
