@@ -1263,8 +1263,10 @@ def main(argv=None):
     per_rank = ctx.gather_over_ranks(local_elapsed / args.steps * 1e3)
 
     box = None
-    if ctx.rank == 0 and ctx.on_gpu and not args.dry and not args.profile:
-        box = box_state(wl, ctx, elapsed / args.steps * 1e3)      # first thing after the timed region: same load, same clocks
+    if ctx.on_gpu and not args.dry and not args.profile:
+        # first thing after the timed region: same load, same clocks.  On EVERY rank: the step holds the gradient all-reduce, and the
+        # number of extra steps follows from `elapsed`, the maximum over the ranks -- the same on all of them; rank 0 reports its own GPU
+        box = box_state(wl, ctx, elapsed / args.steps * 1e3)
 
     hipgraph = None
     if args.graph and ctx.on_gpu and args.config == "cfg2" and not args.dry:

@@ -116,16 +116,31 @@ __global__ __launch_bounds__(512) void skel_h(const float* __restrict__ x, const
         hand[wave][lane] = s[0] + s[1] + s[2] + s[3];
       }
       issue(i + d + DEPTH, d);
-      if constexpr (LOAD == 1 || LOAD == 2) {
+      if constexpr (LOAD == 1 || LOAD == 2 || LOAD == 5) {
 #pragma unroll
-        for (int m = 0; m < 12; ++m) {
+        for (int m = 0; m < (LOAD == 5 ? 24 : 12); ++m) {
           acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc1, 0, 0, 0);
           acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc2, 0, 0, 0);
           acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc3, 0, 0, 0);
         }
       }
-      if constexpr (LOAD >= 2) {
+      if constexpr (LOAD == 4) {                              // the same 48 MFMAs and 400 v_fma_f32, one MFMA then eight v_fma_f32
+#pragma unroll
+        for (int m = 0; m < 12; ++m) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (q == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc0, 0, 0, 0);
+            if (q == 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc1, 0, 0, 0);
+            if (q == 2) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc2, 0, 0, 0);
+            if (q == 3) acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc3, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) va[e] = __builtin_fmaf(va[e], vm, vb);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      if constexpr (LOAD == 2 || LOAD == 3) {
 #pragma unroll
         for (int m = 0; m < 50; ++m) {
 #pragma unroll
@@ -276,6 +291,10 @@ int main(int argc, char** argv) {
          timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 1>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
     line("H  pairs + 48 bf16 MFMAs + 400 v_fma_f32 per wave and graph",
          timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 2>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("H  pairs + 48 MFMAs and 400 v_fma_f32 INTERLEAVED (1 : 8)",
+         timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 4>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("H  pairs + 96 bf16 MFMAs per wave and graph (twice the kernel's)",
+         timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 5>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
     line("H  pairs + 400 v_fma_f32 per wave and graph",
          timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 3>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
     line("H  pairs, depth 1, 8 waves/CU, NO barrier",
