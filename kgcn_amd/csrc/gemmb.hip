@@ -47,6 +47,11 @@
 namespace kgcn {
 
 constexpr int GB_R = 32;                      // rows per stage
+#ifdef KGCN_ABL_HOT                           // development: every workgroup re-reads (and re-writes) its first stage -- the kernel without HBM traffic
+#define GB_HOT_STEP 0
+#else
+#define GB_HOT_STEP G
+#endif
 constexpr int GB_PLANE = 20480;               // bytes of one piece plane
 constexpr int GB_BUF = 2 * GB_PLANE;          // h | l
 // k-steps of W' held in registers; the others live in LDS (below).  The form that adds the read-out's gradient to a row gradient
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
       compute_dx(t, t + G, t + 2 * G, buf);
       gh_barrier_lds();
       GBP(5)
-      t += G;
+      t += GB_HOT_STEP;
     }
     if constexpr (DOT) {                                      // fixed order: lanes (butterfly), then the four dX waves (below)
 #pragma unroll
@@ -566,7 +571,7 @@ __global__ __launch_bounds__(512, 2) void gemmb_kernel(const float* __restrict__
       GBP(2)
       gh_barrier_lds();
       GBP(5)
-      t += G;
+      t += GB_HOT_STEP;
     }
     // ---- the wave's partial dW rows [128 half + 32 w4 .. + 32) x all columns, unscaled; one partial per PAIR --------------------
     float* pw = part_dw + q0 * (long)ndim * kdim;

@@ -381,7 +381,9 @@ __global__ __launch_bounds__(512, 2) void gemmh_fwd_kernel(const float* __restri
       gh_barrier_lds();
     }
     GHP(4)
+#ifndef KGCN_ABL_HOT                          // (development: with it every workgroup re-reads its first tile -- the kernel without HBM traffic)
     t += G;
+#endif
   }
   GHP_FLUSH
   if constexpr (DK != 0) {
