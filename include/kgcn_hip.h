@@ -656,6 +656,18 @@ int kgcn_reduce_flush(void* stream);
  * kind 0: y = act(x W + b) / dx = dy W^T (din = contraction width), 1: dx with the activation derivative, 2: weight gradient. */
 int kgcn_dense_mfma_products(int32_t kind, int64_t m, int32_t din, int32_t dout);
 
+/* Several strided 2-D fp32 copies in ONE launch: dst[r * dst_ld + c] = src[r * src_ld + c] for r < rows, c < cols of every job.
+ * Used for the operand of a multi-channel GraphConv's single GEMM, [W_0 | W_1 | ...] and [b_0 | b_1 | ...] (kgcn/layers.py:68-78
+ * builds one MatMul per channel; one GEMM over the concatenated kernels produces the same FW[b][ch] blocks side by side), and for
+ * the split of that operand's gradient into one contiguous tensor per parameter. */
+#define KGCN_COPY2D_MAX_JOBS 16
+typedef struct kgcn_copy2d_job {
+  const float* src;
+  float* dst;
+  int64_t rows, cols, src_ld, dst_ld;
+} kgcn_copy2d_job;
+int kgcn_copy2d_multi_f32(const kgcn_copy2d_job* jobs, int32_t num_jobs, void* stream);
+
 /* Measurement aid (bench.py: `roofline.hbm_probe`, SURVEY 8(d) "report both nominal and achievable"): one grid-stride float4
  * stream over `bytes` bytes per operand in the read : write mix of the kernel being priced, so that a bench line carries what
  * THIS box's HBM delivers right after the timed region.  mix 0: b = a (1 : 1, the batched SpMM's mix); 1: b = a + a2 (2 : 1, the

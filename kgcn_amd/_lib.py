@@ -74,6 +74,11 @@ class AdamSegment(ctypes.Structure):
     _fields_ = [("grad", ctypes.c_void_p), ("offset", c_i64), ("numel", c_i64)]
 
 
+class Copy2dJob(ctypes.Structure):
+    """struct kgcn_copy2d_job (include/kgcn_hip.h)."""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("rows", c_i64), ("cols", c_i64), ("src_ld", c_i64), ("dst_ld", c_i64)]
+
+
 class WtableJob(ctypes.Structure):
     """struct kgcn_wtable_job (include/kgcn_hip.h)."""
     _fields_ = [("w", ctypes.c_void_p), ("w_ld", c_i64), ("trans_w", c_i32), ("k", c_i32), ("n", c_i32), ("k_w", c_i32),
@@ -222,6 +227,7 @@ SIGNATURES = {
     "kgcn_ragged_gather_bwd_f32": (ctypes.c_int, [c_f32p, c_i32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32p,
                                                   ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_dense_mfma_products": (ctypes.c_int, [c_i32, c_i64, c_i32, c_i32]),
+    "kgcn_copy2d_multi_f32": (ctypes.c_int, [ctypes.c_void_p, c_i32, ctypes.c_void_p]),
     "kgcn_hbm_probe": (ctypes.c_int, [c_i32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_i64, ctypes.c_void_p]),
     "kgcn_reduce_defer": (ctypes.c_int, [c_i32]),
     "kgcn_reduce_pending": (ctypes.c_int, []),

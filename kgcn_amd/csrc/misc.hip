@@ -175,9 +175,53 @@ __global__ __launch_bounds__(256) void hbm_probe_kernel(const f32x4* __restrict_
   }
 }
 
+// Several strided 2-D copies in one launch (grid.y = job): the concatenation of the C kernels / biases of a multi-channel GraphConv
+// into the operand of its ONE GEMM, and the split of that operand's gradient into C contiguous tensors (layers.py:68-78 builds C
+// MatMul ops; here it is one GEMM over [W_0 | W_1 | ...]).
+struct Copy2dJobs {
+  const float* src[KGCN_COPY2D_MAX_JOBS];
+  float* dst[KGCN_COPY2D_MAX_JOBS];
+  long rows[KGCN_COPY2D_MAX_JOBS], cols[KGCN_COPY2D_MAX_JOBS], src_ld[KGCN_COPY2D_MAX_JOBS], dst_ld[KGCN_COPY2D_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void copy2d_multi_kernel(Copy2dJobs jb) {
+  const int q = blockIdx.y;
+  const float* __restrict__ src = jb.src[q];
+  float* __restrict__ dst = jb.dst[q];
+  const long cols = jb.cols[q], total = jb.rows[q] * cols, sl = jb.src_ld[q], dl = jb.dst_ld[q];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / cols, c = i - r * cols;
+    dst[r * dl + c] = src[r * sl + c];
+  }
+}
+
 }  // namespace kgcn
 
 using namespace kgcn;
+
+extern "C" int kgcn_copy2d_multi_f32(const kgcn_copy2d_job* jobs, int32_t num_jobs, void* stream) {
+  if (num_jobs < 0 || (num_jobs > 0 && !jobs)) return fail("kgcn_copy2d_multi_f32: bad job list");
+  for (int base = 0; base < num_jobs; base += KGCN_COPY2D_MAX_JOBS) {
+    const int n = num_jobs - base < KGCN_COPY2D_MAX_JOBS ? num_jobs - base : KGCN_COPY2D_MAX_JOBS;
+    Copy2dJobs jb{};
+    long most = 0;
+    for (int q = 0; q < n; ++q) {
+      const kgcn_copy2d_job& j = jobs[base + q];
+      if (j.rows < 0 || j.cols < 0 || j.src_ld < j.cols || j.dst_ld < j.cols)
+        return fail("kgcn_copy2d_multi_f32: job %d: rows=%lld cols=%lld src_ld=%lld dst_ld=%lld", base + q, (long long)j.rows,
+                    (long long)j.cols, (long long)j.src_ld, (long long)j.dst_ld);
+      if (j.rows * j.cols > 0 && (!j.src || !j.dst)) return fail("kgcn_copy2d_multi_f32: job %d: NULL operand", base + q);
+      jb.src[q] = j.src; jb.dst[q] = j.dst; jb.rows[q] = (long)j.rows; jb.cols[q] = (long)j.cols;
+      jb.src_ld[q] = (long)j.src_ld; jb.dst_ld[q] = (long)j.dst_ld;
+      if (j.rows * j.cols > most) most = (long)(j.rows * j.cols);
+    }
+    if (most == 0) continue;
+    long blocks = (most + 255) / 256;
+    if (blocks > 4L * kNumCU) blocks = 4L * kNumCU;
+    hipLaunchKernelGGL(copy2d_multi_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, static_cast<hipStream_t>(stream), jb);
+    if (int rc = check_launch("copy2d_multi_kernel")) return rc;
+  }
+  return 0;
+}
 
 extern "C" int kgcn_hbm_probe(int32_t mix, const void* a, const void* a2, void* b, int64_t bytes, void* stream) {
   if (mix < 0 || mix > 3) return fail("kgcn_hbm_probe: mix %d", mix);

@@ -148,21 +148,23 @@ class GraphConv(nn.Module):
             xa = getattr(inputs, "_kgcn_aug", None)     # rows assembled as [x | 1 | 0] already (ragged.StaticRaggedBatch)
             if xa is None or tuple(xa.shape) != (B * N, dp) or inputs.requires_grad or xa.data_ptr() != inputs.data_ptr():
                 xa = ops.augment_ones(x2d, dp)
-            z = [ops.bspmm(a.channels[c], xa) for c in range(C)]
             if getattr(self, "_agg_pad", None) is None or tuple(self._agg_pad.shape) != (dp - din - 1, dout) or \
                     self._agg_pad.device != inputs.device:
                 self._agg_pad = self.w[0].new_zeros((dp - din - 1, dout))          # constant: allocated and zeroed once
             pad = self._agg_pad
-            if C == 1 and not z[0].requires_grad:
-                # [W; b; 0] is never assembled: its fragment table is split from the two parameters by the step's one table launch
-                return ops.dense_stacked(z[0], self.w[0], self.bias[0], activation=act).reshape(B, N, dout)
-            wa = ops.stack_rows(self.w[0], self.bias[0], pad) if C == 1 else \
-                torch.cat([t for c in range(C) for t in (self.w[c], self.bias[c], pad)], dim=0)
-            return ops.dense(z[0] if C == 1 else torch.cat(z, dim=1), wa, None, activation=act).reshape(B, N, dout)
+            if C == 1:
+                z0 = ops.bspmm(a.channels[0], xa)
+                if not z0.requires_grad:
+                    # [W; b; 0] is never assembled: its fragment table is split from the two parameters by the step's one table launch
+                    return ops.dense_stacked(z0, self.w[0], self.bias[0], activation=act).reshape(B, N, dout)
+                return ops.dense(z0, ops.stack_rows(self.w[0], self.bias[0], pad), None, activation=act).reshape(B, N, dout)
+            # several channels: [A_0 X' | A_1 X' | ...] from ONE launch that reads X' once, the stacked operand from one more
+            z = ops.fan_out(a, xa)
+            return ops.dense(z, ops.stack_channel_rows(self.w, self.bias, pad), None, activation=act).reshape(B, N, dout)
         if C == 1:
             fw = ops.dense(x2d, self.w[0], self.bias[0])
         else:
-            fw = ops.dense(x2d, torch.cat(list(self.w), dim=1), torch.cat(list(self.bias), dim=1))
+            fw = ops.dense(x2d, *ops.cat_channels(self.w, self.bias))         # [W_0 | W_1 | ...]: one launch, no torch.cat
         return ops.bconv(a, fw, dout, activation=act).reshape(B, N, dout)
 
     def _forward_reference_branches(self, inputs, a, x2d, B, N, din, C, dout):
@@ -176,7 +178,7 @@ class GraphConv(nn.Module):
             return o.reshape(B, N, dout)
         if enabled_bconv:
             # kgcn/layers.py:68-78: FW[b][ch] for every channel, ONE fused op (SpMM + add-n)
-            fw = ops.dense(x2d, torch.cat(list(self.w), dim=1), torch.cat(list(self.bias), dim=1))
+            fw = ops.dense(x2d, *ops.cat_channels(self.w, self.bias))
             return ops.bconv(a, fw, dout).reshape(B, N, dout)
         if enabled_bspmm:
             # kgcn/layers.py:79-90: one Bspmm per channel, channel results added

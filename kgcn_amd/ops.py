@@ -258,6 +258,133 @@ def bspmm(csr, rhs, values=None):
 
 
 # -------------------------------------------------------------------------------------------------
+# [W_0 | W_1 | ...] and [b_0 | b_1 | ...] of a multi-channel GraphConv: ONE launch (kgcn_copy2d_multi_f32) instead of two torch.cat,
+# and in the backward ONE launch that splits the operand's gradient into a fresh contiguous tensor per parameter (the narrowed
+# views a cat's backward returns are cloned by AccumulateGrad: 2 C more launches per step)
+# -------------------------------------------------------------------------------------------------
+def _copy2d(jobs):
+    import ctypes
+    arr = (_lib.Copy2dJob * len(jobs))(*[_lib.Copy2dJob(*j) for j in jobs])
+    check(lib.kgcn_copy2d_multi_f32(ctypes.cast(arr, ctypes.c_void_p), len(jobs), current_stream()), "kgcn_copy2d_multi_f32")
+
+
+class _CatChannels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *tensors):
+        C = len(tensors) // 2
+        ws = [_f32c(t, "kernel") for t in tensors[:C]]
+        bs = [_f32c(t, "bias") for t in tensors[C:]]
+        din, dout = ws[0].shape
+        if any(tuple(w.shape) != (din, dout) for w in ws) or any(b.numel() != dout for b in bs):
+            raise _lib.KgcnHipError("cat_channels: the kernels / biases of the channels differ in shape")
+        wcat = torch.empty((din, C * dout), device=ws[0].device, dtype=torch.float32)
+        bcat = torch.empty((1, C * dout), device=ws[0].device, dtype=torch.float32)
+        jobs = [(w.data_ptr(), wcat.data_ptr() + 4 * c * dout, din, dout, dout, C * dout) for c, w in enumerate(ws)]
+        jobs += [(b.data_ptr(), bcat.data_ptr() + 4 * c * dout, 1, dout, dout, C * dout) for c, b in enumerate(bs)]
+        _copy2d(jobs)
+        ctx.shapes = [tuple(t.shape) for t in tensors]
+        ctx.dims = (C, din, dout)
+        return wcat, bcat
+
+    @staticmethod
+    def backward(ctx, gw, gb):
+        C, din, dout = ctx.dims
+        gw, gb = _f32c(gw, "grad"), _f32c(gb, "grad")
+        dws = [torch.empty(ctx.shapes[c], device=gw.device, dtype=torch.float32) for c in range(C)]
+        dbs = [torch.empty(ctx.shapes[C + c], device=gw.device, dtype=torch.float32) for c in range(C)]
+        jobs = [(gw.data_ptr() + 4 * c * dout, dws[c].data_ptr(), din, dout, C * dout, dout) for c in range(C)]
+        jobs += [(gb.data_ptr() + 4 * c * dout, dbs[c].data_ptr(), 1, dout, C * dout, dout) for c in range(C)]
+        _copy2d(jobs)
+        return tuple(dws) + tuple(dbs)
+
+
+class _StackChannelRows(torch.autograd.Function):
+    """[W_0; b_0; 0; W_1; b_1; 0; ...]  [C dp, dout]: the operand of an aggregate-first multi-channel GraphConv
+    ([A_0 X' | A_1 X' | ...] [W_0; b_0; 0; ...], X' = [X | 1 | 0]) in one launch; `pad` = the constant zero rows."""
+
+    @staticmethod
+    def forward(ctx, pad, *tensors):
+        C = len(tensors) // 2
+        ws = [_f32c(t, "kernel") for t in tensors[:C]]
+        bs = [_f32c(t, "bias") for t in tensors[C:]]
+        din, dout = ws[0].shape
+        npad = pad.shape[0]
+        dp = din + 1 + npad
+        wa = torch.empty((C * dp, dout), device=ws[0].device, dtype=torch.float32)
+        jobs = []
+        for c in range(C):
+            base = wa.data_ptr() + 4 * c * dp * dout
+            jobs.append((ws[c].data_ptr(), base, din, dout, dout, dout))
+            jobs.append((bs[c].data_ptr(), base + 4 * din * dout, 1, dout, dout, dout))
+            if npad:
+                jobs.append((pad.data_ptr(), base + 4 * (din + 1) * dout, npad, dout, dout, dout))
+        _copy2d(jobs)
+        ctx.shapes = [tuple(t.shape) for t in tensors]
+        ctx.dims = (C, din, dout, dp)
+        return wa
+
+    @staticmethod
+    def backward(ctx, gwa):
+        C, din, dout, dp = ctx.dims
+        gwa = _f32c(gwa, "grad")
+        dws = [torch.empty(ctx.shapes[c], device=gwa.device, dtype=torch.float32) for c in range(C)]
+        dbs = [torch.empty(ctx.shapes[C + c], device=gwa.device, dtype=torch.float32) for c in range(C)]
+        jobs = []
+        for c in range(C):
+            base = gwa.data_ptr() + 4 * c * dp * dout
+            jobs.append((base, dws[c].data_ptr(), din, dout, dout, dout))
+            jobs.append((base + 4 * din * dout, dbs[c].data_ptr(), 1, dout, dout, dout))
+        _copy2d(jobs)
+        return (None,) + tuple(dws) + tuple(dbs)
+
+
+def stack_channel_rows(ws, bs, pad):
+    return _StackChannelRows.apply(pad, *(list(ws) + list(bs)))
+
+
+class _FanOut(torch.autograd.Function):
+    """z[:, c d : (c + 1) d] = A_c @ x for every channel c: ONE launch that reads x once (kgcn_bconv_fanout_f32 on the channels'
+    own containers); backward d x = sum_c A_c^T gz_c: the multi-channel aggregation over the transposed containers."""
+
+    @staticmethod
+    def forward(ctx, x, adj):
+        x = _f32c(x, "inputs")
+        C = adj.num_channels
+        T, M, K = adj.num_graphs, adj.n_nodes, adj.channels[0].cols
+        d = x.shape[1]
+        if x.shape[0] != T * K:
+            raise _lib.KgcnHipError("inputs must be [T*K, d] = [%d, d], got %s" % (T * K, tuple(x.shape)))
+        z = torch.empty((T * M, C * d), device=x.device, dtype=torch.float32)
+        check(lib.kgcn_bconv_fanout_f32(adj.desc_array(False), C, ptr(x), None, d, K * d, d, 0, ptr(z), C * d, M * C * d, d,
+                                        current_stream()), "kgcn_bconv_fanout_f32")
+        ctx.adj, ctx.d = adj, d
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        adj, d = ctx.adj, ctx.d
+        if not ctx.needs_input_grad[0]:
+            return None, None
+        gz = _f32c(gz, "grad")
+        C = adj.num_channels
+        T, M, K = adj.num_graphs, adj.n_nodes, adj.channels[0].cols
+        dx = torch.empty((T * K, d), device=gz.device, dtype=torch.float32)
+        check(lib.kgcn_bconv_act_f32(adj.desc_array(True), C, ptr(gz), C * d, M * C * d, d, d, ptr(dx), d, K * d, 0, current_stream()),
+              "kgcn_bconv_act_f32")
+        return dx, None
+
+
+def fan_out(adj, x2d):
+    """[A_0 x | A_1 x | ...]  [T*M, C d]"""
+    return _FanOut.apply(x2d, adj)
+
+
+def cat_channels(ws, bs):
+    """-> ([W_0 | W_1 | ...] [din, C dout], [b_0 | b_1 | ...] [1, C dout]) as differentiable functions of the 2 C parameters."""
+    return _CatChannels.apply(*(list(ws) + list(bs)))
+
+
+# -------------------------------------------------------------------------------------------------
 # Bconv: out[t] = sum_c A_c[t] @ rhs_c[t], rhs given as ONE [T*K, C*D] tensor (channel c = columns
 # c*D..(c+1)*D) -- exactly what one GEMM with the concatenated kernels produces.
 # -------------------------------------------------------------------------------------------------

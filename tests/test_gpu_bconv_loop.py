@@ -110,3 +110,54 @@ def test_fanout_argument_checks():
     assert lib.kgcn_bconv_fanout_f32(at, 2, ptr(g), None, 8, 80, 8, 1, ptr(o), 16, 160, 8, current_stream()) != 0     # act without act_out
     assert lib.kgcn_bconv_fanout_f32(at, 2, ptr(g), None, 4, 80, 8, 0, ptr(o), 16, 160, 8, current_stream()) != 0     # ld < d
     assert lib.kgcn_bconv_fanout_f32(at, 2, ptr(g), None, 8, 80, 8, 0, ptr(o), 16, 160, 8, current_stream()) == 0
+
+
+@pytest.mark.parametrize("T,N,C,din,dout,route", [
+    (200, 10, 3, 5, 32, "aggregate-first"),      # din + 1 < dout, >= 1,024 rows: [A_0 X' | A_1 X' | ...] [W_0; b_0; 0; ...]
+    (120, 10, 6, 3, 50, "aggregate-first"),      # model.py's first layer with split adjacency
+    (64, 32, 6, 64, 64, "contract-first"),       # one GEMM over [W_0 | W_1 | ...] + the channel-loop Bconv
+    (30, 10, 6, 50, 50, "contract-first"),       # synthetic.jbl's batch with split adjacency (below 1,024 rows)
+])
+def test_multichannel_graphconv_layer_without_torch_glue(T, N, C, din, dout, route):
+    """The multi-channel GraphConv layer on both of its routes against the oracle (kgcn/layers.py:64-116) -- and no torch operator
+    may launch anything inside its forward + backward (the two torch.cat of the C kernels / biases and the 2 C gradient clones
+    they caused are one launch each way now: kgcn_copy2d_multi_f32)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import aten_in_step
+    from kgcn_amd import layers
+    from kgcn_amd.batched_csr import BatchedAdjacency
+    rng = np.random.default_rng(T + N + C + din)
+    adjs = _channels(rng, T, N, C, 0.15, empty_graph_every=7)
+    adj = BatchedAdjacency.from_adjs(adjs, n_nodes=N, device=dev())
+    x = rng.standard_normal((T, N, din)).astype(np.float32)
+    g = rng.standard_normal((T, N, dout)).astype(np.float32)
+    layer = layers.GraphConv(dout, C).to(dev())
+    layer.build((T, N, din), dev())
+    with torch.no_grad():
+        for b in layer.bias:
+            b.copy_(t32(rng.standard_normal((1, dout)).astype(np.float32) * 0.1))
+    assert (route == "aggregate-first") == (layers.aggregate_first and (din + 1 + 3) // 4 * 4 < dout and T * N >= 1024)
+    tx = t32(x).requires_grad_(True)
+    tg = t32(g)
+    out = layer(tx, adj=adj)
+    out.backward(tg)
+    w = [p.detach().cpu().numpy() for p in layer.w]
+    b = [p.detach().cpu().numpy() for p in layer.bias]
+    close(out, K.graphconv_fwd(x, adjs, w, b), rel=2e-6, what="multi-channel GraphConv forward (%s)" % route)
+    dx, dw, db = K.graphconv_bwd(x, adjs, w, b, g)
+    close(tx.grad, dx, rel=2e-6, what="d inputs")
+    for c in range(C):
+        close(layer.w[c].grad, dw[c], rel=1e-5, what="d kernel%d" % c)
+        close(layer.bias[c].grad, db[c].reshape(1, dout), rel=1e-5, what="d bias%d" % c)
+
+    def step():
+        tx.grad = None
+        for p in layer.parameters():
+            p.grad = None
+        layer(tx, adj=adj).backward(tg)
+
+    step()
+    seen = aten_in_step.log_step(step)
+    assert not seen, "torch operators inside the multi-channel layer: %s" % list(seen.items())

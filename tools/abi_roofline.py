@@ -84,6 +84,23 @@ def _cost(name, a):
         c = _csr(a[0], 0)
         b += 4 * d * c.num_graphs * c.rows
         return b, f, "C=%d T=%d %dx%d d=%d" % (C, c.num_graphs, c.rows, c.cols, d)
+    if name == "kgcn_bconv_fanout_f32":
+        # (at_ch, C, grad, act_out, ld, gs, d, act, out, ...): the gradient block (and the saved output with act') in ONCE, C CSR slices,
+        # C output blocks out
+        C, d, act = a[1], a[6], a[7]
+        c0 = _csr(a[0], 0)
+        T = c0.num_graphs
+        b = 4 * d * T * c0.cols * (2 if act else 1)
+        f = 0
+        for i in range(C):
+            c = _csr(a[0], i)
+            b += _csr_bytes(c) + 4 * d * T * c.rows
+            f += 2 * c.nnz * d
+        return b, f, "T=%d %dx%d C=%d d=%d act=%d" % (T, c0.rows, c0.cols, C, d, act)
+    if name == "kgcn_copy2d_multi_f32":
+        jobs = ctypes.cast(a[0], ctypes.POINTER(_lib.Copy2dJob))
+        b = sum(8 * jobs[i].rows * jobs[i].cols for i in range(a[1]))
+        return b, 0, "%d strided copies" % a[1]
     if name == "kgcn_bspmm_dact_f32":
         c = _csr(a[0]); d = a[5]
         b, f = _spmm(c, d, n_rhs=2)

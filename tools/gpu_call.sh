@@ -1,4 +1,3 @@
 #!/bin/bash
-REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO; OUT=gpurun_out/r06i; mkdir -p $OUT
-for v in gb_head gb_hot; do echo "== $v"; KGCN_HIP_LIB=$REPO/build/variants/libkgcn_$v.so timeout 600 python tools/dense_bwd_bench.py 200000 2>/dev/null | cut -c1-220; done
-for v in gb_head gh_hot; do echo "== $v (gemmh family)"; KGCN_HIP_LIB=$REPO/build/variants/libkgcn_$v.so timeout 600 python tools/gemmh_bench.py --rows 200000 --quick 2>/dev/null | tail -12 | cut -c1-250; done
+REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO; OUT=gpurun_out/r06k; mkdir -p $OUT
+timeout 1200 python -m pytest tests/test_gpu_bconv_loop.py tests/test_gpu_bench.py tests/test_gpu_step_no_aten.py -m gpu -q > $OUT/pytest.log 2>&1; tail -25 $OUT/pytest.log | cut -c1-250
