@@ -239,6 +239,40 @@ __global__ __launch_bounds__(NT) void skel_f(const float* __restrict__ x, const 
   }
 }
 
+// forward, persistent, prefetch depth DEPTH (graphs in flight per wave beyond the one being written), NT threads per workgroup
+template <int DEPTH, int NT>
+__global__ __launch_bounds__(NT) void skel_fd(const float* __restrict__ x, const f4* __restrict__ cv, float* __restrict__ out, int T) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = gridDim.x * (NT / 64);
+  const int t0 = blockIdx.x * (NT / 64) + wave;
+  if (t0 >= T) return;
+  const int cnt = (T - 1 - t0) / nw + 1;
+  f4 r[DEPTH][8], c0[DEPTH], c1[DEPTH];
+  auto issue = [&](int k, int slot) {
+    const int t = t0 + (k < cnt ? k : cnt - 1) * nw;
+    const f4* s = reinterpret_cast<const f4*>(x + (long)t * 2048);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r[slot][q] = s[lane + 64 * q];
+    c0[slot] = cv[(long)t * 80 + lane];
+    c1[slot] = lane < 16 ? cv[(long)t * 80 + 64 + lane] : f4{0, 0, 0, 0};
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) issue(d, d);
+  for (int i = 0; i < cnt; i += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      if (i + d >= cnt) break;
+      f4 o[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = r[d][q] + ((q & 1) ? c1[d] : c0[d]);
+      issue(i + d + DEPTH, d);
+      f4* dst = reinterpret_cast<f4*>(out + (long)(t0 + (i + d) * nw) * 2048);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) dst[lane + 64 * q] = o[q];
+    }
+  }
+}
+
 static float* X; static float* G; static float* DX; static f4* CV; static int T;
 template <typename L>
 static float timeit(L launch) {
@@ -311,6 +345,20 @@ int main(int argc, char** argv) {
           timeit([&] { hipLaunchKernelGGL((skel_f<0, 0, 512>), dim3(256), dim3(512), 0, 0, X, CV, DX, T); }));
     linef("F  forward: persistent, 8 waves/CU (2 x 256-thread workgroups), no barrier",
           timeit([&] { hipLaunchKernelGGL((skel_f<0, 0, 256>), dim3(512), dim3(256), 0, 0, X, CV, DX, T); }));
+    linef("FD forward: persistent, depth 1, 8 waves/CU (2 x 256)",
+          timeit([&] { hipLaunchKernelGGL((skel_fd<1, 256>), dim3(512), dim3(256), 0, 0, X, CV, DX, T); }));
+    linef("FD forward: persistent, depth 2, 8 waves/CU (2 x 256)",
+          timeit([&] { hipLaunchKernelGGL((skel_fd<2, 256>), dim3(512), dim3(256), 0, 0, X, CV, DX, T); }));
+    linef("FD forward: persistent, depth 3, 8 waves/CU (2 x 256)",
+          timeit([&] { hipLaunchKernelGGL((skel_fd<3, 256>), dim3(512), dim3(256), 0, 0, X, CV, DX, T); }));
+    linef("FD forward: persistent, depth 1, 16 waves/CU",
+          timeit([&] { hipLaunchKernelGGL((skel_fd<1, 256>), dim3(1024), dim3(256), 0, 0, X, CV, DX, T); }));
+    linef("FD forward: persistent, depth 1, 32 waves/CU",
+          timeit([&] { hipLaunchKernelGGL((skel_fd<1, 256>), dim3(2048), dim3(256), 0, 0, X, CV, DX, T); }));
+    linef("FD forward: persistent, depth 2, 16 waves/CU",
+          timeit([&] { hipLaunchKernelGGL((skel_fd<2, 256>), dim3(1024), dim3(256), 0, 0, X, CV, DX, T); }));
+    linef("FD forward: NON persistent, one wave per graph (64-thread workgroups)",
+          timeit([&] { hipLaunchKernelGGL((skel_fd<1, 64>), dim3(T), dim3(64), 0, 0, X, CV, DX, T); }));
     linef("FB forward: persistent, 8 waves/CU (512-thread workgroup), barrier per graph",
           timeit([&] { hipLaunchKernelGGL((skel_f<0, 1, 512>), dim3(256), dim3(512), 0, 0, X, CV, DX, T); }));
     linef("FB forward: persistent, 4 waves/CU, barrier per graph",

@@ -24,7 +24,7 @@ python bench.py --graphs 4096 --graph --no-cpu-baseline --steps 50 --warmup 5 2>
 port=29711
 for c in cfg2 cfg4 cfg5; do
   port=$((port+1))
-  timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port $port bench.py --gpus 1 --config $c --force-dist --no-cpu-baseline --steps 30 --warmup 5 2>/dev/null | tail -1 > $OUT/${c}_forcedist.json
+  timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port $port bench.py --gpus 1 --config $c --force-dist --no-cpu-baseline --steps 30 --warmup 5 2> $OUT/${c}_forcedist.err | tail -1 > $OUT/${c}_forcedist.json
 done
 python - <<PY
 import json

@@ -58,15 +58,25 @@ def timed_start(per):
     dispatches are the timed ones: the region starts with the earliest of those over all such kernels.  Kernels with fewer
     dispatches than that -- model construction, data generation, graph capture: the torch fill / copy kernels an earlier form of
     this script spread over the steps as "1 per step" -- do not define the region, and what they launched before it is not counted."""
-    t0 = None
+    cands, names, t_end = [], [], max(r[-1][0] for r in per.values())
     for name, rows in per.items():
         n = round(len(rows) / PASSES)
         if n >= 1 and len(rows) >= n * (PASSES - 2):
-            s0 = rows[-min(len(rows), n * STEPS)][0]
-            t0 = s0 if t0 is None else min(t0, s0)
-    if t0 is None:                                           # (no kernel ran once per pass: count everything)
-        t0 = min(r[0][0] for r in per.values())
-    return t0
+            cands.append(rows[-min(len(rows), n * STEPS)][0])
+            names.append(name)
+    if not cands:                                            # (no kernel ran once per pass: count everything)
+        return min(r[0][0] for r in per.values())
+    # a name that ALSO ran during set-up (torch copies: 90 uploads + one per step) passes the count test by accident and would pull the
+    # region back by whole steps: the candidates of the step's own kernels all lie inside the first timed step, i.e. within one step
+    # of the latest candidate
+    latest = max(cands)
+    step = (t_end - latest) / max(STEPS - 1, 1)
+    keep = [(c, n) for c, n in zip(cands, names) if c >= latest - 1.25 * step]
+    t0 = min(c for c, _ in keep)
+    # ... and what was launched between the END of the previous step's last kernel and t0 (an index upload in front of the step's
+    # first kernel) belongs to the first timed step
+    prev_end = max([s_ + d * 1e3 for _, n in keep for s_, d in per[n] if s_ < t0] or [t0 - 1])
+    return min(t0, prev_end + 1)
 
 
 dur, meta, pmc = {}, {}, {}
