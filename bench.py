@@ -661,7 +661,8 @@ class Cfg2:
         self.x.grad = None
         for p in self.layer.parameters():
             p.grad = None
-        with torch.cuda.graph(graph):
+        from kgcn_amd.train import capture_mode
+        with torch.cuda.graph(graph, **capture_mode()):            # (a live process group's watchdog thread must not break the capture)
             self.step()
         for _ in range(max(warmup, 3)):
             graph.replay()

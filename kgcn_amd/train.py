@@ -143,6 +143,21 @@ def train_step(model, optimizer, loss_fn, features, adjs, labels, mask, bucket=N
     return float(cost_sum.detach()), logits.detach()
 
 
+def capture_mode():
+    """Keyword arguments for torch.cuda.graph().  With a process group alive, ProcessGroupNCCL's watchdog THREAD polls the events of
+    the collectives enqueued before the capture (the warm-up steps' all-reduces, the barrier) every ~100 ms; under the default
+    capture_error_mode="global" such a hipEventQuery from another thread invalidates the capture ("operation not permitted when stream
+    is capturing": seen once in fifteen one-rank RCCL runs of cfg4, profiles/r06_capture_vs_watchdog.txt).  The device is idle at this
+    point (the caller has synchronised), so one watchdog period later its work list is empty; and the capture only polices its OWN
+    thread (the all-reduce of the step is issued by the capturing thread and is captured like any kernel)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        import time
+        time.sleep(0.25)
+        return {"capture_error_mode": "thread_local"}
+    return {}
+
+
 class GraphedTrainStep:
     """One mini-batch step (forward, loss, backward, TF-Adam update) captured ONCE in a hipGraph and
     replayed per batch.  At the reference's own batch size (30 graphs of 10 nodes, example_config/synth.json)
@@ -184,7 +199,7 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, **capture_mode()):
             self._eager()
         with torch.no_grad():
             for dst, src in zip(list(optimizer.params) + optimizer.m + optimizer.v, saved):
