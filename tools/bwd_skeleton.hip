@@ -74,7 +74,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 // LOAD: synthetic arithmetic per wave and graph next to the memory streams (no LDS traffic, no dependence on the loaded data beyond a
 // final select): 1 = 48 v_mfma_f32_32x32x16_bf16 (the kernel's 96 per graph over the pair), 2 = those + 400 v_fma_f32, 3 = 400 v_fma_f32 only
-template <int DEPTH, int BAR = 1, int LOAD = 0>
+template <int DEPTH, int BAR = 1, int LOAD = 0, int NT = 0>
 __global__ __launch_bounds__(512) void skel_h(const float* __restrict__ x, const float* __restrict__ g,
                                               const f4* __restrict__ cv, float* __restrict__ dx, int T) {
   __shared__ float hand[8][64];
@@ -96,7 +96,10 @@ __global__ __launch_bounds__(512) void skel_h(const float* __restrict__ x, const
     const int t = cnt > 0 ? t0 + kk * npairs : 0;
     const f4* s = reinterpret_cast<const f4*>((role ? x : g) + (long)t * 2048);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) r[slot][q] = s[lane + 64 * q];
+    for (int q = 0; q < 8; ++q) {
+      if constexpr ((NT & 1) != 0) r[slot][q] = __builtin_nontemporal_load(s + lane + 64 * q);
+      else r[slot][q] = s[lane + 64 * q];
+    }
     if (!role) {
       cr[slot][0] = cv[(long)t * 80 + lane];
       cr[slot][1] = lane < 16 ? cv[(long)t * 80 + 64 + lane] : f4{0, 0, 0, 0};
@@ -152,8 +155,12 @@ __global__ __launch_bounds__(512) void skel_h(const float* __restrict__ x, const
         const float hv = hand[wave + 1][lane];
         float* dst = dx + (long)(t0 + (i + d) * npairs) * 2048;
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-          *reinterpret_cast<f4*>(dst + li * 64 + (q >> 2) * 32 + 8 * (q & 3) + 4 * hi) = o[q] * hv + cr[d][q & 1];
+        for (int q = 0; q < 8; ++q) {
+          const f4 val = o[q] * hv + cr[d][q & 1];
+          f4* dp = reinterpret_cast<f4*>(dst + li * 64 + (q >> 2) * 32 + 8 * (q & 3) + 4 * hi);
+          if constexpr ((NT & 2) != 0) __builtin_nontemporal_store(val, dp);
+          else *dp = val;
+        }
       }
     }
   }
@@ -321,6 +328,14 @@ int main(int argc, char** argv) {
          timeit([&] { hipLaunchKernelGGL((skel_h<2>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
     line("H  pairs, depth 2, 16 waves/CU",
          timeit([&] { hipLaunchKernelGGL((skel_h<2>), dim3(512), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("H  pairs, nontemporal LOADS",
+         timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 0, 1>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("H  pairs, nontemporal STORES",
+         timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 0, 2>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("H  pairs, nontemporal loads and stores",
+         timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 0, 3>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("H  pairs + MFMAs + FMAs, nontemporal loads",
+         timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 2, 1>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
     line("H  pairs + 48 bf16 MFMAs per wave and graph",
          timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 1>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
     line("H  pairs + 48 bf16 MFMAs + 400 v_fma_f32 per wave and graph",
