@@ -575,13 +575,15 @@ def test_bf16_split_edge_values(case, T):
     _row_close(out, out_u.detach().cpu().numpy(), 3e-6, case + ": fused vs unfused")
 
 
-def test_bf16_split_non_finite_inputs():
+@pytest.mark.parametrize("T", [66, 2100])
+def test_bf16_split_non_finite_inputs(T):
     """Documented behaviour (include/kgcn_hip.h): the split of +-inf is (inf, nan, nan), so a non-finite
     input value makes every output element that depends on it NaN or +-inf (the f32 kernels and TF give +-inf or NaN
-    there), and leaves every other element untouched -- never a silently finite wrong value."""
+    there), and leaves every other element untouched -- never a silently finite wrong value.  (2,100 graphs: the backward
+    with two waves per graph slot, graphconv_bwd_pairs_kernel.)"""
     from kgcn_amd import BatchedCSR, ops
     rng = np.random.default_rng(11)
-    T, N, D = 66, 32, 64
+    N, D = 32, 64
     adjs = K.synth_mol_graphs(rng, T, N, 3)
     x = rng.standard_normal((T, N, D)).astype(np.float32)
     w = K.glorot_uniform(rng, D, D)

@@ -1,3 +1,3 @@
 #!/bin/bash
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO
-time python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v Warning | tail -12
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "non_finite or repeats_bit" 2>&1 | tail -4
