@@ -74,7 +74,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 // LOAD: synthetic arithmetic per wave and graph next to the memory streams (no LDS traffic, no dependence on the loaded data beyond a
 // final select): 1 = 48 v_mfma_f32_32x32x16_bf16 (the kernel's 96 per graph over the pair), 2 = those + 400 v_fma_f32, 3 = 400 v_fma_f32 only
-template <int DEPTH, int BAR = 1, int LOAD = 0, int NT = 0>
+template <int DEPTH, int BAR = 1, int LOAD = 0, int NT = 0, int CONTIG = 0>
 __global__ __launch_bounds__(512) void skel_h(const float* __restrict__ x, const float* __restrict__ g,
                                               const f4* __restrict__ cv, float* __restrict__ dx, int T) {
   __shared__ float hand[8][64];
@@ -93,7 +93,11 @@ __global__ __launch_bounds__(512) void skel_h(const float* __restrict__ x, const
   const float vm = 0.999f + 1e-9f * lane, vb = 1e-7f * lane;
   auto issue = [&](int k, int slot) {
     const int kk = k < cnt ? k : (cnt > 0 ? cnt - 1 : 0);
-    const int t = cnt > 0 ? t0 + kk * npairs : 0;
+    int t = cnt > 0 ? t0 + kk * npairs : 0;
+    if constexpr (CONTIG != 0) {                               // every pair walks a contiguous range of graphs instead of a strided one
+      const long tc = (long)t0 * cnt_max + kk;
+      t = (int)(tc < T ? tc : T - 1);
+    }
     const f4* s = reinterpret_cast<const f4*>((role ? x : g) + (long)t * 2048);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -153,7 +157,9 @@ __global__ __launch_bounds__(512) void skel_h(const float* __restrict__ x, const
       if constexpr (BAR != 0) __syncthreads();   // one workgroup barrier per graph, as the two-role kernel would pay
       if (!role && live) {
         const float hv = hand[wave + 1][lane];
-        float* dst = dx + (long)(t0 + (i + d) * npairs) * 2048;
+        long td = t0 + (long)(i + d) * npairs;
+        if constexpr (CONTIG != 0) { td = (long)t0 * cnt_max + (i + d); if (td >= T) td = T - 1; }
+        float* dst = dx + td * 2048;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const f4 val = o[q] * hv + cr[d][q & 1];
@@ -328,6 +334,10 @@ int main(int argc, char** argv) {
          timeit([&] { hipLaunchKernelGGL((skel_h<2>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
     line("H  pairs, depth 2, 16 waves/CU",
          timeit([&] { hipLaunchKernelGGL((skel_h<2>), dim3(512), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("H  pairs, every pair a CONTIGUOUS range of graphs",
+         timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 0, 0, 1>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("H  pairs + MFMAs + FMAs, contiguous ranges",
+         timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 2, 0, 1>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
     line("H  pairs, nontemporal LOADS",
          timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 0, 1>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
     line("H  pairs, nontemporal STORES",
