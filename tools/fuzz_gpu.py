@@ -101,6 +101,45 @@ for case in range(CASES):
     check("gram fwd", od, K.gram_fwd(xm, wv), ctx=("gram", N, Dm, T))
     dxd, dwd = K.gram_bwd(xm, wv, gd)
     check("gram dx", txd.grad, dxd, ctx=("gram", N, Dm, T)); check("gram dw", twd.grad, dwd, rel=1e-4, ctx=("gram", N, Dm, T))
+    # ---- multi-channel GraphConv (round 6: channel-loop Bconv, fan-out adjoint, both routes of the layer), C = 2 .. 9 ------------
+    Cm, Nm = int(rng.integers(2, 10)), int(rng.integers(1, 70))
+    dim_, dom = int(rng.integers(1, 40)), int(rng.integers(1, 70))
+    Tm = int(rng.integers(1, 60)) if case % 3 else int(rng.integers(1100 // max(Nm, 1) + 1, 1100 // max(Nm, 1) + 40))
+    adjm = [[rand_graphs(1, Nm, rng.uniform(0.02, 0.4), dup=bool(rng.integers(0, 2)))[0][0] for _ in range(Cm)] for _ in range(Tm)]
+    xmc = rng.standard_normal((Tm, Nm, dim_)).astype(np.float32)
+    gmc = rng.standard_normal((Tm, Nm, dom)).astype(np.float32)
+    lay = layers.GraphConv(dom, Cm).to(dev)
+    lay.build((Tm, Nm, dim_), dev)
+    with torch.no_grad():
+        for bb in lay.bias:
+            bb.copy_(t32(rng.standard_normal((1, dom)) * 0.1))
+    txc = t32(xmc).requires_grad_(True)
+    oc = lay(txc, adj=BatchedAdjacency.from_adjs(adjm, n_nodes=Nm, device=dev))
+    oc.backward(t32(gmc))
+    wl_, bl_ = [p_.detach().cpu().numpy() for p_ in lay.w], [p_.detach().cpu().numpy() for p_ in lay.bias]
+    ctx = ("multi-channel conv", Cm, Nm, dim_, dom, Tm)
+    check("mc fwd", oc, K.graphconv_fwd(xmc, adjm, wl_, bl_), ctx=ctx)
+    dxm, dwm, dbm = K.graphconv_bwd(xmc, adjm, wl_, bl_, gmc)
+    check("mc dx", txc.grad, dxm, ctx=ctx)
+    for cc in range(Cm):
+        check("mc dw%d" % cc, lay.w[cc].grad, dwm[cc], ctx=ctx); check("mc db%d" % cc, lay.bias[cc].grad, dbm[cc].reshape(1, dom), ctx=ctx)
+    # ---- the FULL-shape backward with two waves per graph slot (>= 2,048 graphs) ---------------------------------------------------
+    if case % 8 == 0:
+        Tf = int(rng.integers(2048, 2700))
+        adjf = K.synth_mol_graphs(rng, Tf, 32, int(rng.integers(0, 6)), normalize=bool(rng.integers(0, 2)))
+        for tz in rng.integers(0, Tf, size=5):
+            adjf[int(tz)] = [(np.zeros((0, 2), np.int32), np.zeros(0, np.float32), [32, 32])]        # empty graphs
+        xf = rng.standard_normal((Tf, 32, 64)).astype(np.float32); gf = rng.standard_normal((Tf, 32, 64)).astype(np.float32)
+        wf = K.glorot_uniform(rng, 64, 64); bf = rng.standard_normal((1, 64)).astype(np.float32)
+        csf = BatchedCSR.from_coo_list([a[0] for a in adjf], rows=32, cols=32, device=dev)
+        txf, twf, tbf = t32(xf).requires_grad_(True), t32(wf).requires_grad_(True), t32(bf).requires_grad_(True)
+        of = ops.graphconv_fused(txf, twf, tbf, csf)
+        of.backward(t32(gf))
+        ctx = ("pairs backward", Tf)
+        check("full fwd", of, K.graphconv_fwd_fast(xf, adjf, [wf], [bf]), ctx=ctx)
+        dxf, dwf, dbf = K.graphconv_bwd_fast(xf, adjf, [wf], gf)
+        check("full dx", txf.grad, dxf, ctx=ctx); check("full dw", twf.grad, dwf[0], rel=1e-5, atol=1e-5 * float(np.abs(dwf[0]).max()), ctx=ctx)
+        check("full db", tbf.grad, dbf[0], rel=1e-5, atol=1e-5 * float(np.abs(dbf[0]).max()), ctx=ctx)
     # ---- dense, both kernel families (gemm3 above 128 output columns) ------------------------------------------------
     M, di, do = int(rng.integers(1, 3000)), int(rng.integers(1, 400)), int(rng.integers(1, 400))
     xd = rng.standard_normal((M, di)).astype(np.float32)
