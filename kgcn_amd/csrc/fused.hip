@@ -2134,7 +2134,7 @@ extern "C" int kgcn_graphconv_bwd_f32(const kgcn_csr_batch* at, const float* x, 
   // each walking 1 / k of the graphs with its own pipeline fill, W' split and dW partial (k x 256 partials in the second stage) --
   // the form the kernel's LDS footprint (one 4-wave workgroup per CU) allows.  profiles/r05_headline_experiments.txt
   static const char* gm = dev_knob("KGCN_BWD_GRID_MULT");
-  if (gm && atoi(gm) > 1 && atoi(gm) <= 16 && (long)blocks * atoi(gm) * wpb * 2 <= at->num_graphs) blocks *= atoi(gm);
+  if (!pairs && gm && atoi(gm) > 1 && atoi(gm) <= 16 && (long)blocks * atoi(gm) * wpb * 2 <= at->num_graphs) blocks *= atoi(gm);
   const int64_t need = (int64_t)blocks * ((int64_t)din * dout + dout) * 4;
   if (!workspace || workspace_bytes < need)
     return fail("kgcn_graphconv_bwd_f32: workspace %lld < %lld bytes", (long long)workspace_bytes,
