@@ -62,7 +62,9 @@ extern "C" {
  * pooled_ld and kgcn_masked_sigmoid_ce_f32 gained pos_weight_per_task.  A binder built against version 1 must not call a
  * version-2 library: compare kgcn_abi_version() with the KGCN_HIP_ABI_VERSION it was compiled against AND
  * kgcn_csr_batch_size() with its own sizeof(kgcn_csr_batch) before the first call (kgcn_amd/_lib.py and
- * tests/abi_consumer.c do both). */
+ * tests/abi_consumer.c do both).
+ * Round 6 ADDED entry points only (no signature or layout changed, the version stays 2): kgcn_bconv_fanout_f32,
+ * kgcn_copy2d_multi_f32 (+ kgcn_copy2d_job), kgcn_hbm_probe. */
 #define KGCN_HIP_ABI_VERSION 2
 
 /* Column index of the padding entries of a row-padded batch (see row_pad): they carry value 0 and
