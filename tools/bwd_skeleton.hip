@@ -74,7 +74,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 // LOAD: synthetic arithmetic per wave and graph next to the memory streams (no LDS traffic, no dependence on the loaded data beyond a
 // final select): 1 = 48 v_mfma_f32_32x32x16_bf16 (the kernel's 96 per graph over the pair), 2 = those + 400 v_fma_f32, 3 = 400 v_fma_f32 only
-template <int DEPTH, int BAR = 1, int LOAD = 0, int NT = 0, int CONTIG = 0>
+template <int DEPTH, int BAR = 1, int LOAD = 0, int NT = 0, int CONTIG = 0, int LATE = 0>
 __global__ __launch_bounds__(512) void skel_h(const float* __restrict__ x, const float* __restrict__ g,
                                               const f4* __restrict__ cv, float* __restrict__ dx, int T) {
   __shared__ float hand[8][64];
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512) void skel_h(const float* __restrict__ x, const
         f4 s = o[0] + o[1] + o[2] + o[3] + o[4] + o[5] + o[6] + o[7];
         hand[wave][lane] = s[0] + s[1] + s[2] + s[3];
       }
-      issue(i + d + DEPTH, d);
+      if constexpr (LATE == 0) issue(i + d + DEPTH, d);      // LATE: the next graph is requested BEHIND the arithmetic (as the kernel's roles do)
       if constexpr (LOAD == 1 || LOAD == 2 || LOAD == 5) {
 #pragma unroll
         for (int m = 0; m < (LOAD == 5 ? 24 : 12); ++m) {
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(512) void skel_h(const float* __restrict__ x, const
           for (int e = 0; e < 8; ++e) va[e] = __builtin_fmaf(va[e], vm, vb);
         }
       }
+      if constexpr (LATE != 0) issue(i + d + DEPTH, d);
       if constexpr (BAR != 0) __syncthreads();   // one workgroup barrier per graph, as the two-role kernel would pay
       if (!role && live) {
         const float hv = hand[wave + 1][lane];
@@ -338,6 +339,10 @@ int main(int argc, char** argv) {
          timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 0, 0, 1>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
     line("H  pairs + MFMAs + FMAs, contiguous ranges",
          timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 2, 0, 1>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("H  pairs + MFMAs + FMAs, the next graph requested BEHIND the arithmetic",
+         timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 2, 0, 0, 1>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
+    line("H  pairs, the next graph requested just before the barrier (no arithmetic)",
+         timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 0, 0, 0, 1>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
     line("H  pairs, nontemporal LOADS",
          timeit([&] { hipLaunchKernelGGL((skel_h<1, 1, 0, 1>), dim3(256), dim3(512), 0, 0, X, G, CV, DX, T); }));
     line("H  pairs, nontemporal STORES",
